@@ -1,0 +1,175 @@
+"""The CPU oracle (oracle/restatement.py) against fixtures generated from the reference's own
+Python (tests/golden/make_golden.py).  CPU-only; this is what pins the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import rot_mvgaze_amd  # noqa: F401
+from rot_mvgaze_amd import synth
+from oracle import restatement as R
+
+torch.set_num_threads(8)
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_geometry_known_answers(golden_dir):
+    g = _load(golden_dir, "geometry_loss.npz")
+    hp = torch.from_numpy(g["hp"])
+    np.testing.assert_allclose(R.rotation_matrix_2d(hp).numpy(), g["R"], rtol=0, atol=1e-7)
+    np.testing.assert_array_equal(R.rotation_matrix_2d(hp, inverse=True).numpy(),
+                                  R.rotation_matrix_2d(hp).transpose(1, 2).numpy())
+    np.testing.assert_allclose(R.rotation_matrix_2d(hp, inverse=True).numpy(), g["R_inv"], atol=1e-7)
+    np.testing.assert_allclose(R.rotation_matrix_2d(hp[0]).numpy(), g["R_1d"], atol=1e-7)
+    np.testing.assert_allclose(R.pitchyaw_to_vector(hp).numpy(), g["vec"], atol=1e-7)
+    # SURVEY §8(a) A1 known answer, hp = (0.1, 0.2)
+    np.testing.assert_allclose(g["R"][0], [[0.98006660, -0.01983384, 0.19767681],
+                                           [0.0, 0.99500418, 0.09983342],
+                                           [-0.19866933, -0.09784340, 0.97517037]], atol=1e-7)
+    # R @ e_z == pitchyaw_to_vector(hp)  (same convention for head pose and gaze)
+    np.testing.assert_allclose(g["R"][:, :, 2], g["vec"], atol=1e-6)
+
+
+def test_loss_known_answers(golden_dir):
+    g = _load(golden_dir, "geometry_loss.npz")
+    pred = torch.from_numpy(g["loss_pred"]).requires_grad_(True)
+    gt = torch.from_numpy(g["loss_gt"])
+    loss = R.gaze_angular_loss(pred, gt)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-6)
+    np.testing.assert_allclose(pred.grad.numpy(), g["loss_dpred"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(g["ka_loss"], 11.706101, rtol=1e-6)
+    np.testing.assert_allclose(g["ka_dpred"], [[-0.07152022, -28.50628471], [-24.10472298, 15.48111153]], rtol=1e-5)
+    np.testing.assert_allclose(R.angular_error_numpy(g["loss_pred"].astype(np.float64),
+                                                     g["loss_gt"].astype(np.float64))[[0, 1] + list(range(3, 32))],
+                               g["ang_err_np"][[0, 1] + list(range(3, 32))], rtol=1e-9, atol=1e-9)
+
+
+def test_pair_index_bit_exact(golden_dir):
+    with open(os.path.join(golden_dir, "pair_index.json")) as f:
+        cases = json.load(f)
+    n = 0
+    for key, c in cases.items():
+        if key == "shared_stream":
+            rng = R.MT19937(c["seed"])
+            assert [list(t) for t in R.build_pair_index(c["train_rows"], "novel_train", rng)] == c["train"]
+            # the test set was built from file f1 only -> file index 0 in ITS list
+            assert [list(t) for t in R.build_pair_index(c["test_rows"], "novel_test", rng)] == c["test"]
+            continue
+        got = R.build_pair_index(c["rows"], c["tag"], R.MT19937(c["seed"]))
+        assert [list(t) for t in got] == c["tuples"], key
+        n += len(got)
+    assert n > 1000
+    a = cases["a|0|all"]["tuples"]
+    assert len(a) == 76 and a[:3] == [[0, 0, 13], [0, 1, 14], [0, 2, 1]] and a[-1] == [1, 39, 36]
+
+
+def test_mt19937_matches_cpython():
+    import random
+    for seed in (0, 1, 42, 2**40 + 17):
+        random.seed(seed)
+        rng = R.MT19937(seed)
+        assert [random.getrandbits(32) for _ in range(1500)] == [rng.u32() for _ in range(1500)]
+
+
+def _torch_sd(depth, seed=0):
+    return {k: torch.from_numpy(np.array(v)) for k, v in synth.make_state_dict(depth, seed, 3, perturb_bn=True).items()}
+
+
+def _data(batch, hw, seed=1234):
+    inp = synth.make_inputs(batch, 2, seed, hw)
+    img, hp, gt = (torch.from_numpy(inp[k]) for k in ("img", "head_pose", "gt_gaze"))
+    return {"img_0": img[:, 0].contiguous(), "img_1": img[:, 1].contiguous(),
+            "rot_0": R.rotation_matrix_2d(hp[:, 0]), "rot_1": R.rotation_matrix_2d(hp[:, 1]),
+            "gt_gaze": gt[:, 0].contiguous(), "gt_gaze_1": gt[:, 1].contiguous()}
+
+
+def _check_outputs(data, g, prefix, rtol):
+    for k in ("img_feat_0", "img_feat_1", "initial_rot_feat_0", "initial_rot_feat_1", "pred_gaze"):
+        ref = g[f"{prefix}.{k}"]
+        np.testing.assert_allclose(data[k].detach().numpy(), ref, rtol=rtol, atol=rtol * np.abs(ref).max())
+    for i in range(3):
+        for k in ("feat_0", "feat_1", "pred_gaze_0", "pred_gaze_1"):
+            ref = g[f"{prefix}.iter_{i}.{k}"]
+            np.testing.assert_allclose(data[f"iter_{i}"][k].detach().numpy(), ref, rtol=rtol,
+                                       atol=rtol * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("depth,batch,hw", [(18, 2, 224), (50, 2, 224), (18, 3, 64), (50, 3, 64)])
+def test_model_forward_backward_vs_reference(golden_dir, depth, batch, hw):
+    g = _load(golden_dir, f"model_r{depth}_b{batch}_hw{hw}.npz")
+    # eval
+    sd = _torch_sd(depth)
+    with torch.no_grad():
+        data = R.model_forward(sd, _data(batch, hw), depth, 3, training=False)
+    _check_outputs(data, g, "eval", 1e-6)
+    # train: forward + loss + backward + running stats
+    sd = _torch_sd(depth)
+    leaves = {k: v.requires_grad_(True) for k, v in sd.items()
+              if v.dtype == torch.float32 and "running" not in k}
+    data = _data(batch, hw)
+    data["img_0"].requires_grad_(True)
+    data = R.model_forward(sd, data, depth, 3, training=True)
+    loss = R.iteration_loss(data)
+    loss.backward()
+    _check_outputs(data, g, "train", 1e-6)
+    np.testing.assert_allclose(loss.item(), g["train.loss"], rtol=1e-6)
+    for key in [k[5:] for k in g.files if k.startswith("grad._")]:
+        ref = g["grad." + key]
+        got = leaves[key].grad.reshape(-1)[: ref.size].numpy()
+        np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max() + 1e-12)
+        np.testing.assert_allclose(float(leaves[key].grad.double().norm()), g["gradnorm." + key], rtol=1e-5)
+    assert leaves["_feat_extractor.0.fc.weight"].grad is None
+    np.testing.assert_allclose(data["img_0"].grad[:, :, ::16, ::16].numpy(), g["grad.img_0"], rtol=1e-5,
+                               atol=1e-5 * np.abs(g["grad.img_0"]).max())
+    for k in [k for k in g.files if k.startswith("stat.")]:
+        np.testing.assert_allclose(sd[k[5:]].detach().numpy(), g[k], rtol=1e-6, atol=1e-7)
+    assert int(sd["_feat_extractor.0.bn1.num_batches_tracked"]) == 2
+
+
+def test_view_swap_symmetry_is_bit_exact():
+    """swapping the two views swaps the outputs bit-exactly in eval mode."""
+    sd = _torch_sd(18)
+    with torch.no_grad():
+        a = R.model_forward(sd, _data(2, 64), 18, 3, False)
+        d = _data(2, 64)
+        d = {"img_0": d["img_1"], "img_1": d["img_0"], "rot_0": d["rot_1"], "rot_1": d["rot_0"]}
+        b = R.model_forward(sd, d, 18, 3, False)
+    for i in range(3):
+        assert torch.equal(a[f"iter_{i}"]["pred_gaze_0"], b[f"iter_{i}"]["pred_gaze_1"])
+        assert torch.equal(a[f"iter_{i}"]["feat_1"], b[f"iter_{i}"]["feat_0"])
+
+
+def test_multiview_pairs_equal_two_view_recurrence():
+    """A9: every pair (i,j) of the V-view generalisation equals the two-view oracle on views i,j
+    (eval mode, shared backbone features)."""
+    sd = _torch_sd(18)
+    inp = synth.make_inputs(2, 3, 99, 64)
+    img, hp, gt = (torch.from_numpy(inp[k]) for k in ("img", "head_pose", "gt_gaze"))
+    rot = R.rotation_matrix_2d(hp.reshape(-1, 2)).reshape(2, 3, 3, 3)
+    with torch.no_grad():
+        mv = R.multiview_forward(sd, img, rot, 18, 3, False)
+        for (i, j) in R.view_pairs(3):
+            two = R.model_forward(sd, {"img_0": img[:, i], "img_1": img[:, j], "rot_0": rot[:, i], "rot_1": rot[:, j]},
+                                  18, 3, False)
+            for it in range(3):
+                for k in ("feat_0", "feat_1", "pred_gaze_0", "pred_gaze_1"):
+                    assert torch.equal(mv["pairs"][(i, j)][f"iter_{it}"][k], two[f"iter_{it}"][k])
+        loss = R.multiview_loss(mv, gt)
+    assert loss.ndim == 0 and torch.isfinite(loss)
+
+
+def test_iteration_loss_weights():
+    """IterationLoss weights are exactly (0.25, 0.5, 1.0) for decay 0.5 and 3 iterations."""
+    gt = torch.tensor([[0.1, 0.2], [0.0, -0.1]])
+    preds = [torch.tensor([[0.2, 0.1], [0.1, 0.0]]) * (k + 1) for k in range(3)]
+    data = {"num_iter": 3, "gt_gaze": gt, "gt_gaze_1": gt}
+    for i in range(3):
+        data[f"iter_{i}"] = {"pred_gaze_0": preds[i], "pred_gaze_1": preds[i]}
+    Ls = [R.stereo_loss(preds[i], preds[i], gt, gt) for i in range(3)]
+    np.testing.assert_allclose(R.iteration_loss(data).item(), (0.25 * Ls[0] + 0.5 * Ls[1] + Ls[2]).item(), rtol=1e-6)
