@@ -1,0 +1,214 @@
+/*
+ * rotmvgaze.h - C ABI of librotmvgaze_hip.so, the MI355X (gfx950) compute library behind the
+ * Rot-MVGaze hot path (FeatRotationSymm forward / loss / backward).
+ *
+ * The reference has NO native layer and no FFI: every FLOP is a stock PyTorch ATen op
+ * (SURVEY.md §2).  Each entry point below therefore replaces the ATen op(s) that the cited
+ * reference lines dispatch; INTEGRATION.md shows the ctypes stub that binds them and how the
+ * drop-in nn.Module calls them.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless named host_*;
+ *   - all activations are NHWC fp32, images ordered [group][n][h][w][c]; a "group" is one
+ *     view's batch: BatchNorm statistics are reduced per group because the reference runs the
+ *     backbone once per view (rot_mv.py:196-197);
+ *   - conv weights are KRSC fp32 ([cout][r][s][cin]) = the physical layout of a PyTorch
+ *     [O,I,H,W] tensor in torch.channels_last; linear weights are [out][in] (PyTorch native);
+ *   - the caller owns every buffer, including workspaces; the library never allocates device
+ *     memory and never synchronises (except mvg_prof_collect);
+ *   - every launch goes to the caller's hipStream_t (passed as void*; NULL = default stream);
+ *   - return 0 on success, non-zero on error; mvg_last_error() gives the message. No exceptions
+ *     cross the boundary.
+ */
+#ifndef ROTMVGAZE_H
+#define ROTMVGAZE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVG_ABI_VERSION 1
+
+/* ---------------------------------------------------------------- library */
+int mvg_abi_version(void);
+const char *mvg_last_error(void);
+/* number of CUs of the current device (used by the host to size split-K). */
+int mvg_device_cus(void);
+
+/* ---------------------------------------------------------------- profiling (bench.py)
+ * When enabled, every launch is bracketed by hipEvents on its own stream; mvg_prof_collect
+ * synchronises those events and returns, per kernel family, launches, summed milliseconds,
+ * algorithmic FLOPs and algorithmic bytes since mvg_prof_reset. */
+enum {
+  MVG_K_CONV_FPROP = 0, MVG_K_CONV_DGRAD = 1, MVG_K_CONV_WGRAD = 2, MVG_K_WGRAD_REDUCE = 3,
+  MVG_K_BN_FINALIZE = 4, MVG_K_BN_APPLY = 5, MVG_K_BN_BWD_REDUCE = 6, MVG_K_BN_BWD_APPLY = 7,
+  MVG_K_POOL = 8, MVG_K_LAYOUT = 9, MVG_K_LINEAR_FPROP = 10, MVG_K_LINEAR_DGRAD = 11,
+  MVG_K_LINEAR_WGRAD = 12, MVG_K_ROTCAT = 13, MVG_K_COLSUM = 14, MVG_K_LOSS = 15,
+  MVG_K_GEOMETRY = 16, MVG_K_ELEMENTWISE = 17, MVG_K_FAMILIES = 18
+};
+typedef struct {
+  int64_t launches;
+  double ms;
+  double flops;
+  double bytes;
+} mvg_prof_entry;
+int mvg_prof_enable(int on);
+int mvg_prof_reset(void);
+int mvg_prof_collect(mvg_prof_entry *host_out /* [MVG_K_FAMILIES] */);
+const char *mvg_prof_family_name(int family);
+
+/* ---------------------------------------------------------------- convolution
+ * Replaces nn.Conv2d(bias=False) forward/backward: resnet.py:31-47 (conv3x3/conv1x1), :184
+ * (7x7 stem) as used by BasicBlock.forward :80-96 and Bottleneck.forward :128-148, and - with
+ * h = w = r = s = 1 - nn.Linear inside Mlp (backbones/blocks.py:41-47,57-60). */
+typedef struct {
+  int32_t groups;      /* view groups; total images = groups * n */
+  int32_t n;           /* images per group */
+  int32_t h, w;        /* input spatial size */
+  int32_t cin, cout;   /* cin % 4 == 0, cout % 4 == 0 (the stem's 3 channels are padded to 4) */
+  int32_t r, s;        /* filter size */
+  int32_t stride, pad;
+  int32_t ho, wo;      /* output spatial size */
+} mvg_conv_desc;
+
+/* y[g][n][ho][wo][cout] = conv(x[g][n][h][w][cin], wgt[cout][r][s][cin]).
+ * Epilogue (all optional, NULL = off):
+ *   bias[cout]   added to every row, then relu != 0 clamps at 0            (Linear [+ReLU]);
+ *   stats        per-(group, 32|64-row partial, channel) {sum, centred sum of squares} of y,
+ *                the input of mvg_bn_finalize; needs mvg_conv_stats_partials() * cout * 2 floats
+ *                per group.                                                  (conv -> BatchNorm) */
+int mvg_conv_fprop(const mvg_conv_desc *d, const float *x, const float *wgt, float *y,
+                   const float *bias, int relu, float *stats, void *stream);
+/* number of row-partials per group that mvg_conv_fprop writes into `stats`, and the rows per
+ * partial (out_rows_per_partial, may be NULL). */
+int mvg_conv_stats_partials(const mvg_conv_desc *d, int32_t *out_rows_per_partial);
+
+/* dx[g][n][h][w][cin] = conv_transpose(dy[g][n][ho][wo][cout], wgt).  Epilogue (optional):
+ *   mask   (same shape as dx): result multiplied by (mask > 0)   (ReLU backward of the producer);
+ *   addend (same shape as dx, may alias dx): added after masking (residual / fan-in accumulation). */
+int mvg_conv_dgrad(const mvg_conv_desc *d, const float *dy, const float *wgt, float *dx,
+                   const float *mask, const float *addend, void *stream);
+
+/* dw[cout][r][s][cin] (+)= sum over all groups/images/pixels of dy (x) x.  Split over the pixel
+ * axis into `splits` slabs in `workspace` (splits * cout*r*s*cin floats, ignored when
+ * splits == 1) that a second kernel sums in a fixed order (bitwise reproducible).
+ * accumulate != 0 adds to the existing dw. */
+int mvg_conv_wgrad(const mvg_conv_desc *d, const float *x, const float *dy, float *dw,
+                   float *workspace, int splits, int accumulate, void *stream);
+/* a split count that fills the device for this shape (host helper, no launch). */
+int mvg_conv_wgrad_splits(const mvg_conv_desc *d);
+
+/* ---------------------------------------------------------------- BatchNorm2d (train + eval)
+ * Replaces nn.BatchNorm2d (eps 1e-5, momentum 0.1, affine, track_running_stats) as constructed
+ * at resnet.py:185,72-76,119-125 and the ReLU / residual add around it (:74,93-94,140-146). */
+
+/* Merge the conv epilogue's partials into per-(group, channel) batch statistics, produce the
+ * fused affine (scale = gamma*invstd, shift = beta - mean*scale) and update the running stats
+ * once per group IN GROUP ORDER (view 0 first: rot_mv.py:196-197) with the unbiased variance.
+ *   stats        [groups][partials][2][c]     rows_per_partial, rows_per_group as given
+ *   mean,invstd  [groups][c] (saved for backward), scale, shift [groups][c]
+ *   running_mean/var [c] updated in place unless NULL; num_batches_tracked is host-side. */
+int mvg_bn_finalize(const float *stats, int groups, int partials, int rows_per_partial,
+                    int64_t rows_per_group, int c, const float *gamma, const float *beta,
+                    float *running_mean, float *running_var, float momentum, float eps,
+                    float *mean, float *invstd, float *scale, float *shift, void *stream);
+/* eval mode: scale/shift from the running statistics (same for every group). */
+int mvg_bn_eval_affine(int groups, int c, const float *gamma, const float *beta,
+                       const float *running_mean, const float *running_var, float eps,
+                       float *scale, float *shift, void *stream);
+/* out = [relu]( y*scale[g] + shift[g] [+ residual] );  y,out,residual: [groups][rows][c]. */
+int mvg_bn_apply(const float *y, const float *scale, const float *shift, const float *residual,
+                 int relu, float *out, int groups, int64_t rows_per_group, int c, void *stream);
+/* Backward, step 1: per (group, channel) s1 = sum(dz), s2 = sum(dz * xhat) with
+ * dz = g * (act > 0) when act != NULL else g, xhat = (y - mean) * invstd.
+ * Also dgamma[c] (+)= sum_g s2, dbeta[c] (+)= sum_g s1 (accumulate flag).
+ * workspace: mvg_bn_bwd_workspace_floats() floats. */
+int mvg_bn_bwd_reduce(const float *g, const float *act, const float *y, const float *mean,
+                      const float *invstd, int groups, int64_t rows_per_group, int c,
+                      float *s1, float *s2, float *dgamma, float *dbeta, int accumulate,
+                      float *workspace, void *stream);
+size_t mvg_bn_bwd_workspace_floats(int groups, int64_t rows_per_group, int c);
+/* Backward, step 2: dy = gamma*invstd*(dz - s1/n - xhat*s2/n); dz_out (optional, may alias g)
+ * receives the masked gradient for the residual branch. */
+int mvg_bn_bwd_apply(const float *g, const float *act, const float *y, const float *mean,
+                     const float *invstd, const float *gamma, const float *s1, const float *s2,
+                     int groups, int64_t rows_per_group, int c, float *dy, float *dz_out,
+                     void *stream);
+
+/* ---------------------------------------------------------------- pooling / layout
+ * nn.MaxPool2d(3,2,1) resnet.py:189; nn.AdaptiveAvgPool2d((1,1)) resnet.py:200 + rot_mv.py:126;
+ * NCHW float input of FeatRotationSymm.forward (rot_mv.py:188-189) -> NHWC4. */
+int mvg_maxpool3x3s2_fwd(const float *x, float *y, uint8_t *argmax, int n, int h, int w, int c,
+                         int ho, int wo, void *stream);
+int mvg_maxpool3x3s2_bwd(const float *dy, const uint8_t *argmax, float *dx, int n, int h, int w,
+                         int c, int ho, int wo, void *stream);
+int mvg_avgpool_fwd(const float *x, float *y, int n, int hw, int c, void *stream);
+int mvg_avgpool_bwd(const float *dy, float *dx, int n, int hw, int c, void *stream);
+int mvg_nchw_to_nhwc4(const float *src, float *dst, int n, int c, int h, int w, void *stream);
+int mvg_nhwc4_to_nchw(const float *src, float *dst, int n, int c, int h, int w, void *stream);
+
+/* ---------------------------------------------------------------- geometry
+ * rotation_matrix_2d utils/math.py:188-219; relative rotations rot_mv.py:193-194. */
+int mvg_rotation_matrix_2d(const float *pitch_yaw /*[n][2]*/, float *rot /*[n][3][3]*/, int n,
+                           int inverse, void *stream);
+/* rel[d][b] = rot[b][vi[d]] @ rot[b][vj[d]]^T for d < dirs; rot [b][views][3][3]. */
+int mvg_relative_rotation(const float *rot, const int32_t *vi, const int32_t *vj, float *rel,
+                          int batch, int views, int dirs, void *stream);
+
+/* ---------------------------------------------------------------- cross-view fusion operands
+ * ImageFeatFuser.forward's cat([img_feat, (R @ F).flatten]) rot_mv.py:44-50,234-239 and the head's
+ * cat([img_feat, F.flatten]) :249-254.  Row (d, b) of x = [ img_feat[view_of[d]][b] (cf floats),
+ * rel[d][b] @ feat[src_of[d]][b] (3*nvec floats, axis-major) ]; rel == NULL means identity. */
+int mvg_rotcat_fwd(const float *img_feat /*[views][batch][cf]*/, const float *feat /*[dirs][batch][3][nvec]*/,
+                   const float *rel /*[dirs][batch][3][3] or NULL*/, const int32_t *view_of,
+                   const int32_t *src_of, float *x /*[dirs][batch][cf+3*nvec]*/, int batch, int dirs,
+                   int cf, int nvec, void *stream);
+/* dfeat[src_of[d]][b] = rel[d][b]^T @ dx_rot  (src_of must be injective: every slot written once). */
+int mvg_rotcat_bwd(const float *dx, const float *rel, const int32_t *src_of, float *dfeat, int batch,
+                   int dirs, int cf, int nvec, void *stream);
+/* out[v][b][0:width] (+)= sum over d with seg_of[d] == v, ascending d (reproducible), of
+ * x[(d*batch + b)*row_stride + 0:width].  Gradient fan-in of the per-view features that several
+ * directed pairs read (img_feat in every fuser/head input, the lifted feature at iteration 0). */
+int mvg_segment_sum(const float *x, int64_t row_stride, int width, const int32_t *seg_of, float *out,
+                    int batch, int dirs, int segments, int accumulate, void *stream);
+
+/* out[c] (+)= sum_rows x[rows][c]   (bias gradient of nn.Linear). */
+int mvg_colsum(const float *x, float *out, int64_t rows, int c, int accumulate, void *stream);
+/* y = a*x + b*y (n floats) - gradient fan-in accumulation. */
+int mvg_axpby(const float *x, float *y, float a, float b, int64_t n, void *stream);
+/* out = x * scale[0] with the scale read on the device (upstream gradient of a scalar loss). */
+int mvg_scale_by(const float *x, const float *scale, float *out, int64_t n, void *stream);
+
+/* Linear with out_features <= 4 (the gaze head's Linear(512 -> 2), rot_mv.py:179-184), for which a
+ * 32-wide MFMA tile would be >90% padding.  bwd: dx = (dy @ w) * (mask > 0) [mask optional],
+ * dw (+)= dy^T @ x, db (+)= colsum(dy); dx / dw may be NULL to skip. */
+int mvg_linear_skinny_fwd(const float *x, const float *w, const float *bias, float *y, int rows, int k,
+                          int nout, void *stream);
+int mvg_linear_skinny_bwd(const float *dy, const float *x, const float *w, const float *mask, float *dx,
+                          float *dw, float *db, int rows, int k, int nout, int accumulate, void *stream);
+
+/* ---------------------------------------------------------------- loss
+ * gaze_angular_loss losses/gaze_loss.py:42-52 over pitchyaw_to_vector utils/math.py:52-60:
+ * theta_i = acos(clamp(cos_sim(v(gt_i), v(pred_i), eps 1e-6), -1, 1)) * 180/pi;
+ * loss[0] (+)= sum_i row_weight * theta_i ; dpred_i = row_weight * dtheta_i/dpred_i (optional).
+ * (row_weight = 1/batch gives the reference's batch mean.)  theta_out optional [n]. */
+int mvg_gaze_angular_loss(const float *pred, const float *gt, int n, float row_weight,
+                          float *loss, int accumulate, float *dpred, float *theta_out, void *stream);
+
+/* ---------------------------------------------------------------- stereo pair index (HOST)
+ * GazeDataset.__init__'s idx_to_kv build, dataset/gaze.py:39-73, driven by CPython's
+ * random.seed(int)/random.choice stream (MT19937 + getrandbits rejection).  Pure host integer
+ * code; state (625 words: mt[624] + index) persists across calls like Python's global RNG.
+ *   camera_tag: 0 = all, 1 = novel_train, 2 = novel_test.
+ * Returns the number of tuples written (<= capacity) or -1 on error. */
+int mvg_mt19937_seed(uint32_t *host_state /*[625]*/, uint64_t seed);
+int64_t mvg_pair_index_build(uint32_t *host_state, const int64_t *host_file_rows, int n_files,
+                             int camera_tag, int64_t *host_out /*[capacity][3]*/, int64_t capacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROTMVGAZE_H */

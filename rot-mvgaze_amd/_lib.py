@@ -1,0 +1,113 @@
+"""ctypes binding of librotmvgaze_hip.so (the C ABI declared in include/rotmvgaze.h).
+
+There is no fallback: if the library is missing or fails to load, ``lib()`` raises.  Build it with
+``python rot-mvgaze_amd/csrc/build.py`` (or ``__graft_entry__.build()``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librotmvgaze_hip.so")
+
+K_FAMILIES = 18
+ABI_VERSION = 1
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("groups", "n", "h", "w", "cin", "cout", "r", "s", "stride", "pad", "ho", "wo")]
+
+    @classmethod
+    def make(cls, groups, n, h, w, cin, cout, k, stride, pad):
+        ho = (h + 2 * pad - k) // stride + 1
+        wo = (w + 2 * pad - k) // stride + 1
+        return cls(groups, n, h, w, cin, cout, k, k, stride, pad, ho, wo)
+
+    @classmethod
+    def linear(cls, rows, fin, fout):
+        return cls(1, rows, 1, 1, fin, fout, 1, 1, 1, 0, 1, 1)
+
+
+class ProfEntry(C.Structure):
+    _fields_ = [("launches", C.c_int64), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_I64 = C.c_int64
+_F = C.c_float
+_D = C.POINTER(ConvDesc)
+
+# name -> (restype, argtypes); must list every function include/rotmvgaze.h declares
+SIGNATURES = {
+    "mvg_abi_version": (_I, []),
+    "mvg_last_error": (C.c_char_p, []),
+    "mvg_device_cus": (_I, []),
+    "mvg_prof_enable": (_I, [_I]),
+    "mvg_prof_reset": (_I, []),
+    "mvg_prof_collect": (_I, [C.POINTER(ProfEntry)]),
+    "mvg_prof_family_name": (C.c_char_p, [_I]),
+    "mvg_conv_fprop": (_I, [_D, _P, _P, _P, _P, _I, _P, _P]),
+    "mvg_conv_stats_partials": (_I, [_D, C.POINTER(C.c_int32)]),
+    "mvg_conv_dgrad": (_I, [_D, _P, _P, _P, _P, _P, _P]),
+    "mvg_conv_wgrad": (_I, [_D, _P, _P, _P, _P, _I, _I, _P]),
+    "mvg_conv_wgrad_splits": (_I, [_D]),
+    "mvg_bn_finalize": (_I, [_P, _I, _I, _I, _I64, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
+    "mvg_bn_eval_affine": (_I, [_I, _I, _P, _P, _P, _P, _F, _P, _P, _P]),
+    "mvg_bn_apply": (_I, [_P, _P, _P, _P, _I, _P, _I, _I64, _I, _P]),
+    "mvg_bn_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _I, _I64, _I, _P, _P, _P, _P, _I, _P, _P]),
+    "mvg_bn_bwd_workspace_floats": (C.c_size_t, [_I, _I64, _I]),
+    "mvg_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _P, _P, _P]),
+    "mvg_maxpool3x3s2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "mvg_maxpool3x3s2_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "mvg_avgpool_fwd": (_I, [_P, _P, _I, _I, _I, _P]),
+    "mvg_avgpool_bwd": (_I, [_P, _P, _I, _I, _I, _P]),
+    "mvg_nchw_to_nhwc4": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "mvg_nhwc4_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "mvg_rotation_matrix_2d": (_I, [_P, _P, _I, _I, _P]),
+    "mvg_relative_rotation": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "mvg_rotcat_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "mvg_rotcat_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "mvg_segment_sum": (_I, [_P, _I64, _I, _P, _P, _I, _I, _I, _I, _P]),
+    "mvg_colsum": (_I, [_P, _P, _I64, _I, _I, _P]),
+    "mvg_axpby": (_I, [_P, _P, _F, _F, _I64, _P]),
+    "mvg_scale_by": (_I, [_P, _P, _P, _I64, _P]),
+    "mvg_linear_skinny_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "mvg_linear_skinny_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "mvg_gaze_angular_loss": (_I, [_P, _P, _I, _F, _P, _I, _P, _P, _P]),
+    "mvg_mt19937_seed": (_I, [_P, C.c_uint64]),
+    "mvg_pair_index_build": (_I64, [_P, _P, _I, _I, _P, _I64]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the library; raise if it is not there - no CPU fallback exists."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is required (python rot-mvgaze_amd/csrc/build.py); "
+            "this package has no CPU fallback")
+    try:
+        l = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    except OSError as e:  # pragma: no cover
+        raise RuntimeError(f"failed to load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(l, name)           # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    if l.mvg_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"librotmvgaze_hip.so ABI {l.mvg_abi_version()} != binding ABI {ABI_VERSION}")
+    _lib = l
+    return l
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().mvg_last_error()
+        raise RuntimeError(f"librotmvgaze_hip {what} failed (rc={rc}): {msg.decode() if msg else '?'}")

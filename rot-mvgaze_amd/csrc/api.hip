@@ -1,0 +1,111 @@
+// Library-level entry points: version, error string, per-family HIP-event profiler.
+#include <stdarg.h>
+
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+
+namespace mvg {
+
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+struct ProfRec {
+  int fam;
+  hipEvent_t a, b;
+};
+static bool g_prof = false;
+static std::mutex g_mu;
+static std::vector<ProfRec> g_recs;
+static std::vector<hipEvent_t> g_pool;
+static mvg_prof_entry g_acc[MVG_K_FAMILIES];
+static hipEvent_t g_open[MVG_K_FAMILIES];
+
+bool prof_on() { return g_prof; }
+
+static hipEvent_t get_event() {
+  if (!g_pool.empty()) {
+    hipEvent_t e = g_pool.back();
+    g_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  hipEventCreate(&e);
+  return e;
+}
+
+void prof_begin(int fam, hipStream_t s, double flops, double bytes) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  hipEvent_t a = get_event();
+  hipEventRecord(a, s);
+  g_open[fam] = a;
+  g_acc[fam].launches += 1;
+  g_acc[fam].flops += flops;
+  g_acc[fam].bytes += bytes;
+}
+void prof_end(int fam, hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  hipEvent_t b = get_event();
+  hipEventRecord(b, s);
+  g_recs.push_back({fam, g_open[fam], b});
+}
+
+static const char *kNames[MVG_K_FAMILIES] = {
+    "conv_fprop", "conv_dgrad", "conv_wgrad", "wgrad_reduce", "bn_finalize", "bn_apply",
+    "bn_bwd_reduce", "bn_bwd_apply", "pool", "layout", "linear_fprop", "linear_dgrad",
+    "linear_wgrad", "rotcat", "colsum", "loss", "geometry", "elementwise"};
+
+}  // namespace mvg
+
+extern "C" {
+
+int mvg_abi_version(void) { return MVG_ABI_VERSION; }
+const char *mvg_last_error(void) { return mvg::g_err; }
+
+int mvg_device_cus(void) {
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
+  return cus;
+}
+
+int mvg_prof_enable(int on) {
+  mvg::g_prof = on != 0;
+  return 0;
+}
+int mvg_prof_reset(void) {
+  std::lock_guard<std::mutex> lk(mvg::g_mu);
+  for (auto &r : mvg::g_recs) {
+    mvg::g_pool.push_back(r.a);
+    mvg::g_pool.push_back(r.b);
+  }
+  mvg::g_recs.clear();
+  memset(mvg::g_acc, 0, sizeof(mvg::g_acc));
+  return 0;
+}
+int mvg_prof_collect(mvg_prof_entry *out) {
+  std::lock_guard<std::mutex> lk(mvg::g_mu);
+  for (auto &r : mvg::g_recs) {
+    if (hipEventSynchronize(r.b) != hipSuccess) {
+      mvg::set_error("prof_collect: event sync failed");
+      return 1;
+    }
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, r.a, r.b);
+    mvg::g_acc[r.fam].ms += ms;
+    mvg::g_pool.push_back(r.a);
+    mvg::g_pool.push_back(r.b);
+  }
+  mvg::g_recs.clear();
+  memcpy(out, mvg::g_acc, sizeof(mvg::g_acc));
+  return 0;
+}
+const char *mvg_prof_family_name(int f) { return (f >= 0 && f < MVG_K_FAMILIES) ? mvg::kNames[f] : "?"; }
+
+}  // extern "C"

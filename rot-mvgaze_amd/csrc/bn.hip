@@ -1,0 +1,330 @@
+// BatchNorm2d (train + eval) forward / backward around the conv kernels.  All HBM-bound passes:
+// float4 accesses, channel index carried incrementally (no per-element division).
+#include "common.h"
+
+namespace mvg {
+
+// ---- finalize: merge the conv epilogue's per-wave partials (sum, centred sumsq) -------------
+// grid = c/16 blocks, 1024 threads = 16 channels x 64 partial-lanes; ONE group per launch so
+// that the running statistics are updated in group (= view) order by stream order.
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restrict__ stats, int partials,
+                                                           int rows_per_partial, long long rows, int c,
+                                                           const float *__restrict__ gamma,
+                                                           const float *__restrict__ beta, float *running_mean,
+                                                           float *running_var, float momentum, float eps,
+                                                           float *mean_out, float *invstd_out, float *scale,
+                                                           float *shift) {
+  __shared__ double sh[3][64][16];
+  const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int ch = blockIdx.x * 16 + cl;
+  double s = 0.0, q = 0.0, ss = 0.0;
+  if (ch < c) {
+    for (int p = pl; p < partials; p += 64) {
+      long long cnt = rows - (long long)p * rows_per_partial;
+      if (cnt <= 0) break;
+      if (cnt > rows_per_partial) cnt = rows_per_partial;
+      const double sp = stats[((long long)p * 2) * c + ch];
+      const double qp = stats[((long long)p * 2 + 1) * c + ch];
+      s += sp;
+      q += qp;
+      ss += sp * sp / (double)cnt;
+    }
+  }
+  sh[0][pl][cl] = s;
+  sh[1][pl][cl] = q;
+  sh[2][pl][cl] = ss;
+  __syncthreads();
+  for (int o = 32; o > 0; o >>= 1) {
+    if (pl < o) {
+      sh[0][pl][cl] += sh[0][pl + o][cl];
+      sh[1][pl][cl] += sh[1][pl + o][cl];
+      sh[2][pl][cl] += sh[2][pl + o][cl];
+    }
+    __syncthreads();
+  }
+  if (pl == 0 && ch < c) {
+    const double n = (double)rows;
+    const double mean = sh[0][0][cl] / n;
+    double m2 = sh[1][0][cl] + (sh[2][0][cl] - sh[0][0][cl] * mean);   // Chan merge of the partials
+    if (m2 < 0.0) m2 = 0.0;
+    const double var = m2 / n;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float fmean = (float)mean;
+    mean_out[ch] = fmean;
+    invstd_out[ch] = invstd;
+    const float sc = gamma[ch] * invstd;
+    scale[ch] = sc;
+    shift[ch] = beta[ch] - fmean * sc;
+    if (running_mean) running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * fmean;
+    if (running_var) {
+      const float unbiased = (float)(rows > 1 ? m2 / (n - 1.0) : var);
+      running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * unbiased;
+    }
+  }
+}
+
+__global__ void bn_eval_affine_kernel(int groups, int c, const float *gamma, const float *beta, const float *rm,
+                                      const float *rv, float eps, float *scale, float *shift) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= groups * c) return;
+  const int ch = i % c;
+  const float sc = gamma[ch] / sqrtf(rv[ch] + eps);
+  scale[i] = sc;
+  shift[i] = beta[ch] - rm[ch] * sc;
+}
+
+// ---- apply: out = [relu](y*scale + shift [+ residual]) -------------------------------------
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float4 *__restrict__ y, const float *__restrict__ scale,
+                                                       const float *__restrict__ shift,
+                                                       const float4 *__restrict__ residual, int relu,
+                                                       float4 *__restrict__ out, long long n4_per_group, int c4n, int c) {
+  const int g = blockIdx.y;
+  const float4 *sc4 = reinterpret_cast<const float4 *>(scale + (long long)g * c);
+  const float4 *sh4 = reinterpret_cast<const float4 *>(shift + (long long)g * c);
+  const long long base = (long long)g * n4_per_group;
+  const long long stride = (long long)gridDim.x * 256;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  int cq = (int)(i % c4n);
+  const int step = (int)(stride % c4n);
+  for (; i < n4_per_group; i += stride) {
+    const float4 v = y[base + i];
+    const float4 a = sc4[cq], b = sh4[cq];
+    float4 o = make_float4(v.x * a.x + b.x, v.y * a.y + b.y, v.z * a.z + b.z, v.w * a.w + b.w);
+    if (residual) {
+      const float4 r = residual[base + i];
+      o.x += r.x;
+      o.y += r.y;
+      o.z += r.z;
+      o.w += r.w;
+    }
+    if (relu) {
+      o.x = fmaxf(o.x, 0.f);
+      o.y = fmaxf(o.y, 0.f);
+      o.z = fmaxf(o.z, 0.f);
+      o.w = fmaxf(o.w, 0.f);
+    }
+    out[base + i] = o;
+    cq += step;
+    if (cq >= c4n) cq -= c4n;
+  }
+}
+
+// ---- backward reduce ------------------------------------------------------------------------
+// grid = (chunks, column blocks, groups); thread = one float4 column group x one row lane.
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float4 *__restrict__ g, const float4 *__restrict__ act,
+                                                            const float4 *__restrict__ y,
+                                                            const float *__restrict__ mean,
+                                                            const float *__restrict__ invstd, long long rows,
+                                                            long long rows_per_chunk, int c, int c4n, int cw,
+                                                            float *__restrict__ partial, int chunks) {
+  __shared__ float4 sh[2][256];
+  const int grp = blockIdx.z;
+  const int rl = threadIdx.x / cw, cl = threadIdx.x % cw;
+  const int nrl = 256 / cw;
+  const int cq = blockIdx.y * cw + cl;
+  const bool cok = cq < c4n;
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  if (cok) {
+    const float4 mu = reinterpret_cast<const float4 *>(mean + (long long)grp * c)[cq];
+    const float4 is = reinterpret_cast<const float4 *>(invstd + (long long)grp * c)[cq];
+    const long long r0 = (long long)blockIdx.x * rows_per_chunk;
+    long long r1 = r0 + rows_per_chunk;
+    if (r1 > rows) r1 = rows;
+    const long long gbase = (long long)grp * rows * c4n;
+    for (long long r = r0 + rl; r < r1; r += nrl) {
+      const long long off = gbase + r * c4n + cq;
+      float4 d = g[off];
+      if (act) {
+        const float4 a = act[off];
+        d.x = a.x > 0.f ? d.x : 0.f;
+        d.y = a.y > 0.f ? d.y : 0.f;
+        d.z = a.z > 0.f ? d.z : 0.f;
+        d.w = a.w > 0.f ? d.w : 0.f;
+      }
+      const float4 v = y[off];
+      s1.x += d.x;
+      s1.y += d.y;
+      s1.z += d.z;
+      s1.w += d.w;
+      s2.x += d.x * ((v.x - mu.x) * is.x);
+      s2.y += d.y * ((v.y - mu.y) * is.y);
+      s2.z += d.z * ((v.z - mu.z) * is.z);
+      s2.w += d.w * ((v.w - mu.w) * is.w);
+    }
+  }
+  sh[0][threadIdx.x] = s1;
+  sh[1][threadIdx.x] = s2;
+  __syncthreads();
+  if (rl == 0 && cok) {
+    for (int k = 1; k < nrl; ++k) {
+      const float4 a = sh[0][k * cw + cl], b = sh[1][k * cw + cl];
+      s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
+      s2.x += b.x; s2.y += b.y; s2.z += b.z; s2.w += b.w;
+    }
+    float4 *p = reinterpret_cast<float4 *>(partial + (((long long)grp * chunks + blockIdx.x) * 2) * c);
+    p[cq] = s1;
+    p[c4n + cq] = s2;
+  }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float *__restrict__ partial, int groups, int chunks, int c, float *s1,
+                                       float *s2, float *dgamma, float *dbeta, int accumulate) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  double tg = 0.0, tb = 0.0;
+  for (int g = 0; g < groups; ++g) {
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < chunks; ++k) {
+      a += partial[(((long long)g * chunks + k) * 2) * c + ch];
+      b += partial[(((long long)g * chunks + k) * 2 + 1) * c + ch];
+    }
+    s1[(long long)g * c + ch] = (float)a;
+    s2[(long long)g * c + ch] = (float)b;
+    tb += a;
+    tg += b;
+  }
+  if (dgamma) dgamma[ch] = (accumulate ? dgamma[ch] : 0.f) + (float)tg;
+  if (dbeta) dbeta[ch] = (accumulate ? dbeta[ch] : 0.f) + (float)tb;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float4 *__restrict__ g, const float4 *__restrict__ act,
+                                                           const float4 *__restrict__ y,
+                                                           const float *__restrict__ mean,
+                                                           const float *__restrict__ invstd,
+                                                           const float *__restrict__ gamma,
+                                                           const float *__restrict__ s1, const float *__restrict__ s2,
+                                                           long long n4_per_group, float inv_rows, int c4n, int c,
+                                                           float4 *__restrict__ dy, float4 *__restrict__ dz_out) {
+  const int grp = blockIdx.y;
+  const float4 *mu4 = reinterpret_cast<const float4 *>(mean + (long long)grp * c);
+  const float4 *is4 = reinterpret_cast<const float4 *>(invstd + (long long)grp * c);
+  const float4 *ga4 = reinterpret_cast<const float4 *>(gamma);
+  const float4 *a4 = reinterpret_cast<const float4 *>(s1 + (long long)grp * c);
+  const float4 *b4 = reinterpret_cast<const float4 *>(s2 + (long long)grp * c);
+  const long long base = (long long)grp * n4_per_group;
+  const long long stride = (long long)gridDim.x * 256;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  int cq = (int)(i % c4n);
+  const int step = (int)(stride % c4n);
+  for (; i < n4_per_group; i += stride) {
+    float4 d = g[base + i];
+    if (act) {
+      const float4 a = act[base + i];
+      d.x = a.x > 0.f ? d.x : 0.f;
+      d.y = a.y > 0.f ? d.y : 0.f;
+      d.z = a.z > 0.f ? d.z : 0.f;
+      d.w = a.w > 0.f ? d.w : 0.f;
+    }
+    const float4 v = y[base + i];
+    const float4 mu = mu4[cq], is = is4[cq], ga = ga4[cq], sa = a4[cq], sb = b4[cq];
+    float4 o;
+    o.x = ga.x * is.x * (d.x - sa.x * inv_rows - (v.x - mu.x) * is.x * (sb.x * inv_rows));
+    o.y = ga.y * is.y * (d.y - sa.y * inv_rows - (v.y - mu.y) * is.y * (sb.y * inv_rows));
+    o.z = ga.z * is.z * (d.z - sa.z * inv_rows - (v.z - mu.z) * is.z * (sb.z * inv_rows));
+    o.w = ga.w * is.w * (d.w - sa.w * inv_rows - (v.w - mu.w) * is.w * (sb.w * inv_rows));
+    if (dz_out) dz_out[base + i] = d;
+    dy[base + i] = o;
+    cq += step;
+    if (cq >= c4n) cq -= c4n;
+  }
+}
+
+static int bwd_chunks(int groups, long long rows, int c) {
+  // ~2048 workgroups in total, at least 64 rows per chunk
+  const int c4n = c / 4;
+  const int cw = c4n < 256 ? c4n : 256;
+  const int colblocks = ceil_div(c4n, cw);
+  long long want = 2048 / ((long long)groups * colblocks);
+  if (want < 1) want = 1;
+  long long maxc = (rows + 63) / 64;
+  if (want > maxc) want = maxc;
+  return (int)want;
+}
+
+static int grid_for(long long n4) {
+  long long b = (n4 + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace mvg
+
+using namespace mvg;
+
+extern "C" {
+
+int mvg_bn_finalize(const float *stats, int groups, int partials, int rows_per_partial, int64_t rows_per_group, int c,
+                    const float *gamma, const float *beta, float *running_mean, float *running_var, float momentum,
+                    float eps, float *mean, float *invstd, float *scale, float *shift, void *stream) {
+  MVG_REQUIRE(groups > 0 && partials > 0 && c > 0 && rows_per_group > 0, "bn_finalize: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(MVG_K_BN_FINALIZE, st, 0.0, 4.0 * groups * (double)partials * 2 * c);
+  for (int g = 0; g < groups; ++g) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(c, 16)), dim3(1024), 0, st,
+                       stats + (long long)g * partials * 2 * c, partials, rows_per_partial, (long long)rows_per_group, c,
+                       gamma, beta, running_mean, running_var, momentum, eps, mean + (long long)g * c,
+                       invstd + (long long)g * c, scale + (long long)g * c, shift + (long long)g * c);
+  }
+  return check_launch("bn_finalize");
+}
+
+int mvg_bn_eval_affine(int groups, int c, const float *gamma, const float *beta, const float *running_mean,
+                       const float *running_var, float eps, float *scale, float *shift, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(MVG_K_BN_FINALIZE, st, 0.0, 4.0 * 6 * c);
+  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(ceil_div((long long)groups * c, 256)), dim3(256), 0, st, groups, c, gamma,
+                     beta, running_mean, running_var, eps, scale, shift);
+  return check_launch("bn_eval_affine");
+}
+
+int mvg_bn_apply(const float *y, const float *scale, const float *shift, const float *residual, int relu, float *out,
+                 int groups, int64_t rows_per_group, int c, void *stream) {
+  MVG_REQUIRE(c % 4 == 0, "bn_apply: c %% 4 != 0");
+  hipStream_t st = (hipStream_t)stream;
+  const long long n4 = rows_per_group * (c / 4);
+  ProfScope ps(MVG_K_BN_APPLY, st, 0.0, 16.0 * groups * (double)n4 * (residual ? 3 : 2));
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(n4), groups), dim3(256), 0, st, (const float4 *)y, scale, shift,
+                     (const float4 *)residual, relu, (float4 *)out, n4, c / 4, c);
+  return check_launch("bn_apply");
+}
+
+size_t mvg_bn_bwd_workspace_floats(int groups, int64_t rows_per_group, int c) {
+  return (size_t)groups * bwd_chunks(groups, rows_per_group, c) * 2 * c;
+}
+
+int mvg_bn_bwd_reduce(const float *g, const float *act, const float *y, const float *mean, const float *invstd,
+                      int groups, int64_t rows_per_group, int c, float *s1, float *s2, float *dgamma, float *dbeta,
+                      int accumulate, float *workspace, void *stream) {
+  MVG_REQUIRE(c % 4 == 0, "bn_bwd_reduce: c %% 4 != 0");
+  MVG_REQUIRE(workspace != nullptr, "bn_bwd_reduce: workspace required");
+  hipStream_t st = (hipStream_t)stream;
+  const int c4n = c / 4;
+  const int cw = c4n < 256 ? c4n : 256;
+  MVG_REQUIRE(256 % cw == 0, "bn_bwd_reduce: c/4 must divide 256 or be a multiple of it (c=%d)", c);
+  const int chunks = bwd_chunks(groups, rows_per_group, c);
+  const long long rpc = (rows_per_group + chunks - 1) / chunks;
+  ProfScope ps(MVG_K_BN_BWD_REDUCE, st, 0.0, 4.0 * groups * (double)rows_per_group * c * (act ? 3 : 2));
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(chunks, ceil_div(c4n, cw), groups), dim3(256), 0, st, (const float4 *)g,
+                     (const float4 *)act, (const float4 *)y, mean, invstd, (long long)rows_per_group, rpc, c, c4n, cw,
+                     workspace, chunks);
+  if (check_launch("bn_bwd_reduce")) return 1;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(c, 128)), dim3(128), 0, st, workspace, groups, chunks, c, s1, s2,
+                     dgamma, dbeta, accumulate);
+  return check_launch("bn_bwd_finalize");
+}
+
+int mvg_bn_bwd_apply(const float *g, const float *act, const float *y, const float *mean, const float *invstd,
+                     const float *gamma, const float *s1, const float *s2, int groups, int64_t rows_per_group, int c,
+                     float *dy, float *dz_out, void *stream) {
+  MVG_REQUIRE(c % 4 == 0, "bn_bwd_apply: c %% 4 != 0");
+  hipStream_t st = (hipStream_t)stream;
+  const long long n4 = rows_per_group * (c / 4);
+  ProfScope ps(MVG_K_BN_BWD_APPLY, st, 0.0, 16.0 * groups * (double)n4 * ((act ? 4 : 3) + (dz_out ? 1 : 0)));
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n4), groups), dim3(256), 0, st, (const float4 *)g,
+                     (const float4 *)act, (const float4 *)y, mean, invstd, gamma, s1, s2, n4,
+                     1.0f / (float)rows_per_group, c / 4, c, (float4 *)dy, (float4 *)dz_out);
+  return check_launch("bn_bwd_apply");
+}
+
+}  // extern "C"

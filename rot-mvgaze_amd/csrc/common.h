@@ -1,0 +1,61 @@
+// Internal helpers shared by the HIP translation units of librotmvgaze_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/rotmvgaze.h"
+
+namespace mvg {
+
+void set_error(const char *fmt, ...);
+bool prof_on();
+// Bracket a launch with events when profiling is enabled.
+void prof_begin(int family, hipStream_t s, double flops, double bytes);
+void prof_end(int family, hipStream_t s);
+
+struct ProfScope {
+  int fam;
+  hipStream_t s;
+  bool on;
+  ProfScope(int family, hipStream_t st, double flops, double bytes) : fam(family), s(st), on(prof_on()) {
+    if (on) prof_begin(fam, s, flops, bytes);
+  }
+  ~ProfScope() {
+    if (on) prof_end(fam, s);
+  }
+};
+
+inline int check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return 1;
+  }
+  return 0;
+}
+
+#define MVG_REQUIRE(cond, ...)       \
+  do {                               \
+    if (!(cond)) {                   \
+      mvg::set_error(__VA_ARGS__);   \
+      return 2;                      \
+    }                                \
+  } while (0)
+
+static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// wave-level sum over 64 lanes
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+}  // namespace mvg

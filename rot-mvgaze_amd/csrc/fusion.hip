@@ -1,0 +1,353 @@
+// Geometry, cross-view fusion operand builders, bias-gradient sums, the 2-wide gaze head and
+// the angular loss.  All of these are tiny / HBM-bound next to the GEMMs.
+#include "common.h"
+
+namespace mvg {
+
+// R = Ry(yaw) @ Rx(-pitch)  (utils/math.py:188-219)
+__global__ void rotation_matrix_kernel(const float *__restrict__ py, float *__restrict__ rot, int n, int inverse) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float p = -py[2 * i], y = py[2 * i + 1];
+  const float cp = cosf(p), sp = sinf(p), cy = cosf(y), sy = sinf(y);
+  float m[9] = {cy, sy * sp, sy * cp, 0.f, cp, -sp, -sy, cy * sp, cy * cp};
+  float *o = rot + 9 * (long long)i;
+  if (inverse) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) o[a * 3 + b] = m[b * 3 + a];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) o[k] = m[k];
+  }
+}
+
+// rel[d][b] = rot[b][vi[d]] @ rot[b][vj[d]]^T
+__global__ void relative_rotation_kernel(const float *__restrict__ rot, const int *__restrict__ vi,
+                                         const int *__restrict__ vj, float *__restrict__ rel, int batch, int views,
+                                         int dirs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= dirs * batch) return;
+  const int d = i / batch, b = i - d * batch;
+  const float *ra = rot + ((long long)b * views + vi[d]) * 9;
+  const float *rb = rot + ((long long)b * views + vj[d]) * 9;
+  float *o = rel + (long long)i * 9;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[r * 3 + c] = ra[r * 3 + 0] * rb[c * 3 + 0] + ra[r * 3 + 1] * rb[c * 3 + 1] + ra[r * 3 + 2] * rb[c * 3 + 2];
+}
+
+// x[(d,b)] = [ img_feat[view_of[d]][b] | rel[d][b] @ feat[src_of[d]][b] ]
+__global__ __launch_bounds__(256) void rotcat_fwd_kernel(const float *__restrict__ img_feat,
+                                                         const float *__restrict__ feat, const float *__restrict__ rel,
+                                                         const int *__restrict__ view_of, const int *__restrict__ src_of,
+                                                         float *__restrict__ x, int batch, int cf, int nvec) {
+  const int row = blockIdx.x;            // d*batch + b
+  const int d = row / batch, b = row - d * batch;
+  const int kin = cf + 3 * nvec;
+  float *xo = x + (long long)row * kin;
+  const float4 *src = reinterpret_cast<const float4 *>(img_feat + ((long long)view_of[d] * batch + b) * cf);
+  for (int i = threadIdx.x; i < cf / 4; i += 256) reinterpret_cast<float4 *>(xo)[i] = src[i];
+  const float *f = feat + ((long long)src_of[d] * batch + b) * 3 * nvec;
+  float r[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
+  if (rel) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r[k] = rel[(long long)row * 9 + k];
+  }
+  for (int k = threadIdx.x; k < nvec; k += 256) {
+    const float f0 = f[k], f1 = f[nvec + k], f2 = f[2 * nvec + k];
+    xo[cf + k] = r[0] * f0 + r[1] * f1 + r[2] * f2;
+    xo[cf + nvec + k] = r[3] * f0 + r[4] * f1 + r[5] * f2;
+    xo[cf + 2 * nvec + k] = r[6] * f0 + r[7] * f1 + r[8] * f2;
+  }
+}
+
+// dfeat[src_of[d]][b] = rel^T @ dx_rot
+__global__ __launch_bounds__(256) void rotcat_bwd_feat_kernel(const float *__restrict__ dx, const float *__restrict__ rel,
+                                                              const int *__restrict__ src_of, float *__restrict__ dfeat,
+                                                              int batch, int cf, int nvec) {
+  const int row = blockIdx.x;
+  const int d = row / batch, b = row - d * batch;
+  const int kin = cf + 3 * nvec;
+  const float *g = dx + (long long)row * kin + cf;
+  float *o = dfeat + ((long long)src_of[d] * batch + b) * 3 * nvec;
+  float r[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
+  if (rel) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r[k] = rel[(long long)row * 9 + k];
+  }
+  for (int k = threadIdx.x; k < nvec; k += 256) {
+    const float g0 = g[k], g1 = g[nvec + k], g2 = g[2 * nvec + k];
+    o[k] = r[0] * g0 + r[3] * g1 + r[6] * g2;
+    o[nvec + k] = r[1] * g0 + r[4] * g1 + r[7] * g2;
+    o[2 * nvec + k] = r[2] * g0 + r[5] * g1 + r[8] * g2;
+  }
+}
+
+// out[v][b][0:width] (+)= sum over d with seg_of[d] == v (ascending d: reproducible) of x rows
+__global__ __launch_bounds__(256) void segment_sum_kernel(const float *__restrict__ x, long long row_stride, int w4n,
+                                                          const int *__restrict__ seg_of, float *__restrict__ out,
+                                                          int batch, int dirs, int segments, int accumulate) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // over segments*batch*width/4
+  if (i >= (long long)segments * batch * w4n) return;
+  const int cq = (int)(i % w4n);
+  const long long t = i / w4n;
+  const int b = (int)(t % batch), v = (int)(t / batch);
+  float4 s = accumulate ? reinterpret_cast<float4 *>(out)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int d = 0; d < dirs; ++d) {
+    if (seg_of[d] != v) continue;
+    const float4 g = reinterpret_cast<const float4 *>(x + ((long long)d * batch + b) * row_stride)[cq];
+    s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
+  }
+  reinterpret_cast<float4 *>(out)[i] = s;
+}
+
+__global__ __launch_bounds__(256) void scale_by_kernel(const float *__restrict__ x, const float *__restrict__ scale,
+                                                       float *__restrict__ out, long long n) {
+  const float s = scale[0];
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) out[i] = x[i] * s;
+}
+
+// out[c] (+)= sum_rows x[rows][c] : block = 64 channels x 4 row lanes
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x, float *__restrict__ out, long long rows,
+                                                     int c, int accumulate) {
+  __shared__ float sh[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int ch = blockIdx.x * 64 + cl;
+  float s = 0.f;
+  if (ch < c)
+    for (long long r = rl; r < rows; r += 4) s += x[r * c + ch];
+  sh[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && ch < c) {
+    s = sh[0][cl] + sh[1][cl] + sh[2][cl] + sh[3][cl];
+    out[ch] = (accumulate ? out[ch] : 0.f) + s;
+  }
+}
+
+__global__ __launch_bounds__(256) void axpby_kernel(const float *__restrict__ x, float *__restrict__ y, float a, float b,
+                                                    long long n) {
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) y[i] = a * x[i] + (b != 0.f ? b * y[i] : 0.f);
+}
+
+// ---- skinny linear (out_features <= 4): the Linear(512 -> 2) of the gaze head ------------------
+// fwd: one wave per row.
+__global__ __launch_bounds__(256) void skinny_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                         const float *__restrict__ bias, float *__restrict__ y,
+                                                         int rows, int k, int nout) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = lane; i < k; i += 64) {
+    const float v = x[(long long)row * k + i];
+    for (int j = 0; j < nout; ++j) acc[j] += v * w[(long long)j * k + i];
+  }
+  for (int j = 0; j < nout; ++j) {
+    const float s = wave_sum(acc[j]);
+    if (lane == 0) y[(long long)row * nout + j] = s + (bias ? bias[j] : 0.f);
+  }
+}
+// bwd: dx[m][i] = mask * sum_j dy[m][j] w[j][i]
+__global__ __launch_bounds__(256) void skinny_bwd_dx_kernel(const float *__restrict__ dy, const float *__restrict__ w,
+                                                            const float *__restrict__ mask, float *__restrict__ dx,
+                                                            long long total, int k, int nout) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const long long m = i / k;
+  const int col = (int)(i - m * k);
+  float s = 0.f;
+  for (int j = 0; j < nout; ++j) s += dy[m * nout + j] * w[(long long)j * k + col];
+  if (mask && !(mask[i] > 0.f)) s = 0.f;
+  dx[i] = s;
+}
+// dw[j][i] = sum_m dy[m][j] x[m][i];  db[j] = sum_m dy[m][j]
+__global__ __launch_bounds__(256) void skinny_bwd_dw_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                            float *__restrict__ dw, float *__restrict__ db, int rows,
+                                                            int k, int nout, int accumulate) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < k) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < rows; ++m) {
+      const float v = x[(long long)m * k + i];
+      for (int j = 0; j < nout; ++j) acc[j] += dy[(long long)m * nout + j] * v;
+    }
+    for (int j = 0; j < nout; ++j) dw[(long long)j * k + i] = (accumulate ? dw[(long long)j * k + i] : 0.f) + acc[j];
+  }
+  if (db && blockIdx.x == 0 && threadIdx.x < nout) {
+    float s = 0.f;
+    for (int m = 0; m < rows; ++m) s += dy[(long long)m * nout + threadIdx.x];
+    db[threadIdx.x] = (accumulate ? db[threadIdx.x] : 0.f) + s;
+  }
+}
+
+// ---- angular loss ------------------------------------------------------------------------------
+// v(p,y) = (cos p sin y, sin p, cos p cos y); sim = <u/|u|, v/|v|> with the norms clamped at 1e-6
+// (ATen cosine_similarity); clamp to [-1,1] (hardtanh: zero gradient AT and beyond the bounds);
+// theta = acos(sim) * 180/pi.
+__global__ __launch_bounds__(256) void gaze_loss_kernel(const float *__restrict__ pred, const float *__restrict__ gt,
+                                                        int n, float row_weight, float *__restrict__ loss,
+                                                        int accumulate, float *__restrict__ dpred,
+                                                        float *__restrict__ theta_out) {
+  __shared__ double sh[4];
+  double local = 0.0;
+  const float k180 = 57.29577951308232f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float pp = pred[2 * i], py = pred[2 * i + 1], gp = gt[2 * i], gy = gt[2 * i + 1];
+    const float cpp = cosf(pp), spp = sinf(pp), cpy = cosf(py), spy = sinf(py);
+    const float cgp = cosf(gp), sgp = sinf(gp), cgy = cosf(gy), sgy = sinf(gy);
+    const float v0 = cpp * spy, v1 = spp, v2 = cpp * cpy;
+    const float u0 = cgp * sgy, u1 = sgp, u2 = cgp * cgy;
+    const float nv = fmaxf(sqrtf(v0 * v0 + v1 * v1 + v2 * v2), 1e-6f);
+    const float nu = fmaxf(sqrtf(u0 * u0 + u1 * u1 + u2 * u2), 1e-6f);
+    const float a0 = u0 / nu, a1 = u1 / nu, a2 = u2 / nu;
+    const float b0 = v0 / nv, b1 = v1 / nv, b2 = v2 / nv;
+    const float sim = a0 * b0 + a1 * b1 + a2 * b2;
+    const float sc = fminf(fmaxf(sim, -1.f), 1.f);
+    const float theta = acosf(sc) * k180;
+    local += (double)theta;
+    if (theta_out) theta_out[i] = theta;
+    if (dpred) {
+      float gpitch = 0.f, gyaw = 0.f;
+      if (sim > -1.f && sim < 1.f) {
+        const float dth = -k180 / sqrtf(1.f - sc * sc);          // dtheta/dsim
+        // dsim/dv = (a - sim*b)/|v|   (gradient through the normalisation)
+        const float d0 = (a0 - sim * b0) / nv, d1 = (a1 - sim * b1) / nv, d2 = (a2 - sim * b2) / nv;
+        // dv/dpitch = (-sin p sin y, cos p, -sin p cos y); dv/dyaw = (cos p cos y, 0, -cos p sin y)
+        gpitch = dth * (d0 * (-spp * spy) + d1 * cpp + d2 * (-spp * cpy));
+        gyaw = dth * (d0 * (cpp * cpy) + d2 * (-cpp * spy));
+      }
+      dpred[2 * i] = row_weight * gpitch;
+      dpred[2 * i + 1] = row_weight * gyaw;
+    }
+  }
+  local = wave_sum_d(local);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double tot = (sh[0] + sh[1] + sh[2] + sh[3]) * (double)row_weight;
+    loss[0] = (accumulate ? loss[0] : 0.f) + (float)tot;
+  }
+}
+
+}  // namespace mvg
+
+using namespace mvg;
+
+extern "C" {
+
+int mvg_rotation_matrix_2d(const float *pitch_yaw, float *rot, int n, int inverse, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(MVG_K_GEOMETRY, st, 0.0, 44.0 * n);
+  hipLaunchKernelGGL(rotation_matrix_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, pitch_yaw, rot, n, inverse);
+  return check_launch("rotation_matrix_2d");
+}
+
+int mvg_relative_rotation(const float *rot, const int32_t *vi, const int32_t *vj, float *rel, int batch, int views,
+                          int dirs, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(MVG_K_GEOMETRY, st, 0.0, 108.0 * dirs * batch);
+  hipLaunchKernelGGL(relative_rotation_kernel, dim3(ceil_div((long long)dirs * batch, 256)), dim3(256), 0, st, rot, vi, vj,
+                     rel, batch, views, dirs);
+  return check_launch("relative_rotation");
+}
+
+int mvg_rotcat_fwd(const float *img_feat, const float *feat, const float *rel, const int32_t *view_of,
+                   const int32_t *src_of, float *x, int batch, int dirs, int cf, int nvec, void *stream) {
+  MVG_REQUIRE(cf % 4 == 0, "rotcat: cf %% 4 != 0");
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(MVG_K_ROTCAT, st, 18.0 * dirs * batch * nvec, 8.0 * dirs * (double)batch * (cf + 3 * nvec));
+  hipLaunchKernelGGL(rotcat_fwd_kernel, dim3(dirs * batch), dim3(256), 0, st, img_feat, feat, rel, view_of, src_of, x,
+                     batch, cf, nvec);
+  return check_launch("rotcat_fwd");
+}
+
+int mvg_rotcat_bwd(const float *dx, const float *rel, const int32_t *src_of, float *dfeat, int batch, int dirs, int cf,
+                   int nvec, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(MVG_K_ROTCAT, st, 18.0 * dirs * batch * nvec, 24.0 * dirs * (double)batch * nvec);
+  hipLaunchKernelGGL(rotcat_bwd_feat_kernel, dim3(dirs * batch), dim3(256), 0, st, dx, rel, src_of, dfeat, batch, cf, nvec);
+  return check_launch("rotcat_bwd");
+}
+
+int mvg_segment_sum(const float *x, int64_t row_stride, int width, const int32_t *seg_of, float *out, int batch, int dirs,
+                    int segments, int accumulate, void *stream) {
+  MVG_REQUIRE(width % 4 == 0 && row_stride % 4 == 0, "segment_sum: width/row_stride %% 4 != 0");
+  hipStream_t st = (hipStream_t)stream;
+  const long long total = (long long)segments * batch * (width / 4);
+  ProfScope ps(MVG_K_ELEMENTWISE, st, 0.0, 4.0 * (double)batch * width * (dirs + segments));
+  hipLaunchKernelGGL(segment_sum_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, x, (long long)row_stride, width / 4,
+                     seg_of, out, batch, dirs, segments, accumulate);
+  return check_launch("segment_sum");
+}
+
+int mvg_scale_by(const float *x, const float *scale, float *out, int64_t n, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(MVG_K_ELEMENTWISE, st, 0.0, 8.0 * (double)n);
+  long long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(scale_by_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, scale, out, (long long)n);
+  return check_launch("scale_by");
+}
+
+int mvg_colsum(const float *x, float *out, int64_t rows, int c, int accumulate, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(MVG_K_COLSUM, st, 0.0, 4.0 * (double)rows * c);
+  hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(c, 64)), dim3(256), 0, st, x, out, (long long)rows, c, accumulate);
+  return check_launch("colsum");
+}
+
+int mvg_axpby(const float *x, float *y, float a, float b, int64_t n, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(MVG_K_ELEMENTWISE, st, 0.0, 12.0 * (double)n);
+  long long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, y, a, b, (long long)n);
+  return check_launch("axpby");
+}
+
+int mvg_linear_skinny_fwd(const float *x, const float *w, const float *bias, float *y, int rows, int k, int nout,
+                          void *stream) {
+  MVG_REQUIRE(nout >= 1 && nout <= 4, "skinny linear: out_features must be 1..4");
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(MVG_K_LINEAR_FPROP, st, 2.0 * rows * (double)k * nout, 4.0 * ((double)rows * k + (double)k * nout));
+  hipLaunchKernelGGL(skinny_fwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, st, x, w, bias, y, rows, k, nout);
+  return check_launch("skinny_fwd");
+}
+
+int mvg_linear_skinny_bwd(const float *dy, const float *x, const float *w, const float *mask, float *dx, float *dw,
+                          float *db, int rows, int k, int nout, int accumulate, void *stream) {
+  MVG_REQUIRE(nout >= 1 && nout <= 4, "skinny linear: out_features must be 1..4");
+  hipStream_t st = (hipStream_t)stream;
+  if (dx) {
+    ProfScope ps(MVG_K_LINEAR_DGRAD, st, 2.0 * rows * (double)k * nout, 8.0 * (double)rows * k);
+    const long long total = (long long)rows * k;
+    hipLaunchKernelGGL(skinny_bwd_dx_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, dy, w, mask, dx, total, k, nout);
+    if (check_launch("skinny_bwd_dx")) return 1;
+  }
+  if (dw) {
+    ProfScope ps(MVG_K_LINEAR_WGRAD, st, 2.0 * rows * (double)k * nout, 4.0 * (double)rows * k);
+    hipLaunchKernelGGL(skinny_bwd_dw_kernel, dim3(ceil_div(k, 256)), dim3(256), 0, st, dy, x, dw, db, rows, k, nout,
+                       accumulate);
+    if (check_launch("skinny_bwd_dw")) return 1;
+  }
+  return 0;
+}
+
+int mvg_gaze_angular_loss(const float *pred, const float *gt, int n, float row_weight, float *loss, int accumulate,
+                          float *dpred, float *theta_out, void *stream) {
+  MVG_REQUIRE(n > 0, "gaze loss: n <= 0");
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(MVG_K_LOSS, st, 0.0, 24.0 * n);
+  hipLaunchKernelGGL(gaze_loss_kernel, dim3(1), dim3(256), 0, st, pred, gt, n, row_weight, loss, accumulate, dpred,
+                     theta_out);
+  return check_launch("gaze_angular_loss");
+}
+
+}  // extern "C"

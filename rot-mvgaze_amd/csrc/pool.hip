@@ -1,0 +1,202 @@
+// MaxPool2d(3,2,1), global average pool, and the NCHW <-> NHWC4 boundary repack.  HBM-bound.
+#include "common.h"
+
+namespace mvg {
+
+// one thread = one (n, ho, wo, 4 channels).  argmax = index (0..8) of the FIRST maximum in
+// (kh, kw) scan order over the in-bounds window (ATen's max_pool2d tie rule: strict >).
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float4 *__restrict__ x, float4 *__restrict__ y,
+                                                          uchar4 *__restrict__ argmax, long long total, int h, int w,
+                                                          int c4n, int ho, int wo) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int cq = (int)(i % c4n);
+  long long t = i / c4n;
+  const int ox = (int)(t % wo);
+  t /= wo;
+  const int oy = (int)(t % ho);
+  const long long n = t / ho;
+  float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  uchar4 idx = make_uchar4(0, 0, 0, 0);
+  bool first = true;
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const int iy = oy * 2 - 1 + kh;
+    if ((unsigned)iy >= (unsigned)h) continue;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int ix = ox * 2 - 1 + kw;
+      if ((unsigned)ix >= (unsigned)w) continue;
+      const float4 v = x[((n * h + iy) * w + ix) * c4n + cq];
+      const unsigned char k = (unsigned char)(kh * 3 + kw);
+      if (first) {
+        best = v;
+        idx = make_uchar4(k, k, k, k);
+        first = false;
+      } else {
+        if (v.x > best.x || v.x != v.x) { best.x = v.x; idx.x = k; }
+        if (v.y > best.y || v.y != v.y) { best.y = v.y; idx.y = k; }
+        if (v.z > best.z || v.z != v.z) { best.z = v.z; idx.z = k; }
+        if (v.w > best.w || v.w != v.w) { best.w = v.w; idx.w = k; }
+      }
+    }
+  }
+  y[i] = best;
+  argmax[i] = idx;
+}
+
+// gather form (no atomics): an input pixel collects the gradient of every window it won.
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float4 *__restrict__ dy,
+                                                          const uchar4 *__restrict__ argmax, float4 *__restrict__ dx,
+                                                          long long total, int h, int w, int c4n, int ho, int wo) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int cq = (int)(i % c4n);
+  long long t = i / c4n;
+  const int ix = (int)(t % w);
+  t /= w;
+  const int iy = (int)(t % h);
+  const long long n = t / h;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  // windows (oy, ox) with oy*2-1 <= iy <= oy*2+1
+  const int oy0 = iy >> 1, ox0 = ix >> 1;   // candidates: floor(iy/2) and floor((iy+1)/2)
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int oy = oy0 + a;
+    const int kh = iy - (oy * 2 - 1);
+    if (kh < 0 || kh > 2 || oy >= ho) continue;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int ox = ox0 + b;
+      const int kw = ix - (ox * 2 - 1);
+      if (kw < 0 || kw > 2 || ox >= wo) continue;
+      const long long o = ((n * ho + oy) * wo + ox) * c4n + cq;
+      const uchar4 am = argmax[o];
+      const float4 g = dy[o];
+      const unsigned char k = (unsigned char)(kh * 3 + kw);
+      if (am.x == k) acc.x += g.x;
+      if (am.y == k) acc.y += g.y;
+      if (am.z == k) acc.z += g.z;
+      if (am.w == k) acc.w += g.w;
+    }
+  }
+  dx[i] = acc;
+}
+
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float4 *__restrict__ x, float4 *__restrict__ y, int n,
+                                                          int hw, int c4n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)n * c4n) return;
+  const int cq = (int)(i % c4n);
+  const long long img = i / c4n;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int p = 0; p < hw; ++p) {
+    const float4 v = x[(img * hw + p) * c4n + cq];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  const float inv = 1.f / (float)hw;
+  y[i] = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
+}
+
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float4 *__restrict__ dy, float4 *__restrict__ dx,
+                                                          long long total, int hw, int c4n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int cq = (int)(i % c4n);
+  const long long img = i / ((long long)hw * c4n);
+  const float inv = 1.f / (float)hw;
+  const float4 g = dy[img * c4n + cq];
+  dx[i] = make_float4(g.x * inv, g.y * inv, g.z * inv, g.w * inv);
+}
+
+__global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float *__restrict__ src, float4 *__restrict__ dst,
+                                                            long long pixels, int c, long long hw) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= pixels) return;
+  const long long n = i / hw, p = i - n * hw;
+  const float *s = src + n * c * hw + p;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < c; ++k) v[k] = s[k * hw];
+  dst[i] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+__global__ __launch_bounds__(256) void nhwc4_to_nchw_kernel(const float4 *__restrict__ src, float *__restrict__ dst,
+                                                            long long pixels, int c, long long hw) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= pixels) return;
+  const long long n = i / hw, p = i - n * hw;
+  const float4 v4 = src[i];
+  const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+  float *d = dst + n * c * hw + p;
+  for (int k = 0; k < c; ++k) d[k * hw] = v[k];
+}
+
+}  // namespace mvg
+
+using namespace mvg;
+
+extern "C" {
+
+int mvg_maxpool3x3s2_fwd(const float *x, float *y, uint8_t *argmax, int n, int h, int w, int c, int ho, int wo,
+                         void *stream) {
+  MVG_REQUIRE(c % 4 == 0, "maxpool: c %% 4 != 0");
+  MVG_REQUIRE(ho == (h + 2 - 3) / 2 + 1 && wo == (w + 2 - 3) / 2 + 1, "maxpool: bad output size");
+  const long long total = (long long)n * ho * wo * (c / 4);
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(MVG_K_POOL, st, 0.0, 4.0 * ((double)n * h * w * c + (double)total * 5));
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, (const float4 *)x, (float4 *)y,
+                     (uchar4 *)argmax, total, h, w, c / 4, ho, wo);
+  return check_launch("maxpool_fwd");
+}
+
+int mvg_maxpool3x3s2_bwd(const float *dy, const uint8_t *argmax, float *dx, int n, int h, int w, int c, int ho, int wo,
+                         void *stream) {
+  MVG_REQUIRE(c % 4 == 0, "maxpool: c %% 4 != 0");
+  const long long total = (long long)n * h * w * (c / 4);
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(MVG_K_POOL, st, 0.0, 4.0 * ((double)n * h * w * c + (double)n * ho * wo * c * 1.25));
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, (const float4 *)dy,
+                     (const uchar4 *)argmax, (float4 *)dx, total, h, w, c / 4, ho, wo);
+  return check_launch("maxpool_bwd");
+}
+
+int mvg_avgpool_fwd(const float *x, float *y, int n, int hw, int c, void *stream) {
+  MVG_REQUIRE(c % 4 == 0, "avgpool: c %% 4 != 0");
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(MVG_K_POOL, st, 0.0, 4.0 * (double)n * (hw + 1) * c);
+  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(ceil_div((long long)n * (c / 4), 256)), dim3(256), 0, st,
+                     (const float4 *)x, (float4 *)y, n, hw, c / 4);
+  return check_launch("avgpool_fwd");
+}
+
+int mvg_avgpool_bwd(const float *dy, float *dx, int n, int hw, int c, void *stream) {
+  MVG_REQUIRE(c % 4 == 0, "avgpool: c %% 4 != 0");
+  hipStream_t st = (hipStream_t)stream;
+  const long long total = (long long)n * hw * (c / 4);
+  ProfScope ps(MVG_K_POOL, st, 0.0, 4.0 * (double)n * (hw + 1) * c);
+  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, (const float4 *)dy, (float4 *)dx,
+                     total, hw, c / 4);
+  return check_launch("avgpool_bwd");
+}
+
+int mvg_nchw_to_nhwc4(const float *src, float *dst, int n, int c, int h, int w, void *stream) {
+  MVG_REQUIRE(c >= 1 && c <= 4, "nchw_to_nhwc4: c must be 1..4");
+  hipStream_t st = (hipStream_t)stream;
+  const long long pixels = (long long)n * h * w;
+  ProfScope ps(MVG_K_LAYOUT, st, 0.0, 4.0 * (double)pixels * (c + 4));
+  hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3(ceil_div(pixels, 256)), dim3(256), 0, st, src, (float4 *)dst, pixels, c,
+                     (long long)h * w);
+  return check_launch("nchw_to_nhwc4");
+}
+
+int mvg_nhwc4_to_nchw(const float *src, float *dst, int n, int c, int h, int w, void *stream) {
+  MVG_REQUIRE(c >= 1 && c <= 4, "nhwc4_to_nchw: c must be 1..4");
+  hipStream_t st = (hipStream_t)stream;
+  const long long pixels = (long long)n * h * w;
+  ProfScope ps(MVG_K_LAYOUT, st, 0.0, 4.0 * (double)pixels * (c + 4));
+  hipLaunchKernelGGL(nhwc4_to_nchw_kernel, dim3(ceil_div(pixels, 256)), dim3(256), 0, st, (const float4 *)src, dst, pixels,
+                     c, (long long)h * w);
+  return check_launch("nhwc4_to_nchw");
+}
+
+}  // extern "C"

@@ -1,0 +1,185 @@
+"""Tensor-level wrappers over the C ABI: raw device pointers + the current HIP stream.
+
+PyTorch is used here for device memory and streams only; every computation is a launch of a
+hand-written gfx950 kernel inside librotmvgaze_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from ._lib import ConvDesc, K_FAMILIES, ProfEntry, check, lib
+
+Tensor = torch.Tensor
+
+
+def _p(t: Optional[Tensor]):
+    if t is None:
+        return None
+    assert t.is_cuda and t.dtype in (torch.float32, torch.int32, torch.uint8), (t.device, t.dtype)
+    return C.c_void_p(t.data_ptr())
+
+
+def _s():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32c(t: Tensor) -> Tensor:
+    assert t.dtype == torch.float32 and t.is_cuda and t.is_contiguous(), "expected contiguous fp32 device tensor"
+    return t
+
+
+# ---------------------------------------------------------------- conv / linear
+def conv_stats_partials(d: ConvDesc):
+    rpp = C.c_int32(0)
+    n = lib().mvg_conv_stats_partials(C.byref(d), C.byref(rpp))
+    if n < 0:
+        check(1, "conv_stats_partials")
+    return n, rpp.value
+
+
+def conv_fprop(d: ConvDesc, x: Tensor, w: Tensor, y: Tensor, bias: Optional[Tensor] = None, relu: bool = False,
+               stats: Optional[Tensor] = None):
+    check(lib().mvg_conv_fprop(C.byref(d), _p(x), _p(w), _p(y), _p(bias), int(relu), _p(stats), _s()), "conv_fprop")
+
+
+def conv_dgrad(d: ConvDesc, dy: Tensor, w: Tensor, dx: Tensor, mask: Optional[Tensor] = None,
+               addend: Optional[Tensor] = None):
+    check(lib().mvg_conv_dgrad(C.byref(d), _p(dy), _p(w), _p(dx), _p(mask), _p(addend), _s()), "conv_dgrad")
+
+
+def conv_wgrad(d: ConvDesc, x: Tensor, dy: Tensor, dw: Tensor, accumulate: bool = False):
+    splits = lib().mvg_conv_wgrad_splits(C.byref(d))
+    if splits < 1:
+        check(1, "conv_wgrad_splits")
+    ws = None
+    if splits > 1:
+        ws = torch.empty(splits * d.cout * d.r * d.s * d.cin, dtype=torch.float32, device=x.device)
+    check(lib().mvg_conv_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _p(ws), splits, int(accumulate), _s()), "conv_wgrad")
+
+
+# ---------------------------------------------------------------- batch norm
+def bn_finalize(stats, groups, partials, rows_per_partial, rows_per_group, c, gamma, beta, running_mean, running_var,
+                momentum, eps, mean, invstd, scale, shift):
+    check(lib().mvg_bn_finalize(_p(stats), groups, partials, rows_per_partial, rows_per_group, c, _p(gamma), _p(beta),
+                                _p(running_mean), _p(running_var), momentum, eps, _p(mean), _p(invstd), _p(scale),
+                                _p(shift), _s()), "bn_finalize")
+
+
+def bn_eval_affine(groups, c, gamma, beta, running_mean, running_var, eps, scale, shift):
+    check(lib().mvg_bn_eval_affine(groups, c, _p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, _p(scale),
+                                   _p(shift), _s()), "bn_eval_affine")
+
+
+def bn_apply(y, scale, shift, residual, relu, out, groups, rows_per_group, c):
+    check(lib().mvg_bn_apply(_p(y), _p(scale), _p(shift), _p(residual), int(relu), _p(out), groups, rows_per_group, c,
+                             _s()), "bn_apply")
+
+
+def bn_bwd_reduce(g, act, y, mean, invstd, groups, rows_per_group, c, s1, s2, dgamma, dbeta, accumulate):
+    n = lib().mvg_bn_bwd_workspace_floats(groups, rows_per_group, c)
+    ws = torch.empty(n, dtype=torch.float32, device=g.device)
+    check(lib().mvg_bn_bwd_reduce(_p(g), _p(act), _p(y), _p(mean), _p(invstd), groups, rows_per_group, c, _p(s1), _p(s2),
+                                  _p(dgamma), _p(dbeta), int(accumulate), _p(ws), _s()), "bn_bwd_reduce")
+
+
+def bn_bwd_apply(g, act, y, mean, invstd, gamma, s1, s2, groups, rows_per_group, c, dy, dz_out=None):
+    check(lib().mvg_bn_bwd_apply(_p(g), _p(act), _p(y), _p(mean), _p(invstd), _p(gamma), _p(s1), _p(s2), groups,
+                                 rows_per_group, c, _p(dy), _p(dz_out), _s()), "bn_bwd_apply")
+
+
+# ---------------------------------------------------------------- pooling / layout
+def maxpool_fwd(x, y, argmax, n, h, w, c, ho, wo):
+    check(lib().mvg_maxpool3x3s2_fwd(_p(x), _p(y), _p(argmax), n, h, w, c, ho, wo, _s()), "maxpool_fwd")
+
+
+def maxpool_bwd(dy, argmax, dx, n, h, w, c, ho, wo):
+    check(lib().mvg_maxpool3x3s2_bwd(_p(dy), _p(argmax), _p(dx), n, h, w, c, ho, wo, _s()), "maxpool_bwd")
+
+
+def avgpool_fwd(x, y, n, hw, c):
+    check(lib().mvg_avgpool_fwd(_p(x), _p(y), n, hw, c, _s()), "avgpool_fwd")
+
+
+def avgpool_bwd(dy, dx, n, hw, c):
+    check(lib().mvg_avgpool_bwd(_p(dy), _p(dx), n, hw, c, _s()), "avgpool_bwd")
+
+
+def nchw_to_nhwc4(src, dst, n, c, h, w):
+    check(lib().mvg_nchw_to_nhwc4(_p(src), _p(dst), n, c, h, w, _s()), "nchw_to_nhwc4")
+
+
+def nhwc4_to_nchw(src, dst, n, c, h, w):
+    check(lib().mvg_nhwc4_to_nchw(_p(src), _p(dst), n, c, h, w, _s()), "nhwc4_to_nchw")
+
+
+# ---------------------------------------------------------------- geometry / fusion operands
+def rotation_matrix_2d(pitch_yaw: Tensor, rot: Tensor, inverse: bool = False):
+    check(lib().mvg_rotation_matrix_2d(_p(pitch_yaw), _p(rot), pitch_yaw.shape[0], int(inverse), _s()), "rotation_matrix_2d")
+
+
+def relative_rotation(rot, vi, vj, rel, batch, views, dirs):
+    check(lib().mvg_relative_rotation(_p(rot), _p(vi), _p(vj), _p(rel), batch, views, dirs, _s()), "relative_rotation")
+
+
+def rotcat_fwd(img_feat, feat, rel, view_of, src_of, x, batch, dirs, cf, nvec):
+    check(lib().mvg_rotcat_fwd(_p(img_feat), _p(feat), _p(rel), _p(view_of), _p(src_of), _p(x), batch, dirs, cf, nvec,
+                               _s()), "rotcat_fwd")
+
+
+def rotcat_bwd(dx, rel, src_of, dfeat, batch, dirs, cf, nvec):
+    check(lib().mvg_rotcat_bwd(_p(dx), _p(rel), _p(src_of), _p(dfeat), batch, dirs, cf, nvec, _s()), "rotcat_bwd")
+
+
+def segment_sum(x, row_stride, width, seg_of, out, batch, dirs, segments, accumulate):
+    check(lib().mvg_segment_sum(_p(x), row_stride, width, _p(seg_of), _p(out), batch, dirs, segments, int(accumulate),
+                                _s()), "segment_sum")
+
+
+def colsum(x, out, rows, c, accumulate=False):
+    check(lib().mvg_colsum(_p(x), _p(out), rows, c, int(accumulate), _s()), "colsum")
+
+
+def axpby(x, y, a=1.0, b=1.0):
+    check(lib().mvg_axpby(_p(x), _p(y), a, b, x.numel(), _s()), "axpby")
+
+
+def scale_by(x, scale, out):
+    check(lib().mvg_scale_by(_p(x), _p(scale), _p(out), x.numel(), _s()), "scale_by")
+
+
+def linear_skinny_fwd(x, w, bias, y, rows, k, nout):
+    check(lib().mvg_linear_skinny_fwd(_p(x), _p(w), _p(bias), _p(y), rows, k, nout, _s()), "linear_skinny_fwd")
+
+
+def linear_skinny_bwd(dy, x, w, mask, dx, dw, db, rows, k, nout, accumulate=False):
+    check(lib().mvg_linear_skinny_bwd(_p(dy), _p(x), _p(w), _p(mask), _p(dx), _p(dw), _p(db), rows, k, nout,
+                                      int(accumulate), _s()), "linear_skinny_bwd")
+
+
+def gaze_angular_loss(pred, gt, n, row_weight, loss, accumulate=False, dpred=None, theta=None):
+    check(lib().mvg_gaze_angular_loss(_p(pred), _p(gt), n, row_weight, _p(loss), int(accumulate), _p(dpred), _p(theta),
+                                      _s()), "gaze_angular_loss")
+
+
+# ---------------------------------------------------------------- profiling
+def prof_enable(on: bool):
+    lib().mvg_prof_enable(int(on))
+
+
+def prof_reset():
+    lib().mvg_prof_reset()
+
+
+def prof_collect():
+    arr = (ProfEntry * K_FAMILIES)()
+    check(lib().mvg_prof_collect(arr), "prof_collect")
+    out = {}
+    for i in range(K_FAMILIES):
+        e = arr[i]
+        if e.launches:
+            out[lib().mvg_prof_family_name(i).decode()] = {
+                "launches": int(e.launches), "ms": e.ms, "flops": e.flops, "bytes": e.bytes}
+    return out

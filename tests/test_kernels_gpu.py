@@ -1,0 +1,314 @@
+"""Per-kernel parity: every C-ABI entry point against the same op of the CPU oracle vocabulary
+(torch-CPU functional ops, fp32/fp64) on seeded inputs.  Runs on a real MI355X only."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import rot_mvgaze_amd  # noqa: F401
+from rot_mvgaze_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 2e-5      # fp32 MFMA (exact products, fp32 accumulate) vs oneDNN fp32: reduction-order noise
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(shape, seed, tag="t", scale=1.0):
+    n = int(np.prod(shape))
+    return torch.from_numpy((synth.normal(n, seed, tag) * scale).astype(np.float32).reshape(shape))
+
+
+def close(got, ref, rtol=RTOL, what=""):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item() + 1e-30
+    assert err <= rtol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e} (rel {err / scale:.3e})"
+
+
+def to_nhwc(x):     # [G,N,C,H,W] -> [G,N,H,W,C]
+    return x.permute(0, 1, 3, 4, 2).contiguous()
+
+
+CONV_CASES = [
+    # G, N, H, W, Cin, Cout, k, stride, pad
+    (2, 3, 14, 14, 64, 128, 3, 1, 1),
+    (2, 3, 15, 13, 64, 128, 3, 2, 1),
+    (1, 5, 14, 14, 128, 64, 1, 1, 0),
+    (2, 2, 14, 14, 64, 256, 1, 2, 0),
+    (2, 2, 36, 36, 4, 64, 7, 2, 3),       # stem (3 channels padded to 4)
+    (2, 8, 56, 56, 64, 256, 1, 1, 0),     # large M -> 128x128 tile
+    (1, 16, 28, 28, 128, 128, 3, 1, 1),   # -> 128x64 / 128x128
+    (2, 2, 7, 7, 512, 512, 3, 1, 1),
+    (1, 3, 9, 9, 32, 32, 3, 1, 1),        # 32-wide -> 128x32 tile
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fprop_dgrad_wgrad(case):
+    from rot_mvgaze_amd import ops
+    from rot_mvgaze_amd._lib import ConvDesc
+    G, N, H, W, Cin, Cout, k, st, pad = case
+    x = rnd((G, N, Cin, H, W), 1, "x")
+    if Cin == 4:
+        x[:, :, 3] = 0
+    w = rnd((Cout, Cin, k, k), 2, "w", 1.0 / np.sqrt(Cin * k * k))
+    d = ConvDesc.make(G, N, H, W, Cin, Cout, k, st, pad)
+    xr = x.reshape(G * N, Cin, H, W).double().requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, st, pad)
+    gy = rnd(tuple(yr.shape), 3, "gy")
+    yr.backward(gy.double())
+
+    xd = to_nhwc(x).to(dev())
+    wd = w.permute(0, 2, 3, 1).contiguous().to(dev())        # KRSC
+    y = torch.empty(G, N, d.ho, d.wo, Cout, device=dev())
+    P, rpp = ops.conv_stats_partials(d)
+    stats = torch.full((G, P, 2, Cout), float("nan"), device=dev())
+    ops.conv_fprop(d, xd, wd, y, None, False, stats)
+    y_ref = yr.detach().float().reshape(G, N, Cout, d.ho, d.wo).permute(0, 1, 3, 4, 2)
+    close(y, y_ref, what="fprop")
+
+    # statistics -> finalize
+    rows = N * d.ho * d.wo
+    gamma, beta = rnd((Cout,), 4, "g") * 0.1 + 1, rnd((Cout,), 5, "b") * 0.1
+    rm, rv = torch.zeros(Cout), torch.ones(Cout)
+    mean, invstd, scale, shift = (torch.empty(G, Cout, device=dev()) for _ in range(4))
+    rmd, rvd = rm.to(dev()), rv.to(dev())
+    ops.bn_finalize(stats, G, P, rpp, rows, Cout, gamma.to(dev()), beta.to(dev()), rmd, rvd, 0.1, 1e-5, mean, invstd,
+                    scale, shift)
+    yg = y_ref.double().reshape(G, rows, Cout)
+    m_ref, v_ref = yg.mean(1), yg.var(1, unbiased=False)
+    close(mean, m_ref, 1e-5, "bn mean")
+    close(invstd, 1.0 / torch.sqrt(v_ref + 1e-5), 1e-5, "bn invstd")
+    for g in range(G):      # running stats: group order
+        rm = 0.9 * rm + 0.1 * m_ref[g].float()
+        rv = 0.9 * rv + 0.1 * (yg[g].var(0, unbiased=True)).float()
+    close(rmd, rm, 1e-5, "running_mean")
+    close(rvd, rv, 1e-5, "running_var")
+
+    gyd = to_nhwc(gy.reshape(G, N, Cout, d.ho, d.wo)).to(dev())
+    dx = torch.empty(G, N, H, W, Cin, device=dev())
+    ops.conv_dgrad(d, gyd, wd, dx)
+    dx_ref = xr.grad.float().reshape(G, N, Cin, H, W).permute(0, 1, 3, 4, 2)
+    close(dx, dx_ref, what="dgrad")
+    # dgrad epilogue: mask + addend (aliasing dx)
+    mask = rnd((G, N, H, W, Cin), 6, "m").to(dev())
+    add = rnd((G, N, H, W, Cin), 7, "a").to(dev())
+    dx2 = add.clone()
+    ops.conv_dgrad(d, gyd, wd, dx2, mask, dx2)
+    close(dx2, dx_ref * (mask.cpu() > 0) + add.cpu(), what="dgrad epilogue")
+
+    dw = torch.empty(Cout, k, k, Cin, device=dev())
+    ops.conv_wgrad(d, xd, gyd, dw, False)
+    dw_ref = wr.grad.float().permute(0, 2, 3, 1)
+    close(dw, dw_ref, what="wgrad")
+    ops.conv_wgrad(d, xd, gyd, dw, True)
+    close(dw, 2 * dw_ref, what="wgrad accumulate")
+
+
+@pytest.mark.parametrize("rows,fin,fout,relu", [(128, 2048, 2048, True), (6, 512, 1536, False), (70, 3584, 512, True),
+                                                (33, 1536, 1536, False)])
+def test_linear_via_conv(rows, fin, fout, relu):
+    from rot_mvgaze_amd import ops
+    from rot_mvgaze_amd._lib import ConvDesc
+    x, w, b = rnd((rows, fin), 1), rnd((fout, fin), 2, "w", fin ** -0.5), rnd((fout,), 3, "b")
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = F.linear(xr, wr, br)
+    if relu:
+        yr = F.relu(yr)
+    gy = rnd((rows, fout), 4)
+    yr.backward(gy.double())
+    d = ConvDesc.linear(rows, fin, fout)
+    xd, wd, bd = x.to(dev()), w.to(dev()), b.to(dev())
+    y = torch.empty(rows, fout, device=dev())
+    ops.conv_fprop(d, xd, wd, y, bd, relu, None)
+    close(y, yr, what="linear fwd")
+    g = gy.to(dev())
+    if relu:
+        g = g * (y > 0)
+    dx = torch.empty(rows, fin, device=dev())
+    ops.conv_dgrad(d, g, wd, dx)
+    close(dx, xr.grad, what="linear dgrad")
+    dw = torch.empty(fout, fin, device=dev())
+    ops.conv_wgrad(d, xd, g, dw)
+    close(dw, wr.grad, what="linear wgrad")
+    db = torch.empty(fout, device=dev())
+    ops.colsum(g, db, rows, fout)
+    close(db, br.grad, what="bias grad")
+
+
+def test_linear_skinny():
+    from rot_mvgaze_amd import ops
+    rows, k, nout = 37, 512, 2
+    x, w, b = F.relu(rnd((rows, k), 1)), rnd((nout, k), 2, "w", k ** -0.5), rnd((nout,), 3, "b")
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = F.linear(xr, wr, br)
+    gy = rnd((rows, nout), 4)
+    yr.backward(gy.double())
+    xd, wd, bd, g = x.to(dev()), w.to(dev()), b.to(dev()), gy.to(dev())
+    y = torch.empty(rows, nout, device=dev())
+    ops.linear_skinny_fwd(xd, wd, bd, y, rows, k, nout)
+    close(y, yr, what="skinny fwd")
+    dx, dw, db = torch.empty(rows, k, device=dev()), torch.empty(nout, k, device=dev()), torch.empty(nout, device=dev())
+    ops.linear_skinny_bwd(g, xd, wd, xd, dx, dw, db, rows, k, nout)
+    close(dx, xr.grad * (x > 0), what="skinny dx")
+    close(dw, wr.grad, what="skinny dw")
+    close(db, br.grad, what="skinny db")
+
+
+@pytest.mark.parametrize("G,N,H,W,C,relu,res", [(2, 3, 9, 9, 64, True, True), (2, 2, 7, 7, 2048, True, False),
+                                                (1, 4, 12, 12, 256, False, False), (3, 2, 28, 28, 128, True, True)])
+def test_bn_apply_and_backward(G, N, H, W, C, relu, res):
+    from rot_mvgaze_amd import ops
+    rows = N * H * W
+    y = rnd((G, rows, C), 1) * 2 + 0.5
+    r = rnd((G, rows, C), 2, "r") if res else None
+    gamma, beta = rnd((C,), 3) * 0.2 + 1, rnd((C,), 4) * 0.2
+    yr = y.double().requires_grad_(True)
+    rr = r.double().requires_grad_(True) if res else None
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    outs = []
+    for g in range(G):          # per-group statistics (one backbone call per view in the reference)
+        o = F.batch_norm(yr[g].reshape(N, H, W, C).permute(0, 3, 1, 2), None, None, gr, br, True, 0.1, 1e-5)
+        o = o.permute(0, 2, 3, 1).reshape(rows, C)
+        if res:
+            o = o + rr[g]
+        outs.append(F.relu(o) if relu else o)
+    out_ref = torch.stack(outs)
+    go = rnd((G, rows, C), 5, "go")
+    out_ref.backward(go.double())
+
+    yd = y.to(dev())
+    yg = y.double()
+    mean = yg.mean(1).float().to(dev())
+    invstd = (1.0 / torch.sqrt(yg.var(1, unbiased=False) + 1e-5)).float().to(dev())
+    gd, bd = gamma.to(dev()), beta.to(dev())
+    scale = gd[None] * invstd
+    shift = bd[None] - mean * scale
+    out = torch.empty(G, rows, C, device=dev())
+    ops.bn_apply(yd, scale, shift, r.to(dev()) if res else None, relu, out, G, rows, C)
+    close(out, out_ref, what="bn_apply")
+
+    s1, s2 = torch.empty(G, C, device=dev()), torch.empty(G, C, device=dev())
+    dgamma, dbeta = torch.empty(C, device=dev()), torch.empty(C, device=dev())
+    god = go.to(dev())
+    act = out if relu else None
+    ops.bn_bwd_reduce(god, act, yd, mean, invstd, G, rows, C, s1, s2, dgamma, dbeta, False)
+    close(dgamma, gr.grad, 1e-4, "dgamma")
+    close(dbeta, br.grad, 1e-4, "dbeta")
+    dy = torch.empty(G, rows, C, device=dev())
+    dz = torch.empty(G, rows, C, device=dev()) if res else None
+    ops.bn_bwd_apply(god, act, yd, mean, invstd, gd, s1, s2, G, rows, C, dy, dz)
+    close(dy, yr.grad, 1e-4, "bn dy")
+    if res:
+        close(dz, rr.grad, what="residual grad")
+
+
+def test_pools_and_layout():
+    from rot_mvgaze_amd import ops
+    n, h, w, c = 3, 15, 17, 64
+    x = rnd((n, c, h, w), 1)
+    xr = x.double().requires_grad_(True)
+    yr = F.max_pool2d(F.relu(xr), 3, 2, 1)
+    gy = rnd(tuple(yr.shape), 2)
+    yr.backward(gy.double())
+    ho, wo = yr.shape[2], yr.shape[3]
+    xd = F.relu(x).permute(0, 2, 3, 1).contiguous().to(dev())
+    y = torch.empty(n, ho, wo, c, device=dev())
+    am = torch.empty(n, ho, wo, c, dtype=torch.uint8, device=dev())
+    ops.maxpool_fwd(xd, y, am, n, h, w, c, ho, wo)
+    assert torch.equal(y.cpu(), yr.detach().float().permute(0, 2, 3, 1))
+    dx = torch.empty(n, h, w, c, device=dev())
+    ops.maxpool_bwd(gy.permute(0, 2, 3, 1).contiguous().to(dev()), am, dx, n, h, w, c, ho, wo)
+    # the reference then applies ReLU backward (mask x>0): ties at 0 may route differently but are masked away
+    mask = (xd > 0).cpu()
+    close(dx.cpu() * mask, xr.grad.float().permute(0, 2, 3, 1) * mask, what="maxpool bwd")
+
+    z = rnd((5, 49, 512), 3)
+    zd = z.to(dev())
+    p = torch.empty(5, 512, device=dev())
+    ops.avgpool_fwd(zd, p, 5, 49, 512)
+    close(p, z.double().mean(1), what="avgpool")
+    gp = rnd((5, 512), 4).to(dev())
+    dz = torch.empty(5, 49, 512, device=dev())
+    ops.avgpool_bwd(gp, dz, 5, 49, 512)
+    close(dz, (gp.cpu() / 49)[:, None, :].expand(5, 49, 512), what="avgpool bwd")
+
+    img = rnd((4, 3, 20, 24), 5)
+    d4 = torch.empty(4, 20, 24, 4, device=dev())
+    ops.nchw_to_nhwc4(img.to(dev()), d4, 4, 3, 20, 24)
+    assert torch.equal(d4[..., :3].cpu(), img.permute(0, 2, 3, 1)) and float(d4[..., 3].abs().max()) == 0.0
+    back = torch.empty(4, 3, 20, 24, device=dev())
+    ops.nhwc4_to_nchw(d4, back, 4, 3, 20, 24)
+    assert torch.equal(back.cpu(), img)
+
+
+def test_geometry_and_loss_golden(golden_dir):
+    import os
+    from rot_mvgaze_amd import ops
+    g = np.load(os.path.join(golden_dir, "geometry_loss.npz"))
+    hp = torch.from_numpy(g["hp"]).to(dev())
+    R = torch.empty(hp.shape[0], 3, 3, device=dev())
+    ops.rotation_matrix_2d(hp, R, False)
+    np.testing.assert_allclose(R.cpu().numpy(), g["R"], atol=2e-7)
+    ops.rotation_matrix_2d(hp, R, True)
+    np.testing.assert_allclose(R.cpu().numpy(), g["R_inv"], atol=2e-7)
+
+    pred, gt = torch.from_numpy(g["loss_pred"]).to(dev()), torch.from_numpy(g["loss_gt"]).to(dev())
+    n = pred.shape[0]
+    loss, dpred = torch.zeros(1, device=dev()), torch.empty(n, 2, device=dev())
+    ops.gaze_angular_loss(pred, gt, n, 1.0 / n, loss, False, dpred, None)
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-5)
+    ref = g["loss_dpred"]
+    np.testing.assert_allclose(dpred.cpu().numpy(), ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+    p2 = torch.tensor([[0.1, 0.2], [0.0, 0.0]], device=dev())
+    g2 = torch.tensor([[0.1, 0.25], [0.3, -0.2]], device=dev())
+    d2 = torch.empty(2, 2, device=dev())
+    ops.gaze_angular_loss(p2, g2, 2, 0.5, loss, False, d2, None)
+    np.testing.assert_allclose(loss.item(), 11.706101, rtol=1e-5)
+    np.testing.assert_allclose(d2.cpu().numpy(), g["ka_dpred"], rtol=1e-4)
+
+
+def test_rotcat_and_relative_rotation():
+    from rot_mvgaze_amd import ops
+    B, V, cf, nvec = 5, 3, 512, 512
+    pairs = [(i, j) for i in range(V) for j in range(i + 1, V)]
+    vi = [x for (i, j) in pairs for x in (i, j)]
+    vj = [x for (i, j) in pairs for x in (j, i)]
+    D = len(vi)
+    hp = torch.from_numpy((synth.uniform01(B * V * 2, 3, "hp") - 0.5).astype(np.float32)).reshape(B * V, 2)
+    from oracle import restatement as R
+    rot = R.rotation_matrix_2d(hp).reshape(B, V, 3, 3)
+    rel_ref = torch.stack([rot[:, vi[d]] @ rot[:, vj[d]].transpose(-1, -2) for d in range(D)])
+    vid, vjd = torch.tensor(vi, dtype=torch.int32, device=dev()), torch.tensor(vj, dtype=torch.int32, device=dev())
+    rel = torch.empty(D, B, 3, 3, device=dev())
+    ops.relative_rotation(rot.to(dev()), vid, vjd, rel, B, V, D)
+    close(rel, rel_ref, 1e-6, "relative rotation")
+
+    img_feat, feat = rnd((V, B, cf), 1), rnd((D, B, 3, nvec), 2)
+    src = torch.tensor([d ^ 1 for d in range(D)], dtype=torch.int32, device=dev())
+    x = torch.empty(D, B, cf + 3 * nvec, device=dev())
+    ops.rotcat_fwd(img_feat.to(dev()), feat.to(dev()), rel, vid, src, x, B, D, cf, nvec)
+    x_ref = torch.stack([torch.cat([img_feat[vi[d]], (rel_ref[d] @ feat[d ^ 1]).flatten(-2, -1)], -1) for d in range(D)])
+    close(x, x_ref, 1e-6, "rotcat fwd")
+    gx = rnd((D, B, cf + 3 * nvec), 3)
+    dfeat = torch.empty(D, B, 3, nvec, device=dev())
+    ops.rotcat_bwd(gx.to(dev()), rel, src, dfeat, B, D, cf, nvec)
+    df_ref = torch.empty(D, B, 3, nvec)
+    for d in range(D):
+        df_ref[d ^ 1] = rel_ref[d].transpose(-1, -2) @ gx[d, :, cf:].reshape(B, 3, nvec)
+    close(dfeat, df_ref, 1e-6, "rotcat bwd")
+    dimg = torch.ones(V, B, cf, device=dev())
+    ops.segment_sum(gx.to(dev()), cf + 3 * nvec, cf, vid, dimg, B, D, V, True)
+    di_ref = torch.ones(V, B, cf)
+    for d in range(D):
+        di_ref[vi[d]] += gx[d, :, :cf]
+    close(dimg, di_ref, 1e-6, "segment sum")
+    a, b = rnd((1000,), 5).to(dev()), rnd((1000,), 6).to(dev())
+    b0 = b.clone()
+    ops.axpby(a, b, 2.0, 0.5)
+    close(b, 2 * a + 0.5 * b0, 1e-6, "axpby")
