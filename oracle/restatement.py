@@ -74,72 +74,95 @@ def angular_error_numpy(a: np.ndarray, b: np.ndarray) -> np.ndarray:
 # --------------------------------------------------------------------------------------------
 # backbone
 # --------------------------------------------------------------------------------------------
-def _conv_bn(sd: SD, x: Tensor, c: ConvSpec, training: bool, relu: bool) -> Tensor:
-    """conv (bias=False) -> BatchNorm2d(eps 1e-5, momentum 0.1) [-> ReLU].
+def _relu(x: Tensor, masks) -> Tensor:
+    """ReLU; with ``masks`` (an iterator of 0/1 tensors shaped like x) the activation pattern is
+    IMPOSED (x * mask) instead of derived from the sign of x.  Test aid: fp32 reduction-order noise
+    flips a handful of ReLU decisions on elements within rounding of 0, which changes gradients
+    discontinuously; imposing the checked implementation's pattern makes gradients comparable to
+    1e-4 (tests/test_model_gpu.py::test_backward_strict_with_imposed_relu_pattern)."""
+    if masks is None:
+        return F.relu(x)
+    return x * next(masks).to(x.dtype)
+
+
+def _conv_bn(sd: SD, x: Tensor, c: ConvSpec, training: bool) -> Tensor:
+    """conv (bias=False) -> BatchNorm2d(eps 1e-5, momentum 0.1).
     Train mode: batch statistics over this call's (B,H,W); running stats updated in place in
     ``sd`` (unbiased var, num_batches_tracked += 1) exactly like nn.BatchNorm2d.
     /root/reference/models/resnet.py:31-47 (convs), :187,73 (BN use)."""
     y = F.conv2d(x, sd[c.name + ".weight"], None, c.stride, c.pad)
     if training:
         sd[c.bn + ".num_batches_tracked"] += 1
-    y = F.batch_norm(y, sd[c.bn + ".running_mean"], sd[c.bn + ".running_var"],
-                     sd[c.bn + ".weight"], sd[c.bn + ".bias"], training, 0.1, 1e-5)
-    return F.relu(y) if relu else y
+    return F.batch_norm(y, sd[c.bn + ".running_mean"], sd[c.bn + ".running_var"],
+                        sd[c.bn + ".weight"], sd[c.bn + ".bias"], training, 0.1, 1e-5)
 
 
-def backbone_forward(sd: SD, x: Tensor, spec: BackboneSpec, training: bool) -> Tensor:
+def backbone_forward(sd: SD, x: Tensor, spec: BackboneSpec, training: bool, trace: Optional[list] = None,
+                     relu_masks=None) -> Tensor:
     """One ResNet pass over ONE view's images [B,3,H,W] -> pooled feature [B, fc_dim].
 
     /root/reference/models/resnet.py:261-275 (stem, maxpool, layer1..4, avgpool) wrapped by
     /root/reference/models/rot_mv.py:124-128 (avgpool again - identity on 1x1 - and flatten);
     residual blocks :80-96 (basic) and :128-148 (bottleneck)."""
-    x = _conv_bn(sd, x, spec.stem, training, relu=True)
+    x = _relu(_conv_bn(sd, x, spec.stem, training), relu_masks)
     x = F.max_pool2d(x, 3, 2, 1)
+    if trace is not None:
+        trace.append(x)
     for blk in spec.blocks:
         identity = x
         out = x
         for i, c in enumerate(blk.convs):
-            out = _conv_bn(sd, out, c, training, relu=(i + 1 < len(blk.convs)))
+            out = _conv_bn(sd, out, c, training)
+            if i + 1 < len(blk.convs):
+                out = _relu(out, relu_masks)
         if blk.downsample is not None:
-            identity = _conv_bn(sd, x, blk.downsample, training, relu=False)
-        x = F.relu(out + identity)
+            identity = _conv_bn(sd, x, blk.downsample, training)
+        x = _relu(out + identity, relu_masks)
+        if trace is not None:       # debugging aid: per-block activations (tests may retain_grad them)
+            trace.append(x)
     return F.adaptive_avg_pool2d(x, 1).flatten(1)
 
 
 # --------------------------------------------------------------------------------------------
 # MLP blocks, lifter, fuser, head
 # --------------------------------------------------------------------------------------------
-def mlp(sd: SD, prefix: str, x: Tensor, n_layers: int) -> Tensor:
+def mlp(sd: SD, prefix: str, x: Tensor, n_layers: int, relu_masks=None) -> Tensor:
     """[Linear, ReLU]*(n-1), Linear.  /root/reference/models/backbones/blocks.py:27-82."""
     for i in range(n_layers):
         x = F.linear(x, sd[f"{prefix}blocks.{i}.0.weight"], sd[f"{prefix}blocks.{i}.0.bias"])
         if i + 1 < n_layers:
-            x = F.relu(x)
+            x = _relu(x, relu_masks)
     return x
 
 
-def lift(sd: SD, img_feat: Tensor) -> Tensor:
+def _one(mask):
+    return None if mask is None else iter([mask])
+
+
+def lift(sd: SD, img_feat: Tensor, mask=None) -> Tensor:
     """Feat3dLifter: Mlp(C_f,[1536,1536]) -> [B,3,512].  /root/reference/models/rot_mv.py:91-98."""
-    return mlp(sd, "_lifter._lifter.", img_feat, 2).reshape(-1, 3, NUM_FEAT_VEC)
+    return mlp(sd, "_lifter._lifter.", img_feat, 2, _one(mask)).reshape(-1, 3, NUM_FEAT_VEC)
 
 
-def fuse(sd: SD, it: int, img_feat: Tensor, rotated: Tensor) -> Tensor:
+def fuse(sd: SD, it: int, img_feat: Tensor, rotated: Tensor, mask=None) -> Tensor:
     """ImageFeatFuser: cat([img_feat, rotated.flatten(-2,-1)]) -> Mlp(K_in,[K_in,1536]) -> [B,3,512].
     /root/reference/models/rot_mv.py:35-50, reshape at :234-239."""
     x = torch.cat([img_feat, rotated.flatten(-2, -1)], dim=-1)
-    return mlp(sd, f"_img_fusers.{it}._fuser.", x, 2).reshape(-1, 3, NUM_FEAT_VEC)
+    return mlp(sd, f"_img_fusers.{it}._fuser.", x, 2, _one(mask)).reshape(-1, 3, NUM_FEAT_VEC)
 
 
-def gaze_head(sd: SD, it: int, img_feat: Tensor, feat: Tensor) -> Tensor:
+def gaze_head(sd: SD, it: int, img_feat: Tensor, feat: Tensor, mask=None) -> Tensor:
     """Mlp(K_in,[512,2]) on cat([img_feat, feat.flatten(1)]).  /root/reference/models/rot_mv.py:179-184,249-254."""
     x = torch.cat([img_feat, feat.flatten(1, -1)], dim=-1)
-    return mlp(sd, f"_gaze_estimators.{it}.", x, 2)
+    return mlp(sd, f"_gaze_estimators.{it}.", x, 2, _one(mask))
 
 
 def fuse_pair(sd: SD, num_iter: int, img_feat_0: Tensor, img_feat_1: Tensor, f0: Tensor, f1: Tensor,
-              rot_0: Tensor, rot_1: Tensor) -> Dict[str, Any]:
+              rot_0: Tensor, rot_1: Tensor, masks: Optional[Dict[Any, Any]] = None) -> Dict[str, Any]:
     """The two-view recurrence of /root/reference/models/rot_mv.py:193-194,205-265 given the
-    per-view pooled and lifted features."""
+    per-view pooled and lifted features.  ``masks`` (test aid, see _relu): {("fuse", it): [m0, m1],
+    ("head", it): [m0, m1]} imposed hidden-layer ReLU patterns."""
+    mk = (lambda kind, it, v: masks[(kind, it)][v]) if masks is not None else (lambda kind, it, v: None)
     rot_10 = rot_0 @ rot_1.transpose(-1, -2)
     rot_01 = rot_1 @ rot_0.transpose(-1, -2)
     pred: Dict[str, Any] = {
@@ -149,26 +172,29 @@ def fuse_pair(sd: SD, num_iter: int, img_feat_0: Tensor, img_feat_1: Tensor, f0:
     }
     for it in range(num_iter):
         f0_prev = f0                                   # rot_mv.py:217 - view 1 reads view 0's OLD feature
-        f0 = fuse(sd, it, img_feat_0, rot_10 @ f1)
-        f1 = fuse(sd, it, img_feat_1, rot_01 @ f0_prev)
+        f0 = fuse(sd, it, img_feat_0, rot_10 @ f1, mk("fuse", it, 0))
+        f1 = fuse(sd, it, img_feat_1, rot_01 @ f0_prev, mk("fuse", it, 1))
         pred[f"iter_{it}"] = {
             "feat_0": f0, "feat_1": f1,
-            "pred_gaze_0": gaze_head(sd, it, img_feat_0, f0),
-            "pred_gaze_1": gaze_head(sd, it, img_feat_1, f1),
+            "pred_gaze_0": gaze_head(sd, it, img_feat_0, f0, mk("head", it, 0)),
+            "pred_gaze_1": gaze_head(sd, it, img_feat_1, f1, mk("head", it, 1)),
         }
     pred["pred_gaze"] = pred[f"iter_{num_iter - 1}"]["pred_gaze_0"]
     return pred
 
 
 def model_forward(sd: SD, data: Dict[str, Any], depth: int, num_iter: int = 3,
-                  training: bool = False) -> Dict[str, Any]:
+                  training: bool = False, masks: Optional[Dict[Any, Any]] = None) -> Dict[str, Any]:
     """FeatRotationSymm.forward (default variant) - /root/reference/models/rot_mv.py:187-269.
-    Mutates and returns ``data`` like the reference (:266)."""
+    Mutates and returns ``data`` like the reference (:266).  ``masks`` (test aid, see _relu):
+    {"backbone": [iter_view0, iter_view1], "lift": [m0, m1], ("fuse", it): ..., ("head", it): ...}."""
     spec = backbone_spec(depth)
-    img_feat_0 = backbone_forward(sd, data["img_0"], spec, training)   # view 0 first: BN running
-    img_feat_1 = backbone_forward(sd, data["img_1"], spec, training)   # stats update order :196-197
-    f0, f1 = lift(sd, img_feat_0), lift(sd, img_feat_1)
-    data.update(fuse_pair(sd, num_iter, img_feat_0, img_feat_1, f0, f1, data["rot_0"], data["rot_1"]))
+    bm = masks["backbone"] if masks is not None else [None, None]
+    lm = masks["lift"] if masks is not None else [None, None]
+    img_feat_0 = backbone_forward(sd, data["img_0"], spec, training, None, bm[0])   # view 0 first: BN running
+    img_feat_1 = backbone_forward(sd, data["img_1"], spec, training, None, bm[1])   # stats update order :196-197
+    f0, f1 = lift(sd, img_feat_0, lm[0]), lift(sd, img_feat_1, lm[1])
+    data.update(fuse_pair(sd, num_iter, img_feat_0, img_feat_1, f0, f1, data["rot_0"], data["rot_1"], masks))
     return data
 
 

@@ -1,0 +1,243 @@
+"""ResNet-18/50 backbone over all views at once, forward and backward, on the HIP kernels.
+
+What it replaces: ``self._feat_extractor(img_k)`` for every view k
+(/root/reference/models/rot_mv.py:124-128,196-197 -> /root/reference/models/resnet.py:261-275 with
+BasicBlock :80-96 / Bottleneck :128-148).  The reference runs one backbone pass per view; here
+all V views go through each kernel launch as V *groups* - BatchNorm statistics stay per group and
+running statistics are updated once per group in view order, so results equal V separate passes.
+
+Data layout in HBM: activations NHWC fp32 ``[V][B][H][W][C]``; per conv+BN unit the tape keeps
+the raw conv output ``y`` (BN backward needs x-hat) and the post-activation ``out`` (next conv's
+input, ReLU mask); weights are the PyTorch parameters themselves in channels_last (= KRSC).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+from . import ops
+from ._lib import ConvDesc
+from .arch import BackboneSpec, ConvSpec, backbone_spec
+
+Tensor = torch.Tensor
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1          # nn.BatchNorm2d defaults (resnet.py:185)
+
+
+class GradSink:
+    """Where parameter gradients go.  ``view(p)`` returns the tensor the kernels write into and
+    ``accumulate(p)`` says whether they must add to it; ``publish(ps)`` is called once a group of
+    parameters has its final gradient (in grad-ready order: DP buckets hang off this)."""
+
+    def view(self, p: torch.nn.Parameter) -> Tensor:
+        raise NotImplementedError
+
+    def accumulate(self, p: torch.nn.Parameter) -> bool:
+        raise NotImplementedError
+
+    def publish(self, ps: List[torch.nn.Parameter]) -> None:
+        raise NotImplementedError
+
+
+class _Unit:
+    """Saved state of one conv + BN (+ReLU) (+residual) for the backward pass."""
+    __slots__ = ("spec", "desc", "x_in", "y", "out", "mean", "invstd", "relu", "rows", "w")
+
+
+class Backbone:
+    def __init__(self, depth: int, params: Dict[str, Tensor], prefix: str = "_feat_extractor.0."):
+        self.spec: BackboneSpec = backbone_spec(depth, prefix)
+        self.p = params                      # name -> Parameter / buffer (live objects)
+        self.fc_dim = self.spec.fc_dim
+
+    # ---------------------------------------------------------------- helpers
+    def _weight(self, c: ConvSpec) -> Tensor:
+        """KRSC device tensor the kernels read.  The 3-channel stem is padded to 4 channels."""
+        w = self.p[c.name + ".weight"]
+        if c.cin == 3:
+            w4 = torch.zeros(c.cout, c.k, c.k, 4, dtype=torch.float32, device=w.device)
+            w4[..., :3].copy_(w.detach().permute(0, 2, 3, 1))          # 9408 floats: layout plumbing
+            return w4
+        assert w.is_contiguous(memory_format=torch.channels_last) or (c.k == 1 and w.is_contiguous()), \
+            f"{c.name}.weight must be channels_last (KRSC)"
+        return w.detach()
+
+    def bn_count_buffers(self) -> List[Tensor]:
+        return [self.p[c.bn + ".num_batches_tracked"] for c in self.spec.all_convs()]
+
+    # ---------------------------------------------------------------- forward
+    def _unit_fwd(self, c: ConvSpec, x: Tensor, G: int, N: int, H: int, W: int, training: bool, relu: bool,
+                  residual: Optional[Tensor], tape: Optional[list]) -> Tensor:
+        cin = 4 if c.cin == 3 else c.cin
+        d = ConvDesc.make(G, N, H, W, cin, c.cout, c.k, c.stride, c.pad)
+        dev = x.device
+        w = self._weight(c)
+        y = torch.empty(G, N, d.ho, d.wo, c.cout, dtype=torch.float32, device=dev)
+        rows = N * d.ho * d.wo
+        gamma, beta = self.p[c.bn + ".weight"].detach(), self.p[c.bn + ".bias"].detach()
+        rm, rv = self.p[c.bn + ".running_mean"], self.p[c.bn + ".running_var"]
+        aff = torch.empty(4, G, c.cout, dtype=torch.float32, device=dev)
+        mean, invstd, scale, shift = aff[0], aff[1], aff[2], aff[3]
+        if training:
+            P, rpp = ops.conv_stats_partials(d)
+            stats = torch.empty(G, P, 2, c.cout, dtype=torch.float32, device=dev)
+            ops.conv_fprop(d, x, w, y, None, False, stats)
+            ops.bn_finalize(stats, G, P, rpp, rows, c.cout, gamma, beta, rm, rv, BN_MOMENTUM, BN_EPS, mean, invstd,
+                            scale, shift)
+        else:
+            ops.conv_fprop(d, x, w, y, None, False, None)
+            ops.bn_eval_affine(G, c.cout, gamma, beta, rm, rv, BN_EPS, scale, shift)
+        keep = tape is not None
+        out = torch.empty_like(y) if keep else y            # inference: normalise in place
+        ops.bn_apply(y, scale, shift, residual, relu, out, G, rows, c.cout)
+        if keep:
+            u = _Unit()
+            u.spec, u.desc, u.x_in, u.y, u.out, u.mean, u.invstd, u.relu, u.rows, u.w = \
+                c, d, x, y, out, mean, invstd, relu, rows, w
+            tape.append(u)
+        return out
+
+    def forward(self, imgs: List[Tensor], training: bool, keep_tape: bool):
+        """imgs: V tensors [B,3,H,W] fp32 NCHW (the reference's input format, rot_mv.py:188-189).
+        Returns (img_feat [V,B,fc_dim], tape or None)."""
+        V = len(imgs)
+        B, C, H, W = imgs[0].shape
+        assert C == 3
+        dev = imgs[0].device
+        x0 = torch.empty(V, B, H, W, 4, dtype=torch.float32, device=dev)
+        for v, im in enumerate(imgs):
+            assert im.shape == imgs[0].shape and im.is_cuda and im.dtype == torch.float32
+            ops.nchw_to_nhwc4(im.detach().contiguous(), x0[v], B, 3, H, W)
+        tape: Optional[dict] = {"units": [], "blocks": [], "V": V, "B": B} if keep_tape else None
+        ulist = tape["units"] if keep_tape else None
+        if training:
+            torch._foreach_add_(self.bn_count_buffers(), V)       # num_batches_tracked += 1 per view call
+        s = self.spec
+        a0 = self._unit_fwd(s.stem, x0, V, B, H, W, training, True, None, ulist)
+        H1, W1 = a0.shape[2], a0.shape[3]
+        Hp, Wp = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
+        x = torch.empty(V, B, Hp, Wp, 64, dtype=torch.float32, device=dev)
+        argmax = torch.empty(V, B, Hp, Wp, 64, dtype=torch.uint8, device=dev)
+        ops.maxpool_fwd(a0, x, argmax, V * B, H1, W1, 64, Hp, Wp)
+        if keep_tape:
+            tape["pool"] = (argmax, H1, W1, Hp, Wp)
+        Hc, Wc = Hp, Wp
+        for blk in s.blocks:
+            first = len(ulist) if keep_tape else 0
+            identity = x
+            out = x
+            h, w = Hc, Wc
+            for c in blk.convs[:-1]:
+                out = self._unit_fwd(c, out, V, B, h, w, training, True, None, ulist)
+                h, w = out.shape[2], out.shape[3]
+            ds_idx = None
+            if blk.downsample is not None:
+                identity = self._unit_fwd(blk.downsample, x, V, B, Hc, Wc, training, False, None, ulist)
+                ds_idx = len(ulist) - 1 if keep_tape else None
+            out = self._unit_fwd(blk.convs[-1], out, V, B, h, w, training, True, identity, ulist)
+            if keep_tape:
+                n_main = len(blk.convs)
+                idx = list(range(first, first + n_main - 1)) + [len(ulist) - 1]
+                tape["blocks"].append((idx, ds_idx))
+            x = out
+            Hc, Wc = out.shape[2], out.shape[3]
+        feat = torch.empty(V, B, self.fc_dim, dtype=torch.float32, device=dev)
+        ops.avgpool_fwd(x, feat, V * B, Hc * Wc, self.fc_dim)
+        if keep_tape:
+            tape["final_hw"] = (Hc, Wc)
+        return feat, tape
+
+    # ---------------------------------------------------------------- backward
+    def _bn_bwd(self, u: _Unit, g: Tensor, need_dz: bool, sink: GradSink):
+        """g = grad wrt the unit's output.  Returns (dy, dz): dy = grad wrt the conv output;
+        dz = g masked by the unit's ReLU (written in place into g) when the residual branch needs it."""
+        c = u.spec
+        G = u.y.shape[0]
+        gp, bp = self.p[c.bn + ".weight"], self.p[c.bn + ".bias"]
+        s12 = torch.empty(2, G, c.cout, dtype=torch.float32, device=g.device)
+        act = u.out if u.relu else None
+        acc = sink.accumulate(gp)
+        assert acc == sink.accumulate(bp)
+        ops.bn_bwd_reduce(g, act, u.y, u.mean, u.invstd, G, u.rows, c.cout, s12[0], s12[1], sink.view(gp), sink.view(bp),
+                          acc)
+        if need_dz:
+            dy = torch.empty_like(g)
+            ops.bn_bwd_apply(g, act, u.y, u.mean, u.invstd, gp.detach(), s12[0], s12[1], G, u.rows, c.cout, dy, g)
+            return dy, g
+        ops.bn_bwd_apply(g, act, u.y, u.mean, u.invstd, gp.detach(), s12[0], s12[1], G, u.rows, c.cout, g, None)
+        return g, None
+
+    def _conv_bwd(self, u: _Unit, dy: Tensor, need_dx: bool, addend: Optional[Tensor], sink: GradSink):
+        c = u.spec
+        wp = self.p[c.name + ".weight"]
+        if c.cin == 3:
+            dw4 = torch.empty(c.cout, c.k, c.k, 4, dtype=torch.float32, device=dy.device)
+            ops.conv_wgrad(u.desc, u.x_in, dy, dw4, False)
+            gv = sink.view(wp).permute(0, 2, 3, 1)
+            if sink.accumulate(wp):
+                gv.add_(dw4[..., :3])
+            else:
+                gv.copy_(dw4[..., :3])
+        else:
+            ops.conv_wgrad(u.desc, u.x_in, dy, sink.view(wp), sink.accumulate(wp))
+        dx = None
+        if need_dx:
+            dx = torch.empty_like(u.x_in)
+            ops.conv_dgrad(u.desc, dy, u.w, dx, None, addend)
+        return dx
+
+    def backward(self, tape: dict, dfeat: Tensor, sink: GradSink, need_dimg: bool = False):
+        """dfeat [V,B,fc_dim] -> parameter gradients into ``sink`` (published layer4 ... stem, the
+        order they become final); returns d(img) as V NCHW tensors when need_dimg."""
+        V, B = tape["V"], tape["B"]
+        units: List[_Unit] = tape["units"]
+        Hc, Wc = tape["final_hw"]
+        g = torch.empty(V, B, Hc, Wc, self.fc_dim, dtype=torch.float32, device=dfeat.device)
+        ops.avgpool_bwd(dfeat.contiguous(), g, V * B, Hc * Wc, self.fc_dim)
+        P = self.p
+        for (idx, ds_idx) in reversed(tape["blocks"]):
+            last = units[idx[-1]]
+            done: List[torch.nn.Parameter] = []
+            dy, dz = self._bn_bwd(last, g, True, sink)
+            d = self._conv_bwd(last, dy, True, None, sink)
+            done += [P[last.spec.name + ".weight"], P[last.spec.bn + ".weight"], P[last.spec.bn + ".bias"]]
+            last.y = last.out = None
+            del dy
+            for k in range(len(idx) - 2, -1, -1):
+                u = units[idx[k]]
+                dy, _ = self._bn_bwd(u, d, False, sink)
+                if k == 0:
+                    d = self._conv_bwd(u, dy, True, dz if ds_idx is None else None, sink)
+                else:
+                    d = self._conv_bwd(u, dy, True, None, sink)
+                done += [P[u.spec.name + ".weight"], P[u.spec.bn + ".weight"], P[u.spec.bn + ".bias"]]
+                u.y = u.out = None
+            if ds_idx is not None:
+                ud = units[ds_idx]
+                dyd, _ = self._bn_bwd(ud, dz, False, sink)
+                ops.conv_wgrad(ud.desc, ud.x_in, dyd, sink.view(P[ud.spec.name + ".weight"]),
+                               sink.accumulate(P[ud.spec.name + ".weight"]))
+                ops.conv_dgrad(ud.desc, dyd, ud.w, d, None, d)            # d += dgrad (aliasing addend)
+                done += [P[ud.spec.name + ".weight"], P[ud.spec.bn + ".weight"], P[ud.spec.bn + ".bias"]]
+                ud.y = ud.out = None
+            sink.publish(done)
+            g = d
+            if "debug" in tape:
+                tape["debug"].append(g.clone())
+        # maxpool + stem
+        argmax, H1, W1, Hp, Wp = tape["pool"]
+        stem = units[0]
+        ga = torch.empty_like(stem.out)
+        ops.maxpool_bwd(g, argmax, ga, V * B, H1, W1, 64, Hp, Wp)
+        dy, _ = self._bn_bwd(stem, ga, False, sink)
+        dx0 = self._conv_bwd(stem, dy, need_dimg, None, sink)
+        sink.publish([P[stem.spec.name + ".weight"], P[stem.spec.bn + ".weight"], P[stem.spec.bn + ".bias"]])
+        if not need_dimg:
+            return None
+        H, W = dx0.shape[2], dx0.shape[3]
+        outs = []
+        for v in range(V):
+            o = torch.empty(B, 3, H, W, dtype=torch.float32, device=dx0.device)
+            ops.nhwc4_to_nchw(dx0[v], o, B, 3, H, W)
+            outs.append(o)
+        return outs

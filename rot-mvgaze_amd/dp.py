@@ -1,0 +1,107 @@
+"""Data parallelism over samples: one process per GPU, RCCL all-reduce of the gradient arena over
+xGMI, overlapped with the rest of backward on a side HIP stream.
+
+Nothing in the reference corresponds to this (it is single-device, trainer.py:42,50;
+SURVEY.md §8(e)); the contract is "N ranks with averaged gradients == N independent reference
+steps with averaged gradients" (BatchNorm statistics stay rank-local: the reference has no SyncBN).
+
+The model's gradient arena is already laid out in grad-ready order (heads/fusers first - final
+before backbone backward even starts - then layer4 ... stem), so buckets are contiguous arena
+slices: no flatten/unflatten copies, one ``all_reduce`` per bucket issued the moment its last
+parameter is published, on a side stream that waits on an event recorded on the compute stream.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class GradAllReducer:
+    def __init__(self, model, bucket_mb: float = 64.0, process_group=None, average: bool = True):
+        self.model = model
+        self.pg = process_group
+        self.average = average
+        self.bucket_bytes = int(bucket_mb * (1 << 20))
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self._built_for = None
+        self._side: Optional[torch.cuda.Stream] = None
+        model._on_grads_ready = self._on_ready
+        model._on_backward_done = self._on_done
+
+    # bucket = [start, end) element range of the arena + the id of its last parameter
+    def _build(self):
+        arena, entries = self.model.grad_arena()
+        if self._built_for == arena.data_ptr():
+            return
+        self.arena = arena
+        self.buckets: List[List[int]] = []
+        self.last_param_bucket = {}
+        start, cur = 0, 0
+        for (p, off, n) in entries:
+            cur = off + n
+            if (cur - start) * 4 >= self.bucket_bytes:
+                self.buckets.append([start, cur])
+                self.last_param_bucket[id(p)] = len(self.buckets) - 1
+                start = cur
+        if cur > start:
+            self.buckets.append([start, cur])
+            self.last_param_bucket[id(entries[-1][0])] = len(self.buckets) - 1
+        self._param_end = {id(p): off + n for (p, off, n) in entries}
+        self._next = 0
+        self._done_upto = 0
+        if arena.is_cuda and self._side is None:
+            self._side = torch.cuda.Stream(device=arena.device)
+        self._built_for = arena.data_ptr()
+
+    def _launch(self, b: int):
+        s, e = self.buckets[b]
+        buf = self.arena[s:e]
+        if self.world == 1:
+            return
+        if self.arena.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self._side.wait_event(ev)
+            with torch.cuda.stream(self._side):
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg)
+                if self.average:
+                    buf.mul_(1.0 / self.world)
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg)
+            if self.average:
+                buf.mul_(1.0 / self.world)
+
+    def _on_ready(self, params):
+        self._build()
+        for p in params:
+            self._done_upto = max(self._done_upto, self._param_end[id(p)])
+        while self._next < len(self.buckets) and self.buckets[self._next][1] <= self._done_upto:
+            self._launch(self._next)
+            self._next += 1
+
+    def _on_done(self):
+        self._build()
+        while self._next < len(self.buckets):         # anything left (should be nothing)
+            self._launch(self._next)
+            self._next += 1
+        if self.arena.is_cuda and self.world > 1:
+            torch.cuda.current_stream().wait_stream(self._side)
+        self._next = 0
+        self._done_upto = 0
+
+
+def allreduce_arena_cpu(arena: torch.Tensor, entries, bucket_mb: float, world: int, pg=None) -> None:
+    """Same bucketing over a CPU tensor with gloo (used by the world_size-2 CPU tests)."""
+    r = GradAllReducer.__new__(GradAllReducer)
+    r.pg, r.average, r.bucket_bytes, r.world = pg, True, int(bucket_mb * (1 << 20)), world
+    r._built_for, r._side = None, None
+
+    class _M:
+        def grad_arena(self_inner):
+            return arena, entries
+    r.model = _M()
+    r._build()
+    r._on_ready([p for (p, _, _) in entries])
+    r._on_done()

@@ -1,0 +1,275 @@
+"""End-to-end parity of the MI355X FeatRotationSymm (forward, loss, backward, BN running stats)
+against (a) the golden fixtures produced by the reference's own Python and (b) the CPU oracle on
+the same seeded inputs.  Tolerance: the north star's 1e-4 relative for gaze vectors and loss
+(fp32); gradients 1e-3 relative to the tensor's max (they pass through ~50 layers of fp32
+reductions in a different order)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import rot_mvgaze_amd  # noqa: F401
+from rot_mvgaze_amd import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4       # gaze vectors and loss (the north star's bar)
+FTOL = 3e-4      # intermediate feature tensors: the fixtures' 2-3 sample batches leave BatchNorm in
+                 # layer4 with 8-12 samples per channel (2x2 maps at 64x64 input), which amplifies
+                 # fp32 reduction-order noise ~10x; predictions and loss still meet 1e-4
+GTOL = 2e-4      # gradients, same ReLU activation pattern on both sides (strict test below)
+# Against the reference's fp32 fixtures the activation pattern itself differs on a handful of
+# elements whose pre-activation is within fp32 rounding of 0 (forward values agree to ~1e-6
+# relative, but a flipped ReLU decision moves downstream gradients discontinuously, and at the tiny
+# fixture batches - 2..3 samples - one element is up to 1/sqrt(rows) of a weight gradient).  Those
+# checks therefore bound the relative L2 error instead of the max error.
+GTOL_L2_FLIPS = 5e-2
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def build(depth, seed=0, train=True):
+    from rot_mvgaze_amd.model import FeatRotationSymm
+    m = FeatRotationSymm(backbone_depth=depth, num_iter=3)
+    sd = synth.make_state_dict(depth, seed, 3, perturb_bn=True)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
+    m.to(dev())
+    return m.train() if train else m.eval()
+
+
+def inputs(batch, hw, seed=1234, views=2):
+    from rot_mvgaze_amd.geometry import rotation_matrix_2d
+    inp = synth.make_inputs(batch, views, seed, hw)
+    img, hp, gt = (torch.from_numpy(inp[k]).to(dev()) for k in ("img", "head_pose", "gt_gaze"))
+    return {"img_0": img[:, 0].contiguous(), "img_1": img[:, 1].contiguous(),
+            "rot_0": rotation_matrix_2d(hp[:, 0].contiguous()), "rot_1": rotation_matrix_2d(hp[:, 1].contiguous()),
+            "gt_gaze": gt[:, 0].contiguous(), "gt_gaze_1": gt[:, 1].contiguous()}
+
+
+def metrics():
+    from rot_mvgaze_amd.losses import IterationLoss, StereoL1Loss
+    return IterationLoss(StereoL1Loss(rel_weight=0.01, reference_decay=1.0, distance_metric="angular_error",
+                                      pred_gaze_key="pred_gaze"), iter_decay=0.5)
+
+
+def rel_close(got, ref, tol, what):
+    got = got.detach().cpu().double().numpy() if isinstance(got, torch.Tensor) else np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    err = np.abs(got - ref).max()
+    scale = np.abs(ref).max() + 1e-30
+    assert err <= tol * scale, f"{what}: max err {err:.3e}, scale {scale:.3e}, rel {err / scale:.3e}"
+
+
+def l2_close(got, ref, tol, what):
+    got = got.detach().cpu().double().numpy() if isinstance(got, torch.Tensor) else np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    err = np.linalg.norm((got - ref).ravel()) / (np.linalg.norm(ref.ravel()) + 1e-30)
+    assert err <= tol, f"{what}: relative L2 error {err:.3e} > {tol}"
+
+
+def check_outputs(data, g, prefix, tol):
+    for k in ("img_feat_0", "img_feat_1", "initial_rot_feat_0", "initial_rot_feat_1", "pred_gaze"):
+        rel_close(data[k], g[f"{prefix}.{k}"], tol if k == "pred_gaze" else FTOL, f"{prefix}.{k}")
+    for i in range(3):
+        for k in ("feat_0", "feat_1", "pred_gaze_0", "pred_gaze_1"):
+            rel_close(data[f"iter_{i}"][k], g[f"{prefix}.iter_{i}.{k}"], tol if "pred" in k else FTOL,
+                      f"{prefix}.iter_{i}.{k}")
+
+
+@pytest.mark.parametrize("depth,batch,hw", [(18, 3, 64), (50, 3, 64), (18, 2, 224), (50, 2, 224)])
+def test_against_reference_golden(golden_dir, depth, batch, hw):
+    g = np.load(os.path.join(golden_dir, f"model_r{depth}_b{batch}_hw{hw}.npz"))
+    # ---- eval
+    m = build(depth, train=False)
+    with torch.no_grad():
+        data = m(inputs(batch, hw))
+    check_outputs(data, g, "eval", TOL)
+    # ---- train step
+    m = build(depth, train=True)
+    data = inputs(batch, hw)
+    data["img_0"].requires_grad_(True)
+    extra = {"idx_0": torch.arange(batch), "something": "else"}
+    data.update(extra)
+    ret = m(data)
+    assert ret is data and data["something"] == "else" and data["num_iter"] == 3      # in-place dict protocol
+    loss = metrics()(data)
+    loss.backward()
+    check_outputs(data, g, "train", TOL)
+    rel_close(loss, g["train.loss"], TOL, "loss")
+    params = dict(m.named_parameters())
+    for key in [k[5:] for k in g.files if k.startswith("grad._")]:
+        ref = g["grad." + key]
+        p = params[key]
+        gr = p.grad
+        if gr.dim() == 4:
+            gr = gr.contiguous()          # logical OIHW order, like the fixture
+        l2_close(gr.reshape(-1)[: ref.size], ref, GTOL_L2_FLIPS, "grad " + key)
+        rel_close(gr.double().norm().item(), g["gradnorm." + key], GTOL_L2_FLIPS, "gradnorm " + key)
+    assert params["_feat_extractor.0.fc.weight"].grad is None
+    l2_close(data["img_0"].grad[:, :, ::16, ::16], g["grad.img_0"], GTOL_L2_FLIPS, "grad img_0")
+    sd = m.state_dict()
+    for k in [k for k in g.files if k.startswith("stat.")]:
+        if k.endswith("num_batches_tracked"):
+            assert int(sd[k[5:]]) == int(g[k]) == 2
+        else:
+            rel_close(sd[k[5:]], g[k], TOL, k)
+
+
+def test_against_oracle_and_generic_loss_path():
+    """Same step as the CPU oracle; the generic (per-call) loss path and the fused one agree."""
+    from oracle import restatement as R
+    from rot_mvgaze_amd.losses import IterationLoss, StereoL1Loss
+    depth, batch, hw = 18, 5, 96
+    m = build(depth)
+    data = inputs(batch, hw, seed=77)
+    data = m(data)
+    loss = metrics()(data)
+    loss.backward()
+    g_fused = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    # generic path: hide the fast-path handle
+    m.zero_grad(set_to_none=True)
+    data2 = m(inputs(batch, hw, seed=77))
+    data2.pop("_mvg_preds")
+    loss2 = metrics()(data2)
+    loss2.backward()
+    rel_close(loss2, loss.item(), 1e-6, "generic vs fused loss")
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            rel_close(p.grad, g_fused[k].cpu().numpy(), 1e-5, "generic vs fused grad " + k)
+    # oracle, free-running (its own ReLU decisions): forward quantities
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in synth.make_state_dict(depth, 0, 3, perturb_bn=True).items()}
+    inp = synth.make_inputs(batch, 2, 77, hw)
+    img, hp, gt = (torch.from_numpy(inp[k]) for k in ("img", "head_pose", "gt_gaze"))
+    od = {"img_0": img[:, 0], "img_1": img[:, 1], "rot_0": R.rotation_matrix_2d(hp[:, 0]),
+          "rot_1": R.rotation_matrix_2d(hp[:, 1]), "gt_gaze": gt[:, 0], "gt_gaze_1": gt[:, 1]}
+    with torch.no_grad():
+        od = R.model_forward(sd, od, depth, 3, True)
+        ol = R.iteration_loss(od)
+    rel_close(loss, ol.item(), TOL, "loss vs oracle")
+    for i in range(3):
+        rel_close(data[f"iter_{i}"]["pred_gaze_1"], od[f"iter_{i}"]["pred_gaze_1"].numpy(), TOL, "pred vs oracle")
+
+
+def _captured_masks(m, V=2):
+    """ReLU patterns of the HIP forward, in the order the oracle applies its ReLUs."""
+    bt, ht = m._last_backbone_tape, m._last_head_tape
+    relu_units = [u for u in bt["units"] if u.relu]
+    masks = {"backbone": [iter([(u.out[v] > 0).permute(0, 3, 1, 2).cpu() for u in relu_units]) for v in range(V)]}
+    B = bt["B"]
+    hl = (ht["hl"] > 0).cpu()
+    masks["lift"] = [hl[v * B:(v + 1) * B] for v in range(V)]
+    for it, (X, H1, Xh, Hh) in enumerate(ht["saved"]):
+        h1, hh = (H1 > 0).cpu(), (Hh > 0).cpu()
+        masks[("fuse", it)] = [h1[d * B:(d + 1) * B] for d in range(2)]
+        masks[("head", it)] = [hh[d * B:(d + 1) * B] for d in range(2)]
+    return masks
+
+
+@pytest.mark.parametrize("depth,batch,hw,gtol", [(18, 4, 96, GTOL), (50, 2, 160, GTOL), (18, 2, 224, GTOL),
+                                                 (50, 3, 64, 1e-3)])   # last: 12-sample BatchNorm in layer4
+def test_backward_strict_with_imposed_relu_pattern(depth, batch, hw, gtol):
+    """Every parameter gradient (and d/d img) against the fp64 oracle evaluated with the SAME
+    ReLU activation pattern as the HIP forward (oracle._relu): isolates the backward kernels from
+    the handful of boundary ReLU decisions that fp32 reduction order flips."""
+    from oracle import restatement as R
+    m = build(depth)
+    m._debug_keep_tapes = True
+    data = inputs(batch, hw, seed=99)
+    data["img_0"].requires_grad_(True)
+    data["img_1"].requires_grad_(True)
+    data = m(data)
+    masks = _captured_masks(m)            # before backward: it releases the saved activations
+    loss = metrics()(data)
+    loss.backward()
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in synth.make_state_dict(depth, 0, 3, perturb_bn=True).items()}
+    sd = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in sd.items()}
+    leaves = {k: v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running" not in k}
+    inp = synth.make_inputs(batch, 2, 99, hw)
+    img, hp, gt = (torch.from_numpy(inp[k]) for k in ("img", "head_pose", "gt_gaze"))
+    od = {"img_0": img[:, 0].double().requires_grad_(True), "img_1": img[:, 1].double().requires_grad_(True),
+          "rot_0": R.rotation_matrix_2d(hp[:, 0]).double(), "rot_1": R.rotation_matrix_2d(hp[:, 1]).double(),
+          "gt_gaze": gt[:, 0], "gt_gaze_1": gt[:, 1]}
+    od = R.model_forward(sd, od, depth, 3, True, masks)
+    ol = R.iteration_loss(od)
+    ol.backward()
+    rel_close(loss, ol.item(), TOL, "loss")
+    n = 0
+    for k, p in m.named_parameters():
+        if leaves[k].grad is None:
+            assert p.grad is None, k
+            continue
+        rel_close(p.grad, leaves[k].grad.numpy(), gtol, "grad " + k)
+        n += 1
+    assert n == len(leaves) - 2          # everything but the unused fc.weight / fc.bias
+    rel_close(data["img_0"].grad, od["img_0"].grad.numpy(), gtol, "grad img_0")
+    rel_close(data["img_1"].grad, od["img_1"].grad.numpy(), gtol, "grad img_1")
+
+
+def test_gradient_accumulation_and_zero_grad():
+    m = build(18)
+    d = m(inputs(3, 64))
+    metrics()(d).backward()
+    g1 = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    d = m(inputs(3, 64))            # running stats moved, same batch statistics -> same gradients
+    metrics()(d).backward()         # accumulates into the existing .grad (PyTorch semantics)
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            rel_close(p.grad, 2 * g1[k].cpu().numpy(), 1e-5, "accumulated " + k)
+    m.zero_grad(set_to_none=False)
+    d = m(inputs(3, 64))
+    metrics()(d).backward()
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            rel_close(p.grad, g1[k].cpu().numpy(), 1e-5, "after zero_grad " + k)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4, weight_decay=1e-6)      # trainer.py:54 (fc has no grad: skipped)
+    opt.step()
+
+
+def test_multiview_v3_against_oracle():
+    """A9: V=3 - shared backbone features, every pair equals the two-view oracle recurrence."""
+    from oracle import restatement as R
+    from rot_mvgaze_amd.geometry import rotation_matrix_2d
+    from rot_mvgaze_amd.losses import MultiViewIterationLoss
+    from rot_mvgaze_amd.model import MultiViewGaze
+    depth, B, V, hw = 18, 4, 3, 64
+    m = MultiViewGaze(depth, 3)
+    sdn = synth.make_state_dict(depth, 0, 3, perturb_bn=True)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sdn.items()})
+    m.to(dev()).train()
+    inp = synth.make_inputs(B, V, 5, hw)
+    img, hp, gt = (torch.from_numpy(inp[k]) for k in ("img", "head_pose", "gt_gaze"))
+    rot_d = rotation_matrix_2d(hp.reshape(-1, 2).to(dev())).reshape(B, V, 3, 3)
+    out = m.forward_multiview(img.to(dev()), rot_d)
+    loss = MultiViewIterationLoss()(out, gt.to(dev()))
+    loss.backward()
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in sdn.items()}
+    leaves = {k: v.requires_grad_(True) for k, v in sd.items() if v.dtype == torch.float32 and "running" not in k}
+    rot = R.rotation_matrix_2d(hp.reshape(-1, 2)).reshape(B, V, 3, 3)
+    oo = R.multiview_forward(sd, img, rot, depth, 3, True)
+    ol = R.multiview_loss(oo, gt)
+    ol.backward()
+    rel_close(loss, ol.item(), TOL, "mv loss")
+    for pr in R.view_pairs(V):
+        for it in range(3):
+            for k in ("feat_0", "feat_1", "pred_gaze_0", "pred_gaze_1"):
+                rel_close(out["pairs"][pr][f"iter_{it}"][k], oo["pairs"][pr][f"iter_{it}"][k].detach().numpy(), TOL,
+                          f"pair {pr} iter {it} {k}")
+    params = dict(m.named_parameters())
+    for k in ("_lifter._lifter.blocks.0.0.weight", "_img_fusers.0._fuser.blocks.0.0.weight",
+              "_gaze_estimators.1.blocks.1.0.weight", "_feat_extractor.0.layer3.0.conv1.weight",
+              "_feat_extractor.0.bn1.bias"):
+        l2_close(params[k].grad, leaves[k].grad.numpy(), GTOL_L2_FLIPS, "mv grad " + k)
+    assert int(m.state_dict()["_feat_extractor.0.bn1.num_batches_tracked"]) == V
+
+
+def test_view_swap_symmetry_eval():
+    m = build(18, train=False)
+    with torch.no_grad():
+        a = m(inputs(2, 64))
+        d = inputs(2, 64)
+        b = m({"img_0": d["img_1"], "img_1": d["img_0"], "rot_0": d["rot_1"], "rot_1": d["rot_0"]})
+    for i in range(3):
+        assert torch.equal(a[f"iter_{i}"]["pred_gaze_0"], b[f"iter_{i}"]["pred_gaze_1"])
+        assert torch.equal(a[f"iter_{i}"]["feat_1"], b[f"iter_{i}"]["feat_0"])
