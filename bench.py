@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Benchmark of the Rot-MVGaze hot path on MI355X: multi-view samples/s, forward + loss + backward
+(+ gradient all-reduce when --gpus > 1), synthetic B x V x 3 x 224 x 224 batches.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line (rank 0).  `value` = samples all ranks processed / max-over-ranks time of
+exactly K steps bracketed by barrier + synchronize; inputs are resident in HBM before the timed
+region.  `roofline` is measured live with HIP events around every launch of the dominant kernel
+family (the fp32-MFMA implicit-GEMM convolutions) in extra, separately run profiled steps;
+`cpu_baseline` times the CPU oracle (a port of the reference path) on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (depth, views, per-GPU batch, description)  - BASELINE.json configs
+    "c2": (18, 2, 64, "C2: ResNet-18, V=2, B=64 per GPU, 3x224x224, fwd+loss+bwd"),
+    "c3": (50, 4, 128, "C3: ResNet-50, V=4, B=128 per GPU, 3x224x224, fwd+loss+bwd"),
+    "c4": (50, 4, 32, "C4: ResNet-50, V=4, B=32 per GPU (256 on 8 GPUs), 3x224x224, fwd+loss+bwd"),
+    "r50v2": (50, 2, 64, "ResNet-50, V=2, B=64 per GPU, 3x224x224, fwd+loss+bwd"),
+}
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def sample_flops(depth, views):
+    """Algorithmic fwd+bwd FLOPs per multi-view sample (BASELINE.md §3 / SURVEY.md §8(d))."""
+    bb = {18: 10.65e9, 50: 24.29e9}[depth]
+    lifter = {18: 6.29e6, 50: 11.01e6}[depth]
+    pair = {18: 100.7e6, 50: 242.2e6}[depth]
+    npairs = views * (views - 1) // 2
+    return views * bb + 3 * (views * lifter + npairs * pair)
+
+
+def cpu_baseline(depth, views, seconds_budget=20.0):
+    """The CPU oracle (restatement of the reference path, validated against the reference's own
+    outputs in tests/) on a bounded sample of the workload: B=8 samples, fwd+loss+bwd."""
+    import numpy as np
+    import torch
+    from rot_mvgaze_amd import synth
+    from oracle import restatement as R            # checker / baseline only - never the product path
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))         # a one-GPU box's CPU share; oversubscribing oneDNN is far slower
+    torch.set_num_threads(cores)
+    B = 8
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in synth.make_state_dict(depth, 0, 3).items()}
+    for k, v in sd.items():
+        if v.dtype == torch.float32 and "running" not in k and ".fc." not in k:
+            v.requires_grad_(True)
+    inp = synth.make_inputs(B, views, 1234, 224)
+    img, hp, gt = (torch.from_numpy(inp[k]) for k in ("img", "head_pose", "gt_gaze"))
+    rot = R.rotation_matrix_2d(hp.reshape(-1, 2)).reshape(B, views, 3, 3)
+
+    def step():
+        for v in sd.values():
+            if v.requires_grad:
+                v.grad = None
+        out = R.multiview_forward(sd, img, rot, depth, 3, True)
+        loss = R.multiview_loss(out, gt)
+        loss.backward()
+
+    step()
+    times = []
+    t_end = time.time() + seconds_budget
+    while len(times) < 10 and (time.time() < t_end or len(times) < 2):
+        t0 = time.time()
+        step()
+        times.append(time.time() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": B / med, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"B=8 of the workload's samples (V={views}, ResNet-{depth}, 224x224), fwd+loss+bwd, "
+                      f"{len(times)} steps, median {med * 1e3:.0f} ms/step, torch CPU {torch.get_num_threads()} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--bucket-mb", type=float, default=64.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import rot_mvgaze_amd  # noqa: F401
+    from rot_mvgaze_amd import ops, synth
+    from rot_mvgaze_amd.dp import GradAllReducer
+    from rot_mvgaze_amd.losses import MultiViewIterationLoss
+    from rot_mvgaze_amd.model import MultiViewGaze
+
+    depth, V, B, desc = WORKLOADS[args.workload]
+    if args.batch:
+        B = args.batch
+        desc += f" [batch overridden to {B}]"
+    world = args.gpus
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        assert int(os.environ.get("WORLD_SIZE", "1")) == world, "launch with torch.distributed.run (see docstring)"
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    # ---- model (same seed on all ranks) and per-rank synthetic data, resident in HBM
+    model = MultiViewGaze(depth, 3)
+    sd = synth.make_state_dict(depth, 0, 3)
+    model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
+    del sd
+    model.to(dev).train()
+    inp = synth.make_inputs(B, V, 1234 + rank, 224)
+    img = [torch.from_numpy(np.ascontiguousarray(inp["img"][:, v])).to(dev) for v in range(V)]   # one tensor per view
+    gt = torch.from_numpy(inp["gt_gaze"]).to(dev)
+    from rot_mvgaze_amd.geometry import rotation_matrix_2d
+    rot = rotation_matrix_2d(torch.from_numpy(inp["head_pose"]).reshape(-1, 2).to(dev)).reshape(B, V, 3, 3)
+    del inp
+    criterion = MultiViewIterationLoss(rel_weight=0.01, reference_decay=1.0, iter_decay=0.5)
+    reducer = GradAllReducer(model, bucket_mb=args.bucket_mb) if world > 1 else None
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        out = model.forward_multiview(img, rot)
+        loss = criterion(out, gt)
+        loss.backward()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * B * args.steps / elapsed
+    loss_val = float(loss.item())
+
+    # ---- roofline of the dominant kernel family (separate, event-instrumented steps)
+    roofline, families = None, None
+    if not args.no_roofline:
+        nprof = min(args.steps, 3)
+        ops.prof_reset()
+        ops.prof_enable(True)
+        for _ in range(nprof):
+            step()
+        torch.cuda.synchronize()
+        ops.prof_enable(False)
+        prof = ops.prof_collect()
+        conv = [prof[k] for k in ("conv_fprop", "conv_dgrad", "conv_wgrad") if k in prof]
+        flops = sum(e["flops"] for e in conv)
+        ms = sum(e["ms"] for e in conv)
+        launches = sum(e["launches"] for e in conv)
+        achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": "igemm_kernel/wgrad_kernel (fp32 MFMA implicit-GEMM conv: fprop+dgrad+wgrad)",
+                    "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "flop_per_launch": flops / max(launches, 1), "avg_launch_ms": ms / max(launches, 1),
+                    "launches_per_step": launches / nprof, "kernel_ms_per_step": ms / nprof}
+        families = {k: {"ms_per_step": round(e["ms"] / nprof, 4), "launches_per_step": e["launches"] / nprof,
+                        "tflops": round(e["flops"] / (e["ms"] * 1e-3) / 1e12, 2) if e["ms"] > 0 and e["flops"] > 0 else None,
+                        "gbs": round(e["bytes"] / (e["ms"] * 1e-3) / 1e9, 1) if e["ms"] > 0 and e["bytes"] > 0 else None}
+                    for k, e in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(depth, V)
+
+    if rank == 0:
+        line = {
+            "metric": "multi-view samples/sec (fwd+bwd), BxVx3x224x224",
+            "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc, "backbone": f"ResNet-{depth}", "views": V, "batch_per_gpu": B,
+                       "global_batch": B * world, "image": "3x224x224", "parallelism": f"dp{world}",
+                       "timed_region": "forward + loss + backward" + (" + RCCL gradient all-reduce" if world > 1 else ""),
+                       "weights": "random init, seed 0 (kaiming-normal convs, default Linear)",
+                       "images_per_s": round(value * V, 1), "loss": loss_val,
+                       "model_tflops": round(value * sample_flops(depth, V) / 1e12, 2)},
+            "roofline": roofline, "cpu_baseline": cpu, "kernel_families": families,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

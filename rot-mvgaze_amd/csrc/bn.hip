@@ -167,24 +167,46 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float4 *__rest
   }
 }
 
-__global__ void bn_bwd_finalize_kernel(const float *__restrict__ partial, int groups, int chunks, int c, float *s1,
-                                       float *s2, float *dgamma, float *dbeta, int accumulate) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= c) return;
+// grid = c/16 blocks, 1024 threads = 16 channels x 64 chunk-lanes; groups handled in order so
+// that dgamma/dbeta are summed in a fixed order (reproducible).
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float *__restrict__ partial, int groups, int chunks,
+                                                               int c, float *s1, float *s2, float *dgamma,
+                                                               float *dbeta, int accumulate) {
+  __shared__ double sh[2][64][16];
+  const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int ch = blockIdx.x * 16 + cl;
   double tg = 0.0, tb = 0.0;
   for (int g = 0; g < groups; ++g) {
     double a = 0.0, b = 0.0;
-    for (int k = 0; k < chunks; ++k) {
-      a += partial[(((long long)g * chunks + k) * 2) * c + ch];
-      b += partial[(((long long)g * chunks + k) * 2 + 1) * c + ch];
+    if (ch < c)
+      for (int k = pl; k < chunks; k += 64) {
+        a += partial[(((long long)g * chunks + k) * 2) * c + ch];
+        b += partial[(((long long)g * chunks + k) * 2 + 1) * c + ch];
+      }
+    sh[0][pl][cl] = a;
+    sh[1][pl][cl] = b;
+    __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) {
+      if (pl < o) {
+        sh[0][pl][cl] += sh[0][pl + o][cl];
+        sh[1][pl][cl] += sh[1][pl + o][cl];
+      }
+      __syncthreads();
     }
-    s1[(long long)g * c + ch] = (float)a;
-    s2[(long long)g * c + ch] = (float)b;
-    tb += a;
-    tg += b;
+    if (pl == 0 && ch < c) {
+      a = sh[0][0][cl];
+      b = sh[1][0][cl];
+      s1[(long long)g * c + ch] = (float)a;
+      s2[(long long)g * c + ch] = (float)b;
+      tb += a;
+      tg += b;
+    }
+    __syncthreads();
   }
-  if (dgamma) dgamma[ch] = (accumulate ? dgamma[ch] : 0.f) + (float)tg;
-  if (dbeta) dbeta[ch] = (accumulate ? dbeta[ch] : 0.f) + (float)tb;
+  if (pl == 0 && ch < c) {
+    if (dgamma) dgamma[ch] = (accumulate ? dgamma[ch] : 0.f) + (float)tg;
+    if (dbeta) dbeta[ch] = (accumulate ? dbeta[ch] : 0.f) + (float)tb;
+  }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float4 *__restrict__ g, const float4 *__restrict__ act,
@@ -234,7 +256,7 @@ static int bwd_chunks(int groups, long long rows, int c) {
   const int c4n = c / 4;
   const int cw = c4n < 256 ? c4n : 256;
   const int colblocks = ceil_div(c4n, cw);
-  long long want = 2048 / ((long long)groups * colblocks);
+  long long want = 1024 / ((long long)groups * colblocks);
   if (want < 1) want = 1;
   long long maxc = (rows + 63) / 64;
   if (want > maxc) want = maxc;
@@ -309,7 +331,7 @@ int mvg_bn_bwd_reduce(const float *g, const float *act, const float *y, const fl
                      (const float4 *)act, (const float4 *)y, mean, invstd, (long long)rows_per_group, rpc, c, c4n, cw,
                      workspace, chunks);
   if (check_launch("bn_bwd_reduce")) return 1;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(c, 128)), dim3(128), 0, st, workspace, groups, chunks, c, s1, s2,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(c, 16)), dim3(1024), 0, st, workspace, groups, chunks, c, s1, s2,
                      dgamma, dbeta, accumulate);
   return check_launch("bn_bwd_finalize");
 }

@@ -14,6 +14,8 @@
 // and B[k=l>>5][j=l&31]; C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).  Because both
 // operands' k index comes from the same lane half, any bijection between (half, step) and k is
 // legal: the k-contiguous LDS images are read with one ds_read_b128 per 4 steps (k = 8g+4h+t).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace mvg {
@@ -214,38 +216,37 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     if (more) load_tiles(kt + 1);
     const float *As = smem + cur * (A_ELEMS + B_ELEMS);
     const float *Bs = As + A_ELEMS;
-#pragma unroll
-    for (int kg = 0; kg < BK / 8; ++kg) {
-      float4 av[TM];
+    // fragments of k-group kg+1 are fetched from LDS while the MFMAs of k-group kg run
+    float4 av[2][TM];
+    float4 bv[2][TN];
+    auto load_frags = [&](int kg, int slot) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        av[i] = *reinterpret_cast<const float4 *>(As + (wm * WTM + i * 32 + li) * LDA + kg * 8 + lh * 4);
+        av[slot][i] = *reinterpret_cast<const float4 *>(As + (wm * WTM + i * 32 + li) * LDA + kg * 8 + lh * 4);
       if (!DGRAD) {
-        float4 bv[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          bv[j] = *reinterpret_cast<const float4 *>(Bs + (wn * WTN + j * 32 + li) * LDA + kg * 8 + lh * 4);
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(((const float *)&av[i])[t], ((const float *)&bv[j])[t],
-                                                               acc[i][j], 0, 0, 0);
+          bv[slot][j] = *reinterpret_cast<const float4 *>(Bs + (wn * WTN + j * 32 + li) * LDA + kg * 8 + lh * 4);
       } else {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          float bs[TN];
-#pragma unroll
-          for (int j = 0; j < TN; ++j) bs[j] = Bs[(kg * 8 + lh * 4 + t) * LDB + wn * WTN + j * 32 + li];
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(((const float *)&av[i])[t], bs[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) {
+          const float *bp = Bs + (kg * 8 + lh * 4) * LDB + wn * WTN + j * 32 + li;
+          bv[slot][j] = make_float4(bp[0], bp[LDB], bp[2 * LDB], bp[3 * LDB]);
         }
       }
+    };
+    load_frags(0, 0);
+#pragma unroll
+    for (int kg = 0; kg < BK / 8; ++kg) {
+      if (kg + 1 < BK / 8) load_frags(kg + 1, (kg + 1) & 1);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(((const float *)&av[kg & 1][i])[t],
+                                                             ((const float *)&bv[kg & 1][j])[t], acc[i][j], 0, 0, 0);
     }
     if (more) store_tiles(cur ^ 1);
     __syncthreads();
@@ -525,14 +526,24 @@ static int launch_igemm(IgemmParams &p, TileChoice t, hipStream_t st) {
   const long long nblk = (long long)p.groups * p.mtiles_per_group * p.ntiles;
   MVG_REQUIRE(nblk < (1LL << 31), "conv: grid too large");
   dim3 grid((unsigned)nblk), block(256);
-  if (t.bm == 128 && t.bn == 128)
-    hipLaunchKernelGGL((igemm_kernel<128, 128, 16, 2, 2, DGRAD>), grid, block, 0, st, p);
-  else if (t.bm == 128 && t.bn == 64)
-    hipLaunchKernelGGL((igemm_kernel<128, 64, 16, 2, 2, DGRAD>), grid, block, 0, st, p);
-  else if (t.bm == 64 && t.bn == 64)
-    hipLaunchKernelGGL((igemm_kernel<64, 64, 16, 2, 2, DGRAD>), grid, block, 0, st, p);
-  else
+  static int bk = 0;
+  if (bk == 0) {
+    const char *e = getenv("MVG_BK");
+    bk = (e && atoi(e) == 16) ? 16 : 32;
+  }
+  const bool k32 = bk == 32 && p.ktotal >= 64;
+  if (t.bm == 128 && t.bn == 128) {
+    if (k32) hipLaunchKernelGGL((igemm_kernel<128, 128, 32, 2, 2, DGRAD>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((igemm_kernel<128, 128, 16, 2, 2, DGRAD>), grid, block, 0, st, p);
+  } else if (t.bm == 128 && t.bn == 64) {
+    if (k32) hipLaunchKernelGGL((igemm_kernel<128, 64, 32, 2, 2, DGRAD>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((igemm_kernel<128, 64, 16, 2, 2, DGRAD>), grid, block, 0, st, p);
+  } else if (t.bm == 64 && t.bn == 64) {
+    if (k32) hipLaunchKernelGGL((igemm_kernel<64, 64, 32, 2, 2, DGRAD>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((igemm_kernel<64, 64, 16, 2, 2, DGRAD>), grid, block, 0, st, p);
+  } else {
     hipLaunchKernelGGL((igemm_kernel<128, 32, 16, 4, 1, DGRAD>), grid, block, 0, st, p);
+  }
   return check_launch(DGRAD ? "conv_dgrad" : "conv_fprop");
 }
 

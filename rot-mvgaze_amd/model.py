@@ -261,10 +261,14 @@ class MultiViewGaze(nn.Module):
         return img_feat, lifted, feats, preds
 
     def forward_multiview(self, img: Tensor, rot: Tensor) -> Dict[str, Any]:
-        """img [B,V,3,H,W], rot [B,V,3,3].  Output: per-view ``img_feat`` /
+        """img [B,V,3,H,W] (or a list of V tensors [B,3,H,W]), rot [B,V,3,3].  Output: per-view ``img_feat`` /
         ``initial_rot_feat`` and per-pair dicts shaped like the reference's two-view output."""
-        V = img.shape[1]
-        imgs = [img[:, v] for v in range(V)]
+        if isinstance(img, (list, tuple)):
+            imgs = list(img)                       # V tensors [B,3,H,W] (already one tensor per view)
+            V = len(imgs)
+        else:
+            V = img.shape[1]
+            imgs = [img[:, v] for v in range(V)]
         img_feat, lifted, feats, preds = self.run_views(imgs, rot)
         out: Dict[str, Any] = {"num_iter": self._num_iter, "views": V, "img_feat": img_feat,
                                "initial_rot_feat": lifted, "pairs": {}, "_mvg_preds": preds}
