@@ -21,6 +21,48 @@
 namespace mvg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// 16-byte load through a buffer descriptor: an offset >= num_records returns zeros in hardware, so
+// predication is a v_cndmask on the offset - no branch, no select on the data.
+// pred_off(off, ok): sets bit 31 when !ok -> beyond any descriptor here (tensors/groups < 2 GiB);
+// written arithmetically so that `off` is computed unconditionally (a select with an "expensive"
+// arm is turned back into a branch by the compiler, splitting the K-step's basic block).
+__device__ __forceinline__ unsigned pred_off(unsigned off, bool ok) { return off | ((unsigned)(!ok) << 31); }
+__device__ __forceinline__ float4 buf_ld16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+// base / bytes must be wave-uniform; readfirstlane makes that provable to the compiler (otherwise it
+// wraps every buffer op in a waterfall loop - cdna_hip_programming.md T20).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, long long bytes) {
+  unsigned n = bytes > 0x7FFFFFF0ll ? 0x7FFFFFF0u : (bytes < 0 ? 0u : (unsigned)bytes);
+  const unsigned long long b = (unsigned long long)base;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  n = __builtin_amdgcn_readfirstlane(n);
+  void *ub = (void *)(((unsigned long long)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(ub, 0, (int)n, 0x00020000);
+}
+
+// exact unsigned 32-bit division by a runtime constant (Granlund-Montgomery round-up form)
+struct FastDiv {
+  unsigned mul, sh1, sh2, d;
+};
+static FastDiv make_fastdiv(unsigned d) {
+  FastDiv f;
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  f.mul = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+  f.sh1 = l < 1 ? l : 1;
+  f.sh2 = l > 0 ? l - 1 : 0;
+  f.d = d;
+  return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv &f) {
+  const unsigned t = __umulhi(f.mul, n);
+  return (t + ((n - t) >> f.sh1)) >> f.sh2;
+}
 
 struct IgemmParams {
   const float *a;       // gathered operand (fprop: x, dgrad: dy)
@@ -45,6 +87,17 @@ struct IgemmParams {
   long long src_img_stride;  // src_h*src_w*src_c
   int imgs_per_group;
   int mtiles_per_group, ntiles;
+  // tap sub-lattice: GEMM k = (ti*tap_ns + tj)*src_c + c with filter tap (r, s) =
+  // (tap_r0 + tap_step*ti, tap_s0 + tap_step*tj).  fprop / stride-1 dgrad: the whole filter.
+  // Stride-2 dgrad runs once per output-pixel parity class (py, px): only the taps with
+  // (y + pad - r) even contribute, so each class is a dense sub-convolution over its own taps
+  // (no multiply-by-zero work); rows are the class's pixels (y, x) = (2*y2 + py, 2*x2 + px).
+  int ntaps, tap_ns, tap_r0, tap_s0, tap_step;
+  int cls_step, cls_py, cls_px, cls_cy, cls_cx;
+  int full_h, full_w;        // dgrad: spatial extent of dx (row decode when cls_step == 2)
+  long long a_group_bytes;   // bytes of one group of the gathered tensor
+  long long b_bytes;         // bytes of the weight tensor
+  FastDiv tap_ns_div;
 };
 
 // bijective XCD-aware remap of a 1-D grid (cdna_hip_programming.md §5 "XCD swizzle must be
@@ -70,7 +123,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   constexpr int KRPP = 256 / NV;             // k-rows per pass (dgrad B)
   constexpr int B_PASSES_D = (BK + KRPP - 1) / KRPP;
   constexpr int A_ELEMS = BM * LDA;
-  constexpr int B_ELEMS = DGRAD ? BK * LDB : BN * LDA;
+  constexpr int B_ELEMS = DGRAD ? (B_PASSES_D * KRPP) * LDB : (B_PASSES_F * RPP) * LDA;
   static_assert(BM % RPP == 0, "tile");
   __shared__ __attribute__((aligned(16))) float smem[2 * (A_ELEMS + B_ELEMS)];
 
@@ -89,7 +142,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   // ---- A loader state -------------------------------------------------------------------
   const int a_kv = tid % KV;
   const int a_r0 = tid / KV;
-  const float *a_base[A_PASSES];
+  unsigned a_img[A_PASSES];            // byte offset of the row's image inside this group
   int a_y0[A_PASSES], a_x0[A_PASSES];
   bool a_ok[A_PASSES];
   const int ohw = p.out_h * p.out_w;
@@ -102,79 +155,68 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     const int rem = mm - img * ohw;
     const int oy = rem / p.out_w, ox = rem - oy * p.out_w;
     if (DGRAD) {
-      a_y0[i] = oy + p.pad;
-      a_x0[i] = ox + p.pad;
+      a_y0[i] = oy + p.cls_cy;
+      a_x0[i] = ox + p.cls_cx;
     } else {
       a_y0[i] = oy * p.stride - p.pad;
       a_x0[i] = ox * p.stride - p.pad;
     }
-    a_base[i] = p.a + ((long long)g * p.imgs_per_group + img) * p.src_img_stride;
+    a_img[i] = (unsigned)(img * p.src_img_stride * 4);
   }
+  const __amdgpu_buffer_rsrc_t rs_a =
+      make_rsrc(p.a + (long long)g * p.imgs_per_group * p.src_img_stride, p.a_group_bytes);
+  const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(p.b, p.b_bytes);
 
   float4 a_reg[A_PASSES];
   float4 b_reg[DGRAD ? B_PASSES_D : B_PASSES_F];
 
+  // Predicated loads are branch-free (buffer loads: an out-of-range offset reads zeros) so that the
+  // whole K-step stays ONE basic block and the scheduler can interleave loader VALU / VMEM / LDS
+  // traffic with the MFMAs.
   auto load_tiles = [&](int kt) {
     // ---- A: one float4 (4 channels of one tap) per row pass
     const int k0 = kt * BK + a_kv * 4;
     int tap = 0, c = k0;
-    if (p.rs > 1) {
+    if (p.ntaps > 1) {
       tap = k0 >> p.src_c_shift;
       c = k0 - (tap << p.src_c_shift);
     }
-    const int fr = tap / p.s, fs = tap - fr * p.s;
+    const int fr = (int)fdiv((unsigned)tap, p.tap_ns_div), fs = tap - fr * p.tap_ns;   // lattice coordinates (ti, tj)
     const bool kok = k0 < p.ktotal;
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
-      int iy, ix;
-      bool ok = a_ok[i] && kok;
-      if (DGRAD) {
-        const int ty = a_y0[i] - fr, tx = a_x0[i] - fs;
-        ok = ok && ty >= 0 && tx >= 0 && ((ty | tx) & (p.stride - 1)) == 0;
-        iy = ty >> p.stride_shift;
-        ix = tx >> p.stride_shift;
-        ok = ok && iy < p.src_h && ix < p.src_w;
-      } else {
-        iy = a_y0[i] + fr;
-        ix = a_x0[i] + fs;
-        ok = ok && (unsigned)iy < (unsigned)p.src_h && (unsigned)ix < (unsigned)p.src_w;
-      }
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok) v = *reinterpret_cast<const float4 *>(a_base[i] + ((long long)(iy * p.src_w + ix) * p.src_c + c));
-      a_reg[i] = v;
+      const int iy = DGRAD ? a_y0[i] - fr : a_y0[i] + fr;
+      const int ix = DGRAD ? a_x0[i] - fs : a_x0[i] + fs;
+      const bool ok = a_ok[i] & kok & ((unsigned)iy < (unsigned)p.src_h) & ((unsigned)ix < (unsigned)p.src_w);
+      a_reg[i] = buf_ld16(rs_a, pred_off(a_img[i] + (unsigned)((iy * p.src_w + ix) * p.src_c + c) * 4u, ok));
     }
     // ---- B
     if (!DGRAD) {
 #pragma unroll
       for (int i = 0; i < B_PASSES_F; ++i) {
-        const int row = a_r0 + i * RPP;
-        const int n = ntile * BN + row;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < BN && n < p.ncols && kok)
-          v = *reinterpret_cast<const float4 *>(p.b + (long long)n * p.ktotal + k0);
-        b_reg[i] = v;
+        const int n = ntile * BN + a_r0 + i * RPP;
+        b_reg[i] = buf_ld16(rs_b, pred_off((unsigned)(n * p.ktotal + k0) * 4u, (n < p.ncols) & kok));
       }
     } else {
       const int nv = tid % NV;
       const int ncol = ntile * BN + nv * 4;
 #pragma unroll
       for (int i = 0; i < B_PASSES_D; ++i) {
-        const int krow = tid / NV + i * KRPP;
-        const int k = kt * BK + krow;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (krow < BK && k < p.ktotal && ncol < p.ncols) {
-          int btap = 0, o = k;
-          if (p.rs > 1) {
-            btap = k >> p.src_c_shift;
-            o = k - (btap << p.src_c_shift);
-          }
-          v = *reinterpret_cast<const float4 *>(p.b + ((long long)o * p.rs + btap) * p.cin + ncol);
+        const int k = kt * BK + tid / NV + i * KRPP;
+        int bt = 0, o = k;
+        if (p.ntaps > 1) {
+          bt = k >> p.src_c_shift;
+          o = k - (bt << p.src_c_shift);
         }
-        b_reg[i] = v;
+        const int bi = (int)fdiv((unsigned)bt, p.tap_ns_div), bj = bt - bi * p.tap_ns;
+        const int btap = (p.tap_r0 + p.tap_step * bi) * p.s + p.tap_s0 + p.tap_step * bj;
+        b_reg[i] = buf_ld16(rs_b, pred_off((unsigned)((o * p.rs + btap) * p.cin + ncol) * 4u, (k < p.ktotal) & (ncol < p.ncols)));
       }
     }
   };
 
+  // LDS images are allocated for every loader pass (rows beyond the tile land in slack), so the
+  // stores need no predicate either.
   auto store_tiles = [&](int buf) {
     float *As = smem + buf * (A_ELEMS + B_ELEMS);
     float *Bs = As + A_ELEMS;
@@ -183,17 +225,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
       *reinterpret_cast<float4 *>(As + (a_r0 + i * RPP) * LDA + a_kv * 4) = a_reg[i];
     if (!DGRAD) {
 #pragma unroll
-      for (int i = 0; i < B_PASSES_F; ++i) {
-        const int row = a_r0 + i * RPP;
-        if (row < BN) *reinterpret_cast<float4 *>(Bs + row * LDA + a_kv * 4) = b_reg[i];
-      }
+      for (int i = 0; i < B_PASSES_F; ++i)
+        *reinterpret_cast<float4 *>(Bs + (a_r0 + i * RPP) * LDA + a_kv * 4) = b_reg[i];
     } else {
       const int nv = tid % NV;
 #pragma unroll
-      for (int i = 0; i < B_PASSES_D; ++i) {
-        const int krow = tid / NV + i * KRPP;
-        if (krow < BK) *reinterpret_cast<float4 *>(Bs + krow * LDB + nv * 4) = b_reg[i];
-      }
+      for (int i = 0; i < B_PASSES_D; ++i)
+        *reinterpret_cast<float4 *>(Bs + (tid / NV + i * KRPP) * LDB + nv * 4) = b_reg[i];
     }
   };
 
@@ -205,15 +243,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  // 3-stage pipeline: while tile kt multiplies out of LDS[kt&1], tile kt+1 (fetched during the
+  // previous step) is written to LDS[(kt+1)&1] and the global loads of tile kt+2 are issued.  Tiles
+  // past the end are predicated off (zeros), so the loop body has no branches.
   const int KT = (p.ktotal + BK - 1) / BK;
   load_tiles(0);
   store_tiles(0);
+  load_tiles(1);
   __syncthreads();
 
   for (int kt = 0; kt < KT; ++kt) {
     const int cur = kt & 1;
-    const bool more = kt + 1 < KT;
-    if (more) load_tiles(kt + 1);
+    store_tiles(cur ^ 1);
+    load_tiles(kt + 2);
     const float *As = smem + cur * (A_ELEMS + B_ELEMS);
     const float *Bs = As + A_ELEMS;
     // fragments of k-group kg+1 are fetched from LDS while the MFMAs of k-group kg run
@@ -248,7 +290,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(((const float *)&av[kg & 1][i])[t],
                                                              ((const float *)&bv[kg & 1][j])[t], acc[i][j], 0, 0, 0);
     }
-    if (more) store_tiles(cur ^ 1);
+    // schedule hint: issue the next tile's global loads early in the MFMA stream (one load every
+    // two MFMAs) so their latency is covered by the remaining MFMAs of this step.
+    {
+      constexpr int NLOADS = A_PASSES + (DGRAD ? B_PASSES_D : B_PASSES_F);
+#pragma unroll
+      for (int l = 0; l < NLOADS; ++l) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
+      }
+    }
     __syncthreads();
   }
 
@@ -270,7 +321,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
         const bool ok = cok && row < p.rows_per_group;
         float v = acc[i][j][e];
         if (ok) {
-          const long long off = (grow0 + row) * p.ncols + col;
+          long long off;
+          if (DGRAD && p.cls_step == 2) {
+            const int rr = (int)row;
+            const int img = rr / ohw, rem = rr - img * ohw;
+            const int y2 = rem / p.out_w, x2 = rem - y2 * p.out_w;
+            off = ((((long long)g * p.imgs_per_group + img) * p.full_h + 2 * y2 + p.cls_py) * p.full_w + 2 * x2 +
+                   p.cls_px) * p.ncols + col;
+          } else {
+            off = (grow0 + row) * p.ncols + col;
+          }
           if (DGRAD) {
             if (p.mask) v = (p.mask[off] > 0.f) ? v : 0.f;
             if (p.addend) v += p.addend[off];
@@ -323,8 +383,10 @@ struct WgradParams {
   int ncols;        // rs*cin
   long long pixels; // imgs*ho*wo
   long long pixels_per_split;
+  long long x_bytes;
   int mtiles, ntiles;
   int accumulate;   // only meaningful when splits == 1
+  FastDiv ohw_div, wo_div, cin_div, s_div;
 };
 
 template <int BM, int BN, int BK, int WGM, int WGN>
@@ -335,7 +397,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   constexpr int MV = BM / 4, NVB = BN / 4;
   constexpr int A_KRPP = 256 / MV, B_KRPP = 256 / NVB;
   constexpr int A_PASSES = (BK + A_KRPP - 1) / A_KRPP, B_PASSES = (BK + B_KRPP - 1) / B_KRPP;
-  constexpr int A_ELEMS = BK * LDA, B_ELEMS = BK * LDB;
+  constexpr int A_ELEMS = (A_PASSES * A_KRPP) * LDA, B_ELEMS = (B_PASSES * B_KRPP) * LDB;
   __shared__ __attribute__((aligned(16))) float smem[2 * (A_ELEMS + B_ELEMS)];
 
   const int tid = threadIdx.x;
@@ -347,59 +409,56 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   const long long m_begin = (long long)split * p.pixels_per_split;
   long long m_end = m_begin + p.pixels_per_split;
   if (m_end > p.pixels) m_end = p.pixels;
+  const int m_count = m_end > m_begin ? (int)(m_end - m_begin) : 0;       // pixels of this split
+  const int ohw = p.ho * p.wo;
+  const long long img0 = m_begin / ohw;                                    // scalar, once
+  const unsigned rem0 = (unsigned)(m_begin - img0 * ohw);
 
-  // A: dy rows, contiguous along cout
+  // A: dy rows of this split, contiguous along cout.  B: x gathered per (pixel, tap); this thread's
+  // column (tap, c) is fixed for the whole K loop.
+  const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(p.dy + m_begin * p.cout, 4ll * m_count * p.cout);
+  const long long x_img_elems = (long long)p.h * p.w * p.cin;
+  const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(p.x + img0 * x_img_elems, p.x_bytes - 4ll * img0 * x_img_elems);
   const int a_mv = tid % MV, a_k0 = tid / MV;
   const int a_col = mtile * BM + a_mv * 4;
   const bool a_cok = a_col < p.cout;
-  // B: x gather; this thread's column (tap, c) is fixed
   const int b_nv = tid % NVB, b_k0 = tid / NVB;
   const int b_col = ntile * BN + b_nv * 4;
   const bool b_cok = b_col < p.ncols;
-  const int b_tap = b_cok ? b_col / p.cin : 0;
-  const int b_c = b_col - b_tap * p.cin;
-  const int b_fr = b_tap / p.s, b_fs = b_tap - b_fr * p.s;
-  const int ohw = p.ho * p.wo;
+  const int b_tap = (int)fdiv((unsigned)(b_cok ? b_col : 0), p.cin_div);
+  const int b_c = (b_cok ? b_col : 0) - b_tap * p.cin;
+  const int b_fr = (int)fdiv((unsigned)b_tap, p.s_div), b_fs = b_tap - b_fr * p.s;
+  const int b_dy = b_fr - p.pad, b_dx = b_fs - p.pad;
 
   float4 a_reg[A_PASSES], b_reg[B_PASSES];
-  auto load_tiles = [&](long long m0) {
+  auto load_tiles = [&](int kt) {
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
-      const int kr = a_k0 + i * A_KRPP;
-      const long long m = m0 + kr;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (kr < BK && m < m_end && a_cok) v = *reinterpret_cast<const float4 *>(p.dy + m * p.cout + a_col);
-      a_reg[i] = v;
+      const int m = kt * BK + a_k0 + i * A_KRPP;
+      a_reg[i] = buf_ld16(rs_a, pred_off((unsigned)(m * p.cout + a_col) * 4u, (m < m_count) & a_cok));
     }
 #pragma unroll
     for (int i = 0; i < B_PASSES; ++i) {
-      const int kr = b_k0 + i * B_KRPP;
-      const long long m = m0 + kr;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (kr < BK && m < m_end && b_cok) {
-        const long long img = m / ohw;
-        const int rem = (int)(m - img * ohw);
-        const int oy = rem / p.wo, ox = rem - oy * p.wo;
-        const int iy = oy * p.stride - p.pad + b_fr, ix = ox * p.stride - p.pad + b_fs;
-        if ((unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.w)
-          v = *reinterpret_cast<const float4 *>(p.x + ((img * p.h + iy) * p.w + ix) * p.cin + b_c);
-      }
-      b_reg[i] = v;
+      const int m = kt * BK + b_k0 + i * B_KRPP;
+      const unsigned pix = rem0 + (unsigned)m;
+      const unsigned img = fdiv(pix, p.ohw_div);
+      const unsigned rem = pix - img * (unsigned)ohw;
+      const unsigned oy = fdiv(rem, p.wo_div);
+      const unsigned ox = rem - oy * (unsigned)p.wo;
+      const int iy = (int)oy * p.stride + b_dy, ix = (int)ox * p.stride + b_dx;
+      const bool ok = (m < m_count) & b_cok & ((unsigned)iy < (unsigned)p.h) & ((unsigned)ix < (unsigned)p.w);
+      b_reg[i] = buf_ld16(rs_b, pred_off((unsigned)(((img * p.h + iy) * p.w + ix) * p.cin + b_c) * 4u, ok));
     }
   };
   auto store_tiles = [&](int buf) {
     float *As = smem + buf * (A_ELEMS + B_ELEMS);
     float *Bs = As + A_ELEMS;
 #pragma unroll
-    for (int i = 0; i < A_PASSES; ++i) {
-      const int kr = a_k0 + i * A_KRPP;
-      if (kr < BK) *reinterpret_cast<float4 *>(As + kr * LDA + a_mv * 4) = a_reg[i];
-    }
+    for (int i = 0; i < A_PASSES; ++i)
+      *reinterpret_cast<float4 *>(As + (a_k0 + i * A_KRPP) * LDA + a_mv * 4) = a_reg[i];
 #pragma unroll
-    for (int i = 0; i < B_PASSES; ++i) {
-      const int kr = b_k0 + i * B_KRPP;
-      if (kr < BK) *reinterpret_cast<float4 *>(Bs + kr * LDB + b_nv * 4) = b_reg[i];
-    }
+    for (int i = 0; i < B_PASSES; ++i)
+      *reinterpret_cast<float4 *>(Bs + (b_k0 + i * B_KRPP) * LDB + b_nv * 4) = b_reg[i];
   };
 
   f32x16 acc[TM][TN];
@@ -410,16 +469,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const int KT = (int)((m_end - m_begin + BK - 1) / BK);
-  if (KT > 0) {
-    load_tiles(m_begin);
-    store_tiles(0);
-  }
+  const int KT = (m_count + BK - 1) / BK;
+  load_tiles(0);
+  store_tiles(0);
+  load_tiles(1);
   __syncthreads();
   for (int kt = 0; kt < KT; ++kt) {
     const int cur = kt & 1;
-    const bool more = kt + 1 < KT;
-    if (more) load_tiles(m_begin + (long long)(kt + 1) * BK);
+    store_tiles(cur ^ 1);
+    load_tiles(kt + 2);
     const float *As = smem + cur * (A_ELEMS + B_ELEMS);
     const float *Bs = As + A_ELEMS;
 #pragma unroll
@@ -435,7 +493,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
-    if (more) store_tiles(cur ^ 1);
+    {
+      constexpr int NLOADS = A_PASSES + B_PASSES;
+#pragma unroll
+      for (int l = 0; l < NLOADS; ++l) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+    }
     __syncthreads();
   }
 
@@ -529,9 +594,10 @@ static int launch_igemm(IgemmParams &p, TileChoice t, hipStream_t st) {
   static int bk = 0;
   if (bk == 0) {
     const char *e = getenv("MVG_BK");
-    bk = (e && atoi(e) == 16) ? 16 : 32;
+    bk = (e && atoi(e) == 32) ? 32 : 16;
   }
   const bool k32 = bk == 32 && p.ktotal >= 64;
+  if (p.rows_per_group <= 0) return 0;
   if (t.bm == 128 && t.bn == 128) {
     if (k32) hipLaunchKernelGGL((igemm_kernel<128, 128, 32, 2, 2, DGRAD>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((igemm_kernel<128, 128, 16, 2, 2, DGRAD>), grid, block, 0, st, p);
@@ -594,6 +660,14 @@ int mvg_conv_fprop(const mvg_conv_desc *d, const float *x, const float *wgt, flo
   p.rows_per_group = (long long)d->n * d->ho * d->wo;
   p.src_img_stride = (long long)d->h * d->w * d->cin;
   p.imgs_per_group = d->n;
+  p.ntaps = d->r * d->s;
+  p.tap_ns = d->s;
+  p.tap_step = 1;
+  p.cls_step = 1;
+  p.a_group_bytes = 4ll * d->n * p.src_img_stride;
+  p.b_bytes = 4ll * d->cout * p.ktotal;
+  MVG_REQUIRE(p.a_group_bytes < 0x7FFFFFF0ll && p.b_bytes < 0x7FFFFFF0ll, "conv: a group / the weights exceed 2 GiB");
+  p.tap_ns_div = make_fastdiv((unsigned)p.tap_ns);
   const TileChoice t = choose_tile(p.rows_per_group, d->groups, d->cout);
   const double flops = 2.0 * d->groups * (double)p.rows_per_group * d->cout * p.ktotal;
   const double bytes = 4.0 * (d->groups * (double)d->n * d->h * d->w * d->cin + (double)d->cout * p.ktotal +
@@ -630,17 +704,47 @@ int mvg_conv_dgrad(const mvg_conv_desc *d, const float *dy, const float *wgt, fl
   p.pad = d->pad;
   p.ktotal = d->r * d->s * d->cout;
   p.cin = d->cin;
-  p.rows_per_group = (long long)d->n * d->h * d->w;
   p.src_img_stride = (long long)d->ho * d->wo * d->cout;
   p.imgs_per_group = d->n;
-  const TileChoice t = choose_tile(p.rows_per_group, d->groups, d->cin);
+  p.full_h = d->h;
+  p.full_w = d->w;
+  p.a_group_bytes = 4ll * d->n * p.src_img_stride;
+  p.b_bytes = 4ll * d->cout * d->r * d->s * d->cin;
+  MVG_REQUIRE(p.a_group_bytes < 0x7FFFFFF0ll && p.b_bytes < 0x7FFFFFF0ll, "conv: a group / the weights exceed 2 GiB");
   // algorithmic flops: the transposed conv touches each (output pixel, tap) pair of the fprop once
   const double flops = 2.0 * d->groups * (double)d->n * d->ho * d->wo * d->cout * d->r * d->s * d->cin;
   const double bytes = 4.0 * (d->groups * (double)d->n * d->ho * d->wo * d->cout + (double)d->cout * d->r * d->s * d->cin +
-                              d->groups * (double)p.rows_per_group * d->cin);
+                              d->groups * (double)d->n * d->h * d->w * d->cin);
   const bool lin = d->r == 1 && d->s == 1 && d->h == 1 && d->w == 1;
   ProfScope ps(lin ? MVG_K_LINEAR_DGRAD : MVG_K_CONV_DGRAD, (hipStream_t)stream, flops, bytes);
-  return launch_igemm<true>(p, t, (hipStream_t)stream);
+  const int step = d->stride;
+  for (int py = 0; py < step; ++py)
+    for (int px = 0; px < step; ++px) {
+      const int sub_h = (d->h - py + step - 1) / step, sub_w = (d->w - px + step - 1) / step;
+      if (sub_h <= 0 || sub_w <= 0) continue;
+      const int r0 = (py + d->pad) % step, s0 = (px + d->pad) % step;
+      const int nr = r0 < d->r ? (d->r - r0 + step - 1) / step : 0;
+      const int ns = s0 < d->s ? (d->s - s0 + step - 1) / step : 0;
+      IgemmParams q = p;
+      q.out_h = sub_h;
+      q.out_w = sub_w;
+      q.rows_per_group = (long long)d->n * sub_h * sub_w;
+      q.ntaps = nr * ns;
+      q.tap_ns = ns > 0 ? ns : 1;
+      q.tap_ns_div = make_fastdiv((unsigned)q.tap_ns);
+      q.tap_r0 = r0;
+      q.tap_s0 = s0;
+      q.tap_step = step;
+      q.ktotal = nr * ns * d->cout;
+      q.cls_step = step;
+      q.cls_py = py;
+      q.cls_px = px;
+      q.cls_cy = (py + d->pad - r0) / step;
+      q.cls_cx = (px + d->pad - s0) / step;
+      const TileChoice t = choose_tile(q.rows_per_group, d->groups, d->cin);
+      if (launch_igemm<true>(q, t, (hipStream_t)stream)) return 1;
+    }
+  return 0;
 }
 
 static TileChoice wgrad_tile(const mvg_conv_desc *d) {
@@ -692,6 +796,14 @@ int mvg_conv_wgrad(const mvg_conv_desc *d, const float *x, const float *dy, floa
   p.ncols = d->r * d->s * d->cin;
   p.pixels = (long long)d->groups * d->n * d->ho * d->wo;
   p.pixels_per_split = ((p.pixels + splits - 1) / splits + 15) / 16 * 16;
+  p.x_bytes = 4ll * d->groups * d->n * d->h * d->w * d->cin;
+  p.ohw_div = make_fastdiv((unsigned)(d->ho * d->wo));
+  p.wo_div = make_fastdiv((unsigned)d->wo);
+  p.cin_div = make_fastdiv((unsigned)d->cin);
+  p.s_div = make_fastdiv((unsigned)d->s);
+  MVG_REQUIRE(p.pixels_per_split * d->cout * 4ll < 0x7FFFFFF0ll, "wgrad: split too large for 32-bit offsets");
+  MVG_REQUIRE(4ll * (p.pixels_per_split / (d->ho * d->wo) + 2) * d->h * d->w * d->cin < 0x7FFFFFF0ll,
+              "wgrad: split too large for 32-bit offsets");
   const TileChoice t = wgrad_tile(d);
   p.mtiles = ceil_div(d->cout, t.bm);
   p.ntiles = ceil_div(p.ncols, t.bn);

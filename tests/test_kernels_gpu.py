@@ -44,6 +44,11 @@ CONV_CASES = [
     (1, 16, 28, 28, 128, 128, 3, 1, 1),   # -> 128x64 / 128x128
     (2, 2, 7, 7, 512, 512, 3, 1, 1),
     (1, 3, 9, 9, 32, 32, 3, 1, 1),        # 32-wide -> 128x32 tile
+    (2, 4, 16, 16, 64, 128, 3, 2, 1),     # stride 2, even size (parity-class dgrad)
+    (1, 2, 28, 28, 128, 256, 1, 2, 0),    # 1x1 stride 2: three of four parity classes have no tap
+    (1, 2, 17, 18, 64, 64, 7, 2, 3),      # 7x7 stride 2 dgrad (4/3-tap lattices per axis)
+    (2, 8, 56, 56, 256, 512, 1, 2, 0),
+    (2, 64, 56, 56, 64, 128, 1, 2, 0),    # many more wgrad splits than pixels/272: empty trailing splits
 ]
 
 
