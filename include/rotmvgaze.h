@@ -101,6 +101,17 @@ int mvg_conv_wgrad(const mvg_conv_desc *d, const float *x, const float *dy, floa
 /* a split count that fills the device for this shape (host helper, no launch). */
 int mvg_conv_wgrad_splits(const mvg_conv_desc *d);
 
+/* nn.Linear forward / backward-data (backbones/blocks.py:41-47 inside Mlp): the conv kernels with
+ * h = w = r = s = 1 plus split-K - with a few hundred rows the tile grid cannot fill 256 CUs, so
+ * K is cut into slices whose partial tiles land in `workspace` (mvg_linear_workspace_floats()
+ * floats) and are summed, in fixed order, by a reduce kernel that applies the epilogue.
+ *   fprop: y = [relu](x @ w^T + bias);   dgrad: dx = (dy @ w) * (mask > 0) + addend. */
+size_t mvg_linear_workspace_floats(int rows, int fin, int fout);
+int mvg_linear_fprop(const float *x, const float *w, const float *bias, int relu, float *y, int rows,
+                     int fin, int fout, float *workspace, size_t ws_floats, void *stream);
+int mvg_linear_dgrad(const float *dy, const float *w, const float *mask, const float *addend, float *dx,
+                     int rows, int fin, int fout, float *workspace, size_t ws_floats, void *stream);
+
 /* ---------------------------------------------------------------- BatchNorm2d (train + eval)
  * Replaces nn.BatchNorm2d (eps 1e-5, momentum 0.1, affine, track_running_stats) as constructed
  * at resnet.py:185,72-76,119-125 and the ReLU / residual add around it (:74,93-94,140-146). */

@@ -54,6 +54,9 @@ SIGNATURES = {
     "mvg_conv_dgrad": (_I, [_D, _P, _P, _P, _P, _P, _P]),
     "mvg_conv_wgrad": (_I, [_D, _P, _P, _P, _P, _I, _I, _P]),
     "mvg_conv_wgrad_splits": (_I, [_D]),
+    "mvg_linear_workspace_floats": (C.c_size_t, [_I, _I, _I]),
+    "mvg_linear_fprop": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _P, C.c_size_t, _P]),
+    "mvg_linear_dgrad": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, C.c_size_t, _P]),
     "mvg_bn_finalize": (_I, [_P, _I, _I, _I, _I64, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
     "mvg_bn_eval_affine": (_I, [_I, _I, _P, _P, _P, _P, _F, _P, _P, _P]),
     "mvg_bn_apply": (_I, [_P, _P, _P, _P, _I, _P, _I, _I64, _I, _P]),

@@ -98,6 +98,11 @@ struct IgemmParams {
   long long a_group_bytes;   // bytes of one group of the gathered tensor
   long long b_bytes;         // bytes of the weight tensor
   FastDiv tap_ns_div;
+  // split-K (small-M GEMMs: the Linear layers of the fusion block stream 100-240 MB of weights
+  // over <= a few hundred rows; splitting K spreads that stream over every CU).  Partial tiles go
+  // to `slab` [splits][groups*rows][ncols] and splitk_reduce_kernel applies the epilogue.
+  int splits, ktiles_per_split;
+  float *slab;
 };
 
 // bijective XCD-aware remap of a 1-D grid (cdna_hip_programming.md §5 "XCD swizzle must be
@@ -133,7 +138,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   const int li = lane & 31, lh = lane >> 5;
 
   const int nwg = gridDim.x;
-  const int wg = xcd_remap(blockIdx.x, nwg);
+  const int wg_all = xcd_remap(blockIdx.x, nwg);
+  const int tiles_total = nwg / p.splits;
+  const int split = wg_all / tiles_total;
+  const int wg = wg_all - split * tiles_total;
   const int ntile = wg % p.ntiles;
   const int mt_all = wg / p.ntiles;
   const int g = mt_all / p.mtiles_per_group;
@@ -169,6 +177,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 
   float4 a_reg[A_PASSES];
   float4 b_reg[DGRAD ? B_PASSES_D : B_PASSES_F];
+  int klimit = p.ktotal;        // end of this block's K range (split-K)
 
   // Predicated loads are branch-free (buffer loads: an out-of-range offset reads zeros) so that the
   // whole K-step stays ONE basic block and the scheduler can interleave loader VALU / VMEM / LDS
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
       c = k0 - (tap << p.src_c_shift);
     }
     const int fr = (int)fdiv((unsigned)tap, p.tap_ns_div), fs = tap - fr * p.tap_ns;   // lattice coordinates (ti, tj)
-    const bool kok = k0 < p.ktotal;
+    const bool kok = k0 < klimit;
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
       const int iy = DGRAD ? a_y0[i] - fr : a_y0[i] + fr;
@@ -210,7 +219,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
         }
         const int bi = (int)fdiv((unsigned)bt, p.tap_ns_div), bj = bt - bi * p.tap_ns;
         const int btap = (p.tap_r0 + p.tap_step * bi) * p.s + p.tap_s0 + p.tap_step * bj;
-        b_reg[i] = buf_ld16(rs_b, pred_off((unsigned)((o * p.rs + btap) * p.cin + ncol) * 4u, (k < p.ktotal) & (ncol < p.ncols)));
+        b_reg[i] = buf_ld16(rs_b, pred_off((unsigned)((o * p.rs + btap) * p.cin + ncol) * 4u, (k < klimit) & (ncol < p.ncols)));
       }
     }
   };
@@ -246,13 +255,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   // 3-stage pipeline: while tile kt multiplies out of LDS[kt&1], tile kt+1 (fetched during the
   // previous step) is written to LDS[(kt+1)&1] and the global loads of tile kt+2 are issued.  Tiles
   // past the end are predicated off (zeros), so the loop body has no branches.
-  const int KT = (p.ktotal + BK - 1) / BK;
-  load_tiles(0);
-  store_tiles(0);
-  load_tiles(1);
+  const int KT_all = (p.ktotal + BK - 1) / BK;
+  const int kt_begin = split * p.ktiles_per_split;
+  const int KT = (kt_begin + p.ktiles_per_split < KT_all) ? kt_begin + p.ktiles_per_split : KT_all;
+  klimit = KT * BK < p.ktotal ? KT * BK : p.ktotal;
+  load_tiles(kt_begin);
+  store_tiles(kt_begin & 1);
+  load_tiles(kt_begin + 1);
   __syncthreads();
 
-  for (int kt = 0; kt < KT; ++kt) {
+  for (int kt = kt_begin; kt < KT; ++kt) {
     const int cur = kt & 1;
     store_tiles(cur ^ 1);
     load_tiles(kt + 2);
@@ -306,6 +318,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   // ---- epilogue ---------------------------------------------------------------------------
   const long long row_base = (long long)mtile * BM + wm * WTM;
   const long long grow0 = (long long)g * p.rows_per_group;
+  if (p.splits > 1) {       // raw partial tile -> slab; the epilogue runs in splitk_reduce_kernel
+    float *slab = p.slab + (long long)split * p.groups * p.rows_per_group * p.ncols;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = ntile * BN + wn * WTN + j * 32 + li;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const long long row = row_base + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          if (col < p.ncols && row < p.rows_per_group) slab[(grow0 + row) * p.ncols + col] = acc[i][j][e];
+        }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = ntile * BN + wn * WTN + j * 32 + li;
@@ -369,6 +396,36 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
         st[p.ncols + col] = q;
       }
     }
+  }
+}
+
+// out = epilogue(sum_s slab[s]) : fprop (bias, relu) / dgrad (mask, addend); fixed summation order.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float4 *__restrict__ slab, float4 *out, long long n4,
+                                                            int splits, int c4n, const float4 *__restrict__ bias, int relu,
+                                                            const float4 *__restrict__ mask, const float4 *addend) {
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    float4 s = slab[i];
+    for (int k = 1; k < splits; ++k) {
+      const float4 v = slab[(long long)k * n4 + i];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (bias) {
+      const float4 b = bias[i % c4n];
+      s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+    }
+    if (relu) {
+      s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f);
+    }
+    if (mask) {
+      const float4 m = mask[i];
+      s.x = m.x > 0.f ? s.x : 0.f; s.y = m.y > 0.f ? s.y : 0.f; s.z = m.z > 0.f ? s.z : 0.f; s.w = m.w > 0.f ? s.w : 0.f;
+    }
+    if (addend) {
+      const float4 a = addend[i];
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+    out[i] = s;
   }
 }
 
@@ -588,29 +645,51 @@ template <bool DGRAD>
 static int launch_igemm(IgemmParams &p, TileChoice t, hipStream_t st) {
   p.mtiles_per_group = ceil_div(p.rows_per_group, t.bm);
   p.ntiles = ceil_div(p.ncols, t.bn);
-  const long long nblk = (long long)p.groups * p.mtiles_per_group * p.ntiles;
+  if (p.splits < 1) p.splits = 1;
+  if (p.splits == 1) p.ktiles_per_split = 1 << 30;
+  const long long nblk = (long long)p.groups * p.mtiles_per_group * p.ntiles * p.splits;
   MVG_REQUIRE(nblk < (1LL << 31), "conv: grid too large");
   dim3 grid((unsigned)nblk), block(256);
-  static int bk = 0;
-  if (bk == 0) {
-    const char *e = getenv("MVG_BK");
-    bk = (e && atoi(e) == 32) ? 32 : 16;
-  }
-  const bool k32 = bk == 32 && p.ktotal >= 64;
   if (p.rows_per_group <= 0) return 0;
-  if (t.bm == 128 && t.bn == 128) {
-    if (k32) hipLaunchKernelGGL((igemm_kernel<128, 128, 32, 2, 2, DGRAD>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((igemm_kernel<128, 128, 16, 2, 2, DGRAD>), grid, block, 0, st, p);
-  } else if (t.bm == 128 && t.bn == 64) {
-    if (k32) hipLaunchKernelGGL((igemm_kernel<128, 64, 32, 2, 2, DGRAD>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((igemm_kernel<128, 64, 16, 2, 2, DGRAD>), grid, block, 0, st, p);
-  } else if (t.bm == 64 && t.bn == 64) {
-    if (k32) hipLaunchKernelGGL((igemm_kernel<64, 64, 32, 2, 2, DGRAD>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((igemm_kernel<64, 64, 16, 2, 2, DGRAD>), grid, block, 0, st, p);
-  } else {
+  if (t.bm == 128 && t.bn == 128)
+    hipLaunchKernelGGL((igemm_kernel<128, 128, 16, 2, 2, DGRAD>), grid, block, 0, st, p);
+  else if (t.bm == 128 && t.bn == 64)
+    hipLaunchKernelGGL((igemm_kernel<128, 64, 16, 2, 2, DGRAD>), grid, block, 0, st, p);
+  else if (t.bm == 64 && t.bn == 64)
+    hipLaunchKernelGGL((igemm_kernel<64, 64, 16, 2, 2, DGRAD>), grid, block, 0, st, p);
+  else
     hipLaunchKernelGGL((igemm_kernel<128, 32, 16, 4, 1, DGRAD>), grid, block, 0, st, p);
-  }
   return check_launch(DGRAD ? "conv_dgrad" : "conv_fprop");
+}
+
+// split-K plan for a GEMM whose tile grid cannot fill the device: returns splits (>= 1) and sets
+// ktiles_per_split; bounded by the caller's workspace.
+static int plan_splitk(IgemmParams &p, TileChoice t, size_t ws_floats) {
+  p.splits = 1;
+  if (ws_floats == 0 || p.ncols % 4 != 0) return 1;
+  int cus = mvg_device_cus();
+  if (cus <= 0) cus = 256;
+  const long long tiles = (long long)p.groups * ceil_div(p.rows_per_group, t.bm) * ceil_div(p.ncols, t.bn);
+  if (tiles >= cus) return 1;
+  const int KT = ceil_div(p.ktotal, 16);
+  long long s = (2LL * cus + tiles - 1) / tiles;
+  if (s > KT / 8) s = KT / 8;
+  const long long slab = (long long)p.groups * p.rows_per_group * p.ncols;
+  if (s > (long long)(ws_floats / (size_t)slab)) s = (long long)(ws_floats / (size_t)slab);
+  if (s < 2) return 1;
+  p.ktiles_per_split = ceil_div(KT, s);
+  p.splits = ceil_div(KT, p.ktiles_per_split);
+  return p.splits;
+}
+
+static int launch_splitk_reduce(const IgemmParams &p, hipStream_t st) {
+  const long long n = (long long)p.groups * p.rows_per_group * p.ncols;
+  long long blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float4 *)p.slab, (float4 *)p.out,
+                     n / 4, p.splits, p.ncols / 4, (const float4 *)p.bias, p.relu, (const float4 *)p.mask,
+                     (const float4 *)p.addend);
+  return check_launch("splitk_reduce");
 }
 
 static int wave_rows(TileChoice t) { return (t.bn == 32) ? 32 : t.bm / 2; }
@@ -630,8 +709,8 @@ int mvg_conv_stats_partials(const mvg_conv_desc *d, int32_t *rows_per_partial) {
   return ceil_div(rows, t.bm) * (t.bm / wr);
 }
 
-int mvg_conv_fprop(const mvg_conv_desc *d, const float *x, const float *wgt, float *y, const float *bias, int relu,
-                   float *stats, void *stream) {
+static int fprop_impl(const mvg_conv_desc *d, const float *x, const float *wgt, float *y, const float *bias, int relu,
+                      float *stats, float *ws, size_t ws_floats, void *stream) {
   if (validate(d)) return 2;
   IgemmParams p;
   memset(&p, 0, sizeof(p));
@@ -674,11 +753,16 @@ int mvg_conv_fprop(const mvg_conv_desc *d, const float *x, const float *wgt, flo
                               d->groups * (double)p.rows_per_group * d->cout);
   const bool lin = d->r == 1 && d->s == 1 && d->h == 1 && d->w == 1;
   ProfScope ps(lin ? MVG_K_LINEAR_FPROP : MVG_K_CONV_FPROP, (hipStream_t)stream, flops, bytes);
+  if (!stats && plan_splitk(p, t, ws ? ws_floats : 0) > 1) {
+    p.slab = ws;
+    if (launch_igemm<false>(p, t, (hipStream_t)stream)) return 1;
+    return launch_splitk_reduce(p, (hipStream_t)stream);
+  }
   return launch_igemm<false>(p, t, (hipStream_t)stream);
 }
 
-int mvg_conv_dgrad(const mvg_conv_desc *d, const float *dy, const float *wgt, float *dx, const float *mask,
-                   const float *addend, void *stream) {
+static int dgrad_impl(const mvg_conv_desc *d, const float *dy, const float *wgt, float *dx, const float *mask,
+                      const float *addend, float *ws, size_t ws_floats, void *stream) {
   if (validate(d)) return 2;
   MVG_REQUIRE(d->cout % 4 == 0, "dgrad: cout %% 4 != 0 (%d)", d->cout);
   IgemmParams p;
@@ -742,9 +826,52 @@ int mvg_conv_dgrad(const mvg_conv_desc *d, const float *dy, const float *wgt, fl
       q.cls_cy = (py + d->pad - r0) / step;
       q.cls_cx = (px + d->pad - s0) / step;
       const TileChoice t = choose_tile(q.rows_per_group, d->groups, d->cin);
+      if (step == 1 && plan_splitk(q, t, ws ? ws_floats : 0) > 1) {
+        q.slab = ws;
+        if (launch_igemm<true>(q, t, (hipStream_t)stream)) return 1;
+        if (launch_splitk_reduce(q, (hipStream_t)stream)) return 1;
+        continue;
+      }
       if (launch_igemm<true>(q, t, (hipStream_t)stream)) return 1;
     }
   return 0;
+}
+
+static mvg_conv_desc linear_desc(int rows, int fin, int fout) {
+  mvg_conv_desc d = {1, rows, 1, 1, fin, fout, 1, 1, 1, 0, 1, 1};
+  return d;
+}
+
+}  // extern "C" (helpers above are static)
+
+extern "C" {
+
+int mvg_conv_fprop(const mvg_conv_desc *d, const float *x, const float *wgt, float *y, const float *bias, int relu,
+                   float *stats, void *stream) {
+  return fprop_impl(d, x, wgt, y, bias, relu, stats, nullptr, 0, stream);
+}
+
+int mvg_conv_dgrad(const mvg_conv_desc *d, const float *dy, const float *wgt, float *dx, const float *mask,
+                   const float *addend, void *stream) {
+  return dgrad_impl(d, dy, wgt, dx, mask, addend, nullptr, 0, stream);
+}
+
+size_t mvg_linear_workspace_floats(int rows, int fin, int fout) {
+  // up to 16 K-slices of the larger of the two GEMM outputs (fprop: rows x fout, dgrad: rows x fin)
+  const size_t m = (size_t)rows * (size_t)(fin > fout ? fin : fout);
+  return 16 * m;
+}
+
+int mvg_linear_fprop(const float *x, const float *w, const float *bias, int relu, float *y, int rows, int fin, int fout,
+                     float *workspace, size_t ws_floats, void *stream) {
+  const mvg_conv_desc d = linear_desc(rows, fin, fout);
+  return fprop_impl(&d, x, w, y, bias, relu, nullptr, workspace, ws_floats, stream);
+}
+
+int mvg_linear_dgrad(const float *dy, const float *w, const float *mask, const float *addend, float *dx, int rows,
+                     int fin, int fout, float *workspace, size_t ws_floats, void *stream) {
+  const mvg_conv_desc d = linear_desc(rows, fin, fout);
+  return dgrad_impl(&d, dy, w, dx, mask, addend, workspace, ws_floats, stream);
 }
 
 static TileChoice wgrad_tile(const mvg_conv_desc *d) {

@@ -50,13 +50,12 @@ class _Mlp2:
         rows = x.shape[0]
         dev = x.device
         h = torch.empty(rows, self.hid, dtype=torch.float32, device=dev)
-        ops.conv_fprop(ConvDesc.linear(rows, self.fin, self.hid), x, self.w0.detach(), h, self.b0.detach(), True, None)
+        ops.linear_fprop(x, self.w0.detach(), self.b0.detach(), True, h, rows, self.fin, self.hid)
         y = out if out is not None else torch.empty(rows, self.fout, dtype=torch.float32, device=dev)
         if self.fout <= 4:
             ops.linear_skinny_fwd(h, self.w1.detach(), self.b1.detach(), y, rows, self.hid, self.fout)
         else:
-            ops.conv_fprop(ConvDesc.linear(rows, self.hid, self.fout), h, self.w1.detach(), y, self.b1.detach(), False,
-                           None)
+            ops.linear_fprop(h, self.w1.detach(), self.b1.detach(), False, y, rows, self.hid, self.fout)
         return h, y
 
     def backward(self, x: Tensor, h: Tensor, gy: Tensor, sink: GradSink, dx_addend: Optional[Tensor] = None,
@@ -71,14 +70,14 @@ class _Mlp2:
                                   self.hid, self.fout, acc)
         else:
             d1 = ConvDesc.linear(rows, self.hid, self.fout)
-            ops.conv_dgrad(d1, gy, self.w1.detach(), dh, h, None)                 # (gy @ W1) * (h > 0)
+            ops.linear_dgrad(gy, self.w1.detach(), h, None, dh, rows, self.hid, self.fout)   # (gy @ W1) * (h > 0)
             ops.conv_wgrad(d1, h, gy, sink.view(self.w1), sink.accumulate(self.w1))
             ops.colsum(gy, sink.view(self.b1), rows, self.fout, sink.accumulate(self.b1))
         d0 = ConvDesc.linear(rows, self.fin, self.hid)
         ops.conv_wgrad(d0, x, dh, sink.view(self.w0), sink.accumulate(self.w0))
         ops.colsum(dh, sink.view(self.b0), rows, self.hid, sink.accumulate(self.b0))
         dx = dx_out if dx_out is not None else torch.empty(rows, self.fin, dtype=torch.float32, device=dev)
-        ops.conv_dgrad(d0, dh, self.w0.detach(), dx, None, dx_addend)
+        ops.linear_dgrad(dh, self.w0.detach(), None, dx_addend, dx, rows, self.fin, self.hid)
         return dx
 
 

@@ -60,6 +60,24 @@ def conv_wgrad(d: ConvDesc, x: Tensor, dy: Tensor, dw: Tensor, accumulate: bool 
     check(lib().mvg_conv_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _p(ws), splits, int(accumulate), _s()), "conv_wgrad")
 
 
+def _linear_ws(x: Tensor, rows: int, fin: int, fout: int):
+    n = lib().mvg_linear_workspace_floats(rows, fin, fout)
+    return torch.empty(n, dtype=torch.float32, device=x.device), n
+
+
+def linear_fprop(x: Tensor, w: Tensor, bias: Optional[Tensor], relu: bool, y: Tensor, rows: int, fin: int, fout: int):
+    ws, n = _linear_ws(x, rows, fin, fout)
+    check(lib().mvg_linear_fprop(_p(x), _p(w), _p(bias), int(relu), _p(y), rows, fin, fout, _p(ws), n, _s()),
+          "linear_fprop")
+
+
+def linear_dgrad(dy: Tensor, w: Tensor, mask: Optional[Tensor], addend: Optional[Tensor], dx: Tensor, rows: int,
+                 fin: int, fout: int):
+    ws, n = _linear_ws(dy, rows, fin, fout)
+    check(lib().mvg_linear_dgrad(_p(dy), _p(w), _p(mask), _p(addend), _p(dx), rows, fin, fout, _p(ws), n, _s()),
+          "linear_dgrad")
+
+
 # ---------------------------------------------------------------- batch norm
 def bn_finalize(stats, groups, partials, rows_per_partial, rows_per_group, c, gamma, beta, running_mean, running_var,
                 momentum, eps, mean, invstd, scale, shift):

@@ -144,6 +144,14 @@ def test_linear_via_conv(rows, fin, fout, relu):
     db = torch.empty(fout, device=dev())
     ops.colsum(g, db, rows, fout)
     close(db, br.grad, what="bias grad")
+    # split-K entry points (what the fusion block calls), incl. the fused mask / addend epilogue
+    y2 = torch.empty(rows, fout, device=dev())
+    ops.linear_fprop(xd, wd, bd, relu, y2, rows, fin, fout)
+    close(y2, yr, what="linear_fprop (split-K)")
+    mask, add = rnd((rows, fin), 8).to(dev()), rnd((rows, fin), 9).to(dev())
+    dx2 = add.clone()
+    ops.linear_dgrad(g, wd, mask, dx2, dx2, rows, fin, fout)
+    close(dx2, xr.grad * (mask.cpu() > 0) + add.cpu(), what="linear_dgrad (split-K, mask+addend)")
 
 
 def test_linear_skinny():
