@@ -114,8 +114,15 @@ def main():
     world = args.gpus
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        assert int(os.environ.get("WORLD_SIZE", "1")) == world, "launch with torch.distributed.run (see docstring)"
+    force_dist = os.environ.get("MVG_FORCE_DIST") == "1"      # rehearse the RCCL path with one rank
+    if world > 1 or force_dist:
+        if world > 1:
+            assert int(os.environ.get("WORLD_SIZE", "1")) == world, "launch with torch.distributed.run (see docstring)"
+        else:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank if world > 1 else 0)
@@ -134,7 +141,7 @@ def main():
     rot = rotation_matrix_2d(torch.from_numpy(inp["head_pose"]).reshape(-1, 2).to(dev)).reshape(B, V, 3, 3)
     del inp
     criterion = MultiViewIterationLoss(rel_weight=0.01, reference_decay=1.0, iter_decay=0.5)
-    reducer = GradAllReducer(model, bucket_mb=args.bucket_mb) if world > 1 else None
+    reducer = GradAllReducer(model, bucket_mb=args.bucket_mb, force=force_dist) if (world > 1 or force_dist) else None
 
     def step():
         model.zero_grad(set_to_none=True)
@@ -144,7 +151,7 @@ def main():
         return loss
 
     def fence():
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -180,9 +187,19 @@ def main():
         ms = sum(e["ms"] for e in conv)
         launches = sum(e["launches"] for e in conv)
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        traffic, traffic_src = None, None
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*pmc_traffic_{args.workload}.json")))
+        if cands and not args.batch:
+            with open(cands[-1]) as f:
+                tj = json.load(f)
+            traffic, traffic_src = tj["traffic_bytes_per_launch"], os.path.relpath(cands[-1], ROOT)
         roofline = {"bound": "mfma", "kernel": "igemm_kernel/wgrad_kernel (fp32 MFMA implicit-GEMM conv: fprop+dgrad+wgrad)",
                     "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE*2 + WRITE_SIZE, separate passes)",
+                    "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": sum(e["bytes"] for e in conv) / max(launches, 1),
                     "flop_per_launch": flops / max(launches, 1), "avg_launch_ms": ms / max(launches, 1),
                     "launches_per_step": launches / nprof, "kernel_ms_per_step": ms / nprof}
         families = {k: {"ms_per_step": round(e["ms"] / nprof, 4), "launches_per_step": e["launches"] / nprof,
@@ -209,7 +226,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "kernel_families": families,
         }
         print(json.dumps(line))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

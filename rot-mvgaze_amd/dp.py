@@ -19,12 +19,13 @@ import torch.distributed as dist
 
 
 class GradAllReducer:
-    def __init__(self, model, bucket_mb: float = 64.0, process_group=None, average: bool = True):
+    def __init__(self, model, bucket_mb: float = 64.0, process_group=None, average: bool = True, force: bool = False):
         self.model = model
         self.pg = process_group
         self.average = average
         self.bucket_bytes = int(bucket_mb * (1 << 20))
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.force = force            # run the collectives even with one rank (rehearsal of the RCCL path)
         self._built_for = None
         self._side: Optional[torch.cuda.Stream] = None
         model._on_grads_ready = self._on_ready
@@ -58,7 +59,7 @@ class GradAllReducer:
     def _launch(self, b: int):
         s, e = self.buckets[b]
         buf = self.arena[s:e]
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         if self.arena.is_cuda:
             ev = torch.cuda.Event()
@@ -86,22 +87,7 @@ class GradAllReducer:
         while self._next < len(self.buckets):         # anything left (should be nothing)
             self._launch(self._next)
             self._next += 1
-        if self.arena.is_cuda and self.world > 1:
+        if self.arena.is_cuda and (self.world > 1 or self.force):
             torch.cuda.current_stream().wait_stream(self._side)
         self._next = 0
         self._done_upto = 0
-
-
-def allreduce_arena_cpu(arena: torch.Tensor, entries, bucket_mb: float, world: int, pg=None) -> None:
-    """Same bucketing over a CPU tensor with gloo (used by the world_size-2 CPU tests)."""
-    r = GradAllReducer.__new__(GradAllReducer)
-    r.pg, r.average, r.bucket_bytes, r.world = pg, True, int(bucket_mb * (1 << 20)), world
-    r._built_for, r._side = None, None
-
-    class _M:
-        def grad_arena(self_inner):
-            return arena, entries
-    r.model = _M()
-    r._build()
-    r._on_ready([p for (p, _, _) in entries])
-    r._on_done()
