@@ -41,7 +41,7 @@ class GradSink:
 
 class _Unit:
     """Saved state of one conv + BN (+ReLU) (+residual) for the backward pass."""
-    __slots__ = ("spec", "desc", "x_in", "y", "out", "mean", "invstd", "relu", "rows", "w")
+    __slots__ = ("spec", "desc", "x_in", "y", "out", "mean", "invstd", "relu", "rows", "w", "wp_t")
 
 
 class Backbone:
@@ -78,14 +78,24 @@ class Backbone:
         rm, rv = self.p[c.bn + ".running_mean"], self.p[c.bn + ".running_var"]
         aff = torch.empty(4, G, c.cout, dtype=torch.float32, device=dev)
         mean, invstd, scale, shift = aff[0], aff[1], aff[2], aff[3]
+        # bf16x6 conv math: the weights are split into three bf16 planes once per step (fprop reads
+        # [cout][tap][cin]; backward-data reads the transposed [cin][tap][cout] planes)
+        x6 = ops.conv_math() == 1
+        wp = ops.weight_split(d, w, False) if x6 else None
+
+        def fprop(stats_buf):
+            if wp is not None:
+                ops.conv_fprop_wp(d, x, wp, y, stats_buf)
+            else:
+                ops.conv_fprop(d, x, w, y, None, False, stats_buf)
         if training:
             P, rpp = ops.conv_stats_partials(d)
             stats = torch.empty(G, P, 2, c.cout, dtype=torch.float32, device=dev)
-            ops.conv_fprop(d, x, w, y, None, False, stats)
+            fprop(stats)
             ops.bn_finalize(stats, G, P, rpp, rows, c.cout, gamma, beta, rm, rv, BN_MOMENTUM, BN_EPS, mean, invstd,
                             scale, shift)
         else:
-            ops.conv_fprop(d, x, w, y, None, False, None)
+            fprop(None)
             ops.bn_eval_affine(G, c.cout, gamma, beta, rm, rv, BN_EPS, scale, shift)
         keep = tape is not None
         out = torch.empty_like(y) if keep else y            # inference: normalise in place
@@ -94,6 +104,7 @@ class Backbone:
             u = _Unit()
             u.spec, u.desc, u.x_in, u.y, u.out, u.mean, u.invstd, u.relu, u.rows, u.w = \
                 c, d, x, y, out, mean, invstd, relu, rows, w
+            u.wp_t = x6 and cin >= 64
             tape.append(u)
         return out
 
@@ -183,8 +194,15 @@ class Backbone:
         dx = None
         if need_dx:
             dx = torch.empty_like(u.x_in)
-            ops.conv_dgrad(u.desc, dy, u.w, dx, None, addend)
+            self._dgrad(u, dy, dx, addend)
         return dx
+
+    @staticmethod
+    def _dgrad(u: _Unit, dy: Tensor, dx: Tensor, addend: Optional[Tensor]):
+        if u.wp_t:
+            ops.conv_dgrad_wp(u.desc, dy, ops.weight_split(u.desc, u.w, True), dx, None, addend)
+        else:
+            ops.conv_dgrad(u.desc, dy, u.w, dx, None, addend)
 
     def backward(self, tape: dict, dfeat: Tensor, sink: GradSink, need_dimg: bool = False):
         """dfeat [V,B,fc_dim] -> parameter gradients into ``sink`` (published layer4 ... stem, the
@@ -217,7 +235,7 @@ class Backbone:
                 dyd, _ = self._bn_bwd(ud, dz, False, sink)
                 ops.conv_wgrad(ud.desc, ud.x_in, dyd, sink.view(P[ud.spec.name + ".weight"]),
                                sink.accumulate(P[ud.spec.name + ".weight"]))
-                ops.conv_dgrad(ud.desc, dyd, ud.w, d, None, d)            # d += dgrad (aliasing addend)
+                self._dgrad(ud, dyd, d, d)                                # d += dgrad (aliasing addend)
                 done += [P[ud.spec.name + ".weight"], P[ud.spec.bn + ".weight"], P[ud.spec.bn + ".bias"]]
                 ud.y = ud.out = None
             sink.publish(done)

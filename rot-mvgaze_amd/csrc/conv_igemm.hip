@@ -103,6 +103,7 @@ struct IgemmParams {
   // to `slab` [splits][groups*rows][ncols] and splitk_reduce_kernel applies the epilogue.
   int splits, ktiles_per_split;
   float *slab;
+  int b_row_pad;             // bf16x6 with pre-split weights: padded row length of the planes
 };
 
 // bijective XCD-aware remap of a 1-D grid (cdna_hip_programming.md §5 "XCD swizzle must be
@@ -111,6 +112,97 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
   const int q = nwg >> 3, rr = nwg & 7, xcd = orig & 7;
   const int base = (xcd < rr) ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q;
   return base + (orig >> 3);
+}
+
+// Shared epilogue of the implicit-GEMM kernels (C/D layout of the 32x32 MFMA is dtype-independent):
+// split-K slab store, or bias/ReLU + BN partial statistics (fprop), or ReLU mask + addend (dgrad).
+template <int BM, int BN, int WGM, int WGN, bool DGRAD>
+__device__ __forceinline__ void igemm_epilogue(const IgemmParams &p, f32x16 (&acc)[BM / WGM / 32][BN / WGN / 32], int g,
+                                               int mtile, int ntile, int split, int wm, int wn, int li, int lh,
+                                               int ohw) {
+  constexpr int WTM = BM / WGM, WTN = BN / WGN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  const long long row_base = (long long)mtile * BM + wm * WTM;
+  const long long grow0 = (long long)g * p.rows_per_group;
+  if (p.splits > 1) {       // raw partial tile -> slab; the epilogue runs in splitk_reduce_kernel
+    float *slab = p.slab + (long long)split * p.groups * p.rows_per_group * p.ncols;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = ntile * BN + wn * WTN + j * 32 + li;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const long long row = row_base + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          if (col < p.ncols && row < p.rows_per_group) slab[(grow0 + row) * p.ncols + col] = acc[i][j][e];
+        }
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = ntile * BN + wn * WTN + j * 32 + li;
+    const bool cok = col < p.ncols;
+    float bias = 0.f;
+    if (!DGRAD && p.bias && cok) bias = p.bias[col];
+    float csum = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const long long row = row_base + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const bool ok = cok && row < p.rows_per_group;
+        float v = acc[i][j][e];
+        if (ok) {
+          long long off;
+          if (DGRAD && p.cls_step == 2) {
+            const int rr = (int)row;
+            const int img = rr / ohw, rem = rr - img * ohw;
+            const int y2 = rem / p.out_w, x2 = rem - y2 * p.out_w;
+            off = ((((long long)g * p.imgs_per_group + img) * p.full_h + 2 * y2 + p.cls_py) * p.full_w + 2 * x2 +
+                   p.cls_px) * p.ncols + col;
+          } else {
+            off = (grow0 + row) * p.ncols + col;
+          }
+          if (DGRAD) {
+            if (p.mask) v = (p.mask[off] > 0.f) ? v : 0.f;
+            if (p.addend) v += p.addend[off];
+          } else {
+            v += bias;
+            if (p.relu) v = fmaxf(v, 0.f);
+            csum += v;
+          }
+          p.out[off] = v;
+        }
+      }
+    }
+    if (!DGRAD && p.stats) {
+      // per-wave partial: column sum and sum of squares centred on the partial's own mean
+      long long cnt_ll = p.rows_per_group - row_base;
+      const int cnt = cnt_ll <= 0 ? 0 : (cnt_ll > WTM ? WTM : (int)cnt_ll);
+      csum += __shfl_xor(csum, 32, 64);
+      const float mean = cnt > 0 ? csum / (float)cnt : 0.f;
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const long long row = row_base + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          if (row < p.rows_per_group) {
+            const float dlt = acc[i][j][e] - mean;
+            q += dlt * dlt;
+          }
+        }
+      q += __shfl_xor(q, 32, 64);
+      if (lh == 0 && cok) {
+        const long long P = (long long)p.mtiles_per_group * WGM;
+        const long long pi = (long long)mtile * WGM + wm;
+        float *st = p.stats + (((long long)g * P + pi) * 2) * p.ncols;
+        st[col] = csum;
+        st[p.ncols + col] = q;
+      }
+    }
+  }
 }
 
 template <int BM, int BN, int BK, int WGM, int WGN, bool DGRAD>
@@ -315,87 +407,311 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     __syncthreads();
   }
 
-  // ---- epilogue ---------------------------------------------------------------------------
-  const long long row_base = (long long)mtile * BM + wm * WTM;
-  const long long grow0 = (long long)g * p.rows_per_group;
-  if (p.splits > 1) {       // raw partial tile -> slab; the epilogue runs in splitk_reduce_kernel
-    float *slab = p.slab + (long long)split * p.groups * p.rows_per_group * p.ncols;
+  igemm_epilogue<BM, BN, WGM, WGN, DGRAD>(p, acc, g, mtile, ntile, split, wm, wn, li, lh, ohw);
+}
+
+// ------------------------------------------------------------------------------------------
+// fp32-accurate convolution on the bf16 matrix cores ("bf16x6")
+// ------------------------------------------------------------------------------------------
+// Every fp32 operand is split EXACTLY into three bf16 pieces by truncation,
+//   a = hi + mid + lo,   hi = a & 0xFFFF0000,  mid = (a - hi) & 0xFFFF0000,  lo = a - hi - mid
+// (3 x 8 significant bits = the 24-bit fp32 mantissa), and the product a*b is accumulated in fp32 as
+//   lo*hi' + hi*lo' + mid*mid' + mid*hi' + hi*mid' + hi*hi'
+// with six v_mfma_f32_32x32x16_bf16 (bf16 x bf16 products are exact in fp32; the three dropped
+// cross terms are <= 2^-24 relative).  Six bf16 MFMAs per 16-deep k-step cost 6 x 32 cycles vs
+// 8 x 64 cycles for the fp32 MFMA: a 2.67x higher matrix roof (2.5 PF / 6 = 417 TFLOP/s) at
+// fp32-level accuracy (tests hold the same tolerances for both paths).
+// The split happens once per element when a tile goes registers -> LDS; LDS holds 3 bf16 planes
+// per operand, [row][k] with rows padded to 80 bytes (conflict-free ds_read_b128 fragments).
+// Both operands are k-contiguous: dgrad reads weights pre-transposed to [cin][r][s][cout].
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split3(float v, unsigned &h, unsigned &m, unsigned &l) {
+  h = __float_as_uint(v) & 0xFFFF0000u;
+  const float r1 = v - __uint_as_float(h);
+  m = __float_as_uint(r1) & 0xFFFF0000u;
+  l = __float_as_uint(r1 - __uint_as_float(m));      // <= 8 significant bits left: exact in bf16
+}
+__device__ __forceinline__ unsigned pack_hi16(unsigned e0, unsigned e1) { return (e0 >> 16) | (e1 & 0xFFFF0000u); }
+
+// BPL = the B operand (weights) arrives pre-split as three bf16 planes [3][n][b_row_pad] (made once
+// per step by weight_split_kernel), so only the gathered activations are split in the kernel.
+template <int BM, int BN, int BK, int WGM, int WGN, bool DGRAD, bool BPL>
+__global__ __launch_bounds__(256) void igemm6_kernel(IgemmParams p) {
+  constexpr int WTM = BM / WGM, WTN = BN / WGN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int KV = BK / 4;                 // float4 per row
+  constexpr int RPP = 256 / KV;              // 32 rows per loader pass
+  constexpr int A_PASSES = BM / RPP, B_PASSES = BN / RPP;
+  constexpr int LDK = BK + 8;                // bf16 elements per LDS row (80 bytes)
+  constexpr int A_PLANE = BM * LDK, B_PLANE = BN * LDK;       // elements
+  constexpr int BUF = 3 * (A_PLANE + B_PLANE);
+  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile");
+  __shared__ __attribute__((aligned(16))) unsigned short smem[2 * BUF];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int li = lane & 31, lh = lane >> 5;
+
+  const int nwg = gridDim.x;
+  const int wg_all = xcd_remap(blockIdx.x, nwg);
+  const int tiles_total = nwg / p.splits;
+  const int split = wg_all / tiles_total;
+  const int wg = wg_all - split * tiles_total;
+  const int ntile = wg % p.ntiles;
+  const int mt_all = wg / p.ntiles;
+  const int g = mt_all / p.mtiles_per_group;
+  const int mtile = mt_all - g * p.mtiles_per_group;
+
+  const int a_kv = tid % KV;
+  const int a_r0 = tid / KV;
+  unsigned a_img[A_PASSES];
+  int a_y0[A_PASSES], a_x0[A_PASSES];
+  bool a_ok[A_PASSES];
+  const int ohw = p.out_h * p.out_w;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = ntile * BN + wn * WTN + j * 32 + li;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const long long row = row_base + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-          if (col < p.ncols && row < p.rows_per_group) slab[(grow0 + row) * p.ncols + col] = acc[i][j][e];
-        }
+  for (int i = 0; i < A_PASSES; ++i) {
+    const long long m = (long long)mtile * BM + a_r0 + i * RPP;
+    a_ok[i] = m < p.rows_per_group;
+    const int mm = a_ok[i] ? (int)m : 0;
+    const int img = mm / ohw;
+    const int rem = mm - img * ohw;
+    const int oy = rem / p.out_w, ox = rem - oy * p.out_w;
+    if (DGRAD) {
+      a_y0[i] = oy + p.cls_cy;
+      a_x0[i] = ox + p.cls_cx;
+    } else {
+      a_y0[i] = oy * p.stride - p.pad;
+      a_x0[i] = ox * p.stride - p.pad;
     }
-    return;
+    a_img[i] = (unsigned)(img * p.src_img_stride * 4);
   }
+  const __amdgpu_buffer_rsrc_t rs_a =
+      make_rsrc(p.a + (long long)g * p.imgs_per_group * p.src_img_stride, p.a_group_bytes);
+  const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(p.b, p.b_bytes);
+
+  float4 a_reg[A_PASSES], b_reg[BPL ? 1 : B_PASSES];
+  constexpr int BCH = BK / 8;                          // 16-byte chunks (8 bf16) per row per plane
+  constexpr int B_LOADS = (3 * BN * BCH + 255) / 256;  // pre-split B: 16-byte copies per thread
+  u32x4 bp_reg[BPL ? B_LOADS : 1];
+  int klimit = p.ktotal;
+
+  auto load_tiles = [&](int kt) {
+    const int k0 = kt * BK + a_kv * 4;
+    int tap = 0, c = k0;
+    if (p.ntaps > 1) {
+      tap = k0 >> p.src_c_shift;
+      c = k0 - (tap << p.src_c_shift);
+    }
+    const int fr = (int)fdiv((unsigned)tap, p.tap_ns_div), fs = tap - fr * p.tap_ns;
+    const bool kok = k0 < klimit;
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = ntile * BN + wn * WTN + j * 32 + li;
-    const bool cok = col < p.ncols;
-    float bias = 0.f;
-    if (!DGRAD && p.bias && cok) bias = p.bias[col];
-    float csum = 0.f;
+    for (int i = 0; i < A_PASSES; ++i) {
+      const int iy = DGRAD ? a_y0[i] - fr : a_y0[i] + fr;
+      const int ix = DGRAD ? a_x0[i] - fs : a_x0[i] + fs;
+      const bool ok = a_ok[i] & kok & ((unsigned)iy < (unsigned)p.src_h) & ((unsigned)ix < (unsigned)p.src_w);
+      a_reg[i] = buf_ld16(rs_a, pred_off(a_img[i] + (unsigned)((iy * p.src_w + ix) * p.src_c + c) * 4u, ok));
+    }
+    // B rows are output columns n; fprop: w[n][k] (KRSC); dgrad: w_t[n = cin][filter tap][cout]
+    unsigned bk_off;
+    if (DGRAD) {
+      const int btap = (p.tap_r0 + p.tap_step * fr) * p.s + p.tap_s0 + p.tap_step * fs;
+      bk_off = (unsigned)(btap * p.src_c + c);
+    } else {
+      bk_off = (unsigned)k0;
+    }
+    const unsigned b_row_elems = DGRAD ? (unsigned)(p.rs * p.src_c) : (unsigned)p.ktotal;
+    if (!BPL) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+      for (int i = 0; i < B_PASSES; ++i) {
+        const int n = ntile * BN + a_r0 + i * RPP;
+        b_reg[i] = buf_ld16(rs_b, pred_off(((unsigned)n * b_row_elems + bk_off) * 4u, (n < p.ncols) & kok));
+      }
+    } else {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const long long row = row_base + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        const bool ok = cok && row < p.rows_per_group;
-        float v = acc[i][j][e];
-        if (ok) {
-          long long off;
-          if (DGRAD && p.cls_step == 2) {
-            const int rr = (int)row;
-            const int img = rr / ohw, rem = rr - img * ohw;
-            const int y2 = rem / p.out_w, x2 = rem - y2 * p.out_w;
-            off = ((((long long)g * p.imgs_per_group + img) * p.full_h + 2 * y2 + p.cls_py) * p.full_w + 2 * x2 +
-                   p.cls_px) * p.ncols + col;
-          } else {
-            off = (grow0 + row) * p.ncols + col;
+      for (int i = 0; i < B_LOADS; ++i) {
+        const int idx = tid + i * 256;                 // (plane, row, chunk)
+        const int pl = idx / (BN * BCH);
+        const int rem = idx - pl * (BN * BCH);
+        const int row = rem / BCH, ch = rem - row * BCH;
+        const int n = ntile * BN + row;
+        const int kk = kt * BK + ch * 8;
+        unsigned koff;
+        if (DGRAD) {
+          int t2 = 0, c2 = kk;
+          if (p.ntaps > 1) {
+            t2 = kk >> p.src_c_shift;
+            c2 = kk - (t2 << p.src_c_shift);
           }
-          if (DGRAD) {
-            if (p.mask) v = (p.mask[off] > 0.f) ? v : 0.f;
-            if (p.addend) v += p.addend[off];
-          } else {
-            v += bias;
-            if (p.relu) v = fmaxf(v, 0.f);
-            csum += v;
-          }
-          p.out[off] = v;
+          const int r2 = (int)fdiv((unsigned)t2, p.tap_ns_div), s2 = t2 - r2 * p.tap_ns;
+          koff = (unsigned)(((p.tap_r0 + p.tap_step * r2) * p.s + p.tap_s0 + p.tap_step * s2) * p.src_c + c2);
+        } else {
+          koff = (unsigned)kk;
         }
+        const bool ok = (pl < 3) & (n < p.ncols) & (kk < klimit);
+        const unsigned off = (((unsigned)pl * (unsigned)p.ncols + (unsigned)n) * (unsigned)p.b_row_pad + koff) * 2u;
+        bp_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, pred_off(off, ok), 0, 0);
       }
     }
-    if (!DGRAD && p.stats) {
-      // per-wave partial: column sum and sum of squares centred on the partial's own mean
-      long long cnt_ll = p.rows_per_group - row_base;
-      const int cnt = cnt_ll <= 0 ? 0 : (cnt_ll > WTM ? WTM : (int)cnt_ll);
-      csum += __shfl_xor(csum, 32, 64);
-      const float mean = cnt > 0 ? csum / (float)cnt : 0.f;
-      float q = 0.f;
+  };
+
+  auto store_tiles = [&](int buf) {
+    unsigned short *A0 = smem + buf * BUF;
+    unsigned short *B0 = A0 + 3 * A_PLANE;
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+      unsigned h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
+      split3(a_reg[i].x, h0, m0, l0);
+      split3(a_reg[i].y, h1, m1, l1);
+      split3(a_reg[i].z, h2, m2, l2);
+      split3(a_reg[i].w, h3, m3, l3);
+      unsigned short *d = A0 + (a_r0 + i * RPP) * LDK + a_kv * 4;
+      *reinterpret_cast<uint2 *>(d) = make_uint2(pack_hi16(h0, h1), pack_hi16(h2, h3));
+      *reinterpret_cast<uint2 *>(d + A_PLANE) = make_uint2(pack_hi16(m0, m1), pack_hi16(m2, m3));
+      *reinterpret_cast<uint2 *>(d + 2 * A_PLANE) = make_uint2(pack_hi16(l0, l1), pack_hi16(l2, l3));
+    }
+    if (!BPL) {
+#pragma unroll
+      for (int i = 0; i < B_PASSES; ++i) {
+        unsigned h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
+        split3(b_reg[i].x, h0, m0, l0);
+        split3(b_reg[i].y, h1, m1, l1);
+        split3(b_reg[i].z, h2, m2, l2);
+        split3(b_reg[i].w, h3, m3, l3);
+        unsigned short *d = B0 + (a_r0 + i * RPP) * LDK + a_kv * 4;
+        *reinterpret_cast<uint2 *>(d) = make_uint2(pack_hi16(h0, h1), pack_hi16(h2, h3));
+        *reinterpret_cast<uint2 *>(d + B_PLANE) = make_uint2(pack_hi16(m0, m1), pack_hi16(m2, m3));
+        *reinterpret_cast<uint2 *>(d + 2 * B_PLANE) = make_uint2(pack_hi16(l0, l1), pack_hi16(l2, l3));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < B_LOADS; ++i) {
+        const int idx = tid + i * 256;
+        const int pl = idx / (BN * BCH);
+        const int rem = idx - pl * (BN * BCH);
+        const int row = rem / BCH, ch = rem - row * BCH;
+        if (3 * BN * BCH % 256 == 0 || pl < 3)
+          *reinterpret_cast<u32x4 *>(B0 + pl * B_PLANE + row * LDK + ch * 8) = bp_reg[i];
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int KT_all = (p.ktotal + BK - 1) / BK;
+  const int kt_begin = split * p.ktiles_per_split;
+  const int KT = (kt_begin + p.ktiles_per_split < KT_all) ? kt_begin + p.ktiles_per_split : KT_all;
+  klimit = KT * BK < p.ktotal ? KT * BK : p.ktotal;
+  load_tiles(kt_begin);
+  store_tiles(kt_begin & 1);
+  __syncthreads();
+
+  auto mfma_kstep = [&](const unsigned short *A0, const unsigned short *B0, int ks) {
+    bf16x8 af[3][TM], bf[3][TN];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
+        af[pl][i] = *reinterpret_cast<const bf16x8 *>(A0 + pl * A_PLANE + (wm * WTM + i * 32 + li) * LDK + ks * 16 + lh * 8);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const long long row = row_base + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-          if (row < p.rows_per_group) {
-            const float dlt = acc[i][j][e] - mean;
-            q += dlt * dlt;
-          }
-        }
-      q += __shfl_xor(q, 32, 64);
-      if (lh == 0 && cok) {
-        const long long P = (long long)p.mtiles_per_group * WGM;
-        const long long pi = (long long)mtile * WGM + wm;
-        float *st = p.stats + (((long long)g * P + pi) * 2) * p.ncols;
-        st[col] = csum;
-        st[p.ncols + col] = q;
+      for (int j = 0; j < TN; ++j)
+        bf[pl][j] = *reinterpret_cast<const bf16x8 *>(B0 + pl * B_PLANE + (wn * WTN + j * 32 + li) * LDK + ks * 16 + lh * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        f32x16 c = acc[i][j];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], c, 0, 0, 0);   // lo * hi
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], c, 0, 0, 0);   // hi * lo
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], c, 0, 0, 0);   // mid * mid
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], c, 0, 0, 0);   // mid * hi
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], c, 0, 0, 0);   // hi * mid
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], c, 0, 0, 0);   // hi * hi
+        acc[i][j] = c;
+      }
+  };
+
+  for (int kt = kt_begin; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    const unsigned short *A0 = smem + cur * BUF;
+    const unsigned short *B0 = A0 + 3 * A_PLANE;
+    // Two-stage pipeline with no loop-carried registers: the global loads of tile kt+1 are issued
+    // first and land while the first k-step multiplies; the second k-step's MFMAs are interleaved
+    // with the split (VALU) of the freshly loaded tile, whose ds_writes go to the other LDS buffer
+    // after this step's fragment reads in program order.
+    load_tiles(kt + 1);
+    if (BK == 32) {
+      mfma_kstep(A0, B0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_kstep(A0, B0, BK / 16 - 1);
+    } else {
+      mfma_kstep(A0, B0, 0);
+    }
+    store_tiles(cur ^ 1);
+    {
+      constexpr int NMFMA = TM * TN * 6;
+      constexpr int NVALU = 6 * (A_PASSES + B_PASSES) * 4 + 16;
+      constexpr int PER = (NVALU + NMFMA - 1) / NMFMA;
+#pragma unroll
+      for (int q = 0; q < NMFMA; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, PER, 0);   // PER VALU
       }
     }
+    __syncthreads();
+  }
+  igemm_epilogue<BM, BN, WGM, WGN, DGRAD>(p, acc, g, mtile, ntile, split, wm, wn, li, lh, ohw);
+}
+
+// w_t[c][r][s][o] = w[o][r][s][c]   (dgrad's k-contiguous weight operand; once per step per layer)
+__global__ __launch_bounds__(256) void weight_transpose_kernel(const float *__restrict__ w, float *__restrict__ wt,
+                                                               int cout, int rs, int cin) {
+  __shared__ float tile[32][33];
+  const int tap = blockIdx.z;
+  const int c0 = blockIdx.x * 32, o0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+  for (int k = ty; k < 32; k += 8) {
+    const int o = o0 + k, c = c0 + tx;
+    tile[k][tx] = (o < cout && c < cin) ? w[((long long)o * rs + tap) * cin + c] : 0.f;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int c = c0 + k, o = o0 + tx;
+    if (c < cin && o < cout) wt[((long long)c * rs + tap) * cout + o] = tile[tx][k];
+  }
+}
+
+// planes[pl][n][kpad] (bf16) = exact 3-way split of the weights, rows zero-padded to kpad.
+// transpose == 0: n = cout, k = (tap, cin)  [fprop];  1: n = cin, k = (tap, cout)  [dgrad].
+__global__ __launch_bounds__(256) void weight_split_kernel(const float *__restrict__ w, unsigned short *__restrict__ planes,
+                                                           int cout, int rs, int cin, int kpad, int transpose) {
+  const int nrows = transpose ? cin : cout;
+  const int klen = transpose ? rs * cout : rs * cin;
+  const long long total = (long long)nrows * kpad;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int n = (int)(i / kpad), k = (int)(i - (long long)n * kpad);
+    float v = 0.f;
+    if (k < klen) {
+      if (transpose) {
+        const int tap = k / cout, o = k - tap * cout;
+        v = w[((long long)o * rs + tap) * cin + n];
+      } else {
+        v = w[(long long)n * klen + k];
+      }
+    }
+    unsigned h, m, l;
+    split3(v, h, m, l);
+    planes[i] = (unsigned short)(h >> 16);
+    planes[total + i] = (unsigned short)(m >> 16);
+    planes[2 * total + i] = (unsigned short)(l >> 16);
   }
 }
 
@@ -662,6 +978,49 @@ static int launch_igemm(IgemmParams &p, TileChoice t, hipStream_t st) {
   return check_launch(DGRAD ? "conv_dgrad" : "conv_fprop");
 }
 
+// conv math: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = bf16x6 split on the bf16 MFMA
+static int g_conv_math = -1;
+static int conv_math() {
+  if (g_conv_math < 0) {
+    const char *e = getenv("MVG_CONV_MATH");
+    g_conv_math = (e && (!strcmp(e, "bf16x6") || !strcmp(e, "1"))) ? 1 : 0;
+  }
+  return g_conv_math;
+}
+
+template <bool DGRAD, bool BPL>
+static int launch_igemm6(IgemmParams &p, TileChoice t, hipStream_t st) {
+  p.mtiles_per_group = ceil_div(p.rows_per_group, t.bm);
+  p.ntiles = ceil_div(p.ncols, t.bn);
+  p.splits = 1;
+  p.ktiles_per_split = 1 << 30;
+  const long long nblk = (long long)p.groups * p.mtiles_per_group * p.ntiles;
+  MVG_REQUIRE(nblk < (1LL << 31), "conv: grid too large");
+  if (p.rows_per_group <= 0) return 0;
+  dim3 grid((unsigned)nblk), block(256);
+  if (t.bm == 128 && t.bn == 128)
+    hipLaunchKernelGGL((igemm6_kernel<128, 128, 16, 2, 2, DGRAD, BPL>), grid, block, 0, st, p);
+  else if (t.bm == 128 && t.bn == 64)
+    hipLaunchKernelGGL((igemm6_kernel<128, 64, 16, 2, 2, DGRAD, BPL>), grid, block, 0, st, p);
+  else
+    hipLaunchKernelGGL((igemm6_kernel<64, 64, 16, 2, 2, DGRAD, BPL>), grid, block, 0, st, p);
+  return check_launch(DGRAD ? "conv_dgrad(bf16x6)" : "conv_fprop(bf16x6)");
+}
+
+// tile for the bf16x6 kernels: one workgroup per CU is resident (LDS), so prefer the biggest tile
+// that still gives every CU >= ~2 tiles.
+static TileChoice choose_tile6(long long rows_per_group, int groups, int ncols) {
+  int cus = mvg_device_cus();
+  if (cus <= 0) cus = 256;
+  const TileChoice cand[3] = {{128, 128}, {128, 64}, {64, 64}};
+  for (int i = 0; i < 3; ++i) {
+    if (cand[i].bn > 64 && ncols < 128) continue;
+    const long long blocks = (long long)groups * ceil_div(rows_per_group, cand[i].bm) * ceil_div(ncols, cand[i].bn);
+    if (blocks >= 2LL * cus) return cand[i];
+  }
+  return {64, 64};
+}
+
 // split-K plan for a GEMM whose tile grid cannot fill the device: returns splits (>= 1) and sets
 // ktiles_per_split; bounded by the caller's workspace.
 static int plan_splitk(IgemmParams &p, TileChoice t, size_t ws_floats) {
@@ -703,14 +1062,16 @@ extern "C" {
 int mvg_conv_stats_partials(const mvg_conv_desc *d, int32_t *rows_per_partial) {
   if (validate(d)) return -1;
   const long long rows = (long long)d->n * d->ho * d->wo;
-  const TileChoice t = choose_tile(rows, d->groups, d->cout);
+  const bool lin = d->r == 1 && d->s == 1 && d->h == 1 && d->w == 1;
+  const TileChoice t = (!lin && conv_math() == 1 && d->cout >= 64) ? choose_tile6(rows, d->groups, d->cout)
+                                                                  : choose_tile(rows, d->groups, d->cout);
   const int wr = wave_rows(t);
   if (rows_per_partial) *rows_per_partial = wr;
   return ceil_div(rows, t.bm) * (t.bm / wr);
 }
 
 static int fprop_impl(const mvg_conv_desc *d, const float *x, const float *wgt, float *y, const float *bias, int relu,
-                      float *stats, float *ws, size_t ws_floats, void *stream) {
+                      float *stats, float *ws, size_t ws_floats, void *stream, const void *wplanes = nullptr) {
   if (validate(d)) return 2;
   IgemmParams p;
   memset(&p, 0, sizeof(p));
@@ -753,6 +1114,16 @@ static int fprop_impl(const mvg_conv_desc *d, const float *x, const float *wgt, 
                               d->groups * (double)p.rows_per_group * d->cout);
   const bool lin = d->r == 1 && d->s == 1 && d->h == 1 && d->w == 1;
   ProfScope ps(lin ? MVG_K_LINEAR_FPROP : MVG_K_CONV_FPROP, (hipStream_t)stream, flops, bytes);
+  if (!lin && conv_math() == 1 && d->cout >= 64) {
+    const TileChoice t6 = choose_tile6(p.rows_per_group, d->groups, d->cout);
+    if (wplanes) {
+      p.b = (const float *)wplanes;
+      p.b_row_pad = (p.ktotal + 7) / 8 * 8;
+      p.b_bytes = 3ll * d->cout * p.b_row_pad * 2;
+      return launch_igemm6<false, true>(p, t6, (hipStream_t)stream);
+    }
+    return launch_igemm6<false, false>(p, t6, (hipStream_t)stream);
+  }
   if (!stats && plan_splitk(p, t, ws ? ws_floats : 0) > 1) {
     p.slab = ws;
     if (launch_igemm<false>(p, t, (hipStream_t)stream)) return 1;
@@ -762,7 +1133,8 @@ static int fprop_impl(const mvg_conv_desc *d, const float *x, const float *wgt, 
 }
 
 static int dgrad_impl(const mvg_conv_desc *d, const float *dy, const float *wgt, float *dx, const float *mask,
-                      const float *addend, float *ws, size_t ws_floats, void *stream) {
+                      const float *addend, float *ws, size_t ws_floats, void *stream, bool wgt_transposed = false,
+                      const void *wplanes = nullptr) {
   if (validate(d)) return 2;
   MVG_REQUIRE(d->cout % 4 == 0, "dgrad: cout %% 4 != 0 (%d)", d->cout);
   IgemmParams p;
@@ -825,6 +1197,23 @@ static int dgrad_impl(const mvg_conv_desc *d, const float *dy, const float *wgt,
       q.cls_px = px;
       q.cls_cy = (py + d->pad - r0) / step;
       q.cls_cx = (px + d->pad - s0) / step;
+      if (wgt_transposed) {
+        if (q.ktotal == 0) {       // parity class without taps: zeros (+ mask/addend) via the fp32 kernel's K=0 path
+          const TileChoice t0 = choose_tile(q.rows_per_group, d->groups, d->cin);
+          if (launch_igemm<true>(q, t0, (hipStream_t)stream)) return 1;
+          continue;
+        }
+        const TileChoice t6 = choose_tile6(q.rows_per_group, d->groups, d->cin);
+        if (wplanes) {
+          q.b = (const float *)wplanes;
+          q.b_row_pad = d->r * d->s * d->cout;          // multiple of 8 (cout >= 64)
+          q.b_bytes = 3ll * d->cin * q.b_row_pad * 2;
+          if (launch_igemm6<true, true>(q, t6, (hipStream_t)stream)) return 1;
+        } else {
+          if (launch_igemm6<true, false>(q, t6, (hipStream_t)stream)) return 1;
+        }
+        continue;
+      }
       const TileChoice t = choose_tile(q.rows_per_group, d->groups, d->cin);
       if (step == 1 && plan_splitk(q, t, ws ? ws_floats : 0) > 1) {
         q.slab = ws;
@@ -854,6 +1243,62 @@ int mvg_conv_fprop(const mvg_conv_desc *d, const float *x, const float *wgt, flo
 int mvg_conv_dgrad(const mvg_conv_desc *d, const float *dy, const float *wgt, float *dx, const float *mask,
                    const float *addend, void *stream) {
   return dgrad_impl(d, dy, wgt, dx, mask, addend, nullptr, 0, stream);
+}
+
+int mvg_conv_math(void) { return conv_math(); }
+int mvg_set_conv_math(int mode) {
+  MVG_REQUIRE(mode == 0 || mode == 1, "conv math mode must be 0 (fp32 MFMA) or 1 (bf16x6)");
+  g_conv_math = mode;
+  return 0;
+}
+
+int mvg_weight_transpose(const mvg_conv_desc *d, const float *wgt, float *wgt_t, void *stream) {
+  if (validate(d)) return 2;
+  hipStream_t st = (hipStream_t)stream;
+  const int rs = d->r * d->s;
+  ProfScope ps(MVG_K_LAYOUT, st, 0.0, 8.0 * d->cout * rs * d->cin);
+  hipLaunchKernelGGL(weight_transpose_kernel, dim3(ceil_div(d->cin, 32), ceil_div(d->cout, 32), rs), dim3(256), 0, st, wgt,
+                     wgt_t, d->cout, rs, d->cin);
+  return check_launch("weight_transpose");
+}
+
+size_t mvg_weight_planes_bytes(const mvg_conv_desc *d, int transpose) {
+  const long long nrows = transpose ? d->cin : d->cout;
+  const long long klen = (long long)d->r * d->s * (transpose ? d->cout : d->cin);
+  return (size_t)(3 * nrows * ((klen + 7) / 8 * 8) * 2);
+}
+
+int mvg_weight_split(const mvg_conv_desc *d, const float *wgt, int transpose, void *planes, void *stream) {
+  if (validate(d)) return 2;
+  hipStream_t st = (hipStream_t)stream;
+  const int rs = d->r * d->s;
+  const int klen = rs * (transpose ? d->cout : d->cin);
+  const int kpad = (klen + 7) / 8 * 8;
+  const long long total = (long long)(transpose ? d->cin : d->cout) * kpad;
+  ProfScope ps(MVG_K_LAYOUT, st, 0.0, 10.0 * total);
+  long long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(weight_split_kernel, dim3((unsigned)blocks), dim3(256), 0, st, wgt, (unsigned short *)planes, d->cout, rs,
+                     d->cin, kpad, transpose);
+  return check_launch("weight_split");
+}
+
+int mvg_conv_fprop_wp(const mvg_conv_desc *d, const float *x, const void *wplanes, float *y, float *stats, void *stream) {
+  MVG_REQUIRE(d && d->cout >= 64, "fprop_wp: cout must be >= 64");
+  MVG_REQUIRE(conv_math() == 1, "fprop_wp needs conv math mode 1 (bf16x6)");
+  return fprop_impl(d, x, nullptr, y, nullptr, 0, stats, nullptr, 0, stream, wplanes);
+}
+
+int mvg_conv_dgrad_wp(const mvg_conv_desc *d, const float *dy, const void *wplanes_t, float *dx, const float *mask,
+                      const float *addend, void *stream) {
+  MVG_REQUIRE(d && d->cin >= 64 && d->cout >= 64 && d->cout % 8 == 0, "dgrad_wp: cin, cout must be >= 64");
+  return dgrad_impl(d, dy, nullptr, dx, mask, addend, nullptr, 0, stream, true, wplanes_t);
+}
+
+int mvg_conv_dgrad_wt(const mvg_conv_desc *d, const float *dy, const float *wgt_t, float *dx, const float *mask,
+                      const float *addend, void *stream) {
+  MVG_REQUIRE(d && d->cin >= 64 && d->cin % 4 == 0, "dgrad_wt: cin must be >= 64");
+  return dgrad_impl(d, dy, wgt_t, dx, mask, addend, nullptr, 0, stream, true);
 }
 
 size_t mvg_linear_workspace_floats(int rows, int fin, int fout) {

@@ -18,7 +18,7 @@ Tensor = torch.Tensor
 def _p(t: Optional[Tensor]):
     if t is None:
         return None
-    assert t.is_cuda and t.dtype in (torch.float32, torch.int32, torch.uint8), (t.device, t.dtype)
+    assert t.is_cuda and t.dtype in (torch.float32, torch.int32, torch.uint8, torch.int16), (t.device, t.dtype)
     return C.c_void_p(t.data_ptr())
 
 
@@ -48,6 +48,41 @@ def conv_fprop(d: ConvDesc, x: Tensor, w: Tensor, y: Tensor, bias: Optional[Tens
 def conv_dgrad(d: ConvDesc, dy: Tensor, w: Tensor, dx: Tensor, mask: Optional[Tensor] = None,
                addend: Optional[Tensor] = None):
     check(lib().mvg_conv_dgrad(C.byref(d), _p(dy), _p(w), _p(dx), _p(mask), _p(addend), _s()), "conv_dgrad")
+
+
+def conv_math() -> int:
+    return lib().mvg_conv_math()
+
+
+def set_conv_math(mode: int):
+    check(lib().mvg_set_conv_math(mode), "set_conv_math")
+
+
+def weight_transpose(d: ConvDesc, w: Tensor, wt: Tensor):
+    check(lib().mvg_weight_transpose(C.byref(d), _p(w), _p(wt), _s()), "weight_transpose")
+
+
+def conv_dgrad_wt(d: ConvDesc, dy: Tensor, wt: Tensor, dx: Tensor, mask: Optional[Tensor] = None,
+                  addend: Optional[Tensor] = None):
+    check(lib().mvg_conv_dgrad_wt(C.byref(d), _p(dy), _p(wt), _p(dx), _p(mask), _p(addend), _s()), "conv_dgrad_wt")
+
+
+def weight_split(d: ConvDesc, w: Tensor, transpose: bool) -> Tensor:
+    """three bf16 planes (opaque int16 buffer) of the weights, for conv_fprop_wp / conv_dgrad_wp."""
+    nbytes = lib().mvg_weight_planes_bytes(C.byref(d), int(transpose))
+    planes = torch.empty(nbytes // 2, dtype=torch.int16, device=w.device)
+    check(lib().mvg_weight_split(C.byref(d), _p(w), int(transpose), _p(planes), _s()), "weight_split")
+    return planes
+
+
+def conv_fprop_wp(d: ConvDesc, x: Tensor, wplanes: Tensor, y: Tensor, stats: Optional[Tensor] = None):
+    check(lib().mvg_conv_fprop_wp(C.byref(d), _p(x), _p(wplanes), _p(y), _p(stats), _s()), "conv_fprop_wp")
+
+
+def conv_dgrad_wp(d: ConvDesc, dy: Tensor, wplanes_t: Tensor, dx: Tensor, mask: Optional[Tensor] = None,
+                  addend: Optional[Tensor] = None):
+    check(lib().mvg_conv_dgrad_wp(C.byref(d), _p(dy), _p(wplanes_t), _p(dx), _p(mask), _p(addend), _s()),
+          "conv_dgrad_wp")
 
 
 def conv_wgrad(d: ConvDesc, x: Tensor, dy: Tensor, dw: Tensor, accumulate: bool = False):

@@ -17,8 +17,10 @@ y = torch.empty(G, N, d.ho, d.wo, cout, device=dev)
 P, rpp = ops.conv_stats_partials(d)
 stats = torch.empty(G, P, 2, cout, device=dev)
 gy = torch.randn_like(y); dx = torch.empty_like(x); dw = torch.empty_like(w)
+wp = ops.weight_split(d, w, False) if ops.conv_math() == 1 and cout >= 64 else None
 for _ in range(iters):
-    if op == "fprop": ops.conv_fprop(d, x, w, y, None, False, stats)
+    if op == "fprop" and wp is not None: ops.conv_fprop_wp(d, x, wp, y, stats)
+    elif op == "fprop": ops.conv_fprop(d, x, w, y, None, False, stats)
     elif op == "dgrad": ops.conv_dgrad(d, gy, w, dx)
     else: ops.conv_wgrad(d, x, gy, dw)
 torch.cuda.synchronize()
