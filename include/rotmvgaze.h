@@ -93,25 +93,23 @@ int mvg_conv_dgrad(const mvg_conv_desc *d, const float *dy, const float *wgt, fl
                    const float *mask, const float *addend, void *stream);
 
 /* Conv math mode: 0 = fp32 matrix cores (v_mfma_f32_32x32x2_f32), 1 = "bf16x6": each fp32 operand
- * is split exactly into three bf16 pieces and every product is six bf16 MFMAs accumulated in fp32
- * (fp32-level accuracy at a 2.67x higher matrix roof).  Default 0 (the parity-pinned path); env
- * MVG_CONV_MATH=bf16x6 or mvg_set_conv_math(1) selects 1 (experimental this round).
- * In mode 1 backward-data takes the weights pre-transposed to [cin][r][s][cout] (mvg_weight_transpose,
- * once per step per layer) so that both GEMM operands are k-contiguous. */
+ * is split EXACTLY into three bf16 pieces (hi + mid + lo == value) and every product is six bf16
+ * MFMAs accumulated in fp32 - fp32-level accuracy at a 2.67x higher matrix roof (2.5 PF / 6).
+ * Default 0 (env MVG_CONV_MATH=bf16x6 or mvg_set_conv_math(1) selects 1).  In mode 1
+ * mvg_conv_fprop / mvg_conv_dgrad split their fp32 operands inside the kernel; the _pp entry
+ * points take operands already split by their producers in the plane-interleaved format: a row of
+ * C values is C/8 groups of [hi x8 | mid x8 | lo x8] bf16 (48 bytes), so a K-slice of a row is one
+ * contiguous run.  mvg_split_planes converts any [rows][c] fp32 buffer (c % 8 == 0, 6 bytes per
+ * element out); mvg_weight_split converts the weights once per step (transpose = 0: rows = cout,
+ * k = (tap, cin) for fprop; 1: rows = cin, k = (tap, cout) for dgrad; k zero-padded to 8). */
 int mvg_conv_math(void);
 int mvg_set_conv_math(int mode);
-int mvg_weight_transpose(const mvg_conv_desc *d, const float *wgt, float *wgt_t, void *stream);
-int mvg_conv_dgrad_wt(const mvg_conv_desc *d, const float *dy, const float *wgt_t, float *dx,
-                      const float *mask, const float *addend, void *stream);
-/* bf16x6 with the weight operand split ahead of time: mvg_weight_split writes three bf16 planes
- * [3][rows][kpad] (transpose = 0: rows = cout, k = (tap, cin) for fprop; 1: rows = cin,
- * k = (tap, cout) for dgrad; kpad = k rounded up to 8, zero filled; mvg_weight_planes_bytes bytes)
- * once per step, and the _wp entry points read them, so the kernels split only the activations. */
+int mvg_split_planes(const float *x, void *planes, int64_t rows, int c, void *stream);
 size_t mvg_weight_planes_bytes(const mvg_conv_desc *d, int transpose);
 int mvg_weight_split(const mvg_conv_desc *d, const float *wgt, int transpose, void *planes, void *stream);
-int mvg_conv_fprop_wp(const mvg_conv_desc *d, const float *x, const void *wplanes, float *y, float *stats,
-                      void *stream);
-int mvg_conv_dgrad_wp(const mvg_conv_desc *d, const float *dy, const void *wplanes_t, float *dx,
+int mvg_conv_fprop_pp(const mvg_conv_desc *d, const void *xplanes, const void *wplanes, float *y,
+                      float *stats, void *stream);
+int mvg_conv_dgrad_pp(const mvg_conv_desc *d, const void *dyplanes, const void *wplanes_t, float *dx,
                       const float *mask, const float *addend, void *stream);
 
 /* dw[cout][r][s][cin] (+)= sum over all groups/images/pixels of dy (x) x.  Split over the pixel

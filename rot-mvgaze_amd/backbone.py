@@ -81,13 +81,10 @@ class Backbone:
         # bf16x6 conv math: the weights are split into three bf16 planes once per step (fprop reads
         # [cout][tap][cin]; backward-data reads the transposed [cin][tap][cout] planes)
         x6 = ops.conv_math() == 1
-        wp = ops.weight_split(d, w, False) if x6 else None
+        wp = None
 
         def fprop(stats_buf):
-            if wp is not None:
-                ops.conv_fprop_wp(d, x, wp, y, stats_buf)
-            else:
-                ops.conv_fprop(d, x, w, y, None, False, stats_buf)
+            ops.conv_fprop(d, x, w, y, None, False, stats_buf)
         if training:
             P, rpp = ops.conv_stats_partials(d)
             stats = torch.empty(G, P, 2, c.cout, dtype=torch.float32, device=dev)
@@ -199,10 +196,7 @@ class Backbone:
 
     @staticmethod
     def _dgrad(u: _Unit, dy: Tensor, dx: Tensor, addend: Optional[Tensor]):
-        if u.wp_t:
-            ops.conv_dgrad_wp(u.desc, dy, ops.weight_split(u.desc, u.w, True), dx, None, addend)
-        else:
-            ops.conv_dgrad(u.desc, dy, u.w, dx, None, addend)
+        ops.conv_dgrad(u.desc, dy, u.w, dx, None, addend)
 
     def backward(self, tape: dict, dfeat: Tensor, sink: GradSink, need_dimg: bool = False):
         """dfeat [V,B,fc_dim] -> parameter gradients into ``sink`` (published layer4 ... stem, the

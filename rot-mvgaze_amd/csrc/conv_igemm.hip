@@ -434,10 +434,9 @@ __device__ __forceinline__ void split3(float v, unsigned &h, unsigned &m, unsign
 }
 __device__ __forceinline__ unsigned pack_hi16(unsigned e0, unsigned e1) { return (e0 >> 16) | (e1 & 0xFFFF0000u); }
 
-// BPL = the B operand (weights) arrives pre-split as three bf16 planes [3][n][b_row_pad] (made once
-// per step by weight_split_kernel), so only the gathered activations are split in the kernel.
-template <int BM, int BN, int BK, int WGM, int WGN, bool DGRAD, bool BPL>
+template <int BM, int BN, int BK, int WGM, int WGN, bool DGRAD>
 __global__ __launch_bounds__(256) void igemm6_kernel(IgemmParams p) {
+  constexpr bool BPL = false;
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int KV = BK / 4;                 // float4 per row
@@ -671,26 +670,204 @@ __global__ __launch_bounds__(256) void igemm6_kernel(IgemmParams p) {
   igemm_epilogue<BM, BN, WGM, WGN, DGRAD>(p, acc, g, mtile, ntile, split, wm, wn, li, lh, ohw);
 }
 
-// w_t[c][r][s][o] = w[o][r][s][c]   (dgrad's k-contiguous weight operand; once per step per layer)
-__global__ __launch_bounds__(256) void weight_transpose_kernel(const float *__restrict__ w, float *__restrict__ wt,
-                                                               int cout, int rs, int cin) {
-  __shared__ float tile[32][33];
-  const int tap = blockIdx.z;
-  const int c0 = blockIdx.x * 32, o0 = blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
-  for (int k = ty; k < 32; k += 8) {
-    const int o = o0 + k, c = c0 + tx;
-    tile[k][tx] = (o < cout && c < cin) ? w[((long long)o * rs + tap) * cin + c] : 0.f;
+// bf16x6 with BOTH operands pre-split into bf16 planes by their producers (activations: bn_apply /
+// bn_bwd_apply / maxpool write three planes next to the fp32 tensor; weights: weight_split_kernel):
+// the loader is pure 16-byte copies global -> registers -> LDS, three-stage pipelined like the fp32
+// kernel, and the wave's VALU stays free for addressing.  BM = 128, BK = 16 (one MFMA k-step per
+// tile), LDS 3 planes x (BM + BN) rows x 48 B x 2 buffers = 36-72 KB -> two workgroups per CU.
+template <int BN, int BK, bool DGRAD>
+__global__ __launch_bounds__(256) void igemm6p_kernel(IgemmParams p) {
+  constexpr int BM = 128, WGM = 2, WGN = 2;
+  constexpr int WTM = BM / WGM, WTN = BN / WGN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int BCH = BK / 8;                 // channel groups (8 bf16 = 16 bytes per plane) per row
+  constexpr int RCH = 3 * BCH;                // 16-byte chunks per row: [grp][plane], contiguous in HBM
+  constexpr int LDK = BK + 8;                 // 48-byte LDS rows: conflict-free ds_read_b128
+  constexpr int A_PLANE = BM * LDK, B_PLANE = BN * LDK;
+  constexpr int BUF = 3 * (A_PLANE + B_PLANE);
+  constexpr int A_LOADS = BM * RCH / 256, B_LOADS = (BN * RCH + 255) / 256;
+  static_assert(BM * RCH % 256 == 0, "tile");
+  __shared__ __attribute__((aligned(16))) unsigned short smem[2 * BUF];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int nwg = gridDim.x;
+  const int wg = xcd_remap(blockIdx.x, nwg);
+  const int ntile = wg % p.ntiles;
+  const int mt_all = wg / p.ntiles;
+  const int g = mt_all / p.mtiles_per_group;
+  const int mtile = mt_all - g * p.mtiles_per_group;
+  const int split = 0;
+
+  // A chunk idx = tid + i*256 -> (row = idx / RCH, j = idx % RCH -> group j / 3, plane j % 3):
+  // RCH consecutive lanes copy one row's contiguous 16*RCH bytes.
+  const int ohw = p.out_h * p.out_w;
+  int a_y0[A_LOADS], a_x0[A_LOADS], a_row[A_LOADS], a_j[A_LOADS];
+  unsigned a_img[A_LOADS];
+  bool a_ok[A_LOADS];
+#pragma unroll
+  for (int i = 0; i < A_LOADS; ++i) {
+    const int idx = tid + i * 256;
+    a_row[i] = idx / RCH;
+    a_j[i] = idx - a_row[i] * RCH;
+    const long long am = (long long)mtile * BM + a_row[i];
+    a_ok[i] = am < p.rows_per_group;
+    const int mm = a_ok[i] ? (int)am : 0;
+    const int img = mm / ohw;
+    const int rem = mm - img * ohw;
+    const int oy = rem / p.out_w, ox = rem - oy * p.out_w;
+    a_y0[i] = DGRAD ? oy + p.cls_cy : oy * p.stride - p.pad;
+    a_x0[i] = DGRAD ? ox + p.cls_cx : ox * p.stride - p.pad;
+    a_img[i] = (unsigned)(img * p.src_img_stride * 6);          // 3 planes x 2 bytes per element
   }
+  const unsigned short *a0 = reinterpret_cast<const unsigned short *>(p.a) + (long long)g * p.imgs_per_group * p.src_img_stride * 3;
+  const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(a0, p.a_group_bytes);
+  const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(p.b, p.b_bytes);
+
+  u32x4 a_reg[A_LOADS], b_reg[B_LOADS];
+  auto load_tiles = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+      const int grp = a_j[i] / 3, pl = a_j[i] - grp * 3;
+      const int kk = kt * BK + grp * 8;
+      int tap = 0, c = kk;
+      if (p.ntaps > 1) {
+        tap = kk >> p.src_c_shift;
+        c = kk - (tap << p.src_c_shift);
+      }
+      const int fr = (int)fdiv((unsigned)tap, p.tap_ns_div), fs = tap - fr * p.tap_ns;
+      const int iy = DGRAD ? a_y0[i] - fr : a_y0[i] + fr;
+      const int ix = DGRAD ? a_x0[i] - fs : a_x0[i] + fs;
+      const bool ok = a_ok[i] & (kk < p.ktotal) & ((unsigned)iy < (unsigned)p.src_h) & ((unsigned)ix < (unsigned)p.src_w);
+      const unsigned off = a_img[i] + ((unsigned)((iy * p.src_w + ix) * p.src_c + c) * 3u + (unsigned)pl * 8u) * 2u;
+      a_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, pred_off(off, ok), 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx / RCH, j = idx - row * RCH;
+      const int grp = j / 3, pl = j - grp * 3;
+      const int n = ntile * BN + row;
+      const int kb = kt * BK + grp * 8;
+      unsigned koff;
+      if (DGRAD) {
+        int t2 = 0, c2 = kb;
+        if (p.ntaps > 1) {
+          t2 = kb >> p.src_c_shift;
+          c2 = kb - (t2 << p.src_c_shift);
+        }
+        const int r2 = (int)fdiv((unsigned)t2, p.tap_ns_div), s2 = t2 - r2 * p.tap_ns;
+        koff = (unsigned)(((p.tap_r0 + p.tap_step * r2) * p.s + p.tap_s0 + p.tap_step * s2) * p.src_c + c2);
+      } else {
+        koff = (unsigned)kb;
+      }
+      const bool bok = (row < BN) & (n < p.ncols) & (kb < p.ktotal);
+      const unsigned boff = (((unsigned)n * (unsigned)p.b_row_pad + koff) * 3u + (unsigned)pl * 8u) * 2u;
+      b_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, pred_off(boff, bok), 0, 0);
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    unsigned short *A0 = smem + buf * BUF;
+    unsigned short *B0 = A0 + 3 * A_PLANE;
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+      const int grp = a_j[i] / 3, pl = a_j[i] - grp * 3;
+      *reinterpret_cast<u32x4 *>(A0 + pl * A_PLANE + a_row[i] * LDK + grp * 8) = a_reg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx / RCH, j = idx - row * RCH;
+      const int grp = j / 3, pl = j - grp * 3;
+      if (BN * RCH % 256 == 0 || row < BN)
+        *reinterpret_cast<u32x4 *>(B0 + pl * B_PLANE + row * LDK + grp * 8) = b_reg[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int KT = (p.ktotal + BK - 1) / BK;
+  load_tiles(0);
+  store_tiles(0);
+  load_tiles(1);
   __syncthreads();
-  for (int k = ty; k < 32; k += 8) {
-    const int c = c0 + k, o = o0 + tx;
-    if (c < cin && o < cout) wt[((long long)c * rs + tap) * cout + o] = tile[tx][k];
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    store_tiles(cur ^ 1);
+    load_tiles(kt + 2);
+    const unsigned short *A0 = smem + cur * BUF;
+    const unsigned short *B0 = A0 + 3 * A_PLANE;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      bf16x8 af[3][TM], bf[3][TN];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          af[pl][i] = *reinterpret_cast<const bf16x8 *>(A0 + pl * A_PLANE + (wm * WTM + i * 32 + li) * LDK + ks * 16 + lh * 8);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          bf[pl][j] = *reinterpret_cast<const bf16x8 *>(B0 + pl * B_PLANE + (wn * WTN + j * 32 + li) * LDK + ks * 16 + lh * 8);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          f32x16 c = acc[i][j];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], c, 0, 0, 0);   // lo * hi
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], c, 0, 0, 0);   // hi * lo
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], c, 0, 0, 0);   // mid * mid
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], c, 0, 0, 0);   // mid * hi
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], c, 0, 0, 0);   // hi * mid
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], c, 0, 0, 0);   // hi * hi
+          acc[i][j] = c;
+        }
+    }
+    {
+      constexpr int NLOADS = A_LOADS + B_LOADS;
+#pragma unroll
+      for (int l = 0; l < NLOADS; ++l) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
+      }
+    }
+    __syncthreads();
+  }
+  igemm_epilogue<BM, BN, WGM, WGN, DGRAD>(p, acc, g, mtile, ntile, split, wm, wn, li, lh, ohw);
+}
+
+// Plane-interleaved bf16x6 operand format: a row of C fp32 values becomes C/8 groups of
+// [hi x8 | mid x8 | lo x8] (48 bytes), so a K-slice of one row is ONE contiguous run for all three
+// planes (96 B for 16 channels) - separate planes would cost three 32-B L2 requests instead.
+__global__ __launch_bounds__(256) void split_planes_kernel(const float4 *__restrict__ x, unsigned short *__restrict__ planes,
+                                                           long long n4, int c4n) {
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const float4 v = x[i];
+    unsigned h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
+    split3(v.x, h0, m0, l0);
+    split3(v.y, h1, m1, l1);
+    split3(v.z, h2, m2, l2);
+    split3(v.w, h3, m3, l3);
+    const long long row = i / c4n;
+    const int cq = (int)(i - row * c4n);               // float4 index inside the row
+    unsigned short *d = planes + (row * c4n * 4) * 3 + (cq >> 1) * 24 + (cq & 1) * 4;
+    *reinterpret_cast<uint2 *>(d) = make_uint2(pack_hi16(h0, h1), pack_hi16(h2, h3));
+    *reinterpret_cast<uint2 *>(d + 8) = make_uint2(pack_hi16(m0, m1), pack_hi16(m2, m3));
+    *reinterpret_cast<uint2 *>(d + 16) = make_uint2(pack_hi16(l0, l1), pack_hi16(l2, l3));
   }
 }
 
-// planes[pl][n][kpad] (bf16) = exact 3-way split of the weights, rows zero-padded to kpad.
-// transpose == 0: n = cout, k = (tap, cin)  [fprop];  1: n = cin, k = (tap, cout)  [dgrad].
+// Weights in the plane-interleaved format, rows zero-padded to kpad (multiple of 8).
+// transpose == 0: rows n = cout, k = (tap, cin)  [fprop];  1: n = cin, k = (tap, cout)  [dgrad].
 __global__ __launch_bounds__(256) void weight_split_kernel(const float *__restrict__ w, unsigned short *__restrict__ planes,
                                                            int cout, int rs, int cin, int kpad, int transpose) {
   const int nrows = transpose ? cin : cout;
@@ -709,9 +886,10 @@ __global__ __launch_bounds__(256) void weight_split_kernel(const float *__restri
     }
     unsigned h, m, l;
     split3(v, h, m, l);
-    planes[i] = (unsigned short)(h >> 16);
-    planes[total + i] = (unsigned short)(m >> 16);
-    planes[2 * total + i] = (unsigned short)(l >> 16);
+    unsigned short *d = planes + ((long long)n * kpad) * 3 + (k >> 3) * 24 + (k & 7);
+    d[0] = (unsigned short)(h >> 16);
+    d[8] = (unsigned short)(m >> 16);
+    d[16] = (unsigned short)(l >> 16);
   }
 }
 
@@ -988,7 +1166,7 @@ static int conv_math() {
   return g_conv_math;
 }
 
-template <bool DGRAD, bool BPL>
+template <bool DGRAD>
 static int launch_igemm6(IgemmParams &p, TileChoice t, hipStream_t st) {
   p.mtiles_per_group = ceil_div(p.rows_per_group, t.bm);
   p.ntiles = ceil_div(p.ncols, t.bn);
@@ -999,11 +1177,11 @@ static int launch_igemm6(IgemmParams &p, TileChoice t, hipStream_t st) {
   if (p.rows_per_group <= 0) return 0;
   dim3 grid((unsigned)nblk), block(256);
   if (t.bm == 128 && t.bn == 128)
-    hipLaunchKernelGGL((igemm6_kernel<128, 128, 16, 2, 2, DGRAD, BPL>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((igemm6_kernel<128, 128, 16, 2, 2, DGRAD>), grid, block, 0, st, p);
   else if (t.bm == 128 && t.bn == 64)
-    hipLaunchKernelGGL((igemm6_kernel<128, 64, 16, 2, 2, DGRAD, BPL>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((igemm6_kernel<128, 64, 16, 2, 2, DGRAD>), grid, block, 0, st, p);
   else
-    hipLaunchKernelGGL((igemm6_kernel<64, 64, 16, 2, 2, DGRAD, BPL>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((igemm6_kernel<64, 64, 16, 2, 2, DGRAD>), grid, block, 0, st, p);
   return check_launch(DGRAD ? "conv_dgrad(bf16x6)" : "conv_fprop(bf16x6)");
 }
 
@@ -1012,13 +1190,30 @@ static int launch_igemm6(IgemmParams &p, TileChoice t, hipStream_t st) {
 static TileChoice choose_tile6(long long rows_per_group, int groups, int ncols) {
   int cus = mvg_device_cus();
   if (cus <= 0) cus = 256;
-  const TileChoice cand[3] = {{128, 128}, {128, 64}, {64, 64}};
-  for (int i = 0; i < 3; ++i) {
-    if (cand[i].bn > 64 && ncols < 128) continue;
-    const long long blocks = (long long)groups * ceil_div(rows_per_group, cand[i].bm) * ceil_div(ncols, cand[i].bn);
-    if (blocks >= 2LL * cus) return cand[i];
+  // BM is always 128 in this mode, so that BN partial statistics have one geometry (64-row partials)
+  if (ncols >= 128) {
+    const long long blocks = (long long)groups * ceil_div(rows_per_group, 128) * ceil_div(ncols, 128);
+    if (blocks >= 2LL * cus) return {128, 128};
   }
-  return {64, 64};
+  return {128, 64};
+}
+
+template <bool DGRAD>
+static int launch_igemm6p(IgemmParams &p, TileChoice t, hipStream_t st) {
+  p.mtiles_per_group = ceil_div(p.rows_per_group, 128);
+  p.ntiles = ceil_div(p.ncols, t.bn);
+  p.splits = 1;
+  p.ktiles_per_split = 1 << 30;
+  const long long nblk = (long long)p.groups * p.mtiles_per_group * p.ntiles;
+  MVG_REQUIRE(nblk < (1LL << 31), "conv: grid too large");
+  if (p.rows_per_group <= 0) return 0;
+  dim3 grid((unsigned)nblk), block(256);
+  // BK = 16: two workgroups per CU; BK = 32 (one per CU) measured 20 % slower
+  if (t.bn == 128)
+    hipLaunchKernelGGL((igemm6p_kernel<128, 16, DGRAD>), grid, block, 0, st, p);
+  else
+    hipLaunchKernelGGL((igemm6p_kernel<64, 16, DGRAD>), grid, block, 0, st, p);
+  return check_launch(DGRAD ? "conv_dgrad(bf16x6p)" : "conv_fprop(bf16x6p)");
 }
 
 // split-K plan for a GEMM whose tile grid cannot fill the device: returns splits (>= 1) and sets
@@ -1071,7 +1266,8 @@ int mvg_conv_stats_partials(const mvg_conv_desc *d, int32_t *rows_per_partial) {
 }
 
 static int fprop_impl(const mvg_conv_desc *d, const float *x, const float *wgt, float *y, const float *bias, int relu,
-                      float *stats, float *ws, size_t ws_floats, void *stream, const void *wplanes = nullptr) {
+                      float *stats, float *ws, size_t ws_floats, void *stream, const void *wplanes = nullptr,
+                      const void *aplanes = nullptr) {
   if (validate(d)) return 2;
   IgemmParams p;
   memset(&p, 0, sizeof(p));
@@ -1116,13 +1312,16 @@ static int fprop_impl(const mvg_conv_desc *d, const float *x, const float *wgt, 
   ProfScope ps(lin ? MVG_K_LINEAR_FPROP : MVG_K_CONV_FPROP, (hipStream_t)stream, flops, bytes);
   if (!lin && conv_math() == 1 && d->cout >= 64) {
     const TileChoice t6 = choose_tile6(p.rows_per_group, d->groups, d->cout);
-    if (wplanes) {
+    if (wplanes && aplanes) {
       p.b = (const float *)wplanes;
       p.b_row_pad = (p.ktotal + 7) / 8 * 8;
-      p.b_bytes = 3ll * d->cout * p.b_row_pad * 2;
-      return launch_igemm6<false, true>(p, t6, (hipStream_t)stream);
+      p.b_bytes = 6ll * d->cout * p.b_row_pad;
+      p.a = (const float *)aplanes;
+      p.a_group_bytes = 6ll * d->n * p.src_img_stride;
+      MVG_REQUIRE(p.a_group_bytes < 0x7FFFFFF0ll, "conv: a group of planes exceeds 2 GiB");
+      return launch_igemm6p<false>(p, t6, (hipStream_t)stream);
     }
-    return launch_igemm6<false, false>(p, t6, (hipStream_t)stream);
+    return launch_igemm6<false>(p, t6, (hipStream_t)stream);
   }
   if (!stats && plan_splitk(p, t, ws ? ws_floats : 0) > 1) {
     p.slab = ws;
@@ -1133,8 +1332,8 @@ static int fprop_impl(const mvg_conv_desc *d, const float *x, const float *wgt, 
 }
 
 static int dgrad_impl(const mvg_conv_desc *d, const float *dy, const float *wgt, float *dx, const float *mask,
-                      const float *addend, float *ws, size_t ws_floats, void *stream, bool wgt_transposed = false,
-                      const void *wplanes = nullptr) {
+                      const float *addend, float *ws, size_t ws_floats, void *stream, const void *wplanes = nullptr,
+                      const void *aplanes = nullptr) {
   if (validate(d)) return 2;
   MVG_REQUIRE(d->cout % 4 == 0, "dgrad: cout %% 4 != 0 (%d)", d->cout);
   IgemmParams p;
@@ -1197,21 +1396,16 @@ static int dgrad_impl(const mvg_conv_desc *d, const float *dy, const float *wgt,
       q.cls_px = px;
       q.cls_cy = (py + d->pad - r0) / step;
       q.cls_cx = (px + d->pad - s0) / step;
-      if (wgt_transposed) {
-        if (q.ktotal == 0) {       // parity class without taps: zeros (+ mask/addend) via the fp32 kernel's K=0 path
-          const TileChoice t0 = choose_tile(q.rows_per_group, d->groups, d->cin);
-          if (launch_igemm<true>(q, t0, (hipStream_t)stream)) return 1;
-          continue;
-        }
+      if (wplanes && aplanes) {
+        q.b = (const float *)wplanes;
+        q.b_row_pad = d->r * d->s * d->cout;          // multiple of 8 (cout >= 64)
+        q.b_bytes = 6ll * d->cin * q.b_row_pad;
+        q.a = (const float *)aplanes;
+        q.a_group_bytes = 6ll * d->n * q.src_img_stride;
+        MVG_REQUIRE(q.a_group_bytes < 0x7FFFFFF0ll, "conv: a group of planes exceeds 2 GiB");
+        // a parity class without taps has ktotal == 0: every load is predicated off -> zeros
         const TileChoice t6 = choose_tile6(q.rows_per_group, d->groups, d->cin);
-        if (wplanes) {
-          q.b = (const float *)wplanes;
-          q.b_row_pad = d->r * d->s * d->cout;          // multiple of 8 (cout >= 64)
-          q.b_bytes = 3ll * d->cin * q.b_row_pad * 2;
-          if (launch_igemm6<true, true>(q, t6, (hipStream_t)stream)) return 1;
-        } else {
-          if (launch_igemm6<true, false>(q, t6, (hipStream_t)stream)) return 1;
-        }
+        if (launch_igemm6p<true>(q, t6, (hipStream_t)stream)) return 1;
         continue;
       }
       const TileChoice t = choose_tile(q.rows_per_group, d->groups, d->cin);
@@ -1252,16 +1446,6 @@ int mvg_set_conv_math(int mode) {
   return 0;
 }
 
-int mvg_weight_transpose(const mvg_conv_desc *d, const float *wgt, float *wgt_t, void *stream) {
-  if (validate(d)) return 2;
-  hipStream_t st = (hipStream_t)stream;
-  const int rs = d->r * d->s;
-  ProfScope ps(MVG_K_LAYOUT, st, 0.0, 8.0 * d->cout * rs * d->cin);
-  hipLaunchKernelGGL(weight_transpose_kernel, dim3(ceil_div(d->cin, 32), ceil_div(d->cout, 32), rs), dim3(256), 0, st, wgt,
-                     wgt_t, d->cout, rs, d->cin);
-  return check_launch("weight_transpose");
-}
-
 size_t mvg_weight_planes_bytes(const mvg_conv_desc *d, int transpose) {
   const long long nrows = transpose ? d->cin : d->cout;
   const long long klen = (long long)d->r * d->s * (transpose ? d->cout : d->cin);
@@ -1283,22 +1467,29 @@ int mvg_weight_split(const mvg_conv_desc *d, const float *wgt, int transpose, vo
   return check_launch("weight_split");
 }
 
-int mvg_conv_fprop_wp(const mvg_conv_desc *d, const float *x, const void *wplanes, float *y, float *stats, void *stream) {
-  MVG_REQUIRE(d && d->cout >= 64, "fprop_wp: cout must be >= 64");
-  MVG_REQUIRE(conv_math() == 1, "fprop_wp needs conv math mode 1 (bf16x6)");
-  return fprop_impl(d, x, nullptr, y, nullptr, 0, stats, nullptr, 0, stream, wplanes);
+int mvg_split_planes(const float *x, void *planes, int64_t rows, int c, void *stream) {
+  MVG_REQUIRE(c % 8 == 0, "split_planes: c %% 8 != 0");
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = (long long)rows * c;
+  ProfScope ps(MVG_K_ELEMENTWISE, st, 0.0, 10.0 * (double)n);
+  long long blocks = (n / 4 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float4 *)x, (unsigned short *)planes,
+                     n / 4, c / 4);
+  return check_launch("split_planes");
 }
 
-int mvg_conv_dgrad_wp(const mvg_conv_desc *d, const float *dy, const void *wplanes_t, float *dx, const float *mask,
-                      const float *addend, void *stream) {
-  MVG_REQUIRE(d && d->cin >= 64 && d->cout >= 64 && d->cout % 8 == 0, "dgrad_wp: cin, cout must be >= 64");
-  return dgrad_impl(d, dy, nullptr, dx, mask, addend, nullptr, 0, stream, true, wplanes_t);
+int mvg_conv_fprop_pp(const mvg_conv_desc *d, const void *xplanes, const void *wplanes, float *y, float *stats,
+                      void *stream) {
+  MVG_REQUIRE(d && d->cout >= 64 && d->cin >= 64 && d->cin % 8 == 0, "fprop_pp: cin, cout must be >= 64");
+  MVG_REQUIRE(conv_math() == 1, "fprop_pp needs conv math mode 1 (bf16x6)");
+  return fprop_impl(d, nullptr, nullptr, y, nullptr, 0, stats, nullptr, 0, stream, wplanes, xplanes);
 }
 
-int mvg_conv_dgrad_wt(const mvg_conv_desc *d, const float *dy, const float *wgt_t, float *dx, const float *mask,
+int mvg_conv_dgrad_pp(const mvg_conv_desc *d, const void *dyplanes, const void *wplanes_t, float *dx, const float *mask,
                       const float *addend, void *stream) {
-  MVG_REQUIRE(d && d->cin >= 64 && d->cin % 4 == 0, "dgrad_wt: cin must be >= 64");
-  return dgrad_impl(d, dy, wgt_t, dx, mask, addend, nullptr, 0, stream, true);
+  MVG_REQUIRE(d && d->cin >= 64 && d->cout >= 64 && d->cout % 8 == 0, "dgrad_pp: cin, cout must be >= 64");
+  return dgrad_impl(d, nullptr, nullptr, dx, mask, addend, nullptr, 0, stream, wplanes_t, dyplanes);
 }
 
 size_t mvg_linear_workspace_floats(int rows, int fin, int fout) {

@@ -58,15 +58,6 @@ def set_conv_math(mode: int):
     check(lib().mvg_set_conv_math(mode), "set_conv_math")
 
 
-def weight_transpose(d: ConvDesc, w: Tensor, wt: Tensor):
-    check(lib().mvg_weight_transpose(C.byref(d), _p(w), _p(wt), _s()), "weight_transpose")
-
-
-def conv_dgrad_wt(d: ConvDesc, dy: Tensor, wt: Tensor, dx: Tensor, mask: Optional[Tensor] = None,
-                  addend: Optional[Tensor] = None):
-    check(lib().mvg_conv_dgrad_wt(C.byref(d), _p(dy), _p(wt), _p(dx), _p(mask), _p(addend), _s()), "conv_dgrad_wt")
-
-
 def weight_split(d: ConvDesc, w: Tensor, transpose: bool) -> Tensor:
     """three bf16 planes (opaque int16 buffer) of the weights, for conv_fprop_wp / conv_dgrad_wp."""
     nbytes = lib().mvg_weight_planes_bytes(C.byref(d), int(transpose))
@@ -75,14 +66,23 @@ def weight_split(d: ConvDesc, w: Tensor, transpose: bool) -> Tensor:
     return planes
 
 
-def conv_fprop_wp(d: ConvDesc, x: Tensor, wplanes: Tensor, y: Tensor, stats: Optional[Tensor] = None):
-    check(lib().mvg_conv_fprop_wp(C.byref(d), _p(x), _p(wplanes), _p(y), _p(stats), _s()), "conv_fprop_wp")
+def split_planes(x: Tensor, planes: Optional[Tensor] = None) -> Tensor:
+    """x [..., C] fp32 -> plane-interleaved bf16 [..., C/8, 3, 8] (int16 storage), hi+mid+lo == x."""
+    c = x.shape[-1]
+    if planes is None:
+        planes = torch.empty(tuple(x.shape[:-1]) + (c // 8, 3, 8), dtype=torch.int16, device=x.device)
+    check(lib().mvg_split_planes(_p(x), _p(planes), x.numel() // c, c, _s()), "split_planes")
+    return planes
 
 
-def conv_dgrad_wp(d: ConvDesc, dy: Tensor, wplanes_t: Tensor, dx: Tensor, mask: Optional[Tensor] = None,
+def conv_fprop_pp(d: ConvDesc, xplanes: Tensor, wplanes: Tensor, y: Tensor, stats: Optional[Tensor] = None):
+    check(lib().mvg_conv_fprop_pp(C.byref(d), _p(xplanes), _p(wplanes), _p(y), _p(stats), _s()), "conv_fprop_pp")
+
+
+def conv_dgrad_pp(d: ConvDesc, dyplanes: Tensor, wplanes_t: Tensor, dx: Tensor, mask: Optional[Tensor] = None,
                   addend: Optional[Tensor] = None):
-    check(lib().mvg_conv_dgrad_wp(C.byref(d), _p(dy), _p(wplanes_t), _p(dx), _p(mask), _p(addend), _s()),
-          "conv_dgrad_wp")
+    check(lib().mvg_conv_dgrad_pp(C.byref(d), _p(dyplanes), _p(wplanes_t), _p(dx), _p(mask), _p(addend), _s()),
+          "conv_dgrad_pp")
 
 
 def conv_wgrad(d: ConvDesc, x: Tensor, dy: Tensor, dw: Tensor, accumulate: bool = False):

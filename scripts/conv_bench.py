@@ -56,14 +56,16 @@ for (cin, cout, k, st, pad, h), cnt in shapes.items():
     dx = torch.empty_like(x)
     dw = torch.empty_like(w)
     flops = 2.0 * G * N * d.ho * d.wo * cout * k * k * cin
-    if cout >= 64 and ops.conv_math() == 1:
+    if cout >= 64 and cin >= 64 and ops.conv_math() == 1:
         wp = ops.weight_split(d, w, False)
-        tf = timeit(lambda: ops.conv_fprop_wp(d, x, wp, y, stats))
+        xp = ops.split_planes(x)
+        tf = timeit(lambda: ops.conv_fprop_pp(d, xp, wp, y, stats))
     else:
         tf = timeit(lambda: ops.conv_fprop(d, x, w, y, None, False, stats))
     if cin >= 64 and ops.conv_math() == 1:
         wpt = ops.weight_split(d, w, True)
-        td = timeit(lambda: ops.conv_dgrad_wp(d, gy, wpt, dx))
+        gyp = ops.split_planes(gy)
+        td = timeit(lambda: ops.conv_dgrad_pp(d, gyp, wpt, dx))
     else:
         td = timeit(lambda: ops.conv_dgrad(d, gy, w, dx)) if cin > 4 else float("nan")
     tw = timeit(lambda: ops.conv_wgrad(d, x, gy, dw))

@@ -18,8 +18,9 @@ P, rpp = ops.conv_stats_partials(d)
 stats = torch.empty(G, P, 2, cout, device=dev)
 gy = torch.randn_like(y); dx = torch.empty_like(x); dw = torch.empty_like(w)
 wp = ops.weight_split(d, w, False) if ops.conv_math() == 1 and cout >= 64 else None
+xp = ops.split_planes(x) if wp is not None and cin >= 64 else None
 for _ in range(iters):
-    if op == "fprop" and wp is not None: ops.conv_fprop_wp(d, x, wp, y, stats)
+    if op == "fprop" and xp is not None: ops.conv_fprop_pp(d, xp, wp, y, stats)
     elif op == "fprop": ops.conv_fprop(d, x, w, y, None, False, stats)
     elif op == "dgrad": ops.conv_dgrad(d, gy, w, dx)
     else: ops.conv_wgrad(d, x, gy, dw)

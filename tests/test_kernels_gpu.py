@@ -117,26 +117,19 @@ def test_conv_fprop_dgrad_wgrad(case, conv_math):
     ops.conv_dgrad(d, gyd, wd, dx2, mask, dx2)
     close(dx2, dx_ref * (mask.cpu() > 0) + add.cpu(), what="dgrad epilogue")
 
-    if Cin >= 64:
-        # backward-data with pre-transposed weights (the bf16x6 path: both operands k-contiguous)
-        wt = torch.empty(Cin, k, k, Cout, device=dev())
-        ops.weight_transpose(d, wd, wt)
-        assert torch.equal(wt.cpu(), w.permute(1, 2, 3, 0))
-        dx3 = add.clone()
-        ops.conv_dgrad_wt(d, gyd, wt, dx3, mask, dx3)
-        close(dx3, dx_ref * (mask.cpu() > 0) + add.cpu(), what="dgrad_wt epilogue")
-
-    if Cout >= 64 and ops.conv_math() == 1:
-        # pre-split weight planes (what the backbone uses in bf16x6 mode)
-        y2 = torch.empty_like(y)
-        st2 = torch.full((G, P, 2, Cout), float("nan"), device=dev())
-        ops.conv_fprop_wp(d, xd, ops.weight_split(d, wd, False), y2, st2)
-        close(y2, y_ref, what="fprop_wp")
-        close(st2[:, :, 0].sum(1), y_ref.reshape(G, rows, Cout).sum(1), 1e-4, "fprop_wp stats")
-        if Cin >= 64:
-            dx4 = add.clone()
-            ops.conv_dgrad_wp(d, gyd, ops.weight_split(d, wd, True), dx4, mask, dx4)
-            close(dx4, dx_ref * (mask.cpu() > 0) + add.cpu(), what="dgrad_wp epilogue")
+    if Cout >= 64 and Cin >= 64 and ops.conv_math() == 1:
+        # both operands pre-split by their producers (what the backbone uses in bf16x6 mode)
+        xp = ops.split_planes(xd)
+        rec = xp.view(torch.bfloat16).float().sum(-2).reshape(xd.shape)
+        assert torch.equal(rec, xd), "hi + mid + lo must reproduce the fp32 value exactly"
+        y3 = torch.empty_like(y)
+        st3 = torch.full((G, P, 2, Cout), float("nan"), device=dev())
+        ops.conv_fprop_pp(d, xp, ops.weight_split(d, wd, False), y3, st3)
+        close(y3, y_ref, what="fprop_pp")
+        close(st3[:, :, 0].sum(1), y_ref.reshape(G, rows, Cout).sum(1), 1e-4, "fprop_pp stats")
+        dx5 = add.clone()
+        ops.conv_dgrad_pp(d, ops.split_planes(gyd), ops.weight_split(d, wd, True), dx5, mask, dx5)
+        close(dx5, dx_ref * (mask.cpu() > 0) + add.cpu(), what="dgrad_pp epilogue")
 
     dw = torch.empty(Cout, k, k, Cin, device=dev())
     ops.conv_wgrad(d, xd, gyd, dw, False)
