@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=64.0)
+    ap.add_argument("--no-optimizer", action="store_true", help="time forward+loss+backward only (no Adam step)")
     args = ap.parse_args()
 
     import numpy as np
@@ -141,6 +142,8 @@ def main():
     rot = rotation_matrix_2d(torch.from_numpy(inp["head_pose"]).reshape(-1, 2).to(dev)).reshape(B, V, 3, 3)
     del inp
     criterion = MultiViewIterationLoss(rel_weight=0.01, reference_decay=1.0, iter_decay=0.5)
+    from rot_mvgaze_amd.optim import Adam
+    optimizer = None if args.no_optimizer else Adam(model.parameters(), lr=1e-4, weight_decay=1e-6)   # trainer.py:54
     reducer = GradAllReducer(model, bucket_mb=args.bucket_mb, force=force_dist) if (world > 1 or force_dist) else None
 
     def step():
@@ -148,6 +151,8 @@ def main():
         out = model.forward_multiview(img, rot)
         loss = criterion(out, gt)
         loss.backward()
+        if optimizer is not None:
+            optimizer.step()
         return loss
 
     def fence():
@@ -219,7 +224,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "backbone": f"ResNet-{depth}", "views": V, "batch_per_gpu": B,
                        "global_batch": B * world, "image": "3x224x224", "parallelism": f"dp{world}",
-                       "timed_region": "forward + loss + backward" + (" + RCCL gradient all-reduce" if world > 1 else ""),
+                       "timed_region": "forward + loss + backward" + (" + RCCL gradient all-reduce" if world > 1 else "") +
+                                       ("" if args.no_optimizer else " + fused Adam step"),
                        "weights": "random init, seed 0 (kaiming-normal convs, default Linear)",
                        "images_per_s": round(value * V, 1), "loss": loss_val,
                        "model_tflops": round(value * sample_flops(depth, V) / 1e12, 2)},

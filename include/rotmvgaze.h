@@ -221,6 +221,13 @@ int mvg_linear_skinny_fwd(const float *x, const float *w, const float *bias, flo
 int mvg_linear_skinny_bwd(const float *dy, const float *x, const float *w, const float *mask, float *dx,
                           float *dw, float *db, int rows, int k, int nout, int accumulate, void *stream);
 
+/* ---------------------------------------------------------------- optimizer
+ * torch.optim.Adam step (trainer.py:54,141-143: betas (0.9, 0.999), eps 1e-8, coupled L2
+ * weight_decay 1e-6, bias correction) over flat fp32 arenas - the model keeps parameters and
+ * gradients in two arenas with identical offsets, so one launch updates every parameter. */
+int mvg_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, int step, void *stream);
+
 /* ---------------------------------------------------------------- loss
  * gaze_angular_loss losses/gaze_loss.py:42-52 over pitchyaw_to_vector utils/math.py:52-60:
  * theta_i = acos(clamp(cos_sim(v(gt_i), v(pred_i), eps 1e-6), -1, 1)) * 180/pi;

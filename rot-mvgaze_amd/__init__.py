@@ -21,9 +21,10 @@ def __getattr__(name):
         "angular_error": "geometry",
         "build_pair_index": "pair_index",
         "GradAllReducer": "dp",
+        "Adam": "optim",
     }
     if name in lazy:
         return getattr(importlib.import_module("." + lazy[name], __name__), name)
-    if name in ("model", "losses", "geometry", "pair_index", "dp", "ops", "backbone", "heads", "_lib"):
+    if name in ("model", "losses", "geometry", "pair_index", "dp", "ops", "backbone", "heads", "_lib", "optim"):
         return importlib.import_module("." + name, __name__)
     raise AttributeError(name)

@@ -86,6 +86,7 @@ SIGNATURES = {
     "mvg_scale_by": (_I, [_P, _P, _P, _I64, _P]),
     "mvg_linear_skinny_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "mvg_linear_skinny_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "mvg_adam_step": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _I, _P]),
     "mvg_gaze_angular_loss": (_I, [_P, _P, _I, _F, _P, _I, _P, _P, _P]),
     "mvg_mt19937_seed": (_I, [_P, C.c_uint64]),
     "mvg_pair_index_build": (_I64, [_P, _P, _I, _I, _P, _I64]),

@@ -1,5 +1,7 @@
 // Geometry, cross-view fusion operand builders, bias-gradient sums, the 2-wide gaze head and
 // the angular loss.  All of these are tiny / HBM-bound next to the GEMMs.
+#include <math.h>
+
 #include "common.h"
 
 namespace mvg {
@@ -132,6 +134,31 @@ __global__ __launch_bounds__(256) void axpby_kernel(const float *__restrict__ x,
                                                     long long n) {
   const long long stride = (long long)gridDim.x * 256;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) y[i] = a * x[i] + (b != 0.f ? b * y[i] : 0.f);
+}
+
+// ---- Adam (torch.optim.Adam semantics: coupled L2 weight decay, bias correction) over flat arenas --
+// trainer.py:54 optim.Adam(params, lr, weight_decay=1e-6); one launch updates every parameter.
+__global__ __launch_bounds__(256) void adam_kernel(float4 *__restrict__ p, const float4 *__restrict__ g,
+                                                   float4 *__restrict__ m, float4 *__restrict__ v, long long n4, float lr,
+                                                   float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+  const long long stride = (long long)gridDim.x * 256;
+  const float step_size = lr / bc1;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    float4 pp = p[i], gg = g[i], mm = m[i], vv = v[i];
+#define MVG_ADAM1(c)                                             \
+    {                                                            \
+      const float gr = gg.c + wd * pp.c;                         \
+      mm.c = b1 * mm.c + (1.f - b1) * gr;                        \
+      vv.c = b2 * vv.c + (1.f - b2) * gr * gr;                   \
+      const float denom = sqrtf(vv.c) / bc2_sqrt + eps;          \
+      pp.c = pp.c - step_size * (mm.c / denom);                  \
+    }
+    MVG_ADAM1(x) MVG_ADAM1(y) MVG_ADAM1(z) MVG_ADAM1(w)
+#undef MVG_ADAM1
+    p[i] = pp;
+    m[i] = mm;
+    v[i] = vv;
+  }
 }
 
 // ---- skinny linear (out_features <= 4): the Linear(512 -> 2) of the gaze head ------------------
@@ -310,6 +337,21 @@ int mvg_axpby(const float *x, float *y, float a, float b, int64_t n, void *strea
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, y, a, b, (long long)n);
   return check_launch("axpby");
+}
+
+int mvg_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int step, void *stream) {
+  MVG_REQUIRE(n % 4 == 0 && step >= 1, "adam: n %% 4 != 0 or step < 1");
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(MVG_K_ELEMENTWISE, st, 0.0, 28.0 * (double)n);
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  long long blocks = (n / 4 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (float4 *)param, (const float4 *)grad,
+                     (float4 *)exp_avg, (float4 *)exp_avg_sq, (long long)(n / 4), lr, beta1, beta2, eps, weight_decay,
+                     (float)bc1, (float)sqrt(bc2));
+  return check_launch("adam_step");
 }
 
 int mvg_linear_skinny_fwd(const float *x, const float *w, const float *bias, float *y, int rows, int k, int nout,

@@ -13,6 +13,7 @@ a view of it: no per-parameter copies, and the data-parallel reducer all-reduces
 """
 from __future__ import annotations
 
+import weakref
 from typing import Any, Callable, Dict, List, Optional
 
 import torch
@@ -175,6 +176,9 @@ class MultiViewGaze(nn.Module):
                 node.register_buffer(parts[-1], t)
             else:
                 node.register_parameter(parts[-1], nn.Parameter(t))
+        owner = weakref.ref(self)
+        for prm in self.parameters():
+            prm._mvg_owner = owner            # lets rot_mvgaze_amd.optim.Adam find the arenas
         self._on_grads_ready: Optional[Callable[[List[nn.Parameter]], None]] = None
         self._on_backward_done: Optional[Callable[[], None]] = None
         self._layout_sig = None
@@ -222,26 +226,42 @@ class MultiViewGaze(nn.Module):
         self._backbone_params = bb
         order += bb
         self._grad_order = order
-        total = sum(p.numel() for p in order)
+        total = (sum(p.numel() for p in order) + 3) // 4 * 4          # float4-friendly (zero tail)
         self._grad_arena = torch.zeros(total, dtype=torch.float32, device=first.device)
+        # parameters live in a second arena with the SAME offsets (one-launch optimizer, flat
+        # broadcast / checkpoint staging); each Parameter becomes a view of its slice
+        self._param_arena = torch.zeros(total, dtype=torch.float32, device=first.device)
         self._grad_views: Dict[int, Tensor] = {}
         self._grad_offsets: Dict[int, int] = {}
-        off = 0
-        for p in order:
-            flat = self._grad_arena[off:off + p.numel()]
+
+        def view_of(arena, off, p):
+            flat = arena[off:off + p.numel()]
             if p.dim() == 4:
                 o, i, kh, kw = p.shape
-                v = flat.view(o, kh, kw, i).permute(0, 3, 1, 2)          # channels_last view of the slice
-            else:
-                v = flat.view(p.shape)
-            self._grad_views[id(p)] = v
+                return flat.view(o, kh, kw, i).permute(0, 3, 1, 2)       # channels_last view of the slice
+            return flat.view(p.shape)
+        off = 0
+        for p in order:
+            self._grad_views[id(p)] = view_of(self._grad_arena, off, p)
             self._grad_offsets[id(p)] = off
+            pv = view_of(self._param_arena, off, p)
+            pv.copy_(p.data)
+            p.data = pv
+            p.grad = None
             off += p.numel()
-        self._layout_sig = sig
+        first = next(self.parameters())
+        self._layout_sig = (first.data_ptr(), str(first.device), sum(1 for _ in self.parameters()))
 
     def grad_arena(self):
         """(flat fp32 gradient buffer, [(param, offset, numel)] in grad-ready order)."""
         return self._grad_arena, [(p, self._grad_offsets[id(p)], p.numel()) for p in self._grad_order]
+
+    def param_arena(self) -> Tensor:
+        """Flat fp32 buffer holding every trainable parameter at the offsets of ``grad_arena``."""
+        return self._param_arena
+
+    def ensure_layout(self) -> None:
+        self._ensure_layout(next(self.parameters()).device)
 
     def _finish_backward(self):
         if self._on_backward_done is not None:

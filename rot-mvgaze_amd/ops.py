@@ -212,6 +212,11 @@ def linear_skinny_bwd(dy, x, w, mask, dx, dw, db, rows, k, nout, accumulate=Fals
                                       int(accumulate), _s()), "linear_skinny_bwd")
 
 
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step):
+    check(lib().mvg_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr, beta1, beta2, eps,
+                              weight_decay, step, _s()), "adam_step")
+
+
 def gaze_angular_loss(pred, gt, n, row_weight, loss, accumulate=False, dpred=None, theta=None):
     check(lib().mvg_gaze_angular_loss(_p(pred), _p(gt), n, row_weight, _p(loss), int(accumulate), _p(dpred), _p(theta),
                                       _s()), "gaze_angular_loss")

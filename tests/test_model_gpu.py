@@ -289,6 +289,39 @@ def test_bf16x6_conv_math_end_to_end():
             l2_close(p.grad, g0[k].cpu().numpy(), GTOL_L2_FLIPS, "grad bf16x6 vs fp32 " + k)
 
 
+def test_fused_adam_matches_torch_adam():
+    """mvg_adam_step over the arenas == torch.optim.Adam (trainer.py:54: lr, weight_decay 1e-6),
+    three steps on the same gradients; CyclicLR drives it like the reference scheduler does."""
+    from rot_mvgaze_amd.optim import Adam
+    m = build(18)
+    opt = Adam(m.parameters(), lr=0, weight_decay=1e-6)
+    sched = torch.optim.lr_scheduler.CyclicLR(opt, base_lr=1e-6, max_lr=1e-3, step_size_up=2, step_size_down=2,
+                                              mode="triangular2", cycle_momentum=False)
+    ref_p = {k: p.detach().cpu().clone().contiguous().requires_grad_(True) for k, p in m.named_parameters()}
+    ref_opt = torch.optim.Adam(list(ref_p.values()), lr=0, weight_decay=1e-6)
+    ref_sched = torch.optim.lr_scheduler.CyclicLR(ref_opt, base_lr=1e-6, max_lr=1e-3, step_size_up=2, step_size_down=2,
+                                                  mode="triangular2", cycle_momentum=False)
+    losses = []
+    for it in range(3):
+        opt.zero_grad()
+        d = m(inputs(4, 64, seed=10 + it))
+        loss = metrics()(d)
+        loss.backward()
+        losses.append(loss.item())
+        for k, p in m.named_parameters():                # same gradients on the reference side
+            ref_p[k].grad = None if p.grad is None else p.grad.detach().cpu().contiguous().clone()
+        opt.step()
+        ref_opt.step()
+        sched.step()
+        ref_sched.step()
+        assert abs(opt.param_groups[0]["lr"] - ref_opt.param_groups[0]["lr"]) < 1e-12
+    for k, p in m.named_parameters():
+        rel_close(p.detach(), ref_p[k].detach().numpy(), 2e-6, "param after Adam " + k)
+    sd = m.state_dict()
+    assert torch.equal(sd["_feat_extractor.0.fc.weight"].cpu(), ref_p["_feat_extractor.0.fc.weight"].detach())
+    assert all(np.isfinite(losses))
+
+
 def test_view_swap_symmetry_eval():
     m = build(18, train=False)
     with torch.no_grad():
