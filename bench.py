@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=64.0)
     ap.add_argument("--no-optimizer", action="store_true", help="time forward+loss+backward only (no Adam step)")
+    ap.add_argument("--mode", default="train", choices=["train", "eval"],
+                    help="eval = inference forward only (model.eval(), BN folded into the convs; SURVEY §8(f) rank 2)")
     args = ap.parse_args()
 
     import numpy as np
@@ -146,7 +148,15 @@ def main():
     optimizer = None if args.no_optimizer else Adam(model.parameters(), lr=1e-4, weight_decay=1e-6)   # trainer.py:54
     reducer = GradAllReducer(model, bucket_mb=args.bucket_mb, force=force_dist) if (world > 1 or force_dist) else None
 
+    if args.mode == "eval":
+        model.eval()
+        optimizer = None
+
     def step():
+        if args.mode == "eval":
+            with torch.no_grad():
+                out = model.forward_multiview(img, rot)
+            return out["pred_gaze"].sum()
         model.zero_grad(set_to_none=True)
         out = model.forward_multiview(img, rot)
         loss = criterion(out, gt)
@@ -218,14 +228,16 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "multi-view samples/sec (fwd+bwd), BxVx3x224x224",
+            "metric": "multi-view samples/sec (fwd+bwd), BxVx3x224x224" if args.mode == "train" else
+                      "multi-view samples/sec (inference forward), BxVx3x224x224",
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "backbone": f"ResNet-{depth}", "views": V, "batch_per_gpu": B,
                        "global_batch": B * world, "image": "3x224x224", "parallelism": f"dp{world}",
-                       "timed_region": "forward + loss + backward" + (" + RCCL gradient all-reduce" if world > 1 else "") +
-                                       ("" if args.no_optimizer else " + fused Adam step"),
+                       "timed_region": ("inference forward (BN folded into conv epilogues)" if args.mode == "eval" else
+                                        "forward + loss + backward" + (" + RCCL gradient all-reduce" if world > 1 else "") +
+                                        ("" if args.no_optimizer else " + fused Adam step")),
                        "weights": "random init, seed 0 (kaiming-normal convs, default Linear)",
                        "images_per_s": round(value * V, 1), "loss": loss_val,
                        "model_tflops": round(value * sample_flops(depth, V) / 1e12, 2)},

@@ -82,6 +82,12 @@ typedef struct {
  *                per group.                                                  (conv -> BatchNorm) */
 int mvg_conv_fprop(const mvg_conv_desc *d, const float *x, const float *wgt, float *y,
                    const float *bias, int relu, float *stats, void *stream);
+/* Inference (model.eval(), trainer.py:164-199): BatchNorm uses its running statistics, so it folds
+ * into the conv epilogue: out = [relu]( conv(x, wgt) * scale[cout] + shift[cout] [+ residual] ) in one
+ * launch (scale/shift from mvg_bn_eval_affine) - no separate normalisation pass, no raw conv output. */
+int mvg_conv_fprop_affine(const mvg_conv_desc *d, const float *x, const float *wgt, float *out,
+                          const float *scale, const float *shift, const float *residual, int relu,
+                          void *stream);
 /* number of row-partials per group that mvg_conv_fprop writes into `stats`, and the rows per
  * partial (out_rows_per_partial, may be NULL). */
 int mvg_conv_stats_partials(const mvg_conv_desc *d, int32_t *out_rows_per_partial);
@@ -180,6 +186,11 @@ int mvg_avgpool_fwd(const float *x, float *y, int n, int hw, int c, void *stream
 int mvg_avgpool_bwd(const float *dy, float *dx, int n, int hw, int c, void *stream);
 int mvg_nchw_to_nhwc4(const float *src, float *dst, int n, int c, int h, int w, void *stream);
 int mvg_nhwc4_to_nchw(const float *src, float *dst, int n, int c, int h, int w, void *stream);
+/* GPU input pipeline: raw uint8 [n][h][w][3] face patches (the HDF5
+ * `face_patch` layout, dataset/gaze.py:122) -> optional BGR->RGB (:108-109) -> /255 (ToTensor) ->
+ * (x - mean)/std (Normalize, main.py:38-39,54) -> NHWC4 fp32, the backbone's input layout. */
+int mvg_preprocess_u8hwc(const uint8_t *src, float *dst, int n, int h, int w, float mean0, float mean1,
+                         float mean2, float std0, float std1, float std2, int swap_rb, void *stream);
 
 /* ---------------------------------------------------------------- geometry
  * rotation_matrix_2d utils/math.py:188-219; relative rotations rot_mv.py:193-194. */

@@ -50,6 +50,7 @@ SIGNATURES = {
     "mvg_prof_collect": (_I, [C.POINTER(ProfEntry)]),
     "mvg_prof_family_name": (C.c_char_p, [_I]),
     "mvg_conv_fprop": (_I, [_D, _P, _P, _P, _P, _I, _P, _P]),
+    "mvg_conv_fprop_affine": (_I, [_D, _P, _P, _P, _P, _P, _P, _I, _P]),
     "mvg_conv_stats_partials": (_I, [_D, C.POINTER(C.c_int32)]),
     "mvg_conv_dgrad": (_I, [_D, _P, _P, _P, _P, _P, _P]),
     "mvg_conv_math": (_I, []),
@@ -76,6 +77,7 @@ SIGNATURES = {
     "mvg_avgpool_bwd": (_I, [_P, _P, _I, _I, _I, _P]),
     "mvg_nchw_to_nhwc4": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "mvg_nhwc4_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "mvg_preprocess_u8hwc": (_I, [_P, _P, _I, _I, _I, _F, _F, _F, _F, _F, _F, _I, _P]),
     "mvg_rotation_matrix_2d": (_I, [_P, _P, _I, _I, _P]),
     "mvg_relative_rotation": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "mvg_rotcat_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -22,6 +22,7 @@ from .arch import BackboneSpec, ConvSpec, backbone_spec
 
 Tensor = torch.Tensor
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1          # nn.BatchNorm2d defaults (resnet.py:185)
+IMAGE_MEAN, IMAGE_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)      # main.py:38-39
 
 
 class GradSink:
@@ -91,6 +92,11 @@ class Backbone:
             fprop(stats)
             ops.bn_finalize(stats, G, P, rpp, rows, c.cout, gamma, beta, rm, rv, BN_MOMENTUM, BN_EPS, mean, invstd,
                             scale, shift)
+        elif tape is None:
+            # inference: BN (running statistics) + residual + ReLU folded into the conv epilogue
+            ops.bn_eval_affine(1, c.cout, gamma, beta, rm, rv, BN_EPS, scale[:1], shift[:1])
+            ops.conv_fprop_affine(d, x, w, y, scale[0], shift[0], residual, relu)
+            return y
         else:
             fprop(None)
             ops.bn_eval_affine(G, c.cout, gamma, beta, rm, rv, BN_EPS, scale, shift)
@@ -105,17 +111,26 @@ class Backbone:
             tape.append(u)
         return out
 
-    def forward(self, imgs: List[Tensor], training: bool, keep_tape: bool):
-        """imgs: V tensors [B,3,H,W] fp32 NCHW (the reference's input format, rot_mv.py:188-189).
+    def forward(self, imgs: List[Tensor], training: bool, keep_tape: bool, input_bgr: bool = False):
+        """imgs: V tensors [B,3,H,W] fp32 NCHW (the reference's input format, rot_mv.py:188-189), or
+        V raw uint8 [B,H,W,3] face patches, normalised on the GPU.
         Returns (img_feat [V,B,fc_dim], tape or None)."""
         V = len(imgs)
-        B, C, H, W = imgs[0].shape
+        raw = imgs[0].dtype == torch.uint8
+        if raw:
+            B, H, W, C = imgs[0].shape
+        else:
+            B, C, H, W = imgs[0].shape
         assert C == 3
         dev = imgs[0].device
         x0 = torch.empty(V, B, H, W, 4, dtype=torch.float32, device=dev)
         for v, im in enumerate(imgs):
-            assert im.shape == imgs[0].shape and im.is_cuda and im.dtype == torch.float32
-            ops.nchw_to_nhwc4(im.detach().contiguous(), x0[v], B, 3, H, W)
+            assert im.shape == imgs[0].shape and im.is_cuda and im.dtype == imgs[0].dtype
+            if raw:
+                ops.preprocess_u8hwc(im.contiguous(), x0[v], B, H, W, IMAGE_MEAN, IMAGE_STD, input_bgr)
+            else:
+                assert im.dtype == torch.float32
+                ops.nchw_to_nhwc4(im.detach().contiguous(), x0[v], B, 3, H, W)
         tape: Optional[dict] = {"units": [], "blocks": [], "V": V, "B": B} if keep_tape else None
         ulist = tape["units"] if keep_tape else None
         if training:

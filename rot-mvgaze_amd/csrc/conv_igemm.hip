@@ -69,6 +69,7 @@ struct IgemmParams {
   const float *b;       // weights, KRSC
   float *out;
   const float *bias;    // [ncols] or null (fprop)
+  const float *scale;   // [ncols] or null (fprop, inference: y = acc*scale + bias (+addend) [relu])
   const float *mask;    // like out or null (dgrad)
   const float *addend;  // like out or null (dgrad)
   float *stats;         // [groups][P][2][ncols] or null (fprop)
@@ -143,8 +144,9 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams &p, f32x16 (&ac
   for (int j = 0; j < TN; ++j) {
     const int col = ntile * BN + wn * WTN + j * 32 + li;
     const bool cok = col < p.ncols;
-    float bias = 0.f;
+    float bias = 0.f, scl = 1.f;
     if (!DGRAD && p.bias && cok) bias = p.bias[col];
+    if (!DGRAD && p.scale && cok) scl = p.scale[col];        // inference: BatchNorm folded into the conv
     float csum = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -168,7 +170,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams &p, f32x16 (&ac
             if (p.mask) v = (p.mask[off] > 0.f) ? v : 0.f;
             if (p.addend) v += p.addend[off];
           } else {
-            v += bias;
+            v = v * scl + bias;
+            if (p.addend) v += p.addend[off];                  // inference: residual branch
             if (p.relu) v = fmaxf(v, 0.f);
             csum += v;
           }
@@ -1267,7 +1270,7 @@ int mvg_conv_stats_partials(const mvg_conv_desc *d, int32_t *rows_per_partial) {
 
 static int fprop_impl(const mvg_conv_desc *d, const float *x, const float *wgt, float *y, const float *bias, int relu,
                       float *stats, float *ws, size_t ws_floats, void *stream, const void *wplanes = nullptr,
-                      const void *aplanes = nullptr) {
+                      const void *aplanes = nullptr, const float *scale = nullptr, const float *residual = nullptr) {
   if (validate(d)) return 2;
   IgemmParams p;
   memset(&p, 0, sizeof(p));
@@ -1275,6 +1278,8 @@ static int fprop_impl(const mvg_conv_desc *d, const float *x, const float *wgt, 
   p.b = wgt;
   p.out = y;
   p.bias = bias;
+  p.scale = scale;
+  p.addend = residual;
   p.relu = relu;
   p.stats = stats;
   p.groups = d->groups;
@@ -1437,6 +1442,12 @@ int mvg_conv_fprop(const mvg_conv_desc *d, const float *x, const float *wgt, flo
 int mvg_conv_dgrad(const mvg_conv_desc *d, const float *dy, const float *wgt, float *dx, const float *mask,
                    const float *addend, void *stream) {
   return dgrad_impl(d, dy, wgt, dx, mask, addend, nullptr, 0, stream);
+}
+
+int mvg_conv_fprop_affine(const mvg_conv_desc *d, const float *x, const float *wgt, float *out, const float *scale,
+                          const float *shift, const float *residual, int relu, void *stream) {
+  MVG_REQUIRE(scale && shift, "fprop_affine: scale and shift are required");
+  return fprop_impl(d, x, wgt, out, shift, relu, nullptr, nullptr, 0, stream, nullptr, nullptr, scale, residual);
 }
 
 int mvg_conv_math(void) { return conv_math(); }

@@ -131,6 +131,22 @@ __global__ __launch_bounds__(256) void nhwc4_to_nchw_kernel(const float4 *__rest
   for (int k = 0; k < c; ++k) d[k * hw] = v[k];
 }
 
+// uint8 HWC face patch -> normalised fp32 NHWC4: the deterministic part of the reference's input
+// pipeline (dataset/gaze.py:106-111 BGR->RGB; main.py:50-55 ToTensor = /255, Normalize(mean, std)).
+__global__ __launch_bounds__(256) void preprocess_u8_kernel(const unsigned char *__restrict__ src,
+                                                            float4 *__restrict__ dst, long long pixels, float m0,
+                                                            float m1, float m2, float s0, float s1, float s2,
+                                                            int swap_rb) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= pixels) return;
+  const unsigned char *p = src + 3 * i;
+  float c0 = (float)p[swap_rb ? 2 : 0], c1 = (float)p[1], c2 = (float)p[swap_rb ? 0 : 2];
+  c0 = (c0 / 255.0f - m0) / s0;
+  c1 = (c1 / 255.0f - m1) / s1;
+  c2 = (c2 / 255.0f - m2) / s2;
+  dst[i] = make_float4(c0, c1, c2, 0.f);
+}
+
 }  // namespace mvg
 
 using namespace mvg;
@@ -187,6 +203,17 @@ int mvg_nchw_to_nhwc4(const float *src, float *dst, int n, int c, int h, int w, 
   hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3(ceil_div(pixels, 256)), dim3(256), 0, st, src, (float4 *)dst, pixels, c,
                      (long long)h * w);
   return check_launch("nchw_to_nhwc4");
+}
+
+int mvg_preprocess_u8hwc(const uint8_t *src, float *dst, int n, int h, int w, float mean0, float mean1, float mean2,
+                         float std0, float std1, float std2, int swap_rb, void *stream) {
+  MVG_REQUIRE(std0 > 0.f && std1 > 0.f && std2 > 0.f, "preprocess: std must be positive");
+  hipStream_t st = (hipStream_t)stream;
+  const long long pixels = (long long)n * h * w;
+  ProfScope ps(MVG_K_LAYOUT, st, 0.0, 19.0 * (double)pixels);
+  hipLaunchKernelGGL(preprocess_u8_kernel, dim3(ceil_div(pixels, 256)), dim3(256), 0, st, src, (float4 *)dst, pixels, mean0,
+                     mean1, mean2, std0, std1, std2, swap_rb);
+  return check_launch("preprocess_u8hwc");
 }
 
 int mvg_nhwc4_to_nchw(const float *src, float *dst, int n, int c, int h, int w, void *stream) {

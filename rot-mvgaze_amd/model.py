@@ -102,7 +102,7 @@ class _BackboneFn(torch.autograd.Function):
         imgs = list(tensors[:n_views])
         ctx.set_materialize_grads(False)
         keep = any(ctx.needs_input_grad)          # False under no_grad / when nothing requires grad
-        feat, tape = model._backbone.forward(imgs, training, keep)
+        feat, tape = model._backbone.forward(imgs, training, keep, model.input_bgr)
         ctx.model, ctx.tape, ctx.n_views = model, tape, n_views
         if model._debug_keep_tapes:
             model._last_backbone_tape = tape
@@ -183,6 +183,7 @@ class MultiViewGaze(nn.Module):
         self._on_backward_done: Optional[Callable[[], None]] = None
         self._layout_sig = None
         self._debug_keep_tapes = False            # tests: keep references to the saved activations
+        self.input_bgr = False                    # raw uint8 inputs: swap B and R first (dataset color_type 'bgr')
         self._sink = _ArenaSink(self)
 
     # ---------------------------------------------------------------- plumbing

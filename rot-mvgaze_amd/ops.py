@@ -45,6 +45,12 @@ def conv_fprop(d: ConvDesc, x: Tensor, w: Tensor, y: Tensor, bias: Optional[Tens
     check(lib().mvg_conv_fprop(C.byref(d), _p(x), _p(w), _p(y), _p(bias), int(relu), _p(stats), _s()), "conv_fprop")
 
 
+def conv_fprop_affine(d: ConvDesc, x: Tensor, w: Tensor, out: Tensor, scale: Tensor, shift: Tensor,
+                      residual: Optional[Tensor], relu: bool):
+    check(lib().mvg_conv_fprop_affine(C.byref(d), _p(x), _p(w), _p(out), _p(scale), _p(shift), _p(residual), int(relu),
+                                      _s()), "conv_fprop_affine")
+
+
 def conv_dgrad(d: ConvDesc, dy: Tensor, w: Tensor, dx: Tensor, mask: Optional[Tensor] = None,
                addend: Optional[Tensor] = None):
     check(lib().mvg_conv_dgrad(C.byref(d), _p(dy), _p(w), _p(dx), _p(mask), _p(addend), _s()), "conv_dgrad")
@@ -166,6 +172,11 @@ def nchw_to_nhwc4(src, dst, n, c, h, w):
 
 def nhwc4_to_nchw(src, dst, n, c, h, w):
     check(lib().mvg_nhwc4_to_nchw(_p(src), _p(dst), n, c, h, w, _s()), "nhwc4_to_nchw")
+
+
+def preprocess_u8hwc(src, dst, n, h, w, mean, std, swap_rb):
+    check(lib().mvg_preprocess_u8hwc(_p(src), _p(dst), n, h, w, mean[0], mean[1], mean[2], std[0], std[1], std[2],
+                                     int(swap_rb), _s()), "preprocess_u8hwc")
 
 
 # ---------------------------------------------------------------- geometry / fusion operands

@@ -322,6 +322,31 @@ def test_fused_adam_matches_torch_adam():
     assert all(np.isfinite(losses))
 
 
+def test_raw_uint8_input_pipeline():
+    """raw uint8 HWC patches normalised on the GPU == the float NCHW path fed
+    with ((u8/255) - mean)/std.  The torchvision transforms the reference uses (ToTensor, Normalize,
+    main.py:50-55) are not importable here: this row's host restatement follows their documented
+    arithmetic - parity unpinned against the reference itself."""
+    rng = np.random.default_rng(0)
+    B, hw = 3, 64
+    u8 = [torch.from_numpy(rng.integers(0, 256, size=(B, hw, hw, 3), dtype=np.uint8)) for _ in range(2)]
+    mean = torch.tensor([0.485, 0.456, 0.406])
+    std = torch.tensor([0.229, 0.224, 0.225])
+
+    def host(x, bgr):
+        x = x.flip(-1) if bgr else x
+        return ((x.float().div(255) - mean) / std).permute(0, 3, 1, 2).contiguous()
+    d = inputs(B, hw)
+    for bgr in (False, True):
+        m = build(18, train=False)
+        m.input_bgr = bgr
+        with torch.no_grad():
+            a = m({"img_0": u8[0].to(dev()), "img_1": u8[1].to(dev()), "rot_0": d["rot_0"], "rot_1": d["rot_1"]})
+            b = m({"img_0": host(u8[0], bgr).to(dev()), "img_1": host(u8[1], bgr).to(dev()),
+                   "rot_0": d["rot_0"], "rot_1": d["rot_1"]})
+        assert torch.equal(a["pred_gaze"], b["pred_gaze"]) and torch.equal(a["img_feat_1"], b["img_feat_1"])
+
+
 def test_view_swap_symmetry_eval():
     m = build(18, train=False)
     with torch.no_grad():
