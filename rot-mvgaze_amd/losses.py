@@ -122,23 +122,23 @@ class IterationLoss(AbstractLoss):
         self._addtional_decay = additional_decay
 
     def forward(self, data: Dict[str, Any]) -> Tensor:
-        num_iter: int = data["num_iter"]
-        commmon: Dict[str, Any] = {key: value for key, value in data.items() if not key.startswith("iter_")}
-        fused = self._fused(data, num_iter)
-        total_loss: Any = 0
+        """total = sum_i w_i * loss(iter_i) with Horner weights w_i = iter_decay^(n-1-i) (and the
+        optional separately weighted last iteration), stereo_loss.py:65-84.  Like the reference, every
+        per-iteration dict is first completed with the shared (non ``iter_*``) entries of ``data``."""
+        n = int(data["num_iter"])
+        shared = {k: v for k, v in data.items() if not k.startswith("iter_")}
+        for i in range(n):
+            data[f"iter_{i}"].update(shared)
+        fused = self._fused(data, n)
+        if fused is not None:
+            return fused
+        n_horner = n if self._addtional_decay is None else n - 1
+        total: Any = 0
+        for i in range(n_horner):
+            total = total * self._iter_decay + self._loss(data[f"iter_{i}"])
         if self._addtional_decay is not None:
-            num_iter -= 1
-        for i in range(num_iter):
-            iter_data = data[f"iter_{i}"]
-            iter_data.update(commmon)                                    # reference side effect (:76)
-            if fused is None:
-                total_loss = total_loss * self._iter_decay + self._loss(iter_data)
-        if self._addtional_decay is not None:
-            last_iter_data = data[f"iter_{num_iter}"]
-            last_iter_data.update(commmon)
-            if fused is None:
-                total_loss += self._loss(last_iter_data) * self._addtional_decay
-        return total_loss if fused is None else fused
+            total = total + self._loss(data[f"iter_{n_horner}"]) * self._addtional_decay
+        return total
 
     def _fused(self, data: Dict[str, Any], num_iter: int) -> Optional[Tensor]:
         """One autograd node over the head's stacked predictions when the dict came from the
