@@ -104,6 +104,12 @@ struct IgemmParams {
   // to `slab` [splits][groups*rows][ncols] and splitk_reduce_kernel applies the epilogue.
   int splits, ktiles_per_split;
   float *slab;
+  // stream-K (fp32 conv kernels): sk_tiles > 0 -> the grid is P persistent workgroups that each take
+  // an equal share of the sk_tiles x ceil(ktotal/BK) K-steps, in tile-major order.  A workgroup
+  // whose share starts or ends inside a tile writes that piece's raw accumulators to `slab`
+  // (slot 0: piece that does not start the tile, slot 1: piece that starts it) and
+  // igemm_fixup_kernel sums the pieces in workgroup order and runs the epilogue.
+  int sk_tiles;
   int b_row_pad;             // bf16x6 with pre-split weights: padded row length of the planes
 };
 
@@ -208,8 +214,11 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams &p, f32x16 (&ac
   }
 }
 
+// resident workgroups per CU the register budget is held to (LDS allows 4 / 5 / 8 / 5)
+constexpr int igemm_min_blocks(int bm, int bn, bool dgrad) { return (bm == 128 && bn == 128 && dgrad) ? 3 : 2; }
+
 template <int BM, int BN, int BK, int WGM, int WGN, bool DGRAD>
-__global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
+__global__ __launch_bounds__(256, igemm_min_blocks(BM, BN, DGRAD)) void igemm_kernel(IgemmParams p) {
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int KV = BK / 4;                 // float4 per k-contiguous row
@@ -227,28 +236,54 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   static_assert(BM % RPP == 0, "tile");
   __shared__ __attribute__((aligned(16))) float smem[2 * (A_ELEMS + B_ELEMS)];
 
-  const int tid = threadIdx.x;
+  const int nwg = gridDim.x;
+  const int wg_all = xcd_remap(blockIdx.x, nwg);
+  // a parity class without taps has ktotal == 0: one all-zero K-step, so that the epilogue still runs
+  const int KT_all = p.ktotal > 0 ? (p.ktotal + BK - 1) / BK : 1;
+  // this workgroup's range of (tile, K-step) units
+  long long u0, u1;
+  int split = 0;
+  if (p.sk_tiles > 0) {
+    const long long U = (long long)p.sk_tiles * KT_all;
+    u0 = (long long)wg_all * U / nwg;
+    u1 = (long long)(wg_all + 1) * U / nwg;
+  } else {
+    const int tiles_total = nwg / p.splits;
+    split = wg_all / tiles_total;
+    const int wg0 = wg_all - split * tiles_total;
+    const int kb = split * p.ktiles_per_split;
+    const int ke = (kb + p.ktiles_per_split < KT_all) ? kb + p.ktiles_per_split : KT_all;
+    u0 = (long long)wg0 * KT_all + kb;
+    u1 = (long long)wg0 * KT_all + ke;     // plan_splitk never makes an empty split
+  }
+  const int ohw = p.out_h * p.out_w;
+  const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(p.b, p.b_bytes);
+
+  while (u0 < u1) {
+  // Everything below is derived from `tid` through an opaque copy, so that the compiler treats it
+  // as segment-local: hoisting the per-thread loader state out of this loop costs ~50 VGPRs (one
+  // resident workgroup per CU less) for a once-per-segment saving.
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
   const int li = lane & 31, lh = lane >> 5;
-
-  const int nwg = gridDim.x;
-  const int wg_all = xcd_remap(blockIdx.x, nwg);
-  const int tiles_total = nwg / p.splits;
-  const int split = wg_all / tiles_total;
-  const int wg = wg_all - split * tiles_total;
+  const int a_kv = tid % KV;
+  const int a_r0 = tid / KV;
+  const int wg = (int)(u0 / KT_all);
+  const int kt_begin = (int)(u0 - (long long)wg * KT_all);
+  int KT = kt_begin + (int)(u1 - u0);
+  if (KT > KT_all) KT = KT_all;
+  u0 += KT - kt_begin;
   const int ntile = wg % p.ntiles;
   const int mt_all = wg / p.ntiles;
   const int g = mt_all / p.mtiles_per_group;
   const int mtile = mt_all - g * p.mtiles_per_group;
 
   // ---- A loader state -------------------------------------------------------------------
-  const int a_kv = tid % KV;
-  const int a_r0 = tid / KV;
   unsigned a_img[A_PASSES];            // byte offset of the row's image inside this group
   int a_y0[A_PASSES], a_x0[A_PASSES];
   bool a_ok[A_PASSES];
-  const int ohw = p.out_h * p.out_w;
 #pragma unroll
   for (int i = 0; i < A_PASSES; ++i) {
     const long long m = (long long)mtile * BM + a_r0 + i * RPP;
@@ -268,7 +303,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   }
   const __amdgpu_buffer_rsrc_t rs_a =
       make_rsrc(p.a + (long long)g * p.imgs_per_group * p.src_img_stride, p.a_group_bytes);
-  const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(p.b, p.b_bytes);
 
   float4 a_reg[A_PASSES];
   float4 b_reg[DGRAD ? B_PASSES_D : B_PASSES_F];
@@ -350,9 +384,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   // 3-stage pipeline: while tile kt multiplies out of LDS[kt&1], tile kt+1 (fetched during the
   // previous step) is written to LDS[(kt+1)&1] and the global loads of tile kt+2 are issued.  Tiles
   // past the end are predicated off (zeros), so the loop body has no branches.
-  const int KT_all = (p.ktotal + BK - 1) / BK;
-  const int kt_begin = split * p.ktiles_per_split;
-  const int KT = (kt_begin + p.ktiles_per_split < KT_all) ? kt_begin + p.ktiles_per_split : KT_all;
   klimit = KT * BK < p.ktotal ? KT * BK : p.ktotal;
   load_tiles(kt_begin);
   store_tiles(kt_begin & 1);
@@ -410,7 +441,71 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     __syncthreads();
   }
 
-  igemm_epilogue<BM, BN, WGM, WGN, DGRAD>(p, acc, g, mtile, ntile, split, wm, wn, li, lh, ohw);
+  if (p.sk_tiles > 0 && (kt_begin > 0 || KT < KT_all)) {
+    // a piece of a tile shared with neighbouring workgroups: raw accumulators, fragment order
+    float4 *dst = reinterpret_cast<float4 *>(p.slab) + ((long long)wg_all * 2 + (kt_begin > 0 ? 0 : 1)) * (BM * BN / 4);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          dst[((i * TN + j) * 4 + q) * 256 + tid] =
+              make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+  } else {
+    igemm_epilogue<BM, BN, WGM, WGN, DGRAD>(p, acc, g, mtile, ntile, split, wm, wn, li, lh, ohw);
+  }
+  }  // while (u0 < u1)
+}
+
+// stream-K fix-up: one workgroup per cut between logical workgroups c and c+1; the first cut inside a
+// tile sums that tile's pieces (in workgroup order, so the result is deterministic) and runs the epilogue.
+template <int BM, int BN, int BK, int WGM, int WGN, bool DGRAD>
+__global__ __launch_bounds__(256) void igemm_fixup_kernel(IgemmParams p, int P) {
+  constexpr int WTM = BM / WGM, WTN = BN / WGN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int KT_all = (p.ktotal + BK - 1) / BK;
+  const long long U = (long long)p.sk_tiles * KT_all;
+  const int c = blockIdx.x;
+  const long long ucut = (long long)(c + 1) * U / P;
+  const long long tile = ucut / KT_all;
+  const long long t0 = tile * KT_all, t1 = t0 + KT_all;
+  if (ucut == t0) return;                          // the cut falls on a tile boundary
+  if ((long long)c * U / P > t0) return;           // an earlier cut lies inside the same tile and owns it
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  for (int b = c; b < P; ++b) {
+    const long long ub = (long long)b * U / P;
+    if (ub >= t1) break;
+    const float4 *src = reinterpret_cast<const float4 *>(p.slab) + ((long long)b * 2 + (ub > t0 ? 0 : 1)) * (BM * BN / 4);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = src[((i * TN + j) * 4 + q) * 256 + tid];
+          acc[i][j][4 * q] += v.x;
+          acc[i][j][4 * q + 1] += v.y;
+          acc[i][j][4 * q + 2] += v.z;
+          acc[i][j][4 * q + 3] += v.w;
+        }
+  }
+  const int wg = (int)tile;
+  const int ntile = wg % p.ntiles;
+  const int mt_all = wg / p.ntiles;
+  const int g = mt_all / p.mtiles_per_group;
+  const int mtile = mt_all - g * p.mtiles_per_group;
+  igemm_epilogue<BM, BN, WGM, WGN, DGRAD>(p, acc, g, mtile, ntile, 0, wm, wn, li, lh, p.out_h * p.out_w);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -679,7 +774,7 @@ __global__ __launch_bounds__(256) void igemm6_kernel(IgemmParams p) {
 // kernel, and the wave's VALU stays free for addressing.  BM = 128, BK = 16 (one MFMA k-step per
 // tile), LDS 3 planes x (BM + BN) rows x 48 B x 2 buffers = 36-72 KB -> two workgroups per CU.
 template <int BN, int BK, bool DGRAD>
-__global__ __launch_bounds__(256) void igemm6p_kernel(IgemmParams p) {
+__global__ __launch_bounds__(256, 2) void igemm6p_kernel(IgemmParams p) {
   constexpr int BM = 128, WGM = 2, WGN = 2;
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -729,8 +824,11 @@ __global__ __launch_bounds__(256) void igemm6p_kernel(IgemmParams p) {
   const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(a0, p.a_group_bytes);
   const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(p.b, p.b_bytes);
 
-  u32x4 a_reg[A_LOADS], b_reg[B_LOADS];
-  auto load_tiles = [&](int kt) {
+  // Two register sets: a tile is fetched TWO K-steps before it is written to LDS (a bf16x6 K-step
+  // is only 24 MFMAs = 768 cycles, less than an L2 miss), the K loop is unrolled by two so that
+  // each set is written and read at fixed program points (no dynamic register indexing).
+  u32x4 aR0[A_LOADS], bR0[B_LOADS], aR1[A_LOADS], bR1[B_LOADS];
+  auto load_tiles = [&](int kt, u32x4 (&a_reg)[A_LOADS], u32x4 (&b_reg)[B_LOADS]) {
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
       const int grp = a_j[i] / 3, pl = a_j[i] - grp * 3;
@@ -771,7 +869,7 @@ __global__ __launch_bounds__(256) void igemm6p_kernel(IgemmParams p) {
       b_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, pred_off(boff, bok), 0, 0);
     }
   };
-  auto store_tiles = [&](int buf) {
+  auto store_tiles = [&](int buf, const u32x4 (&a_reg)[A_LOADS], const u32x4 (&b_reg)[B_LOADS]) {
     unsigned short *A0 = smem + buf * BUF;
     unsigned short *B0 = A0 + 3 * A_PLANE;
 #pragma unroll
@@ -797,16 +895,8 @@ __global__ __launch_bounds__(256) void igemm6p_kernel(IgemmParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const int KT = (p.ktotal + BK - 1) / BK;
-  load_tiles(0);
-  store_tiles(0);
-  load_tiles(1);
-  __syncthreads();
-  for (int kt = 0; kt < KT; ++kt) {
-    const int cur = kt & 1;
-    store_tiles(cur ^ 1);
-    load_tiles(kt + 2);
-    const unsigned short *A0 = smem + cur * BUF;
+  auto mfma_tile = [&](int buf) {
+    const unsigned short *A0 = smem + buf * BUF;
     const unsigned short *B0 = A0 + 3 * A_PLANE;
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
@@ -834,15 +924,40 @@ __global__ __launch_bounds__(256) void igemm6p_kernel(IgemmParams p) {
           acc[i][j] = c;
         }
     }
-    {
-      constexpr int NLOADS = A_LOADS + B_LOADS;
+    // schedule: ALL fragment reads of the K-step first (one LDS latency per step instead of one per
+    // MFMA - a 32-cycle bf16 MFMA cannot cover a ~130-cycle ds_read), then the MFMAs with the next
+    // tile's global loads spread between them.
+    constexpr int NLOADS = A_LOADS + B_LOADS;
+    constexpr int NREADS = 3 * (TM + TN) * (BK / 16);
+    constexpr int NMFMA = 6 * TM * TN * (BK / 16);
+    __builtin_amdgcn_sched_group_barrier(0x100, NREADS, 0);
 #pragma unroll
-      for (int l = 0; l < NLOADS; ++l) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
-      }
+    for (int l = 0; l < NLOADS; ++l) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
     }
+    __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - 2 * NLOADS, 0);
+  };
+
+  const int KT = (p.ktotal + BK - 1) / BK;
+  load_tiles(0, aR0, bR0);
+  store_tiles(0, aR0, bR0);
+  load_tiles(1, aR0, bR0);
+  load_tiles(2, aR1, bR1);
+  __syncthreads();
+  for (int kt = 0; kt < KT; kt += 2) {
+    // even step: LDS[0] = tile kt;  R0 = tile kt+1, R1 = tile kt+2
+    store_tiles(1, aR0, bR0);
+    load_tiles(kt + 3, aR0, bR0);
+    mfma_tile(0);
     __syncthreads();
+    if (kt + 1 < KT) {
+      // odd step: LDS[1] = tile kt+1;  R1 = tile kt+2, R0 = tile kt+3
+      store_tiles(0, aR1, bR1);
+      load_tiles(kt + 4, aR1, bR1);
+      mfma_tile(1);
+      __syncthreads();
+    }
   }
   igemm_epilogue<BM, BN, WGM, WGN, DGRAD>(p, acc, g, mtile, ntile, split, wm, wn, li, lh, ohw);
 }
@@ -1121,15 +1236,112 @@ struct TileChoice {
   int bm, bn;
 };
 
-// pick the largest tile that still gives >= 2 workgroups per CU (else the smallest).
-static TileChoice choose_tile(long long rows_per_group, int groups, int ncols) {
+static int g_streamk = -1;
+static bool streamk_enabled() {
+  if (g_streamk < 0) {
+    const char *e = getenv("MVG_STREAMK");
+    g_streamk = (e && !strcmp(e, "0")) ? 0 : 1;
+  }
+  return g_streamk == 1;
+}
+
+// ---- stream-K planning ---------------------------------------------------------------------
+// Library-owned scratch for the stream-K pieces, one buffer per stream (grow-only).
+struct SkScratch {
+  hipStream_t st;
+  float *ptr;
+  size_t floats;
+};
+static SkScratch g_sk_scratch[8];
+static float *sk_scratch(hipStream_t st, size_t floats) {
+  SkScratch *slot = nullptr;
+  for (auto &e : g_sk_scratch)
+    if (e.ptr && e.st == st) slot = &e;
+  if (!slot)
+    for (auto &e : g_sk_scratch)
+      if (!e.ptr) {
+        slot = &e;
+        break;
+      }
+  if (!slot) return nullptr;
+  if (slot->ptr && slot->floats >= floats) return slot->ptr;
+  if (slot->ptr) (void)hipFree(slot->ptr);       // waits for work that may still read it
+  slot->ptr = nullptr;
+  size_t want = floats + floats / 4;
+  if (hipMalloc((void **)&slot->ptr, want * sizeof(float)) != hipSuccess) {
+    (void)hipGetLastError();
+    slot->ptr = nullptr;
+    return nullptr;
+  }
+  slot->st = st;
+  slot->floats = want;
+  return slot->ptr;
+}
+
+template <int BM, int BN, int WGM, int WGN, bool DGRAD>
+static int igemm_occupancy() {
+  static int occ = 0;
+  if (occ <= 0) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<BM, BN, 16, WGM, WGN, DGRAD>, 256, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      n = 1;
+    }
+    occ = n > 0 ? n : 1;
+  }
+  return occ;
+}
+static int tile_occupancy(int bm, int bn, bool dgrad) {
+  if (bm == 128 && bn == 128) return dgrad ? igemm_occupancy<128, 128, 2, 2, true>() : igemm_occupancy<128, 128, 2, 2, false>();
+  if (bm == 128 && bn == 64) return dgrad ? igemm_occupancy<128, 64, 2, 2, true>() : igemm_occupancy<128, 64, 2, 2, false>();
+  if (bm == 64 && bn == 64) return dgrad ? igemm_occupancy<64, 64, 2, 2, true>() : igemm_occupancy<64, 64, 2, 2, false>();
+  return dgrad ? igemm_occupancy<128, 32, 4, 1, true>() : igemm_occupancy<128, 32, 4, 1, false>();
+}
+
+// Decide between one-tile-per-workgroup ("data parallel") and stream-K for `tiles` tiles of BM x BN
+// with KT K-steps each; returns the persistent grid size P (0 = data parallel).  The ResNet layer
+// shapes give tile counts like 49 * 2^k, which never divide the 256 CUs x occupancy slots: the last,
+// partly filled round of workgroups costs a full round.  Model (fitted to tile_probe.py runs): a CU
+// with n resident workgroups runs at min(1, n * solo) of its matrix rate; the fix-up moves each
+// piece twice at ~4 TB/s (128-wide tiles) / ~2.5 TB/s (64-wide: more, smaller pieces).
+static int plan_streamk(long long tiles, int KT, int bm, int bn, int occ) {
+  if (!streamk_enabled() || tiles <= 0 || bm != 128 || bn < 64) return 0;
+  int cus = mvg_device_cus();
+  if (cus <= 0) cus = 256;
+  const long long S = (long long)occ * cus;
+  if (tiles * KT < 8 * S) return 0;                       // < 8 K-steps per workgroup: overheads dominate
+  const double solo = bn >= 128 ? 0.62 : 0.40;
+  const double tile_us = 2.0 * bm * bn * 16.0 * KT / (115e6 / cus);   // one tile on a whole CU at 115 TF/s
+  const long long full_rounds = tiles / S, rem = tiles - full_rounds * S;
+  double t_dp = full_rounds * occ * tile_us;
+  if (rem > 0) {
+    const long long n = (rem + cus - 1) / cus;
+    const double r = n * solo < 1.0 ? n * solo : 1.0;
+    t_dp += n * tile_us / r;
+  }
+  const long long pieces = tiles + S < 2 * S ? tiles + S : 2 * S;
+  const double fix_bw = bn >= 128 ? 4.0e6 : 2.5e6;        // bytes / us
+  const double t_fix = pieces * (double)bm * bn * 4.0 * 2.0 / fix_bw + 4.0;
+  const double t_sk = (double)tiles / cus * tile_us * (bn >= 128 ? 1.0 : 1.04) + t_fix;
+  return t_sk < 0.95 * t_dp ? (int)S : 0;
+}
+
+// Tile choice.  The largest tile the column count allows when stream-K will balance it over the CUs;
+// otherwise the largest tile that still gives >= 2 workgroups per CU (else the smallest).
+static TileChoice choose_tile(long long rows_per_group, int groups, int ncols, int ktotal, bool dgrad) {
   static int cus = 0;
   if (cus <= 0) {
     cus = mvg_device_cus();
     if (cus <= 0) cus = 256;
   }
-  const TileChoice cand[3] = {{128, 128}, {128, 64}, {64, 64}};
   if (ncols <= 32) return {128, 32};
+  {
+    const TileChoice big = ncols >= 128 ? TileChoice{128, 128} : TileChoice{128, 64};
+    const long long tiles = (long long)groups * ceil_div(rows_per_group, big.bm) * ceil_div(ncols, big.bn);
+    if (ktotal > 0 && plan_streamk(tiles, ceil_div(ktotal, 16), big.bm, big.bn, tile_occupancy(big.bm, big.bn, dgrad)) > 0)
+      return big;
+  }
+  const TileChoice cand[3] = {{128, 128}, {128, 64}, {64, 64}};
   for (int i = 0; i < 3; ++i) {
     if (cand[i].bn > 64 && ncols < 128) continue;
     const long long blocks = (long long)groups * ceil_div(rows_per_group, cand[i].bm) * ceil_div(ncols, cand[i].bn);
@@ -1138,25 +1350,41 @@ static TileChoice choose_tile(long long rows_per_group, int groups, int ncols) {
   return (ncols >= 64) ? TileChoice{64, 64} : TileChoice{128, 32};
 }
 
+template <int BM, int BN, int WGM, int WGN, bool DGRAD>
+static int launch_igemm_tile(IgemmParams &p, long long tiles, hipStream_t st) {
+  const int KT = p.ktotal > 0 ? ceil_div(p.ktotal, 16) : 1;
+  int P = 0;
+  if (p.splits == 1 && p.ktotal > 0) P = plan_streamk(tiles, KT, BM, BN, igemm_occupancy<BM, BN, WGM, WGN, DGRAD>());
+  if (P > 0) {
+    float *scratch = sk_scratch(st, (size_t)P * 2 * BM * BN);
+    if (!scratch) P = 0;                                   // no scratch: plain launch
+    else p.slab = scratch;
+  }
+  if (P > 0) {
+    p.sk_tiles = (int)tiles;
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, 16, WGM, WGN, DGRAD>), dim3((unsigned)P), dim3(256), 0, st, p);
+    if (check_launch(DGRAD ? "conv_dgrad(stream-K)" : "conv_fprop(stream-K)")) return 1;
+    hipLaunchKernelGGL((igemm_fixup_kernel<BM, BN, 16, WGM, WGN, DGRAD>), dim3((unsigned)(P - 1)), dim3(256), 0, st, p, P);
+    return check_launch("conv stream-K fix-up");
+  }
+  p.sk_tiles = 0;
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, 16, WGM, WGN, DGRAD>), dim3((unsigned)(tiles * p.splits)), dim3(256), 0, st, p);
+  return check_launch(DGRAD ? "conv_dgrad" : "conv_fprop");
+}
+
 template <bool DGRAD>
 static int launch_igemm(IgemmParams &p, TileChoice t, hipStream_t st) {
   p.mtiles_per_group = ceil_div(p.rows_per_group, t.bm);
   p.ntiles = ceil_div(p.ncols, t.bn);
   if (p.splits < 1) p.splits = 1;
   if (p.splits == 1) p.ktiles_per_split = 1 << 30;
-  const long long nblk = (long long)p.groups * p.mtiles_per_group * p.ntiles * p.splits;
-  MVG_REQUIRE(nblk < (1LL << 31), "conv: grid too large");
-  dim3 grid((unsigned)nblk), block(256);
+  const long long tiles = (long long)p.groups * p.mtiles_per_group * p.ntiles;
+  MVG_REQUIRE(tiles * p.splits < (1LL << 31), "conv: grid too large");
   if (p.rows_per_group <= 0) return 0;
-  if (t.bm == 128 && t.bn == 128)
-    hipLaunchKernelGGL((igemm_kernel<128, 128, 16, 2, 2, DGRAD>), grid, block, 0, st, p);
-  else if (t.bm == 128 && t.bn == 64)
-    hipLaunchKernelGGL((igemm_kernel<128, 64, 16, 2, 2, DGRAD>), grid, block, 0, st, p);
-  else if (t.bm == 64 && t.bn == 64)
-    hipLaunchKernelGGL((igemm_kernel<64, 64, 16, 2, 2, DGRAD>), grid, block, 0, st, p);
-  else
-    hipLaunchKernelGGL((igemm_kernel<128, 32, 16, 4, 1, DGRAD>), grid, block, 0, st, p);
-  return check_launch(DGRAD ? "conv_dgrad" : "conv_fprop");
+  if (t.bm == 128 && t.bn == 128) return launch_igemm_tile<128, 128, 2, 2, DGRAD>(p, tiles, st);
+  if (t.bm == 128 && t.bn == 64) return launch_igemm_tile<128, 64, 2, 2, DGRAD>(p, tiles, st);
+  if (t.bm == 64 && t.bn == 64) return launch_igemm_tile<64, 64, 2, 2, DGRAD>(p, tiles, st);
+  return launch_igemm_tile<128, 32, 4, 1, DGRAD>(p, tiles, st);
 }
 
 // conv math: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = bf16x6 split on the bf16 MFMA
@@ -1262,7 +1490,7 @@ int mvg_conv_stats_partials(const mvg_conv_desc *d, int32_t *rows_per_partial) {
   const long long rows = (long long)d->n * d->ho * d->wo;
   const bool lin = d->r == 1 && d->s == 1 && d->h == 1 && d->w == 1;
   const TileChoice t = (!lin && conv_math() == 1 && d->cout >= 64) ? choose_tile6(rows, d->groups, d->cout)
-                                                                  : choose_tile(rows, d->groups, d->cout);
+                                                                  : choose_tile(rows, d->groups, d->cout, d->r * d->s * d->cin, false);
   const int wr = wave_rows(t);
   if (rows_per_partial) *rows_per_partial = wr;
   return ceil_div(rows, t.bm) * (t.bm / wr);
@@ -1309,7 +1537,7 @@ static int fprop_impl(const mvg_conv_desc *d, const float *x, const float *wgt, 
   p.b_bytes = 4ll * d->cout * p.ktotal;
   MVG_REQUIRE(p.a_group_bytes < 0x7FFFFFF0ll && p.b_bytes < 0x7FFFFFF0ll, "conv: a group / the weights exceed 2 GiB");
   p.tap_ns_div = make_fastdiv((unsigned)p.tap_ns);
-  const TileChoice t = choose_tile(p.rows_per_group, d->groups, d->cout);
+  const TileChoice t = choose_tile(p.rows_per_group, d->groups, d->cout, p.ktotal, false);
   const double flops = 2.0 * d->groups * (double)p.rows_per_group * d->cout * p.ktotal;
   const double bytes = 4.0 * (d->groups * (double)d->n * d->h * d->w * d->cin + (double)d->cout * p.ktotal +
                               d->groups * (double)p.rows_per_group * d->cout);
@@ -1413,7 +1641,7 @@ static int dgrad_impl(const mvg_conv_desc *d, const float *dy, const float *wgt,
         if (launch_igemm6p<true>(q, t6, (hipStream_t)stream)) return 1;
         continue;
       }
-      const TileChoice t = choose_tile(q.rows_per_group, d->groups, d->cin);
+      const TileChoice t = choose_tile(q.rows_per_group, d->groups, d->cin, q.ktotal, true);
       if (step == 1 && plan_splitk(q, t, ws ? ws_floats : 0) > 1) {
         q.slab = ws;
         if (launch_igemm<true>(q, t, (hipStream_t)stream)) return 1;

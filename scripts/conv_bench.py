@@ -13,7 +13,7 @@ from rot_mvgaze_amd.arch import backbone_spec
 depth = int(sys.argv[1]) if len(sys.argv) > 1 else 18
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 G = int(sys.argv[3]) if len(sys.argv) > 3 else 2
-iters = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+iters = int(sys.argv[4]) if len(sys.argv) > 4 else 20
 dev = torch.device("cuda:0")
 spec = backbone_spec(depth)
 # walk the net to get input sizes

@@ -49,6 +49,10 @@ CONV_CASES = [
     (1, 2, 17, 18, 64, 64, 7, 2, 3),      # 7x7 stride 2 dgrad (4/3-tap lattices per axis)
     (2, 8, 56, 56, 256, 512, 1, 2, 0),
     (2, 64, 56, 56, 64, 128, 1, 2, 0),    # many more wgrad splits than pixels/272: empty trailing splits
+    (2, 16, 28, 28, 128, 128, 3, 1, 1),   # 196 tiles of 128x128 on 512 slots -> stream-K (fprop and dgrad)
+    (2, 16, 56, 56, 64, 64, 3, 1, 1),     # 784 tiles of 128x64 -> stream-K with several tiles per workgroup
+    (2, 16, 56, 56, 64, 128, 3, 2, 1),    # stride 2: stream-K fprop, parity-class dgrad
+    (1, 30, 14, 14, 256, 256, 3, 1, 1),   # ragged last M tile (5880 rows) under stream-K
 ]
 
 
