@@ -5,61 +5,74 @@
 namespace mvg {
 
 // ---- finalize: merge the conv epilogue's per-wave partials (sum, centred sumsq) -------------
-// grid = c/16 blocks, 1024 threads = 16 channels x 64 partial-lanes; ONE group per launch so
-// that the running statistics are updated in group (= view) order by stream order.
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restrict__ stats, int partials,
+// grid = c/8 blocks, 1024 threads = 8 channels x 128 partial-lanes.  Every group (= view) is merged
+// by the same workgroup, one after the other, so that the running statistics are updated in group
+// order (the reference runs the backbone on view 0, then view 1: models/rot_mv.py:204-205).
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restrict__ stats, int groups, int partials,
                                                            int rows_per_partial, long long rows, int c,
                                                            const float *__restrict__ gamma,
                                                            const float *__restrict__ beta, float *running_mean,
                                                            float *running_var, float momentum, float eps,
                                                            float *mean_out, float *invstd_out, float *scale,
                                                            float *shift) {
-  __shared__ double sh[3][64][16];
-  const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
-  const int ch = blockIdx.x * 16 + cl;
-  double s = 0.0, q = 0.0, ss = 0.0;
-  if (ch < c) {
-    for (int p = pl; p < partials; p += 64) {
-      long long cnt = rows - (long long)p * rows_per_partial;
-      if (cnt <= 0) break;
-      if (cnt > rows_per_partial) cnt = rows_per_partial;
-      const double sp = stats[((long long)p * 2) * c + ch];
-      const double qp = stats[((long long)p * 2 + 1) * c + ch];
-      s += sp;
-      q += qp;
-      ss += sp * sp / (double)cnt;
-    }
+  __shared__ double sh[3][128][8];
+  const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  const int ch = blockIdx.x * 8 + cl;
+  const double inv_full = 1.0 / (double)rows_per_partial;
+  float rm = 0.f, rv = 0.f;
+  if (pl == 0 && ch < c) {
+    if (running_mean) rm = running_mean[ch];
+    if (running_var) rv = running_var[ch];
   }
-  sh[0][pl][cl] = s;
-  sh[1][pl][cl] = q;
-  sh[2][pl][cl] = ss;
-  __syncthreads();
-  for (int o = 32; o > 0; o >>= 1) {
-    if (pl < o) {
-      sh[0][pl][cl] += sh[0][pl + o][cl];
-      sh[1][pl][cl] += sh[1][pl + o][cl];
-      sh[2][pl][cl] += sh[2][pl + o][cl];
+  for (int g = 0; g < groups; ++g) {
+    const float *st = stats + (long long)g * partials * 2 * c;
+    double s = 0.0, q = 0.0, ss = 0.0;
+    if (ch < c) {
+      for (int p = pl; p < partials; p += 128) {
+        const long long cnt = rows - (long long)p * rows_per_partial;
+        if (cnt <= 0) break;
+        const double sp = st[((long long)p * 2) * c + ch];
+        const double qp = st[((long long)p * 2 + 1) * c + ch];
+        s += sp;
+        q += qp;
+        ss += sp * sp * (cnt >= rows_per_partial ? inv_full : 1.0 / (double)cnt);   // only the ragged last partial divides
+      }
+    }
+    sh[0][pl][cl] = s;
+    sh[1][pl][cl] = q;
+    sh[2][pl][cl] = ss;
+    __syncthreads();
+    for (int o = 64; o > 0; o >>= 1) {
+      if (pl < o) {
+        sh[0][pl][cl] += sh[0][pl + o][cl];
+        sh[1][pl][cl] += sh[1][pl + o][cl];
+        sh[2][pl][cl] += sh[2][pl + o][cl];
+      }
+      __syncthreads();
+    }
+    if (pl == 0 && ch < c) {
+      const double n = (double)rows;
+      const double mean = sh[0][0][cl] / n;
+      double m2 = sh[1][0][cl] + (sh[2][0][cl] - sh[0][0][cl] * mean);   // Chan merge of the partials
+      if (m2 < 0.0) m2 = 0.0;
+      const double var = m2 / n;
+      const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+      const float fmean = (float)mean;
+      const long long o = (long long)g * c + ch;
+      mean_out[o] = fmean;
+      invstd_out[o] = invstd;
+      const float sc = gamma[ch] * invstd;
+      scale[o] = sc;
+      shift[o] = beta[ch] - fmean * sc;
+      rm = (1.f - momentum) * rm + momentum * fmean;
+      const float unbiased = (float)(rows > 1 ? m2 / (n - 1.0) : var);
+      rv = (1.f - momentum) * rv + momentum * unbiased;
     }
     __syncthreads();
   }
   if (pl == 0 && ch < c) {
-    const double n = (double)rows;
-    const double mean = sh[0][0][cl] / n;
-    double m2 = sh[1][0][cl] + (sh[2][0][cl] - sh[0][0][cl] * mean);   // Chan merge of the partials
-    if (m2 < 0.0) m2 = 0.0;
-    const double var = m2 / n;
-    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float fmean = (float)mean;
-    mean_out[ch] = fmean;
-    invstd_out[ch] = invstd;
-    const float sc = gamma[ch] * invstd;
-    scale[ch] = sc;
-    shift[ch] = beta[ch] - fmean * sc;
-    if (running_mean) running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * fmean;
-    if (running_var) {
-      const float unbiased = (float)(rows > 1 ? m2 / (n - 1.0) : var);
-      running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * unbiased;
-    }
+    if (running_mean) running_mean[ch] = rm;
+    if (running_var) running_var[ch] = rv;
   }
 }
 
@@ -282,12 +295,9 @@ int mvg_bn_finalize(const float *stats, int groups, int partials, int rows_per_p
   MVG_REQUIRE(groups > 0 && partials > 0 && c > 0 && rows_per_group > 0, "bn_finalize: bad sizes");
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps(MVG_K_BN_FINALIZE, st, 0.0, 4.0 * groups * (double)partials * 2 * c);
-  for (int g = 0; g < groups; ++g) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(c, 16)), dim3(1024), 0, st,
-                       stats + (long long)g * partials * 2 * c, partials, rows_per_partial, (long long)rows_per_group, c,
-                       gamma, beta, running_mean, running_var, momentum, eps, mean + (long long)g * c,
-                       invstd + (long long)g * c, scale + (long long)g * c, shift + (long long)g * c);
-  }
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(c, 8)), dim3(1024), 0, st, stats, groups, partials, rows_per_partial,
+                     (long long)rows_per_group, c, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale,
+                     shift);
   return check_launch("bn_finalize");
 }
 

@@ -1192,19 +1192,37 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     }
 }
 
-__global__ void wgrad_reduce_kernel(const float *__restrict__ slabs, float *__restrict__ dw, long long n4, int splits,
-                                    int accumulate) {
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    float4 s = accumulate ? reinterpret_cast<const float4 *>(dw)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k = 0; k < splits; ++k) {
+// Sum of the per-split slabs.  A workgroup covers 256/lanes float4 columns; `lanes` threads per column
+// each add every lanes-th slab, then the lanes are summed through LDS in a fixed order
+// (deterministic).  With one thread per column (the obvious form) a 64-channel layer has 144
+// workgroups each issuing 150 dependent loads: latency-bound at ~1.2 TB/s.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ slabs, float *__restrict__ dw,
+                                                           long long n4, int splits, int accumulate, int lanes) {
+  __shared__ float4 sh[256];
+  const int cols = 256 / lanes;
+  const int c = threadIdx.x % cols, l = threadIdx.x / cols;
+  const long long i = (long long)blockIdx.x * cols + c;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4)
+    for (int k = l; k < splits; k += lanes) {
       const float4 v = reinterpret_cast<const float4 *>(slabs)[(long long)k * n4 + i];
       s.x += v.x;
       s.y += v.y;
       s.z += v.z;
       s.w += v.w;
     }
-    reinterpret_cast<float4 *>(dw)[i] = s;
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (l == 0 && i < n4) {
+    float4 t = accumulate ? reinterpret_cast<const float4 *>(dw)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < lanes; ++k) {
+      const float4 v = sh[k * cols + c];
+      t.x += v.x;
+      t.y += v.y;
+      t.z += v.z;
+      t.w += v.w;
+    }
+    reinterpret_cast<float4 *>(dw)[i] = t;
   }
 }
 
@@ -1758,6 +1776,31 @@ static TileChoice wgrad_tile(const mvg_conv_desc *d) {
   return {128, 32};
 }
 
+}  // extern "C"
+
+template <int BM, int BN, int WGM, int WGN>
+static int wgrad_occupancy_t() {
+  static int occ = 0;
+  if (occ <= 0) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wgrad_kernel<BM, BN, 16, WGM, WGN>, 256, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      n = 2;
+    }
+    occ = n > 0 ? n : 1;
+  }
+  return occ;
+}
+static int wgrad_occupancy(TileChoice t) {
+  if (t.bm == 128 && t.bn == 128) return wgrad_occupancy_t<128, 128, 2, 2>();
+  if (t.bm == 64 && t.bn == 128) return wgrad_occupancy_t<64, 128, 2, 2>();
+  if (t.bm == 64 && t.bn == 64) return wgrad_occupancy_t<64, 64, 2, 2>();
+  if (t.bm == 32 && t.bn == 128) return wgrad_occupancy_t<32, 128, 1, 4>();
+  return wgrad_occupancy_t<128, 32, 4, 1>();
+}
+
+extern "C" {
+
 int mvg_conv_wgrad_splits(const mvg_conv_desc *d) {
   if (validate(d)) return -1;
   const TileChoice t = wgrad_tile(d);
@@ -1766,7 +1809,17 @@ int mvg_conv_wgrad_splits(const mvg_conv_desc *d) {
   const long long pixels = (long long)d->groups * d->n * d->ho * d->wo;
   int cus = mvg_device_cus();
   if (cus <= 0) cus = 256;
-  long long want = (3LL * cus + tiles - 1) / tiles;      // ~3 workgroups per CU
+  // one resident round: tiles x splits <= CUs x workgroups-per-CU (rounding the split count UP puts a
+  // handful of workgroups into a second round that costs as much as the first)
+  static int wpc_env = -1;
+  if (wpc_env < 0) {
+    const char *e = getenv("MVG_WGRAD_WPC");
+    wpc_env = e ? atoi(e) : 0;
+  }
+  int wpc = wgrad_occupancy(t);
+  if (wpc > 4) wpc = 4;
+  if (wpc_env > 0) wpc = wpc_env;
+  long long want = ((long long)wpc * cus) / tiles;
   long long maxs = pixels / 256;                           // at least 256 pixels (16 K-steps) per split
   if (maxs < 1) maxs = 1;
   if (want > maxs) want = maxs;
@@ -1835,8 +1888,10 @@ int mvg_conv_wgrad(const mvg_conv_desc *d, const float *x, const float *dy, floa
     const long long n = (long long)d->cout * p.ncols;
     MVG_REQUIRE(n % 4 == 0, "wgrad: weight elements %% 4 != 0");
     ProfScope ps(MVG_K_WGRAD_REDUCE, st, 0.0, 4.0 * n * (splits + 1));
-    const int blocks = (int)((n / 4 + 255) / 256 > 2048 ? 2048 : (n / 4 + 255) / 256);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, dw, n / 4, splits, accumulate);
+    const int lanes = splits >= 32 ? 16 : (splits >= 8 ? 4 : 1);
+    const long long blocks = (n / 4 + 256 / lanes - 1) / (256 / lanes);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, workspace, dw, n / 4, splits, accumulate,
+                       lanes);
     if (check_launch("wgrad_reduce")) return 1;
   }
   return 0;
