@@ -64,6 +64,23 @@ __device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv &f) {
   return (t + ((n - t) >> f.sh1)) >> f.sh2;
 }
 
+// Per-class view of a launch.  fprop and stride-1 dgrad have one class; a stride-2 dgrad has one per
+// output-pixel parity (py, px) - each a dense sub-convolution over its own taps - and all of them
+// run in ONE launch, so that the short classes (one tap: 8 K-steps per tile) share the device with
+// the long ones instead of each paying a partly filled round of workgroups.
+struct IgemmClass {
+  int out_h, out_w;          // spatial extent of the GEMM's row space
+  int ntaps, tap_ns, tap_r0, tap_s0;
+  int ktotal;                // ntaps * src_c
+  int cls_py, cls_px, cls_cy, cls_cx;
+  int mtiles_per_group;
+  long long rows_per_group;
+  FastDiv tap_ns_div, ohw_div, ow_div;
+  long long unit0;           // first (tile, K-step) unit of this class in the launch's unit space
+  int tile0;                 // first tile of this class
+  int KT;                    // K-steps per tile (>= 1: a class without taps runs one all-zero step)
+};
+
 struct IgemmParams {
   const float *a;       // gathered operand (fprop: x, dgrad: dy)
   const float *b;       // weights, KRSC
@@ -99,6 +116,7 @@ struct IgemmParams {
   long long a_group_bytes;   // bytes of one group of the gathered tensor
   long long b_bytes;         // bytes of the weight tensor
   FastDiv tap_ns_div;
+  FastDiv ohw_div, ow_div;   // row -> (image, y, x) of the GEMM's row space (out_h*out_w, out_w)
   // split-K (small-M GEMMs: the Linear layers of the fusion block stream 100-240 MB of weights
   // over <= a few hundred rows; splitting K spreads that stream over every CU).  Partial tiles go
   // to `slab` [splits][groups*rows][ncols] and splitk_reduce_kernel applies the epilogue.
@@ -110,6 +128,9 @@ struct IgemmParams {
   // (slot 0: piece that does not start the tile, slot 1: piece that starts it) and
   // igemm_fixup_kernel sums the pieces in workgroup order and runs the epilogue.
   int sk_tiles;
+  int no_remap;              // several classes, one tile per workgroup: keep the dispatch order (longest class first)
+  int ncls;
+  IgemmClass cls[4];         // the fp32 kernels read the class view from here (top-level copies: bf16x6 kernels)
   int b_row_pad;             // bf16x6 with pre-split weights: padded row length of the planes
 };
 
@@ -124,15 +145,15 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
 // Shared epilogue of the implicit-GEMM kernels (C/D layout of the 32x32 MFMA is dtype-independent):
 // split-K slab store, or bias/ReLU + BN partial statistics (fprop), or ReLU mask + addend (dgrad).
 template <int BM, int BN, int WGM, int WGN, bool DGRAD>
-__device__ __forceinline__ void igemm_epilogue(const IgemmParams &p, f32x16 (&acc)[BM / WGM / 32][BN / WGN / 32], int g,
+__device__ __forceinline__ void igemm_epilogue(const IgemmParams &p, const IgemmClass &c, f32x16 (&acc)[BM / WGM / 32][BN / WGN / 32], int g,
                                                int mtile, int ntile, int split, int wm, int wn, int li, int lh,
                                                int ohw) {
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   const long long row_base = (long long)mtile * BM + wm * WTM;
-  const long long grow0 = (long long)g * p.rows_per_group;
+  const long long grow0 = (long long)g * c.rows_per_group;
   if (p.splits > 1) {       // raw partial tile -> slab; the epilogue runs in splitk_reduce_kernel
-    float *slab = p.slab + (long long)split * p.groups * p.rows_per_group * p.ncols;
+    float *slab = p.slab + (long long)split * p.groups * c.rows_per_group * p.ncols;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = ntile * BN + wn * WTN + j * 32 + li;
@@ -141,7 +162,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams &p, f32x16 (&ac
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const long long row = row_base + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-          if (col < p.ncols && row < p.rows_per_group) slab[(grow0 + row) * p.ncols + col] = acc[i][j][e];
+          if (col < p.ncols && row < c.rows_per_group) slab[(grow0 + row) * p.ncols + col] = acc[i][j][e];
         }
     }
     return;
@@ -159,16 +180,16 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams &p, f32x16 (&ac
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const long long row = row_base + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        const bool ok = cok && row < p.rows_per_group;
+        const bool ok = cok && row < c.rows_per_group;
         float v = acc[i][j][e];
         if (ok) {
           long long off;
           if (DGRAD && p.cls_step == 2) {
             const int rr = (int)row;
-            const int img = rr / ohw, rem = rr - img * ohw;
-            const int y2 = rem / p.out_w, x2 = rem - y2 * p.out_w;
-            off = ((((long long)g * p.imgs_per_group + img) * p.full_h + 2 * y2 + p.cls_py) * p.full_w + 2 * x2 +
-                   p.cls_px) * p.ncols + col;
+            const int img = (int)fdiv((unsigned)rr, c.ohw_div), rem = rr - img * ohw;
+            const int y2 = (int)fdiv((unsigned)rem, c.ow_div), x2 = rem - y2 * c.out_w;
+            off = ((((long long)g * p.imgs_per_group + img) * p.full_h + 2 * y2 + c.cls_py) * p.full_w + 2 * x2 +
+                   c.cls_px) * p.ncols + col;
           } else {
             off = (grow0 + row) * p.ncols + col;
           }
@@ -187,7 +208,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams &p, f32x16 (&ac
     }
     if (!DGRAD && p.stats) {
       // per-wave partial: column sum and sum of squares centred on the partial's own mean
-      long long cnt_ll = p.rows_per_group - row_base;
+      long long cnt_ll = c.rows_per_group - row_base;
       const int cnt = cnt_ll <= 0 ? 0 : (cnt_ll > WTM ? WTM : (int)cnt_ll);
       csum += __shfl_xor(csum, 32, 64);
       const float mean = cnt > 0 ? csum / (float)cnt : 0.f;
@@ -197,14 +218,14 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams &p, f32x16 (&ac
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const long long row = row_base + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-          if (row < p.rows_per_group) {
+          if (row < c.rows_per_group) {
             const float dlt = acc[i][j][e] - mean;
             q += dlt * dlt;
           }
         }
       q += __shfl_xor(q, 32, 64);
       if (lh == 0 && cok) {
-        const long long P = (long long)p.mtiles_per_group * WGM;
+        const long long P = (long long)c.mtiles_per_group * WGM;
         const long long pi = (long long)mtile * WGM + wm;
         float *st = p.stats + (((long long)g * P + pi) * 2) * p.ncols;
         st[col] = csum;
@@ -237,26 +258,26 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN, DGRAD)) void igemm_ke
   __shared__ __attribute__((aligned(16))) float smem[2 * (A_ELEMS + B_ELEMS)];
 
   const int nwg = gridDim.x;
-  const int wg_all = xcd_remap(blockIdx.x, nwg);
-  // a parity class without taps has ktotal == 0: one all-zero K-step, so that the epilogue still runs
-  const int KT_all = p.ktotal > 0 ? (p.ktotal + BK - 1) / BK : 1;
-  // this workgroup's range of (tile, K-step) units
+  const int wg_all = p.no_remap ? (int)blockIdx.x : xcd_remap(blockIdx.x, nwg);
+  // this workgroup's range of (tile, K-step) units; the unit space runs class by class, tile by tile
   long long u0, u1;
   int split = 0;
   if (p.sk_tiles > 0) {
-    const long long U = (long long)p.sk_tiles * KT_all;
+    const long long U = p.cls[p.ncls - 1].unit0 + (long long)(p.sk_tiles - p.cls[p.ncls - 1].tile0) * p.cls[p.ncls - 1].KT;
     u0 = (long long)wg_all * U / nwg;
     u1 = (long long)(wg_all + 1) * U / nwg;
   } else {
     const int tiles_total = nwg / p.splits;
     split = wg_all / tiles_total;
     const int wg0 = wg_all - split * tiles_total;
+    int ci = 0;
+    for (int i = 1; i < p.ncls; ++i) ci += wg0 >= p.cls[i].tile0;
+    const int KTc = p.cls[ci].KT;
     const int kb = split * p.ktiles_per_split;
-    const int ke = (kb + p.ktiles_per_split < KT_all) ? kb + p.ktiles_per_split : KT_all;
-    u0 = (long long)wg0 * KT_all + kb;
-    u1 = (long long)wg0 * KT_all + ke;     // plan_splitk never makes an empty split
+    const int ke = (kb + p.ktiles_per_split < KTc) ? kb + p.ktiles_per_split : KTc;
+    u0 = p.cls[ci].unit0 + (long long)(wg0 - p.cls[ci].tile0) * KTc + kb;
+    u1 = u0 + (ke - kb);                   // plan_splitk never makes an empty split
   }
-  const int ohw = p.out_h * p.out_w;
   const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(p.b, p.b_bytes);
 
   while (u0 < u1) {
@@ -270,15 +291,21 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN, DGRAD)) void igemm_ke
   const int li = lane & 31, lh = lane >> 5;
   const int a_kv = tid % KV;
   const int a_r0 = tid / KV;
-  const int wg = (int)(u0 / KT_all);
-  const int kt_begin = (int)(u0 - (long long)wg * KT_all);
+  int ci = 0;
+  for (int i = 1; i < p.ncls; ++i) ci += u0 >= p.cls[i].unit0;
+  const IgemmClass &c = p.cls[ci];
+  const int KT_all = c.KT;
+  const int ohw = c.out_h * c.out_w;
+  const long long ur = u0 - c.unit0;
+  const int wg = (int)(ur / KT_all);              // tile within the class
+  const int kt_begin = (int)(ur - (long long)wg * KT_all);
   int KT = kt_begin + (int)(u1 - u0);
   if (KT > KT_all) KT = KT_all;
   u0 += KT - kt_begin;
   const int ntile = wg % p.ntiles;
   const int mt_all = wg / p.ntiles;
-  const int g = mt_all / p.mtiles_per_group;
-  const int mtile = mt_all - g * p.mtiles_per_group;
+  const int g = mt_all / c.mtiles_per_group;
+  const int mtile = mt_all - g * c.mtiles_per_group;
 
   // ---- A loader state -------------------------------------------------------------------
   unsigned a_img[A_PASSES];            // byte offset of the row's image inside this group
@@ -287,14 +314,14 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN, DGRAD)) void igemm_ke
 #pragma unroll
   for (int i = 0; i < A_PASSES; ++i) {
     const long long m = (long long)mtile * BM + a_r0 + i * RPP;
-    a_ok[i] = m < p.rows_per_group;
+    a_ok[i] = m < c.rows_per_group;
     const int mm = a_ok[i] ? (int)m : 0;
-    const int img = mm / ohw;
+    const int img = (int)fdiv((unsigned)mm, c.ohw_div);
     const int rem = mm - img * ohw;
-    const int oy = rem / p.out_w, ox = rem - oy * p.out_w;
+    const int oy = (int)fdiv((unsigned)rem, c.ow_div), ox = rem - oy * c.out_w;
     if (DGRAD) {
-      a_y0[i] = oy + p.cls_cy;
-      a_x0[i] = ox + p.cls_cx;
+      a_y0[i] = oy + c.cls_cy;
+      a_x0[i] = ox + c.cls_cx;
     } else {
       a_y0[i] = oy * p.stride - p.pad;
       a_x0[i] = ox * p.stride - p.pad;
@@ -306,7 +333,7 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN, DGRAD)) void igemm_ke
 
   float4 a_reg[A_PASSES];
   float4 b_reg[DGRAD ? B_PASSES_D : B_PASSES_F];
-  int klimit = p.ktotal;        // end of this block's K range (split-K)
+  int klimit = c.ktotal;        // end of this block's K range (split-K)
 
   // Predicated loads are branch-free (buffer loads: an out-of-range offset reads zeros) so that the
   // whole K-step stays ONE basic block and the scheduler can interleave loader VALU / VMEM / LDS
@@ -314,26 +341,26 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN, DGRAD)) void igemm_ke
   auto load_tiles = [&](int kt) {
     // ---- A: one float4 (4 channels of one tap) per row pass
     const int k0 = kt * BK + a_kv * 4;
-    int tap = 0, c = k0;
-    if (p.ntaps > 1) {
+    int tap = 0, ch = k0;
+    if (c.ntaps > 1) {
       tap = k0 >> p.src_c_shift;
-      c = k0 - (tap << p.src_c_shift);
+      ch = k0 - (tap << p.src_c_shift);
     }
-    const int fr = (int)fdiv((unsigned)tap, p.tap_ns_div), fs = tap - fr * p.tap_ns;   // lattice coordinates (ti, tj)
+    const int fr = (int)fdiv((unsigned)tap, c.tap_ns_div), fs = tap - fr * c.tap_ns;   // lattice coordinates (ti, tj)
     const bool kok = k0 < klimit;
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
       const int iy = DGRAD ? a_y0[i] - fr : a_y0[i] + fr;
       const int ix = DGRAD ? a_x0[i] - fs : a_x0[i] + fs;
       const bool ok = a_ok[i] & kok & ((unsigned)iy < (unsigned)p.src_h) & ((unsigned)ix < (unsigned)p.src_w);
-      a_reg[i] = buf_ld16(rs_a, pred_off(a_img[i] + (unsigned)((iy * p.src_w + ix) * p.src_c + c) * 4u, ok));
+      a_reg[i] = buf_ld16(rs_a, pred_off(a_img[i] + (unsigned)((iy * p.src_w + ix) * p.src_c + ch) * 4u, ok));
     }
     // ---- B
     if (!DGRAD) {
 #pragma unroll
       for (int i = 0; i < B_PASSES_F; ++i) {
         const int n = ntile * BN + a_r0 + i * RPP;
-        b_reg[i] = buf_ld16(rs_b, pred_off((unsigned)(n * p.ktotal + k0) * 4u, (n < p.ncols) & kok));
+        b_reg[i] = buf_ld16(rs_b, pred_off((unsigned)(n * c.ktotal + k0) * 4u, (n < p.ncols) & kok));
       }
     } else {
       const int nv = tid % NV;
@@ -342,12 +369,12 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN, DGRAD)) void igemm_ke
       for (int i = 0; i < B_PASSES_D; ++i) {
         const int k = kt * BK + tid / NV + i * KRPP;
         int bt = 0, o = k;
-        if (p.ntaps > 1) {
+        if (c.ntaps > 1) {
           bt = k >> p.src_c_shift;
           o = k - (bt << p.src_c_shift);
         }
-        const int bi = (int)fdiv((unsigned)bt, p.tap_ns_div), bj = bt - bi * p.tap_ns;
-        const int btap = (p.tap_r0 + p.tap_step * bi) * p.s + p.tap_s0 + p.tap_step * bj;
+        const int bi = (int)fdiv((unsigned)bt, c.tap_ns_div), bj = bt - bi * c.tap_ns;
+        const int btap = (c.tap_r0 + p.tap_step * bi) * p.s + c.tap_s0 + p.tap_step * bj;
         b_reg[i] = buf_ld16(rs_b, pred_off((unsigned)((o * p.rs + btap) * p.cin + ncol) * 4u, (k < klimit) & (ncol < p.ncols)));
       }
     }
@@ -384,7 +411,7 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN, DGRAD)) void igemm_ke
   // 3-stage pipeline: while tile kt multiplies out of LDS[kt&1], tile kt+1 (fetched during the
   // previous step) is written to LDS[(kt+1)&1] and the global loads of tile kt+2 are issued.  Tiles
   // past the end are predicated off (zeros), so the loop body has no branches.
-  klimit = KT * BK < p.ktotal ? KT * BK : p.ktotal;
+  klimit = KT * BK < c.ktotal ? KT * BK : c.ktotal;
   load_tiles(kt_begin);
   store_tiles(kt_begin & 1);
   load_tiles(kt_begin + 1);
@@ -453,7 +480,7 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN, DGRAD)) void igemm_ke
           dst[((i * TN + j) * 4 + q) * 256 + tid] =
               make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
   } else {
-    igemm_epilogue<BM, BN, WGM, WGN, DGRAD>(p, acc, g, mtile, ntile, split, wm, wn, li, lh, ohw);
+    igemm_epilogue<BM, BN, WGM, WGN, DGRAD>(p, c, acc, g, mtile, ntile, split, wm, wn, li, lh, ohw);
   }
   }  // while (u0 < u1)
 }
@@ -468,14 +495,16 @@ __global__ __launch_bounds__(256) void igemm_fixup_kernel(IgemmParams p, int P) 
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
   const int li = lane & 31, lh = lane >> 5;
-  const int KT_all = (p.ktotal + BK - 1) / BK;
-  const long long U = (long long)p.sk_tiles * KT_all;
-  const int c = blockIdx.x;
-  const long long ucut = (long long)(c + 1) * U / P;
-  const long long tile = ucut / KT_all;
-  const long long t0 = tile * KT_all, t1 = t0 + KT_all;
+  const long long U = p.cls[p.ncls - 1].unit0 + (long long)(p.sk_tiles - p.cls[p.ncls - 1].tile0) * p.cls[p.ncls - 1].KT;
+  const int cut = blockIdx.x;
+  const long long ucut = (long long)(cut + 1) * U / P;
+  int ci = 0;
+  for (int i = 1; i < p.ncls; ++i) ci += ucut >= p.cls[i].unit0;
+  const IgemmClass &c = p.cls[ci];
+  const long long tile = (ucut - c.unit0) / c.KT;
+  const long long t0 = c.unit0 + tile * c.KT, t1 = t0 + c.KT;
   if (ucut == t0) return;                          // the cut falls on a tile boundary
-  if ((long long)c * U / P > t0) return;           // an earlier cut lies inside the same tile and owns it
+  if ((long long)cut * U / P > t0) return;         // an earlier cut lies inside the same tile and owns it
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -483,7 +512,7 @@ __global__ __launch_bounds__(256) void igemm_fixup_kernel(IgemmParams p, int P) 
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  for (int b = c; b < P; ++b) {
+  for (int b = cut; b < P; ++b) {
     const long long ub = (long long)b * U / P;
     if (ub >= t1) break;
     const float4 *src = reinterpret_cast<const float4 *>(p.slab) + ((long long)b * 2 + (ub > t0 ? 0 : 1)) * (BM * BN / 4);
@@ -503,9 +532,9 @@ __global__ __launch_bounds__(256) void igemm_fixup_kernel(IgemmParams p, int P) 
   const int wg = (int)tile;
   const int ntile = wg % p.ntiles;
   const int mt_all = wg / p.ntiles;
-  const int g = mt_all / p.mtiles_per_group;
-  const int mtile = mt_all - g * p.mtiles_per_group;
-  igemm_epilogue<BM, BN, WGM, WGN, DGRAD>(p, acc, g, mtile, ntile, 0, wm, wn, li, lh, p.out_h * p.out_w);
+  const int g = mt_all / c.mtiles_per_group;
+  const int mtile = mt_all - g * c.mtiles_per_group;
+  igemm_epilogue<BM, BN, WGM, WGN, DGRAD>(p, c, acc, g, mtile, ntile, 0, wm, wn, li, lh, c.out_h * c.out_w);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -572,9 +601,9 @@ __global__ __launch_bounds__(256) void igemm6_kernel(IgemmParams p) {
     const long long m = (long long)mtile * BM + a_r0 + i * RPP;
     a_ok[i] = m < p.rows_per_group;
     const int mm = a_ok[i] ? (int)m : 0;
-    const int img = mm / ohw;
+    const int img = (int)fdiv((unsigned)mm, p.ohw_div);
     const int rem = mm - img * ohw;
-    const int oy = rem / p.out_w, ox = rem - oy * p.out_w;
+    const int oy = (int)fdiv((unsigned)rem, p.ow_div), ox = rem - oy * p.out_w;
     if (DGRAD) {
       a_y0[i] = oy + p.cls_cy;
       a_x0[i] = ox + p.cls_cx;
@@ -765,7 +794,7 @@ __global__ __launch_bounds__(256) void igemm6_kernel(IgemmParams p) {
     }
     __syncthreads();
   }
-  igemm_epilogue<BM, BN, WGM, WGN, DGRAD>(p, acc, g, mtile, ntile, split, wm, wn, li, lh, ohw);
+  igemm_epilogue<BM, BN, WGM, WGN, DGRAD>(p, p.cls[0], acc, g, mtile, ntile, split, wm, wn, li, lh, ohw);
 }
 
 // bf16x6 with BOTH operands pre-split into bf16 planes by their producers (activations: bn_apply /
@@ -813,9 +842,9 @@ __global__ __launch_bounds__(256, 2) void igemm6p_kernel(IgemmParams p) {
     const long long am = (long long)mtile * BM + a_row[i];
     a_ok[i] = am < p.rows_per_group;
     const int mm = a_ok[i] ? (int)am : 0;
-    const int img = mm / ohw;
+    const int img = (int)fdiv((unsigned)mm, p.ohw_div);
     const int rem = mm - img * ohw;
-    const int oy = rem / p.out_w, ox = rem - oy * p.out_w;
+    const int oy = (int)fdiv((unsigned)rem, p.ow_div), ox = rem - oy * p.out_w;
     a_y0[i] = DGRAD ? oy + p.cls_cy : oy * p.stride - p.pad;
     a_x0[i] = DGRAD ? ox + p.cls_cx : ox * p.stride - p.pad;
     a_img[i] = (unsigned)(img * p.src_img_stride * 6);          // 3 planes x 2 bytes per element
@@ -959,7 +988,7 @@ __global__ __launch_bounds__(256, 2) void igemm6p_kernel(IgemmParams p) {
       __syncthreads();
     }
   }
-  igemm_epilogue<BM, BN, WGM, WGN, DGRAD>(p, acc, g, mtile, ntile, split, wm, wn, li, lh, ohw);
+  igemm_epilogue<BM, BN, WGM, WGN, DGRAD>(p, p.cls[0], acc, g, mtile, ntile, split, wm, wn, li, lh, ohw);
 }
 
 // Plane-interleaved bf16x6 operand format: a row of C fp32 values becomes C/8 groups of
@@ -1226,6 +1255,24 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
   }
 }
 
+// A stride-2 parity class without taps (e.g. three of the four classes of a 1x1 stride-2 conv):
+// dx = 0 there, plus the addend.
+__global__ __launch_bounds__(256) void dgrad_empty_class_kernel(float4 *__restrict__ dx, const float4 *__restrict__ addend,
+                                                                long long n, int sub_h, int sub_w, int full_h, int full_w,
+                                                                int c4, int py, int px) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int cc = (int)(i % c4);
+    long long t = i / c4;
+    const int x2 = (int)(t % sub_w);
+    t /= sub_w;
+    const int y2 = (int)(t % sub_h);
+    const long long img = t / sub_h;
+    const long long off = ((img * full_h + 2 * y2 + py) * full_w + 2 * x2 + px) * c4 + cc;
+    dx[off] = addend ? addend[off] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -1253,6 +1300,28 @@ static int validate(const mvg_conv_desc *d) {
 struct TileChoice {
   int bm, bn;
 };
+
+// the class view of the top-level fields (single-class launches; bf16x6 kernels' epilogue)
+static void class_from_params(IgemmClass &c, const IgemmParams &p) {
+  memset(&c, 0, sizeof(c));
+  c.out_h = p.out_h;
+  c.out_w = p.out_w;
+  c.ntaps = p.ntaps;
+  c.tap_ns = p.tap_ns;
+  c.tap_r0 = p.tap_r0;
+  c.tap_s0 = p.tap_s0;
+  c.ktotal = p.ktotal;
+  c.cls_py = p.cls_py;
+  c.cls_px = p.cls_px;
+  c.cls_cy = p.cls_cy;
+  c.cls_cx = p.cls_cx;
+  c.mtiles_per_group = p.mtiles_per_group;
+  c.rows_per_group = p.rows_per_group;
+  c.tap_ns_div = p.tap_ns_div;
+  c.ohw_div = p.ohw_div;
+  c.ow_div = p.ow_div;
+  c.KT = p.ktotal > 0 ? ceil_div(p.ktotal, 16) : 1;
+}
 
 static int g_streamk = -1;
 static bool streamk_enabled() {
@@ -1344,35 +1413,49 @@ static int plan_streamk(long long tiles, int KT, int bm, int bn, int occ) {
   return t_sk < 0.95 * t_dp ? (int)S : 0;
 }
 
-// Tile choice.  The largest tile the column count allows when stream-K will balance it over the CUs;
-// otherwise the largest tile that still gives >= 2 workgroups per CU (else the smallest).
-static TileChoice choose_tile(long long rows_per_group, int groups, int ncols, int ktotal, bool dgrad) {
+// Tile choice over the classes of one launch (rows_c, ktotal_c).  The largest tile the column count
+// allows when stream-K will balance it over the CUs; otherwise the largest tile that still gives
+// >= 2 workgroups per CU (else the smallest).
+static void count_tiles(const long long *rows, const int *ktotal, int ncls, int groups, int ncols, TileChoice t,
+                        long long &tiles, long long &units) {
+  tiles = units = 0;
+  for (int i = 0; i < ncls; ++i) {
+    const long long ti = (long long)groups * ceil_div(rows[i], t.bm) * ceil_div(ncols, t.bn);
+    tiles += ti;
+    units += ti * (ktotal[i] > 0 ? ceil_div(ktotal[i], 16) : 1);
+  }
+}
+static TileChoice choose_tile_multi(const long long *rows, const int *ktotal, int ncls, int groups, int ncols, bool dgrad) {
   static int cus = 0;
   if (cus <= 0) {
     cus = mvg_device_cus();
     if (cus <= 0) cus = 256;
   }
   if (ncols <= 32) return {128, 32};
+  long long tiles, units;
   {
     const TileChoice big = ncols >= 128 ? TileChoice{128, 128} : TileChoice{128, 64};
-    const long long tiles = (long long)groups * ceil_div(rows_per_group, big.bm) * ceil_div(ncols, big.bn);
-    if (ktotal > 0 && plan_streamk(tiles, ceil_div(ktotal, 16), big.bm, big.bn, tile_occupancy(big.bm, big.bn, dgrad)) > 0)
+    count_tiles(rows, ktotal, ncls, groups, ncols, big, tiles, units);
+    if (tiles > 0 && plan_streamk(tiles, (int)(units / tiles), big.bm, big.bn, tile_occupancy(big.bm, big.bn, dgrad)) > 0)
       return big;
   }
   const TileChoice cand[3] = {{128, 128}, {128, 64}, {64, 64}};
   for (int i = 0; i < 3; ++i) {
     if (cand[i].bn > 64 && ncols < 128) continue;
-    const long long blocks = (long long)groups * ceil_div(rows_per_group, cand[i].bm) * ceil_div(ncols, cand[i].bn);
-    if (blocks >= 2LL * cus) return cand[i];
+    count_tiles(rows, ktotal, ncls, groups, ncols, cand[i], tiles, units);
+    if (tiles >= 2LL * cus) return cand[i];
   }
   return (ncols >= 64) ? TileChoice{64, 64} : TileChoice{128, 32};
 }
+static TileChoice choose_tile(long long rows_per_group, int groups, int ncols, int ktotal, bool dgrad) {
+  return choose_tile_multi(&rows_per_group, &ktotal, 1, groups, ncols, dgrad);
+}
 
 template <int BM, int BN, int WGM, int WGN, bool DGRAD>
-static int launch_igemm_tile(IgemmParams &p, long long tiles, hipStream_t st) {
-  const int KT = p.ktotal > 0 ? ceil_div(p.ktotal, 16) : 1;
+static int launch_igemm_tile(IgemmParams &p, long long tiles, long long units, hipStream_t st) {
   int P = 0;
-  if (p.splits == 1 && p.ktotal > 0) P = plan_streamk(tiles, KT, BM, BN, igemm_occupancy<BM, BN, WGM, WGN, DGRAD>());
+  if (p.splits == 1 && units > tiles)
+    P = plan_streamk(tiles, (int)(units / tiles), BM, BN, igemm_occupancy<BM, BN, WGM, WGN, DGRAD>());
   if (P > 0) {
     float *scratch = sk_scratch(st, (size_t)P * 2 * BM * BN);
     if (!scratch) P = 0;                                   // no scratch: plain launch
@@ -1390,19 +1473,30 @@ static int launch_igemm_tile(IgemmParams &p, long long tiles, hipStream_t st) {
   return check_launch(DGRAD ? "conv_dgrad" : "conv_fprop");
 }
 
+// p.cls[0 .. ncls) hold the classes (out_h .. ow_div filled in); tile and unit offsets are set here
 template <bool DGRAD>
 static int launch_igemm(IgemmParams &p, TileChoice t, hipStream_t st) {
-  p.mtiles_per_group = ceil_div(p.rows_per_group, t.bm);
   p.ntiles = ceil_div(p.ncols, t.bn);
   if (p.splits < 1) p.splits = 1;
   if (p.splits == 1) p.ktiles_per_split = 1 << 30;
-  const long long tiles = (long long)p.groups * p.mtiles_per_group * p.ntiles;
+  long long tiles = 0, units = 0;
+  for (int i = 0; i < p.ncls; ++i) {
+    IgemmClass &c = p.cls[i];
+    c.mtiles_per_group = ceil_div(c.rows_per_group, t.bm);
+    c.KT = c.ktotal > 0 ? ceil_div(c.ktotal, 16) : 1;
+    c.tile0 = (int)tiles;
+    c.unit0 = units;
+    const long long ti = (long long)p.groups * c.mtiles_per_group * p.ntiles;
+    tiles += ti;
+    units += ti * c.KT;
+  }
   MVG_REQUIRE(tiles * p.splits < (1LL << 31), "conv: grid too large");
-  if (p.rows_per_group <= 0) return 0;
-  if (t.bm == 128 && t.bn == 128) return launch_igemm_tile<128, 128, 2, 2, DGRAD>(p, tiles, st);
-  if (t.bm == 128 && t.bn == 64) return launch_igemm_tile<128, 64, 2, 2, DGRAD>(p, tiles, st);
-  if (t.bm == 64 && t.bn == 64) return launch_igemm_tile<64, 64, 2, 2, DGRAD>(p, tiles, st);
-  return launch_igemm_tile<128, 32, 4, 1, DGRAD>(p, tiles, st);
+  MVG_REQUIRE(p.splits == 1 || p.ncls == 1, "conv: split-K with several classes");
+  if (tiles <= 0) return 0;
+  if (t.bm == 128 && t.bn == 128) return launch_igemm_tile<128, 128, 2, 2, DGRAD>(p, tiles, units, st);
+  if (t.bm == 128 && t.bn == 64) return launch_igemm_tile<128, 64, 2, 2, DGRAD>(p, tiles, units, st);
+  if (t.bm == 64 && t.bn == 64) return launch_igemm_tile<64, 64, 2, 2, DGRAD>(p, tiles, units, st);
+  return launch_igemm_tile<128, 32, 4, 1, DGRAD>(p, tiles, units, st);
 }
 
 // conv math: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = bf16x6 split on the bf16 MFMA
@@ -1424,6 +1518,8 @@ static int launch_igemm6(IgemmParams &p, TileChoice t, hipStream_t st) {
   const long long nblk = (long long)p.groups * p.mtiles_per_group * p.ntiles;
   MVG_REQUIRE(nblk < (1LL << 31), "conv: grid too large");
   if (p.rows_per_group <= 0) return 0;
+  p.ncls = 1;
+  class_from_params(p.cls[0], p);
   dim3 grid((unsigned)nblk), block(256);
   if (t.bm == 128 && t.bn == 128)
     hipLaunchKernelGGL((igemm6_kernel<128, 128, 16, 2, 2, DGRAD>), grid, block, 0, st, p);
@@ -1456,6 +1552,8 @@ static int launch_igemm6p(IgemmParams &p, TileChoice t, hipStream_t st) {
   const long long nblk = (long long)p.groups * p.mtiles_per_group * p.ntiles;
   MVG_REQUIRE(nblk < (1LL << 31), "conv: grid too large");
   if (p.rows_per_group <= 0) return 0;
+  p.ncls = 1;
+  class_from_params(p.cls[0], p);
   dim3 grid((unsigned)nblk), block(256);
   // BK = 16: two workgroups per CU; BK = 32 (one per CU) measured 20 % slower
   if (t.bn == 128)
@@ -1555,6 +1653,8 @@ static int fprop_impl(const mvg_conv_desc *d, const float *x, const float *wgt, 
   p.b_bytes = 4ll * d->cout * p.ktotal;
   MVG_REQUIRE(p.a_group_bytes < 0x7FFFFFF0ll && p.b_bytes < 0x7FFFFFF0ll, "conv: a group / the weights exceed 2 GiB");
   p.tap_ns_div = make_fastdiv((unsigned)p.tap_ns);
+  p.ohw_div = make_fastdiv((unsigned)(p.out_h * p.out_w));
+  p.ow_div = make_fastdiv((unsigned)p.out_w);
   const TileChoice t = choose_tile(p.rows_per_group, d->groups, d->cout, p.ktotal, false);
   const double flops = 2.0 * d->groups * (double)p.rows_per_group * d->cout * p.ktotal;
   const double bytes = 4.0 * (d->groups * (double)d->n * d->h * d->w * d->cin + (double)d->cout * p.ktotal +
@@ -1574,6 +1674,8 @@ static int fprop_impl(const mvg_conv_desc *d, const float *x, const float *wgt, 
     }
     return launch_igemm6<false>(p, t6, (hipStream_t)stream);
   }
+  p.ncls = 1;
+  class_from_params(p.cls[0], p);
   if (!stats && plan_splitk(p, t, ws ? ws_floats : 0) > 1) {
     p.slab = ws;
     if (launch_igemm<false>(p, t, (hipStream_t)stream)) return 1;
@@ -1624,6 +1726,11 @@ static int dgrad_impl(const mvg_conv_desc *d, const float *dy, const float *wgt,
   const bool lin = d->r == 1 && d->s == 1 && d->h == 1 && d->w == 1;
   ProfScope ps(lin ? MVG_K_LINEAR_DGRAD : MVG_K_CONV_DGRAD, (hipStream_t)stream, flops, bytes);
   const int step = d->stride;
+  const bool x6 = wplanes && aplanes;
+  IgemmParams m = p;                   // the merged fp32 launch: every parity class in one grid
+  m.ncls = 0;
+  long long cls_rows[4];
+  int cls_k[4];
   for (int py = 0; py < step; ++py)
     for (int px = 0; px < step; ++px) {
       const int sub_h = (d->h - py + step - 1) / step, sub_w = (d->w - px + step - 1) / step;
@@ -1638,6 +1745,8 @@ static int dgrad_impl(const mvg_conv_desc *d, const float *dy, const float *wgt,
       q.ntaps = nr * ns;
       q.tap_ns = ns > 0 ? ns : 1;
       q.tap_ns_div = make_fastdiv((unsigned)q.tap_ns);
+      q.ohw_div = make_fastdiv((unsigned)(sub_h * sub_w));
+      q.ow_div = make_fastdiv((unsigned)sub_w);
       q.tap_r0 = r0;
       q.tap_s0 = s0;
       q.tap_step = step;
@@ -1647,7 +1756,7 @@ static int dgrad_impl(const mvg_conv_desc *d, const float *dy, const float *wgt,
       q.cls_px = px;
       q.cls_cy = (py + d->pad - r0) / step;
       q.cls_cx = (px + d->pad - s0) / step;
-      if (wplanes && aplanes) {
+      if (x6) {
         q.b = (const float *)wplanes;
         q.b_row_pad = d->r * d->s * d->cout;          // multiple of 8 (cout >= 64)
         q.b_bytes = 6ll * d->cin * q.b_row_pad;
@@ -1659,16 +1768,53 @@ static int dgrad_impl(const mvg_conv_desc *d, const float *dy, const float *wgt,
         if (launch_igemm6p<true>(q, t6, (hipStream_t)stream)) return 1;
         continue;
       }
-      const TileChoice t = choose_tile(q.rows_per_group, d->groups, d->cin, q.ktotal, true);
-      if (step == 1 && plan_splitk(q, t, ws ? ws_floats : 0) > 1) {
-        q.slab = ws;
-        if (launch_igemm<true>(q, t, (hipStream_t)stream)) return 1;
-        if (launch_splitk_reduce(q, (hipStream_t)stream)) return 1;
+      if (q.ntaps == 0) {
+        // no tap reaches this class: dx = addend (nothing to do when the caller accumulates in place)
+        if (addend != dx || !addend) {
+          MVG_REQUIRE(d->cin % 4 == 0, "dgrad: cin %% 4 != 0");
+          const long long n = (long long)d->groups * d->n * sub_h * sub_w * (d->cin / 4);
+          long long blocks = (n + 255) / 256;
+          if (blocks > 4096) blocks = 4096;
+          hipLaunchKernelGGL(dgrad_empty_class_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4 *)dx,
+                             (const float4 *)addend, n, sub_h, sub_w, d->h, d->w, d->cin / 4, py, px);
+          if (check_launch("dgrad(empty class)")) return 1;
+        }
         continue;
       }
-      if (launch_igemm<true>(q, t, (hipStream_t)stream)) return 1;
+      if (m.ncls == 0) {               // launch-wide fields that depend on the stride
+        m.tap_step = step;
+        m.cls_step = step;
+        m.rows_per_group = q.rows_per_group;
+        m.ktotal = q.ktotal;
+        m.out_h = q.out_h;
+        m.out_w = q.out_w;
+      }
+      cls_rows[m.ncls] = q.rows_per_group;
+      cls_k[m.ncls] = q.ktotal;
+      class_from_params(m.cls[m.ncls++], q);
     }
-  return 0;
+  if (x6 || m.ncls == 0) return 0;
+  // longest class first: with one tile per workgroup the short tiles then fill the tail
+  for (int i = 1; i < m.ncls; ++i)
+    for (int j = i; j > 0 && cls_k[j] > cls_k[j - 1]; --j) {
+      const IgemmClass tc = m.cls[j];
+      m.cls[j] = m.cls[j - 1];
+      m.cls[j - 1] = tc;
+      const long long tr = cls_rows[j];
+      cls_rows[j] = cls_rows[j - 1];
+      cls_rows[j - 1] = tr;
+      const int tk = cls_k[j];
+      cls_k[j] = cls_k[j - 1];
+      cls_k[j - 1] = tk;
+    }
+  m.no_remap = m.ncls > 1;
+  const TileChoice t = choose_tile_multi(cls_rows, cls_k, m.ncls, d->groups, d->cin, true);
+  if (m.ncls == 1 && step == 1 && plan_splitk(m, t, ws ? ws_floats : 0) > 1) {
+    m.slab = ws;
+    if (launch_igemm<true>(m, t, (hipStream_t)stream)) return 1;
+    return launch_splitk_reduce(m, (hipStream_t)stream);
+  }
+  return launch_igemm<true>(m, t, (hipStream_t)stream);
 }
 
 static mvg_conv_desc linear_desc(int rows, int fin, int fout) {
