@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MVG_ABI_VERSION 1
+#define MVG_ABI_VERSION 2
 
 /* ---------------------------------------------------------------- library */
 int mvg_abi_version(void);
@@ -159,21 +159,23 @@ int mvg_bn_eval_affine(int groups, int c, const float *gamma, const float *beta,
 /* out = [relu]( y*scale[g] + shift[g] [+ residual] );  y,out,residual: [groups][rows][c]. */
 int mvg_bn_apply(const float *y, const float *scale, const float *shift, const float *residual,
                  int relu, float *out, int groups, int64_t rows_per_group, int c, void *stream);
-/* Backward, step 1: per (group, channel) s1 = sum(dz), s2 = sum(dz * xhat) with
- * dz = g * (act > 0) when act != NULL else g, xhat = (y - mean) * invstd.
+/* Backward, step 1: per (group, channel) s1 = sum(dz), s2 = sum(dz * xhat), xhat = (y - mean) * invstd,
+ * dz = g masked by the unit's ReLU.  The mask comes from `act` (the unit's output: act > 0) or, for
+ * a ReLU without residual, from (relu_scale, relu_shift) = the scale/shift mvg_bn_apply used:
+ * fma(y, scale, shift) > 0 is the same bit pattern and saves reading act.  Both NULL: no ReLU.
  * Also dgamma[c] (+)= sum_g s2, dbeta[c] (+)= sum_g s1 (accumulate flag).
  * workspace: mvg_bn_bwd_workspace_floats() floats. */
 int mvg_bn_bwd_reduce(const float *g, const float *act, const float *y, const float *mean,
-                      const float *invstd, int groups, int64_t rows_per_group, int c,
-                      float *s1, float *s2, float *dgamma, float *dbeta, int accumulate,
-                      float *workspace, void *stream);
+                      const float *invstd, const float *relu_scale, const float *relu_shift,
+                      int groups, int64_t rows_per_group, int c, float *s1, float *s2, float *dgamma,
+                      float *dbeta, int accumulate, float *workspace, void *stream);
 size_t mvg_bn_bwd_workspace_floats(int groups, int64_t rows_per_group, int c);
 /* Backward, step 2: dy = gamma*invstd*(dz - s1/n - xhat*s2/n); dz_out (optional, may alias g)
  * receives the masked gradient for the residual branch. */
 int mvg_bn_bwd_apply(const float *g, const float *act, const float *y, const float *mean,
                      const float *invstd, const float *gamma, const float *s1, const float *s2,
-                     int groups, int64_t rows_per_group, int c, float *dy, float *dz_out,
-                     void *stream);
+                     const float *relu_scale, const float *relu_shift, int groups,
+                     int64_t rows_per_group, int c, float *dy, float *dz_out, void *stream);
 
 /* ---------------------------------------------------------------- pooling / layout
  * nn.MaxPool2d(3,2,1) resnet.py:189; nn.AdaptiveAvgPool2d((1,1)) resnet.py:200 + rot_mv.py:126;
@@ -182,6 +184,25 @@ int mvg_maxpool3x3s2_fwd(const float *x, float *y, uint8_t *argmax, int n, int h
                          int ho, int wo, void *stream);
 int mvg_maxpool3x3s2_bwd(const float *dy, const uint8_t *argmax, float *dx, int n, int h, int w,
                          int c, int ho, int wo, void *stream);
+/* Stem tail fused: pooled = MaxPool2d(3,2,1)(relu(y*scale + shift)) without materialising the
+ * normalised activation (torchvision resnet.py:187-189 conv1 -> bn1 -> relu -> maxpool, called from
+ * /root/reference/models/rot_mv.py:204-205).  y [groups][n_per_group][h][w][c]; scale/shift
+ * [groups][c] from mvg_bn_finalize / mvg_bn_eval_affine.  The backward pair rebuilds the gradient
+ * of the BN output from (g_pooled, argmax) and the ReLU mask from y: same results as
+ * mvg_maxpool3x3s2_bwd -> mvg_bn_bwd_reduce -> mvg_bn_bwd_apply, 2.3 GB less traffic at C2. */
+int mvg_bn_relu_maxpool_fwd(const float *y, const float *scale, const float *shift, float *pooled,
+                            uint8_t *argmax, int groups, int n_per_group, int h, int w, int c,
+                            int ho, int wo, void *stream);
+int mvg_bn_relu_maxpool_bwd_reduce(const float *g_pooled, const uint8_t *argmax, const float *y,
+                                   const float *mean, const float *invstd, const float *scale,
+                                   const float *shift, int groups, int n_per_group, int h, int w,
+                                   int c, int ho, int wo, float *s1, float *s2, float *dgamma,
+                                   float *dbeta, int accumulate, float *workspace, void *stream);
+int mvg_bn_relu_maxpool_bwd_apply(const float *g_pooled, const uint8_t *argmax, const float *y,
+                                  const float *mean, const float *invstd, const float *gamma,
+                                  const float *scale, const float *shift, const float *s1,
+                                  const float *s2, int groups, int n_per_group, int h, int w, int c,
+                                  int ho, int wo, float *dy, void *stream);
 int mvg_avgpool_fwd(const float *x, float *y, int n, int hw, int c, void *stream);
 int mvg_avgpool_bwd(const float *dy, float *dx, int n, int hw, int c, void *stream);
 int mvg_nchw_to_nhwc4(const float *src, float *dst, int n, int c, int h, int w, void *stream);

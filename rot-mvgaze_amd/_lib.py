@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "librotmvgaze_hip.so")
 
 K_FAMILIES = 18
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class ConvDesc(C.Structure):
@@ -68,11 +68,15 @@ SIGNATURES = {
     "mvg_bn_finalize": (_I, [_P, _I, _I, _I, _I64, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
     "mvg_bn_eval_affine": (_I, [_I, _I, _P, _P, _P, _P, _F, _P, _P, _P]),
     "mvg_bn_apply": (_I, [_P, _P, _P, _P, _I, _P, _I, _I64, _I, _P]),
-    "mvg_bn_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _I, _I64, _I, _P, _P, _P, _P, _I, _P, _P]),
+    "mvg_bn_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _P, _P, _P, _P, _I, _P, _P]),
     "mvg_bn_bwd_workspace_floats": (C.c_size_t, [_I, _I64, _I]),
-    "mvg_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _P, _P, _P]),
+    "mvg_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _P, _P, _P]),
     "mvg_maxpool3x3s2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "mvg_maxpool3x3s2_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "mvg_bn_relu_maxpool_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "mvg_bn_relu_maxpool_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P,
+                                            _P]),
+    "mvg_bn_relu_maxpool_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "mvg_avgpool_fwd": (_I, [_P, _P, _I, _I, _I, _P]),
     "mvg_avgpool_bwd": (_I, [_P, _P, _I, _I, _I, _P]),
     "mvg_nchw_to_nhwc4": (_I, [_P, _P, _I, _I, _I, _I, _P]),

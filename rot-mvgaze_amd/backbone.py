@@ -42,7 +42,8 @@ class GradSink:
 
 class _Unit:
     """Saved state of one conv + BN (+ReLU) (+residual) for the backward pass."""
-    __slots__ = ("spec", "desc", "x_in", "y", "out", "mean", "invstd", "relu", "rows", "w", "wp_t")
+    __slots__ = ("spec", "desc", "x_in", "y", "out", "mean", "invstd", "relu", "rows", "w", "wp_t", "trained", "pool",
+                 "relu_affine")
 
 
 class Backbone:
@@ -68,7 +69,9 @@ class Backbone:
 
     # ---------------------------------------------------------------- forward
     def _unit_fwd(self, c: ConvSpec, x: Tensor, G: int, N: int, H: int, W: int, training: bool, relu: bool,
-                  residual: Optional[Tensor], tape: Optional[list]) -> Tensor:
+                  residual: Optional[Tensor], tape: Optional[list], pool: bool = False):
+        """conv -> BatchNorm (-> + residual) (-> ReLU).  pool=True (the stem): the 3x3/2 max pool is
+        fused behind the ReLU and (pooled, argmax) is returned; the normalised map is not stored."""
         cin = 4 if c.cin == 3 else c.cin
         d = ConvDesc.make(G, N, H, W, cin, c.cout, c.k, c.stride, c.pad)
         dev = x.device
@@ -96,20 +99,42 @@ class Backbone:
             # inference: BN (running statistics) + residual + ReLU folded into the conv epilogue
             ops.bn_eval_affine(1, c.cout, gamma, beta, rm, rv, BN_EPS, scale[:1], shift[:1])
             ops.conv_fprop_affine(d, x, w, y, scale[0], shift[0], residual, relu)
+            if pool:
+                return self._pool_plain(y, G, N, d.ho, d.wo, c.cout)
             return y
         else:
             fprop(None)
             ops.bn_eval_affine(G, c.cout, gamma, beta, rm, rv, BN_EPS, scale, shift)
         keep = tape is not None
-        out = torch.empty_like(y) if keep else y            # inference: normalise in place
-        ops.bn_apply(y, scale, shift, residual, relu, out, G, rows, c.cout)
+        if pool:
+            assert relu and residual is None
+            hp, wp_ = (d.ho + 2 - 3) // 2 + 1, (d.wo + 2 - 3) // 2 + 1
+            out = torch.empty(G, N, hp, wp_, c.cout, dtype=torch.float32, device=dev)
+            argmax = torch.empty(G, N, hp, wp_, c.cout, dtype=torch.uint8, device=dev)
+            ops.bn_relu_maxpool_fwd(y, scale, shift, out, argmax, G, N, d.ho, d.wo, c.cout, hp, wp_)
+        else:
+            out = torch.empty_like(y) if keep else y            # inference: normalise in place
+            ops.bn_apply(y, scale, shift, residual, relu, out, G, rows, c.cout)
         if keep:
             u = _Unit()
             u.spec, u.desc, u.x_in, u.y, u.out, u.mean, u.invstd, u.relu, u.rows, u.w = \
-                c, d, x, y, out, mean, invstd, relu, rows, w
+                c, d, x, y, (None if pool else out), mean, invstd, relu, rows, w
             u.wp_t = x6 and cin >= 64
+            u.trained = training
+            # ReLU without residual: the backward rebuilds the mask from y (saves reading `out` twice)
+            u.relu_affine = (scale, shift) if (relu and residual is None and not pool) else None
+            if pool:
+                u.pool = (argmax, scale, shift, d.ho, d.wo, hp, wp_)
             tape.append(u)
-        return out
+        return (out, argmax) if pool else out
+
+    @staticmethod
+    def _pool_plain(a0: Tensor, G: int, N: int, h: int, w: int, c: int):
+        hp, wp_ = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+        x = torch.empty(G, N, hp, wp_, c, dtype=torch.float32, device=a0.device)
+        argmax = torch.empty(G, N, hp, wp_, c, dtype=torch.uint8, device=a0.device)
+        ops.maxpool_fwd(a0, x, argmax, G * N, h, w, c, hp, wp_)
+        return x, argmax
 
     def forward(self, imgs: List[Tensor], training: bool, keep_tape: bool, input_bgr: bool = False):
         """imgs: V tensors [B,3,H,W] fp32 NCHW (the reference's input format, rot_mv.py:188-189), or
@@ -136,15 +161,8 @@ class Backbone:
         if training:
             torch._foreach_add_(self.bn_count_buffers(), V)       # num_batches_tracked += 1 per view call
         s = self.spec
-        a0 = self._unit_fwd(s.stem, x0, V, B, H, W, training, True, None, ulist)
-        H1, W1 = a0.shape[2], a0.shape[3]
-        Hp, Wp = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
-        x = torch.empty(V, B, Hp, Wp, 64, dtype=torch.float32, device=dev)
-        argmax = torch.empty(V, B, Hp, Wp, 64, dtype=torch.uint8, device=dev)
-        ops.maxpool_fwd(a0, x, argmax, V * B, H1, W1, 64, Hp, Wp)
-        if keep_tape:
-            tape["pool"] = (argmax, H1, W1, Hp, Wp)
-        Hc, Wc = Hp, Wp
+        x, argmax = self._unit_fwd(s.stem, x0, V, B, H, W, training, True, None, ulist, pool=True)
+        Hc, Wc = x.shape[2], x.shape[3]
         for blk in s.blocks:
             first = len(ulist) if keep_tape else 0
             identity = x
@@ -178,16 +196,17 @@ class Backbone:
         G = u.y.shape[0]
         gp, bp = self.p[c.bn + ".weight"], self.p[c.bn + ".bias"]
         s12 = torch.empty(2, G, c.cout, dtype=torch.float32, device=g.device)
-        act = u.out if u.relu else None
+        ra = u.relu_affine
+        act = u.out if (u.relu and ra is None) else None
         acc = sink.accumulate(gp)
         assert acc == sink.accumulate(bp)
         ops.bn_bwd_reduce(g, act, u.y, u.mean, u.invstd, G, u.rows, c.cout, s12[0], s12[1], sink.view(gp), sink.view(bp),
-                          acc)
+                          acc, ra)
         if need_dz:
             dy = torch.empty_like(g)
-            ops.bn_bwd_apply(g, act, u.y, u.mean, u.invstd, gp.detach(), s12[0], s12[1], G, u.rows, c.cout, dy, g)
+            ops.bn_bwd_apply(g, act, u.y, u.mean, u.invstd, gp.detach(), s12[0], s12[1], G, u.rows, c.cout, dy, g, ra)
             return dy, g
-        ops.bn_bwd_apply(g, act, u.y, u.mean, u.invstd, gp.detach(), s12[0], s12[1], G, u.rows, c.cout, g, None)
+        ops.bn_bwd_apply(g, act, u.y, u.mean, u.invstd, gp.detach(), s12[0], s12[1], G, u.rows, c.cout, g, None, ra)
         return g, None
 
     def _conv_bwd(self, u: _Unit, dy: Tensor, need_dx: bool, addend: Optional[Tensor], sink: GradSink):
@@ -218,6 +237,9 @@ class Backbone:
         order they become final); returns d(img) as V NCHW tensors when need_dimg."""
         V, B = tape["V"], tape["B"]
         units: List[_Unit] = tape["units"]
+        if not all(u.trained for u in units):
+            raise NotImplementedError("backward through eval-mode BatchNorm (running statistics) is not implemented: "
+                                      "call model.train() for gradient steps")
         Hc, Wc = tape["final_hw"]
         g = torch.empty(V, B, Hc, Wc, self.fc_dim, dtype=torch.float32, device=dfeat.device)
         ops.avgpool_bwd(dfeat.contiguous(), g, V * B, Hc * Wc, self.fc_dim)
@@ -251,12 +273,19 @@ class Backbone:
             g = d
             if "debug" in tape:
                 tape["debug"].append(g.clone())
-        # maxpool + stem
-        argmax, H1, W1, Hp, Wp = tape["pool"]
+        # stem: max pool + ReLU + BatchNorm backward fused (the 112x112 gradient map is never built)
         stem = units[0]
-        ga = torch.empty_like(stem.out)
-        ops.maxpool_bwd(g, argmax, ga, V * B, H1, W1, 64, Hp, Wp)
-        dy, _ = self._bn_bwd(stem, ga, False, sink)
+        argmax, scale, shift, H1, W1, Hp, Wp = stem.pool
+        sc = stem.spec
+        gp, bp = P[sc.bn + ".weight"], P[sc.bn + ".bias"]
+        s12 = torch.empty(2, V, sc.cout, dtype=torch.float32, device=g.device)
+        acc = sink.accumulate(gp)
+        assert acc == sink.accumulate(bp)
+        ops.bn_relu_maxpool_bwd_reduce(g, argmax, stem.y, stem.mean, stem.invstd, scale, shift, V, B, H1, W1, sc.cout, Hp, Wp,
+                                       s12[0], s12[1], sink.view(gp), sink.view(bp), acc)
+        dy = torch.empty_like(stem.y)
+        ops.bn_relu_maxpool_bwd_apply(g, argmax, stem.y, stem.mean, stem.invstd, gp.detach(), scale, shift, s12[0], s12[1],
+                                      V, B, H1, W1, sc.cout, Hp, Wp, dy)
         dx0 = self._conv_bwd(stem, dy, need_dimg, None, sink)
         sink.publish([P[stem.spec.name + ".weight"], P[stem.spec.bn + ".weight"], P[stem.spec.bn + ".bias"]])
         if not need_dimg:

@@ -28,14 +28,24 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restri
     const float *st = stats + (long long)g * partials * 2 * c;
     double s = 0.0, q = 0.0, ss = 0.0;
     if (ch < c) {
-      for (int p = pl; p < partials; p += 128) {
-        const long long cnt = rows - (long long)p * rows_per_partial;
-        if (cnt <= 0) break;
-        const double sp = st[((long long)p * 2) * c + ch];
-        const double qp = st[((long long)p * 2 + 1) * c + ch];
+      // branch-free body (no early exit) so that the loads of several iterations are in flight at once
+      const int valid = (int)((rows + rows_per_partial - 1) / rows_per_partial) < partials
+                            ? (int)((rows + rows_per_partial - 1) / rows_per_partial) : partials;
+#pragma unroll 4
+      for (int p = pl; p < valid; p += 128) {
+        const float sp_f = st[((long long)p * 2) * c + ch];
+        const float qp_f = st[((long long)p * 2 + 1) * c + ch];
+        const double sp = sp_f, qp = qp_f;
         s += sp;
         q += qp;
-        ss += sp * sp * (cnt >= rows_per_partial ? inv_full : 1.0 / (double)cnt);   // only the ragged last partial divides
+        ss += sp * sp;
+      }
+      ss *= inv_full;
+      // the ragged last partial was scaled by 1/rows_per_partial above: correct it to 1/cnt
+      const long long last_cnt = rows - (long long)(valid - 1) * rows_per_partial;
+      if (valid > 0 && last_cnt < rows_per_partial && ((valid - 1) & 127) == pl) {
+        const double sp = st[((long long)(valid - 1) * 2) * c + ch];
+        ss += sp * sp * (1.0 / (double)last_cnt - inv_full);
       }
     }
     sh[0][pl][cl] = s;
@@ -102,7 +112,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float4 *__restrict_
   for (; i < n4_per_group; i += stride) {
     const float4 v = y[base + i];
     const float4 a = sc4[cq], b = sh4[cq];
-    float4 o = make_float4(v.x * a.x + b.x, v.y * a.y + b.y, v.z * a.z + b.z, v.w * a.w + b.w);
+    // explicit fma: the backward kernels rebuild the ReLU mask from y with the same expression
+    float4 o = make_float4(__builtin_fmaf(v.x, a.x, b.x), __builtin_fmaf(v.y, a.y, b.y), __builtin_fmaf(v.z, a.z, b.z),
+                           __builtin_fmaf(v.w, a.w, b.w));
     if (residual) {
       const float4 r = residual[base + i];
       o.x += r.x;
@@ -127,7 +139,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float4 *__restrict_
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float4 *__restrict__ g, const float4 *__restrict__ act,
                                                             const float4 *__restrict__ y,
                                                             const float *__restrict__ mean,
-                                                            const float *__restrict__ invstd, long long rows,
+                                                            const float *__restrict__ invstd,
+                                                            const float *__restrict__ mscale,
+                                                            const float *__restrict__ mshift, long long rows,
                                                             long long rows_per_chunk, int c, int c4n, int cw,
                                                             float *__restrict__ partial, int chunks) {
   __shared__ float4 sh[2][256];
@@ -140,6 +154,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float4 *__rest
   if (cok) {
     const float4 mu = reinterpret_cast<const float4 *>(mean + (long long)grp * c)[cq];
     const float4 is = reinterpret_cast<const float4 *>(invstd + (long long)grp * c)[cq];
+    float4 ma = make_float4(0.f, 0.f, 0.f, 0.f), mb = ma;
+    if (mscale) {
+      ma = reinterpret_cast<const float4 *>(mscale + (long long)grp * c)[cq];
+      mb = reinterpret_cast<const float4 *>(mshift + (long long)grp * c)[cq];
+    }
     const long long r0 = (long long)blockIdx.x * rows_per_chunk;
     long long r1 = r0 + rows_per_chunk;
     if (r1 > rows) r1 = rows;
@@ -147,14 +166,19 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float4 *__rest
     for (long long r = r0 + rl; r < r1; r += nrl) {
       const long long off = gbase + r * c4n + cq;
       float4 d = g[off];
+      const float4 v = y[off];
       if (act) {
         const float4 a = act[off];
         d.x = a.x > 0.f ? d.x : 0.f;
         d.y = a.y > 0.f ? d.y : 0.f;
         d.z = a.z > 0.f ? d.z : 0.f;
         d.w = a.w > 0.f ? d.w : 0.f;
+      } else if (mscale) {       // ReLU without residual: out > 0 <=> fma(y, scale, shift) > 0 (bn_apply_kernel)
+        d.x = __builtin_fmaf(v.x, ma.x, mb.x) > 0.f ? d.x : 0.f;
+        d.y = __builtin_fmaf(v.y, ma.y, mb.y) > 0.f ? d.y : 0.f;
+        d.z = __builtin_fmaf(v.z, ma.z, mb.z) > 0.f ? d.z : 0.f;
+        d.w = __builtin_fmaf(v.w, ma.w, mb.w) > 0.f ? d.w : 0.f;
       }
-      const float4 v = y[off];
       s1.x += d.x;
       s1.y += d.y;
       s1.z += d.z;
@@ -228,6 +252,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float4 *__restr
                                                            const float *__restrict__ invstd,
                                                            const float *__restrict__ gamma,
                                                            const float *__restrict__ s1, const float *__restrict__ s2,
+                                                           const float *__restrict__ mscale,
+                                                           const float *__restrict__ mshift,
                                                            long long n4_per_group, float inv_rows, int c4n, int c,
                                                            float4 *__restrict__ dy, float4 *__restrict__ dz_out) {
   const int grp = blockIdx.y;
@@ -243,14 +269,21 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float4 *__restr
   const int step = (int)(stride % c4n);
   for (; i < n4_per_group; i += stride) {
     float4 d = g[base + i];
+    const float4 v = y[base + i];
     if (act) {
       const float4 a = act[base + i];
       d.x = a.x > 0.f ? d.x : 0.f;
       d.y = a.y > 0.f ? d.y : 0.f;
       d.z = a.z > 0.f ? d.z : 0.f;
       d.w = a.w > 0.f ? d.w : 0.f;
+    } else if (mscale) {
+      const float4 ma = reinterpret_cast<const float4 *>(mscale + (long long)grp * c)[cq];
+      const float4 mb = reinterpret_cast<const float4 *>(mshift + (long long)grp * c)[cq];
+      d.x = __builtin_fmaf(v.x, ma.x, mb.x) > 0.f ? d.x : 0.f;
+      d.y = __builtin_fmaf(v.y, ma.y, mb.y) > 0.f ? d.y : 0.f;
+      d.z = __builtin_fmaf(v.z, ma.z, mb.z) > 0.f ? d.z : 0.f;
+      d.w = __builtin_fmaf(v.w, ma.w, mb.w) > 0.f ? d.w : 0.f;
     }
-    const float4 v = y[base + i];
     const float4 mu = mu4[cq], is = is4[cq], ga = ga4[cq], sa = a4[cq], sb = b4[cq];
     float4 o;
     o.x = ga.x * is.x * (d.x - sa.x * inv_rows - (v.x - mu.x) * is.x * (sb.x * inv_rows));
@@ -262,6 +295,182 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float4 *__restr
     cq += step;
     if (cq >= c4n) cq -= c4n;
   }
+}
+
+// ---- stem tail: BatchNorm + ReLU + MaxPool2d(3,2,1), fused --------------------------------------
+// The normalised stem activation (B*V x 112 x 112 x 64 floats, 411 MB at C2) is never written:
+// forward reads the conv output once and writes the pooled map + argmax; backward rebuilds the
+// gradient of the BN output on the fly (gather over the <= 4 pooling windows a pixel can win) and
+// the ReLU mask from y (mask = fma(y, scale, shift) > 0, the same expression as the forward).
+__device__ __forceinline__ float4 bn_relu4(float4 v, float4 a, float4 b) {
+  return make_float4(fmaxf(__builtin_fmaf(v.x, a.x, b.x), 0.f), fmaxf(__builtin_fmaf(v.y, a.y, b.y), 0.f),
+                     fmaxf(__builtin_fmaf(v.z, a.z, b.z), 0.f), fmaxf(__builtin_fmaf(v.w, a.w, b.w), 0.f));
+}
+
+// grid = (ceil(wo*c4n / 256), images*ho): one thread = one (image, oy, ox, 4 channels), no per-thread
+// divisions by runtime values except ox/cq.  First maximum in (kh, kw) scan order (ATen's rule).
+__global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const float4 *__restrict__ y, const float *__restrict__ scale,
+                                                                  const float *__restrict__ shift, float4 *__restrict__ pooled,
+                                                                  uchar4 *__restrict__ argmax, int n_per_group, int h, int w,
+                                                                  int c4n, int ho, int wo) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= wo * c4n) return;
+  const int ox = t / c4n, cq = t - ox * c4n;
+  const int n = blockIdx.y / ho, oy = blockIdx.y - n * ho;
+  const int grp = n / n_per_group;
+  const float4 a = reinterpret_cast<const float4 *>(scale)[(long long)grp * c4n + cq];
+  const float4 b = reinterpret_cast<const float4 *>(shift)[(long long)grp * c4n + cq];
+  float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  uchar4 idx = make_uchar4(0, 0, 0, 0);
+  bool first = true;
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const int iy = oy * 2 - 1 + kh;
+    if ((unsigned)iy >= (unsigned)h) continue;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int ix = ox * 2 - 1 + kw;
+      if ((unsigned)ix >= (unsigned)w) continue;
+      const float4 v = bn_relu4(y[(((long long)n * h + iy) * w + ix) * c4n + cq], a, b);
+      const unsigned char k = (unsigned char)(kh * 3 + kw);
+      if (first) {
+        best = v;
+        idx = make_uchar4(k, k, k, k);
+        first = false;
+      } else {
+        if (v.x > best.x || v.x != v.x) { best.x = v.x; idx.x = k; }
+        if (v.y > best.y || v.y != v.y) { best.y = v.y; idx.y = k; }
+        if (v.z > best.z || v.z != v.z) { best.z = v.z; idx.z = k; }
+        if (v.w > best.w || v.w != v.w) { best.w = v.w; idx.w = k; }
+      }
+    }
+  }
+  const long long o = (((long long)n * ho + oy) * wo + ox) * c4n + cq;
+  pooled[o] = best;
+  argmax[o] = idx;
+}
+
+// gradient wrt the (never stored) ReLU output at pixel (n, iy, ix): the pooled gradients of the windows it won
+__device__ __forceinline__ float4 pool_gather(const float4 *__restrict__ gp, const uchar4 *__restrict__ am, long long n, int iy,
+                                              int ix, int cq, int c4n, int ho, int wo) {
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int oy0 = iy >> 1, ox0 = ix >> 1;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int oy = oy0 + a;
+    const int kh = iy - (oy * 2 - 1);
+    if (kh < 0 || kh > 2 || oy >= ho) continue;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int ox = ox0 + b;
+      const int kw = ix - (ox * 2 - 1);
+      if (kw < 0 || kw > 2 || ox >= wo) continue;
+      const long long o = ((n * ho + oy) * wo + ox) * c4n + cq;
+      const uchar4 k = am[o];
+      const float4 g = gp[o];
+      const unsigned char me = (unsigned char)(kh * 3 + kw);
+      if (k.x == me) acc.x += g.x;
+      if (k.y == me) acc.y += g.y;
+      if (k.z == me) acc.z += g.z;
+      if (k.w == me) acc.w += g.w;
+    }
+  }
+  return acc;
+}
+
+// grid = (chunks, column blocks, groups) and the partial layout of bn_bwd_reduce_kernel; a chunk is a
+// range of image lines (image, iy), the 256/cw row lanes stride along ix - no per-element division.
+__global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const float4 *__restrict__ gp, const uchar4 *__restrict__ am,
+                                                                 const float4 *__restrict__ y, const float *__restrict__ mean,
+                                                                 const float *__restrict__ invstd,
+                                                                 const float *__restrict__ scale,
+                                                                 const float *__restrict__ shift, int lines_per_chunk,
+                                                                 int n_per_group, int h, int w, int ho, int wo, int c, int c4n,
+                                                                 int cw, float *__restrict__ partial, int chunks) {
+  __shared__ float4 sh[2][256];
+  const int grp = blockIdx.z;
+  const int rl = threadIdx.x / cw, cl = threadIdx.x % cw;
+  const int nrl = 256 / cw;
+  const int cq = blockIdx.y * cw + cl;
+  const bool cok = cq < c4n;
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  if (cok) {
+    const float4 mu = reinterpret_cast<const float4 *>(mean + (long long)grp * c)[cq];
+    const float4 is = reinterpret_cast<const float4 *>(invstd + (long long)grp * c)[cq];
+    const float4 sa = reinterpret_cast<const float4 *>(scale + (long long)grp * c)[cq];
+    const float4 sb = reinterpret_cast<const float4 *>(shift + (long long)grp * c)[cq];
+    const int lines = n_per_group * h;
+    const int l0 = blockIdx.x * lines_per_chunk;
+    const int l1 = l0 + lines_per_chunk < lines ? l0 + lines_per_chunk : lines;
+    for (int l = l0; l < l1; ++l) {
+      const int img = l / h, iy = l - img * h;
+      const long long n = (long long)grp * n_per_group + img;
+      const float4 *yl = y + ((n * h + iy) * w) * c4n + cq;
+      for (int ix = rl; ix < w; ix += nrl) {
+        const float4 v = yl[(long long)ix * c4n];
+        float4 d = pool_gather(gp, am, n, iy, ix, cq, c4n, ho, wo);
+        d.x = __builtin_fmaf(v.x, sa.x, sb.x) > 0.f ? d.x : 0.f;
+        d.y = __builtin_fmaf(v.y, sa.y, sb.y) > 0.f ? d.y : 0.f;
+        d.z = __builtin_fmaf(v.z, sa.z, sb.z) > 0.f ? d.z : 0.f;
+        d.w = __builtin_fmaf(v.w, sa.w, sb.w) > 0.f ? d.w : 0.f;
+        s1.x += d.x;
+        s1.y += d.y;
+        s1.z += d.z;
+        s1.w += d.w;
+        s2.x += d.x * ((v.x - mu.x) * is.x);
+        s2.y += d.y * ((v.y - mu.y) * is.y);
+        s2.z += d.z * ((v.z - mu.z) * is.z);
+        s2.w += d.w * ((v.w - mu.w) * is.w);
+      }
+    }
+  }
+  sh[0][threadIdx.x] = s1;
+  sh[1][threadIdx.x] = s2;
+  __syncthreads();
+  if (rl == 0 && cok) {
+    for (int k = 1; k < nrl; ++k) {
+      const float4 a = sh[0][k * cw + cl], b = sh[1][k * cw + cl];
+      s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
+      s2.x += b.x; s2.y += b.y; s2.z += b.z; s2.w += b.w;
+    }
+    float4 *p = reinterpret_cast<float4 *>(partial + (((long long)grp * chunks + blockIdx.x) * 2) * c);
+    p[cq] = s1;
+    p[c4n + cq] = s2;
+  }
+}
+
+// grid = (ceil(w*c4n / 256), images*h): one thread = one (image, iy, ix, 4 channels) of the conv output
+__global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float4 *__restrict__ gp, const uchar4 *__restrict__ am,
+                                                                const float4 *__restrict__ y, const float *__restrict__ mean,
+                                                                const float *__restrict__ invstd,
+                                                                const float *__restrict__ gamma,
+                                                                const float *__restrict__ scale,
+                                                                const float *__restrict__ shift, const float *__restrict__ s1,
+                                                                const float *__restrict__ s2, int n_per_group, int h, int w,
+                                                                int ho, int wo, int c4n, float inv_rows,
+                                                                float4 *__restrict__ dy) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= w * c4n) return;
+  const int ix = t / c4n, cq = t - ix * c4n;
+  const int n = blockIdx.y / h, iy = blockIdx.y - n * h;
+  const long long i = (((long long)n * h + iy) * w + ix) * c4n + cq;
+  const long long gq = (long long)(n / n_per_group) * c4n + cq;
+  const float4 mu = reinterpret_cast<const float4 *>(mean)[gq], is = reinterpret_cast<const float4 *>(invstd)[gq];
+  const float4 sa = reinterpret_cast<const float4 *>(scale)[gq], sb = reinterpret_cast<const float4 *>(shift)[gq];
+  const float4 a1 = reinterpret_cast<const float4 *>(s1)[gq], a2 = reinterpret_cast<const float4 *>(s2)[gq];
+  const float4 ga = reinterpret_cast<const float4 *>(gamma)[cq];
+  const float4 v = y[i];
+  float4 d = pool_gather(gp, am, n, iy, ix, cq, c4n, ho, wo);
+  d.x = __builtin_fmaf(v.x, sa.x, sb.x) > 0.f ? d.x : 0.f;
+  d.y = __builtin_fmaf(v.y, sa.y, sb.y) > 0.f ? d.y : 0.f;
+  d.z = __builtin_fmaf(v.z, sa.z, sb.z) > 0.f ? d.z : 0.f;
+  d.w = __builtin_fmaf(v.w, sa.w, sb.w) > 0.f ? d.w : 0.f;
+  float4 o;
+  o.x = ga.x * is.x * (d.x - a1.x * inv_rows - (v.x - mu.x) * is.x * (a2.x * inv_rows));
+  o.y = ga.y * is.y * (d.y - a1.y * inv_rows - (v.y - mu.y) * is.y * (a2.y * inv_rows));
+  o.z = ga.z * is.z * (d.z - a1.z * inv_rows - (v.z - mu.z) * is.z * (a2.z * inv_rows));
+  o.w = ga.w * is.w * (d.w - a1.w * inv_rows - (v.w - mu.w) * is.w * (a2.w * inv_rows));
+  dy[i] = o;
 }
 
 static int bwd_chunks(int groups, long long rows, int c) {
@@ -326,8 +535,10 @@ size_t mvg_bn_bwd_workspace_floats(int groups, int64_t rows_per_group, int c) {
 }
 
 int mvg_bn_bwd_reduce(const float *g, const float *act, const float *y, const float *mean, const float *invstd,
-                      int groups, int64_t rows_per_group, int c, float *s1, float *s2, float *dgamma, float *dbeta,
-                      int accumulate, float *workspace, void *stream) {
+                      const float *relu_scale, const float *relu_shift, int groups, int64_t rows_per_group, int c, float *s1,
+                      float *s2, float *dgamma, float *dbeta, int accumulate, float *workspace, void *stream) {
+  MVG_REQUIRE(!(act && relu_scale), "bn_bwd_reduce: give the ReLU mask either as act or as (relu_scale, relu_shift)");
+  MVG_REQUIRE((relu_scale == nullptr) == (relu_shift == nullptr), "bn_bwd_reduce: relu_scale and relu_shift go together");
   MVG_REQUIRE(c % 4 == 0, "bn_bwd_reduce: c %% 4 != 0");
   MVG_REQUIRE(workspace != nullptr, "bn_bwd_reduce: workspace required");
   hipStream_t st = (hipStream_t)stream;
@@ -338,8 +549,8 @@ int mvg_bn_bwd_reduce(const float *g, const float *act, const float *y, const fl
   const long long rpc = (rows_per_group + chunks - 1) / chunks;
   ProfScope ps(MVG_K_BN_BWD_REDUCE, st, 0.0, 4.0 * groups * (double)rows_per_group * c * (act ? 3 : 2));
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(chunks, ceil_div(c4n, cw), groups), dim3(256), 0, st, (const float4 *)g,
-                     (const float4 *)act, (const float4 *)y, mean, invstd, (long long)rows_per_group, rpc, c, c4n, cw,
-                     workspace, chunks);
+                     (const float4 *)act, (const float4 *)y, mean, invstd, relu_scale, relu_shift, (long long)rows_per_group,
+                     rpc, c, c4n, cw, workspace, chunks);
   if (check_launch("bn_bwd_reduce")) return 1;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(c, 16)), dim3(1024), 0, st, workspace, groups, chunks, c, s1, s2,
                      dgamma, dbeta, accumulate);
@@ -347,16 +558,75 @@ int mvg_bn_bwd_reduce(const float *g, const float *act, const float *y, const fl
 }
 
 int mvg_bn_bwd_apply(const float *g, const float *act, const float *y, const float *mean, const float *invstd,
-                     const float *gamma, const float *s1, const float *s2, int groups, int64_t rows_per_group, int c,
-                     float *dy, float *dz_out, void *stream) {
+                     const float *gamma, const float *s1, const float *s2, const float *relu_scale, const float *relu_shift,
+                     int groups, int64_t rows_per_group, int c, float *dy, float *dz_out, void *stream) {
+  MVG_REQUIRE(!(act && relu_scale), "bn_bwd_apply: give the ReLU mask either as act or as (relu_scale, relu_shift)");
+  MVG_REQUIRE((relu_scale == nullptr) == (relu_shift == nullptr), "bn_bwd_apply: relu_scale and relu_shift go together");
   MVG_REQUIRE(c % 4 == 0, "bn_bwd_apply: c %% 4 != 0");
   hipStream_t st = (hipStream_t)stream;
   const long long n4 = rows_per_group * (c / 4);
   ProfScope ps(MVG_K_BN_BWD_APPLY, st, 0.0, 16.0 * groups * (double)n4 * ((act ? 4 : 3) + (dz_out ? 1 : 0)));
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n4), groups), dim3(256), 0, st, (const float4 *)g,
-                     (const float4 *)act, (const float4 *)y, mean, invstd, gamma, s1, s2, n4,
+                     (const float4 *)act, (const float4 *)y, mean, invstd, gamma, s1, s2, relu_scale, relu_shift, n4,
                      1.0f / (float)rows_per_group, c / 4, c, (float4 *)dy, (float4 *)dz_out);
   return check_launch("bn_bwd_apply");
+}
+
+int mvg_bn_relu_maxpool_fwd(const float *y, const float *scale, const float *shift, float *pooled, uint8_t *argmax, int groups,
+                            int n_per_group, int h, int w, int c, int ho, int wo, void *stream) {
+  MVG_REQUIRE(c % 4 == 0, "bn_relu_maxpool: c %% 4 != 0");
+  MVG_REQUIRE(ho == (h + 2 - 3) / 2 + 1 && wo == (w + 2 - 3) / 2 + 1, "bn_relu_maxpool: bad output size");
+  const long long total = (long long)groups * n_per_group * ho * wo * (c / 4);
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(MVG_K_POOL, st, 0.0, 4.0 * ((double)groups * n_per_group * h * w * c + (double)total * 5));
+  MVG_REQUIRE((long long)groups * n_per_group * ho < 65536, "bn_relu_maxpool: images*ho must fit grid.y");
+  hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel, dim3(ceil_div((long long)wo * (c / 4), 256), groups * n_per_group * ho),
+                     dim3(256), 0, st, (const float4 *)y, scale, shift, (float4 *)pooled, (uchar4 *)argmax, n_per_group, h, w,
+                     c / 4, ho, wo);
+  return check_launch("bn_relu_maxpool_fwd");
+}
+
+int mvg_bn_relu_maxpool_bwd_reduce(const float *g_pooled, const uint8_t *argmax, const float *y, const float *mean,
+                                   const float *invstd, const float *scale, const float *shift, int groups, int n_per_group,
+                                   int h, int w, int c, int ho, int wo, float *s1, float *s2, float *dgamma, float *dbeta,
+                                   int accumulate, float *workspace, void *stream) {
+  MVG_REQUIRE(c % 4 == 0, "bn_relu_maxpool_bwd_reduce: c %% 4 != 0");
+  MVG_REQUIRE(workspace != nullptr, "bn_relu_maxpool_bwd_reduce: workspace required");
+  hipStream_t st = (hipStream_t)stream;
+  const long long rows = (long long)n_per_group * h * w;
+  const int c4n = c / 4;
+  const int cw = c4n < 256 ? c4n : 256;
+  MVG_REQUIRE(256 % cw == 0, "bn_relu_maxpool_bwd_reduce: c/4 must divide 256 or be a multiple of it (c=%d)", c);
+  // chunk = whole image lines; never more chunks than mvg_bn_bwd_workspace_floats(groups, rows, c) sizes
+  const int lines = n_per_group * h;
+  int chunks = bwd_chunks(groups, rows, c);
+  if (chunks > lines) chunks = lines;
+  const int lpc = (lines + chunks - 1) / chunks;
+  chunks = (lines + lpc - 1) / lpc;
+  ProfScope ps(MVG_K_BN_BWD_REDUCE, st, 0.0,
+               4.0 * groups * ((double)rows * c + (double)n_per_group * ho * wo * c * 1.25));
+  hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3(chunks, ceil_div(c4n, cw), groups), dim3(256), 0, st,
+                     (const float4 *)g_pooled, (const uchar4 *)argmax, (const float4 *)y, mean, invstd, scale, shift, lpc,
+                     n_per_group, h, w, ho, wo, c, c4n, cw, workspace, chunks);
+  if (check_launch("bn_relu_maxpool_bwd_reduce")) return 1;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(c, 16)), dim3(1024), 0, st, workspace, groups, chunks, c, s1, s2,
+                     dgamma, dbeta, accumulate);
+  return check_launch("bn_bwd_finalize");
+}
+
+int mvg_bn_relu_maxpool_bwd_apply(const float *g_pooled, const uint8_t *argmax, const float *y, const float *mean,
+                                  const float *invstd, const float *gamma, const float *scale, const float *shift,
+                                  const float *s1, const float *s2, int groups, int n_per_group, int h, int w, int c, int ho,
+                                  int wo, float *dy, void *stream) {
+  MVG_REQUIRE(c % 4 == 0, "bn_relu_maxpool_bwd_apply: c %% 4 != 0");
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(MVG_K_BN_BWD_APPLY, st, 0.0, 4.0 * groups * ((double)n_per_group * h * w * c * 2 + (double)n_per_group * ho * wo * c * 1.25));
+  MVG_REQUIRE((long long)groups * n_per_group * h < 65536, "bn_relu_maxpool: images*h must fit grid.y");
+  hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(ceil_div((long long)w * (c / 4), 256), groups * n_per_group * h), dim3(256),
+                     0, st, (const float4 *)g_pooled, (const uchar4 *)argmax, (const float4 *)y, mean, invstd, gamma, scale,
+                     shift, s1, s2, n_per_group, h, w, ho, wo, c / 4, 1.0f / (float)((long long)n_per_group * h * w),
+                     (float4 *)dy);
+  return check_launch("bn_relu_maxpool_bwd_apply");
 }
 
 }  // extern "C"

@@ -137,16 +137,19 @@ def bn_apply(y, scale, shift, residual, relu, out, groups, rows_per_group, c):
                              _s()), "bn_apply")
 
 
-def bn_bwd_reduce(g, act, y, mean, invstd, groups, rows_per_group, c, s1, s2, dgamma, dbeta, accumulate):
+def bn_bwd_reduce(g, act, y, mean, invstd, groups, rows_per_group, c, s1, s2, dgamma, dbeta, accumulate, relu_affine=None):
+    """relu_affine = (scale, shift) of the forward bn_apply: ReLU mask rebuilt from y (units without residual)."""
     n = lib().mvg_bn_bwd_workspace_floats(groups, rows_per_group, c)
     ws = torch.empty(n, dtype=torch.float32, device=g.device)
-    check(lib().mvg_bn_bwd_reduce(_p(g), _p(act), _p(y), _p(mean), _p(invstd), groups, rows_per_group, c, _p(s1), _p(s2),
-                                  _p(dgamma), _p(dbeta), int(accumulate), _p(ws), _s()), "bn_bwd_reduce")
+    rs, rh = relu_affine if relu_affine is not None else (None, None)
+    check(lib().mvg_bn_bwd_reduce(_p(g), _p(act), _p(y), _p(mean), _p(invstd), _p(rs), _p(rh), groups, rows_per_group, c,
+                                  _p(s1), _p(s2), _p(dgamma), _p(dbeta), int(accumulate), _p(ws), _s()), "bn_bwd_reduce")
 
 
-def bn_bwd_apply(g, act, y, mean, invstd, gamma, s1, s2, groups, rows_per_group, c, dy, dz_out=None):
-    check(lib().mvg_bn_bwd_apply(_p(g), _p(act), _p(y), _p(mean), _p(invstd), _p(gamma), _p(s1), _p(s2), groups,
-                                 rows_per_group, c, _p(dy), _p(dz_out), _s()), "bn_bwd_apply")
+def bn_bwd_apply(g, act, y, mean, invstd, gamma, s1, s2, groups, rows_per_group, c, dy, dz_out=None, relu_affine=None):
+    rs, rh = relu_affine if relu_affine is not None else (None, None)
+    check(lib().mvg_bn_bwd_apply(_p(g), _p(act), _p(y), _p(mean), _p(invstd), _p(gamma), _p(s1), _p(s2), _p(rs), _p(rh),
+                                 groups, rows_per_group, c, _p(dy), _p(dz_out), _s()), "bn_bwd_apply")
 
 
 # ---------------------------------------------------------------- pooling / layout
@@ -156,6 +159,27 @@ def maxpool_fwd(x, y, argmax, n, h, w, c, ho, wo):
 
 def maxpool_bwd(dy, argmax, dx, n, h, w, c, ho, wo):
     check(lib().mvg_maxpool3x3s2_bwd(_p(dy), _p(argmax), _p(dx), n, h, w, c, ho, wo, _s()), "maxpool_bwd")
+
+
+def bn_relu_maxpool_fwd(y, scale, shift, pooled, argmax, groups, n_per_group, h, w, c, ho, wo):
+    check(lib().mvg_bn_relu_maxpool_fwd(_p(y), _p(scale), _p(shift), _p(pooled), _p(argmax), groups, n_per_group, h, w, c, ho,
+                                        wo, _s()), "bn_relu_maxpool_fwd")
+
+
+def bn_relu_maxpool_bwd_reduce(g_pooled, argmax, y, mean, invstd, scale, shift, groups, n_per_group, h, w, c, ho, wo, s1, s2,
+                               dgamma, dbeta, accumulate):
+    n = lib().mvg_bn_bwd_workspace_floats(groups, n_per_group * h * w, c)
+    ws = torch.empty(n, dtype=torch.float32, device=y.device)
+    check(lib().mvg_bn_relu_maxpool_bwd_reduce(_p(g_pooled), _p(argmax), _p(y), _p(mean), _p(invstd), _p(scale), _p(shift),
+                                               groups, n_per_group, h, w, c, ho, wo, _p(s1), _p(s2), _p(dgamma), _p(dbeta),
+                                               int(accumulate), _p(ws), _s()), "bn_relu_maxpool_bwd_reduce")
+
+
+def bn_relu_maxpool_bwd_apply(g_pooled, argmax, y, mean, invstd, gamma, scale, shift, s1, s2, groups, n_per_group, h, w, c,
+                              ho, wo, dy):
+    check(lib().mvg_bn_relu_maxpool_bwd_apply(_p(g_pooled), _p(argmax), _p(y), _p(mean), _p(invstd), _p(gamma), _p(scale),
+                                              _p(shift), _p(s1), _p(s2), groups, n_per_group, h, w, c, ho, wo, _p(dy), _s()),
+          "bn_relu_maxpool_bwd_apply")
 
 
 def avgpool_fwd(x, y, n, hw, c):

@@ -252,6 +252,14 @@ def test_bn_apply_and_backward(G, N, H, W, C, relu, res):
     close(dy, yr.grad, 1e-4, "bn dy")
     if res:
         close(dz, rr.grad, what="residual grad")
+    if relu and not res:
+        # ReLU mask rebuilt from y (relu_affine): bit-identical to the mask taken from `out`
+        s1b, s2b, dgb, dbb = (torch.empty_like(t) for t in (s1, s2, dgamma, dbeta))
+        ops.bn_bwd_reduce(god, None, yd, mean, invstd, G, rows, C, s1b, s2b, dgb, dbb, False, (scale, shift))
+        assert torch.equal(s1b, s1) and torch.equal(s2b, s2) and torch.equal(dgb, dgamma) and torch.equal(dbb, dbeta)
+        dyb = torch.empty_like(dy)
+        ops.bn_bwd_apply(god, None, yd, mean, invstd, gd, s1, s2, G, rows, C, dyb, None, (scale, shift))
+        assert torch.equal(dyb, dy)
     # the aliased forms the backbone uses: dy in place of g; dz in place of g
     g2 = god.clone()
     ops.bn_bwd_apply(g2, act, yd, mean, invstd, gd, s1, s2, G, rows, C, g2, None)
@@ -261,6 +269,52 @@ def test_bn_apply_and_backward(G, N, H, W, C, relu, res):
         ops.bn_bwd_apply(g3, act, yd, mean, invstd, gd, s1, s2, G, rows, C, dy3, g3)
         close(dy3, yr.grad, 1e-4, "bn dy (dz in place)")
         close(g3, rr.grad, what="residual grad (in place)")
+
+
+@pytest.mark.parametrize("G,N,H,W", [(2, 3, 14, 18), (1, 2, 15, 13)])
+def test_fused_stem_bn_relu_maxpool(G, N, H, W):
+    """mvg_bn_relu_maxpool_{fwd,bwd_reduce,bwd_apply} against torch fp64 batch_norm -> relu ->
+    max_pool2d (one BatchNorm call per group, like the reference's per-view backbone calls)."""
+    from rot_mvgaze_amd import ops
+    C = 64
+    y = rnd((G, N, C, H, W), 11) * 1.5 + 0.2
+    gamma, beta = rnd((C,), 12) * 0.3 + 1.0, rnd((C,), 13) * 0.3
+    gamma[::7] *= -1                                           # negative scales flip the window order
+    yr = y.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    outs = [F.max_pool2d(F.relu(F.batch_norm(yr[g], None, None, gr, br, True, 0.1, 1e-5)), 3, 2, 1) for g in range(G)]
+    pr = torch.stack(outs)
+    gp = rnd(tuple(pr.shape), 14)
+    pr.backward(gp.double())
+    ho, wo = pr.shape[3], pr.shape[4]
+    rows = N * H * W
+    yd = y.permute(0, 1, 3, 4, 2).contiguous().to(dev())
+    yg = y.double().permute(0, 1, 3, 4, 2).reshape(G, rows, C)
+    mean = yg.mean(1).float().to(dev())
+    invstd = (1.0 / torch.sqrt(yg.var(1, unbiased=False) + 1e-5)).float().to(dev())
+    scale = (gamma.to(dev())[None] * invstd).contiguous()
+    shift = (beta.to(dev())[None] - mean * scale).contiguous()
+    pooled = torch.empty(G, N, ho, wo, C, device=dev())
+    am = torch.empty(G, N, ho, wo, C, dtype=torch.uint8, device=dev())
+    ops.bn_relu_maxpool_fwd(yd, scale, shift, pooled, am, G, N, H, W, C, ho, wo)
+    close(pooled, pr.detach().permute(0, 1, 3, 4, 2), 1e-5, "fused stem forward")
+    # the unfused kernels give the same bits (same fma, same scan order)
+    a0 = torch.empty_like(yd)
+    ops.bn_apply(yd, scale, shift, None, True, a0, G, rows, C)
+    p2, am2 = torch.empty_like(pooled), torch.empty_like(am)
+    ops.maxpool_fwd(a0, p2, am2, G * N, H, W, C, ho, wo)
+    assert torch.equal(p2, pooled)
+    gpd = gp.permute(0, 1, 3, 4, 2).contiguous().to(dev())
+    s12 = torch.empty(2, G, C, device=dev())
+    dg, db = torch.empty(C, device=dev()), torch.empty(C, device=dev())
+    ops.bn_relu_maxpool_bwd_reduce(gpd, am, yd, mean, invstd, scale, shift, G, N, H, W, C, ho, wo, s12[0], s12[1], dg, db,
+                                   False)
+    dy = torch.empty_like(yd)
+    ops.bn_relu_maxpool_bwd_apply(gpd, am, yd, mean, invstd, gamma.to(dev()), scale, shift, s12[0], s12[1], G, N, H, W, C,
+                                  ho, wo, dy)
+    close(dg, gr.grad, 1e-4, "fused stem dgamma")
+    close(db, br.grad, 1e-4, "fused stem dbeta")
+    close(dy, yr.grad.permute(0, 1, 3, 4, 2), 1e-4, "fused stem dy")
 
 
 def test_pools_and_layout():

@@ -156,7 +156,15 @@ def _captured_masks(m, V=2):
     """ReLU patterns of the HIP forward, in the order the oracle applies its ReLUs."""
     bt, ht = m._last_backbone_tape, m._last_head_tape
     relu_units = [u for u in bt["units"] if u.relu]
-    masks = {"backbone": [iter([(u.out[v] > 0).permute(0, 3, 1, 2).cpu() for u in relu_units]) for v in range(V)]}
+
+    def unit_mask(u, v):
+        if u.out is not None:
+            return u.out[v] > 0
+        # fused stem: the normalised map is not stored; the kernels use fma(y, scale, shift) > 0, whose
+        # sign equals the sign of the exact value (evaluated here in fp64)
+        scale, shift = u.pool[1], u.pool[2]
+        return (u.y[v].double() * scale[v].double() + shift[v].double()) > 0
+    masks = {"backbone": [iter([unit_mask(u, v).permute(0, 3, 1, 2).cpu() for u in relu_units]) for v in range(V)]}
     B = bt["B"]
     hl = (ht["hl"] > 0).cpu()
     masks["lift"] = [hl[v * B:(v + 1) * B] for v in range(V)]
