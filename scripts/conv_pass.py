@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Run every convolution op of ONE training step of a workload exactly once (fprop with BN partial
+statistics, dgrad, wgrad per layer, in network order) - the launch set bench.py's `roofline`
+averages over - so that `rocprofv3 --pmc` totals divide into per-op HBM traffic.
+Usage: conv_pass.py [depth] [N per view] [views]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import rot_mvgaze_amd
+from rot_mvgaze_amd import ops
+from rot_mvgaze_amd._lib import ConvDesc
+from rot_mvgaze_amd.arch import backbone_spec
+
+depth = int(sys.argv[1]) if len(sys.argv) > 1 else 18
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+G = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+dev = torch.device("cuda:0")
+spec = backbone_spec(depth)
+layers = []
+H = 224
+c = spec.stem
+layers.append((4, c.cout, c.k, c.stride, c.pad, H, False))
+H = (H + 2 * c.pad - c.k) // c.stride + 1
+H = (H + 2 - 3) // 2 + 1
+for blk in spec.blocks:
+    h = H
+    for cv in blk.convs:
+        layers.append((cv.cin, cv.cout, cv.k, cv.stride, cv.pad, h, True))
+        h = (h + 2 * cv.pad - cv.k) // cv.stride + 1
+    if blk.downsample is not None:
+        cv = blk.downsample
+        layers.append((cv.cin, cv.cout, cv.k, cv.stride, cv.pad, H, True))
+    H = h
+n_ops = 0
+flops = 0.0
+for (cin, cout, k, st, pad, h, need_dx) in layers:
+    d = ConvDesc.make(G, N, h, h, cin, cout, k, st, pad)
+    x = torch.randn(G, N, h, h, cin, device=dev)
+    w = torch.randn(cout, k, k, cin, device=dev) * 0.05
+    y = torch.empty(G, N, d.ho, d.wo, cout, device=dev)
+    P, rpp = ops.conv_stats_partials(d)
+    stats = torch.empty(G, P, 2, cout, device=dev)
+    gy = torch.randn_like(y)
+    dw = torch.empty_like(w)
+    ops.conv_fprop(d, x, w, y, None, False, stats)
+    ops.conv_wgrad(d, x, gy, dw)
+    n_ops += 2
+    if need_dx:
+        dx = torch.randn_like(x)
+        ops.conv_dgrad(d, gy, w, dx, None, dx)       # in-place addend, like the residual branches
+        n_ops += 1
+    flops += 2.0 * G * N * d.ho * d.wo * cout * k * k * cin * (3 if need_dx else 2)
+    torch.cuda.synchronize()
+    del x, y, gy, stats
+print(f"conv ops: {n_ops}  flops: {flops:.4e}")

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Aggregate HBM traffic of the dominant kernel family from two rocprofv3 --pmc passes
+"""Aggregate HBM traffic of the dominant kernel family from two rocprofv3 --pmc passes over scripts/conv_pass.py
 (FETCH_SIZE and WRITE_SIZE must be collected separately: TCC has 4 slots, MI355X_MICROARCH.md).
 
   pmc_traffic.py <fetch_dir> <write_dir> <workload> <out.json>
@@ -13,32 +13,38 @@ import json
 import sys
 
 
+CONV_KERNELS = ("igemm_kernel", "wgrad_kernel", "igemm_fixup_kernel", "wgrad_reduce_kernel", "dgrad_empty_class_kernel")
+
+
 def load(d, counter):
     files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
     assert files, d
     per_kernel = collections.defaultdict(lambda: [0, 0.0])
+    ops = 0
     for r in csv.DictReader(open(files[0])):
         if r["Counter_Name"] != counter:
             continue
         name = r["Kernel_Name"]
-        fam = "conv" if ("igemm_kernel" in name or "wgrad_kernel" in name) else name.split("(")[0].split("::")[-1]
+        conv = any(k in name for k in CONV_KERNELS)
+        fam = "conv" if conv else name.split("(")[0].split("::")[-1]
         per_kernel[fam][0] += 1
         per_kernel[fam][1] += float(r["Counter_Value"])
-    return per_kernel
+        ops += ("igemm_kernel<" in name) or ("wgrad_kernel<" in name)      # one main kernel per conv op
+    return per_kernel, ops
 
 
-fetch = load(sys.argv[1], "FETCH_SIZE")
-write = load(sys.argv[2], "WRITE_SIZE")
-n = fetch["conv"][0]
-assert n == write["conv"][0] and n > 0
+(fetch, n), (write, n2) = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+assert n == n2 and n > 0
 rd = 2.0 * fetch["conv"][1] * 1024.0
 wr = write["conv"][1] * 1024.0
-out = {"workload": sys.argv[3], "kernel_family": "igemm_kernel + wgrad_kernel (conv fprop/dgrad/wgrad)",
-       "launches": n, "read_bytes_per_launch": rd / n, "write_bytes_per_launch": wr / n,
+out = {"workload": sys.argv[3],
+       "kernel_family": "conv fprop/dgrad/wgrad ops = igemm_kernel / wgrad_kernel + their stream-K fix-up and slab-reduce kernels",
+       "ops": n, "kernel_launches": fetch["conv"][0], "read_bytes_per_op": rd / n, "write_bytes_per_op": wr / n,
        "traffic_bytes_per_launch": (rd + wr) / n,
-       "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py; "
-                 "read = 2*FETCH_SIZE*1024 (gfx950 correction), write = WRITE_SIZE*1024",
+       "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over scripts/conv_pass.py (every conv "
+                 "op of one C2 step once); read = 2*FETCH_SIZE*1024 (gfx950 correction), write = WRITE_SIZE*1024; "
+                 "summed over the op's kernels, divided by the number of ops",
        "other_kernels_total_MB": {k: round((2.0 * fetch[k][1] + write.get(k, [0, 0])[1]) * 1024 / 1e6, 1)
                                   for k in fetch if k != "conv"}}
 json.dump(out, open(sys.argv[4], "w"), indent=1)
-print(json.dumps(out)[:600])
+print(json.dumps(out)[:700])
