@@ -48,17 +48,32 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restri
         ss += sp * sp * (1.0 / (double)last_cnt - inv_full);
       }
     }
-    sh[0][pl][cl] = s;
-    sh[1][pl][cl] = q;
-    sh[2][pl][cl] = ss;
+    // reduce over the 128 partial lanes: lanes 8/16/32 apart inside the wave (shuffles), then the 16
+    // waves through LDS - two barriers per group instead of an 8-level LDS tree
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+      s += __shfl_xor(s, o, 64);
+      q += __shfl_xor(q, o, 64);
+      ss += __shfl_xor(ss, o, 64);
+    }
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) < 8) {
+      sh[0][wv][cl] = s;
+      sh[1][wv][cl] = q;
+      sh[2][wv][cl] = ss;
+    }
     __syncthreads();
-    for (int o = 64; o > 0; o >>= 1) {
-      if (pl < o) {
-        sh[0][pl][cl] += sh[0][pl + o][cl];
-        sh[1][pl][cl] += sh[1][pl + o][cl];
-        sh[2][pl][cl] += sh[2][pl + o][cl];
+    if (pl == 0) {
+      s = q = ss = 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        s += sh[0][k][cl];
+        q += sh[1][k][cl];
+        ss += sh[2][k][cl];
       }
-      __syncthreads();
+      sh[0][0][cl] = s;
+      sh[1][0][cl] = q;
+      sh[2][0][cl] = ss;
     }
     if (pl == 0 && ch < c) {
       const double n = (double)rows;
@@ -163,7 +178,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float4 *__rest
     long long r1 = r0 + rows_per_chunk;
     if (r1 > rows) r1 = rows;
     const long long gbase = (long long)grp * rows * c4n;
-    for (long long r = r0 + rl; r < r1; r += nrl) {
+    // two rows per iteration with independent loads (the trip count is a runtime value, so the
+    // compiler keeps a single row in flight otherwise: latency-bound at 2.9 TB/s)
+    auto row = [&](long long r, float4 &a1, float4 &a2) {
       const long long off = gbase + r * c4n + cq;
       float4 d = g[off];
       const float4 v = y[off];
@@ -179,15 +196,26 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float4 *__rest
         d.z = __builtin_fmaf(v.z, ma.z, mb.z) > 0.f ? d.z : 0.f;
         d.w = __builtin_fmaf(v.w, ma.w, mb.w) > 0.f ? d.w : 0.f;
       }
-      s1.x += d.x;
-      s1.y += d.y;
-      s1.z += d.z;
-      s1.w += d.w;
-      s2.x += d.x * ((v.x - mu.x) * is.x);
-      s2.y += d.y * ((v.y - mu.y) * is.y);
-      s2.z += d.z * ((v.z - mu.z) * is.z);
-      s2.w += d.w * ((v.w - mu.w) * is.w);
+      a1.x += d.x;
+      a1.y += d.y;
+      a1.z += d.z;
+      a1.w += d.w;
+      a2.x += d.x * ((v.x - mu.x) * is.x);
+      a2.y += d.y * ((v.y - mu.y) * is.y);
+      a2.z += d.z * ((v.z - mu.z) * is.z);
+      a2.w += d.w * ((v.w - mu.w) * is.w);
+    };
+    float4 t1 = make_float4(0.f, 0.f, 0.f, 0.f), t2 = t1, u1 = t1, u2 = t1, w1 = t1, w2 = t1;
+    long long r = r0 + rl;
+    for (; r + 3 * (long long)nrl < r1; r += 4 * (long long)nrl) {
+      row(r, s1, s2);
+      row(r + nrl, t1, t2);
+      row(r + 2 * (long long)nrl, u1, u2);
+      row(r + 3 * (long long)nrl, w1, w2);
     }
+    for (; r < r1; r += nrl) row(r, s1, s2);
+    s1.x += t1.x + (u1.x + w1.x); s1.y += t1.y + (u1.y + w1.y); s1.z += t1.z + (u1.z + w1.z); s1.w += t1.w + (u1.w + w1.w);
+    s2.x += t2.x + (u2.x + w2.x); s2.y += t2.y + (u2.y + w2.y); s2.z += t2.z + (u2.z + w2.z); s2.w += t2.w + (u2.w + w2.w);
   }
   sh[0][threadIdx.x] = s1;
   sh[1][threadIdx.x] = s2;

@@ -193,22 +193,32 @@ __global__ __launch_bounds__(256) void skinny_bwd_dx_kernel(const float *__restr
   dx[i] = s;
 }
 // dw[j][i] = sum_m dy[m][j] x[m][i];  db[j] = sum_m dy[m][j]
+// 16 columns x 16 row lanes per workgroup; the row lanes are summed through LDS in lane order
+// (deterministic).  One thread per column walking all rows was 47 us for 128 rows x 512 columns.
 __global__ __launch_bounds__(256) void skinny_bwd_dw_kernel(const float *__restrict__ dy, const float *__restrict__ x,
                                                             float *__restrict__ dw, float *__restrict__ db, int rows,
                                                             int k, int nout, int accumulate) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < k) {
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int m = 0; m < rows; ++m) {
+  __shared__ float sh[4][16][17];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + cl;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (i < k)
+    for (int m = rl; m < rows; m += 16) {
       const float v = x[(long long)m * k + i];
       for (int j = 0; j < nout; ++j) acc[j] += dy[(long long)m * nout + j] * v;
     }
-    for (int j = 0; j < nout; ++j) dw[(long long)j * k + i] = (accumulate ? dw[(long long)j * k + i] : 0.f) + acc[j];
+  for (int j = 0; j < 4; ++j) sh[j][rl][cl] = acc[j];
+  __syncthreads();
+  if (rl < nout && i < k) {
+    const int j = rl;
+    float t = 0.f;
+    for (int r = 0; r < 16; ++r) t += sh[j][r][cl];
+    dw[(long long)j * k + i] = (accumulate ? dw[(long long)j * k + i] : 0.f) + t;
   }
   if (db && blockIdx.x == 0 && threadIdx.x < nout) {
-    float s = 0.f;
-    for (int m = 0; m < rows; ++m) s += dy[(long long)m * nout + threadIdx.x];
-    db[threadIdx.x] = (accumulate ? db[threadIdx.x] : 0.f) + s;
+    float t = 0.f;
+    for (int m = 0; m < rows; ++m) t += dy[(long long)m * nout + threadIdx.x];
+    db[threadIdx.x] = (accumulate ? db[threadIdx.x] : 0.f) + t;
   }
 }
 
@@ -375,7 +385,7 @@ int mvg_linear_skinny_bwd(const float *dy, const float *x, const float *w, const
   }
   if (dw) {
     ProfScope ps(MVG_K_LINEAR_WGRAD, st, 2.0 * rows * (double)k * nout, 4.0 * (double)rows * k);
-    hipLaunchKernelGGL(skinny_bwd_dw_kernel, dim3(ceil_div(k, 256)), dim3(256), 0, st, dy, x, dw, db, rows, k, nout,
+    hipLaunchKernelGGL(skinny_bwd_dw_kernel, dim3(ceil_div(k, 16)), dim3(256), 0, st, dy, x, dw, db, rows, k, nout,
                        accumulate);
     if (check_launch("skinny_bwd_dw")) return 1;
   }
