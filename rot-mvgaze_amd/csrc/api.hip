@@ -16,6 +16,43 @@ void set_error(const char *fmt, ...) {
   va_end(ap);
 }
 
+struct Scratch {
+  int dev;
+  hipStream_t st;
+  float *ptr;
+  size_t floats;
+};
+static std::mutex g_scratch_mu;
+static Scratch g_scratch[16];
+float *stream_scratch(hipStream_t st, size_t floats) {
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  Scratch *slot = nullptr;
+  for (auto &e : g_scratch)
+    if (e.ptr && e.st == st && e.dev == dev) slot = &e;
+  if (!slot)
+    for (auto &e : g_scratch)
+      if (!e.ptr) {
+        slot = &e;
+        break;
+      }
+  if (!slot) return nullptr;
+  if (slot->ptr && slot->floats >= floats) return slot->ptr;
+  if (slot->ptr) (void)hipFree(slot->ptr);       // waits for work that may still use it
+  slot->ptr = nullptr;
+  const size_t want = floats + floats / 4;
+  if (hipMalloc((void **)&slot->ptr, want * sizeof(float)) != hipSuccess) {
+    (void)hipGetLastError();
+    slot->ptr = nullptr;
+    return nullptr;
+  }
+  slot->dev = dev;
+  slot->st = st;
+  slot->floats = want;
+  return slot->ptr;
+}
+
 struct ProfRec {
   int fam;
   hipEvent_t a, b;

@@ -8,8 +8,9 @@ namespace mvg {
 // grid = c/8 blocks, 1024 threads = 8 channels x 128 partial-lanes.  Every group (= view) is merged
 // by the same workgroup, one after the other, so that the running statistics are updated in group
 // order (the reference runs the backbone on view 0, then view 1: models/rot_mv.py:204-205).
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restrict__ stats, int groups, int partials,
-                                                           int rows_per_partial, long long rows, int c,
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restrict__ stats,
+                                                           const double *__restrict__ sliced, int slices, int groups,
+                                                           int partials, int rows_per_partial, long long rows, int c,
                                                            const float *__restrict__ gamma,
                                                            const float *__restrict__ beta, float *running_mean,
                                                            float *running_var, float momentum, float eps,
@@ -27,7 +28,14 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restri
   for (int g = 0; g < groups; ++g) {
     const float *st = stats + (long long)g * partials * 2 * c;
     double s = 0.0, q = 0.0, ss = 0.0;
-    if (ch < c) {
+    if (ch < c && sliced) {
+      for (int k = pl; k < slices; k += 128) {
+        const double *o = sliced + (((long long)g * slices + k) * 3) * c;
+        s += o[ch];
+        q += o[c + ch];
+        ss += o[2 * c + ch];
+      }
+    } else if (ch < c) {
       // branch-free body (no early exit) so that the loads of several iterations are in flight at once
       const int valid = (int)((rows + rows_per_partial - 1) / rows_per_partial) < partials
                             ? (int)((rows + rows_per_partial - 1) / rows_per_partial) : partials;
@@ -98,6 +106,50 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restri
   if (pl == 0 && ch < c) {
     if (running_mean) running_mean[ch] = rm;
     if (running_var) running_var[ch] = rv;
+  }
+}
+
+// Large partial counts (stem at C2: 25 088 per group) first collapse to <= 64 slices per group with
+// all CUs busy; bn_finalize_kernel then merges the slices.  slice record: (sum, q, sum of s^2/cnt) in
+// fp64, [group][slice][3][c].
+__global__ __launch_bounds__(256) void bn_partials_slice_kernel(const float *__restrict__ stats, int partials,
+                                                                int rows_per_partial, long long rows, int c,
+                                                                int per_slice, double *__restrict__ out, int slices) {
+  __shared__ double sh[3][32][8];
+  const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;                // 8 channels x 32 partial lanes
+  const int ch = blockIdx.x * 8 + cl;
+  const int g = blockIdx.z;
+  const float *st = stats + (long long)g * partials * 2 * c;
+  const int valid = (int)((rows + rows_per_partial - 1) / rows_per_partial) < partials
+                        ? (int)((rows + rows_per_partial - 1) / rows_per_partial) : partials;
+  const int p0 = blockIdx.y * per_slice;
+  const int p1 = p0 + per_slice < valid ? p0 + per_slice : valid;
+  double s = 0.0, q = 0.0, ss = 0.0;
+  if (ch < c) {
+    const double inv_full = 1.0 / (double)rows_per_partial;
+#pragma unroll 4
+    for (int p = p0 + pl; p < p1; p += 32) {
+      const double sp = st[((long long)p * 2) * c + ch], qp = st[((long long)p * 2 + 1) * c + ch];
+      long long cnt = rows - (long long)p * rows_per_partial;
+      s += sp;
+      q += qp;
+      ss += sp * sp * (cnt >= rows_per_partial ? inv_full : 1.0 / (double)cnt);
+    }
+  }
+  sh[0][pl][cl] = s;
+  sh[1][pl][cl] = q;
+  sh[2][pl][cl] = ss;
+  __syncthreads();
+  if (pl == 0 && ch < c) {
+    for (int k = 1; k < 32; ++k) {
+      s += sh[0][k][cl];
+      q += sh[1][k][cl];
+      ss += sh[2][k][cl];
+    }
+    double *o = out + (((long long)g * slices + blockIdx.y) * 3) * c;
+    o[ch] = s;
+    o[c + ch] = q;
+    o[2 * c + ch] = ss;
   }
 }
 
@@ -532,9 +584,23 @@ int mvg_bn_finalize(const float *stats, int groups, int partials, int rows_per_p
   MVG_REQUIRE(groups > 0 && partials > 0 && c > 0 && rows_per_group > 0, "bn_finalize: bad sizes");
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps(MVG_K_BN_FINALIZE, st, 0.0, 4.0 * groups * (double)partials * 2 * c);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(c, 8)), dim3(1024), 0, st, stats, groups, partials, rows_per_partial,
-                     (long long)rows_per_group, c, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale,
-                     shift);
+  const double *sliced = nullptr;
+  int slices = 0;
+  if (partials >= 1024) {
+    slices = 64;
+    const int per_slice = ceil_div(partials, slices);
+    slices = ceil_div(partials, per_slice);
+    double *buf = (double *)stream_scratch(st, (size_t)groups * slices * 3 * c * 2);
+    if (buf) {
+      hipLaunchKernelGGL(bn_partials_slice_kernel, dim3(ceil_div(c, 8), slices, groups), dim3(256), 0, st, stats, partials,
+                         rows_per_partial, (long long)rows_per_group, c, per_slice, buf, slices);
+      if (check_launch("bn_partials_slice")) return 1;
+      sliced = buf;
+    }
+  }
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(c, 8)), dim3(1024), 0, st, stats, sliced, slices, groups, partials,
+                     rows_per_partial, (long long)rows_per_group, c, gamma, beta, running_mean, running_var, momentum, eps, mean,
+                     invstd, scale, shift);
   return check_launch("bn_finalize");
 }
 

@@ -15,6 +15,11 @@ bool prof_on();
 void prof_begin(int family, hipStream_t s, double flops, double bytes);
 void prof_end(int family, hipStream_t s);
 
+// Library-owned device scratch, one grow-only buffer per (device, stream).  Uses on a stream are
+// ordered by the stream, so every kernel sequence that finishes with its scratch before the next
+// launch on that stream may share it (stream-K pieces, bn_finalize slices).  nullptr = no memory.
+float *stream_scratch(hipStream_t st, size_t floats);
+
 struct ProfScope {
   int fam;
   hipStream_t s;

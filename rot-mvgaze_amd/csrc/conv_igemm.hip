@@ -1356,38 +1356,6 @@ static bool streamk_enabled() {
 }
 
 // ---- stream-K planning ---------------------------------------------------------------------
-// Library-owned scratch for the stream-K pieces, one buffer per stream (grow-only).
-struct SkScratch {
-  hipStream_t st;
-  float *ptr;
-  size_t floats;
-};
-static SkScratch g_sk_scratch[8];
-static float *sk_scratch(hipStream_t st, size_t floats) {
-  SkScratch *slot = nullptr;
-  for (auto &e : g_sk_scratch)
-    if (e.ptr && e.st == st) slot = &e;
-  if (!slot)
-    for (auto &e : g_sk_scratch)
-      if (!e.ptr) {
-        slot = &e;
-        break;
-      }
-  if (!slot) return nullptr;
-  if (slot->ptr && slot->floats >= floats) return slot->ptr;
-  if (slot->ptr) (void)hipFree(slot->ptr);       // waits for work that may still read it
-  slot->ptr = nullptr;
-  size_t want = floats + floats / 4;
-  if (hipMalloc((void **)&slot->ptr, want * sizeof(float)) != hipSuccess) {
-    (void)hipGetLastError();
-    slot->ptr = nullptr;
-    return nullptr;
-  }
-  slot->st = st;
-  slot->floats = want;
-  return slot->ptr;
-}
-
 template <int BM, int BN, int WGM, int WGN, bool DGRAD>
 static int igemm_occupancy() {
   static int occ = 0;
@@ -1480,7 +1448,7 @@ static int launch_igemm_tile(IgemmParams &p, long long tiles, long long units, h
   if (p.splits == 1 && units > tiles)
     P = plan_streamk(tiles, (int)(units / tiles), BM, BN, igemm_occupancy<BM, BN, WGM, WGN, DGRAD>());
   if (P > 0) {
-    float *scratch = sk_scratch(st, (size_t)P * 2 * BM * BN);
+    float *scratch = stream_scratch(st, (size_t)P * 2 * BM * BN);
     if (!scratch) P = 0;                                   // no scratch: plain launch
     else p.slab = scratch;
   }

@@ -53,6 +53,7 @@ CONV_CASES = [
     (2, 16, 56, 56, 64, 64, 3, 1, 1),     # 784 tiles of 128x64 -> stream-K with several tiles per workgroup
     (2, 16, 56, 56, 64, 128, 3, 2, 1),    # stride 2: stream-K fprop, parity-class dgrad
     (1, 30, 14, 14, 256, 256, 3, 1, 1),   # ragged last M tile (5880 rows) under stream-K
+    (1, 24, 57, 57, 64, 64, 1, 1, 0),     # 1219 BN partials (ragged last one): two-level bn_finalize
 ]
 
 
