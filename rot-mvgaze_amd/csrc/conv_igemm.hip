@@ -77,7 +77,7 @@ struct IgemmClass {
   long long rows_per_group;
   FastDiv tap_ns_div, ohw_div, ow_div;
   int korder;                // 1: K-steps run (32-channel block, tap, half) - see igemm_kernel
-  FastDiv per_div;           // 2 * ntaps (K-steps per 32-channel block)
+  FastDiv per_div;           // K-steps per 32-channel block: ntaps * 32 / BK
   long long unit0;           // first (tile, K-step) unit of this class in the launch's unit space
   int tile0;                 // first tile of this class
   int KT;                    // K-steps per tile (>= 1: a class without taps runs one all-zero step)
@@ -347,8 +347,8 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN, DGRAD)) void igemm_ke
     // workgroups of the XCD have pushed it out of the 4 MB L2 (9x the algorithmic reads measured).
     int kstart = kt * BK;
     if (c.korder) {
-      const int cblk = (int)fdiv((unsigned)kt, c.per_div), rem = kt - cblk * (2 * c.ntaps);
-      kstart = ((rem >> 1) << p.src_c_shift) + cblk * 32 + (rem & 1) * 16;
+      const int cblk = (int)fdiv((unsigned)kt, c.per_div), rem = kt - cblk * (c.ntaps * (32 / BK));
+      kstart = BK == 32 ? (rem << p.src_c_shift) + cblk * 32 : ((rem >> 1) << p.src_c_shift) + cblk * 32 + (rem & 1) * 16;
     }
     const int k0 = kstart + a_kv * 4;
     int tap = 0, ch = k0;
@@ -1317,6 +1317,17 @@ struct TileChoice {
   int bm, bn;
 };
 
+// K depth of one pipeline step: 32 for the 128x128 fprop tile (half the barriers per MFMA, twice the
+// LDS; +3-4 % on the 128..512-channel layers), 16 elsewhere.  MVG_BK32=0 / 2: off / also dgrad.
+static int tile_bk(int bm, int bn, bool dgrad) {
+  static int bk32 = -1;
+  if (bk32 < 0) {
+    const char *e = getenv("MVG_BK32");
+    bk32 = e ? atoi(e) : 1;
+  }
+  return (bm == 128 && bn == 128 && (dgrad ? bk32 >= 2 : bk32 >= 1)) ? 32 : 16;
+}
+
 // the class view of the top-level fields (single-class launches; bf16x6 kernels' epilogue)
 static void class_from_params(IgemmClass &c, const IgemmParams &p) {
   memset(&c, 0, sizeof(c));
@@ -1343,7 +1354,7 @@ static void class_from_params(IgemmClass &c, const IgemmParams &p) {
     korder_env = (e && !strcmp(e, "0")) ? 0 : 1;
   }
   c.korder = (korder_env && p.ntaps > 1 && p.src_c % 32 == 0) ? 1 : 0;
-  c.per_div = make_fastdiv((unsigned)(p.ntaps > 0 ? 2 * p.ntaps : 1));
+  c.per_div = make_fastdiv((unsigned)(p.ntaps > 0 ? 2 * p.ntaps : 1));      // for BK = 16; launch_igemm resets it
 }
 
 static int g_streamk = -1;
@@ -1356,12 +1367,12 @@ static bool streamk_enabled() {
 }
 
 // ---- stream-K planning ---------------------------------------------------------------------
-template <int BM, int BN, int WGM, int WGN, bool DGRAD>
+template <int BM, int BN, int BK, int WGM, int WGN, bool DGRAD>
 static int igemm_occupancy() {
   static int occ = 0;
   if (occ <= 0) {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<BM, BN, 16, WGM, WGN, DGRAD>, 256, 0) != hipSuccess) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<BM, BN, BK, WGM, WGN, DGRAD>, 256, 0) != hipSuccess) {
       (void)hipGetLastError();
       n = 1;
     }
@@ -1370,10 +1381,13 @@ static int igemm_occupancy() {
   return occ;
 }
 static int tile_occupancy(int bm, int bn, bool dgrad) {
-  if (bm == 128 && bn == 128) return dgrad ? igemm_occupancy<128, 128, 2, 2, true>() : igemm_occupancy<128, 128, 2, 2, false>();
-  if (bm == 128 && bn == 64) return dgrad ? igemm_occupancy<128, 64, 2, 2, true>() : igemm_occupancy<128, 64, 2, 2, false>();
-  if (bm == 64 && bn == 64) return dgrad ? igemm_occupancy<64, 64, 2, 2, true>() : igemm_occupancy<64, 64, 2, 2, false>();
-  return dgrad ? igemm_occupancy<128, 32, 4, 1, true>() : igemm_occupancy<128, 32, 4, 1, false>();
+  if (bm == 128 && bn == 128) {
+    if (dgrad) return tile_bk(128, 128, true) == 32 ? igemm_occupancy<128, 128, 32, 2, 2, true>() : igemm_occupancy<128, 128, 16, 2, 2, true>();
+    return tile_bk(128, 128, false) == 32 ? igemm_occupancy<128, 128, 32, 2, 2, false>() : igemm_occupancy<128, 128, 16, 2, 2, false>();
+  }
+  if (bm == 128 && bn == 64) return dgrad ? igemm_occupancy<128, 64, 16, 2, 2, true>() : igemm_occupancy<128, 64, 16, 2, 2, false>();
+  if (bm == 64 && bn == 64) return dgrad ? igemm_occupancy<64, 64, 16, 2, 2, true>() : igemm_occupancy<64, 64, 16, 2, 2, false>();
+  return dgrad ? igemm_occupancy<128, 32, 16, 4, 1, true>() : igemm_occupancy<128, 32, 16, 4, 1, false>();
 }
 
 // Decide between one-tile-per-workgroup ("data parallel") and stream-K for `tiles` tiles of BM x BN
@@ -1382,14 +1396,14 @@ static int tile_occupancy(int bm, int bn, bool dgrad) {
 // partly filled round of workgroups costs a full round.  Model (fitted to tile_probe.py runs): a CU
 // with n resident workgroups runs at min(1, n * solo) of its matrix rate; the fix-up moves each
 // piece twice at ~4 TB/s (128-wide tiles) / ~2.5 TB/s (64-wide: more, smaller pieces).
-static int plan_streamk(long long tiles, int KT, int bm, int bn, int occ) {
+static int plan_streamk(long long tiles, int KT, int bm, int bn, int occ, int bk = 16) {
   if (!streamk_enabled() || tiles <= 0 || bm != 128 || bn < 64) return 0;
   int cus = mvg_device_cus();
   if (cus <= 0) cus = 256;
   const long long S = (long long)occ * cus;
   if (tiles * KT < 8 * S) return 0;                       // < 8 K-steps per workgroup: overheads dominate
   const double solo = bn >= 128 ? 0.62 : 0.40;
-  const double tile_us = 2.0 * bm * bn * 16.0 * KT / (115e6 / cus);   // one tile on a whole CU at 115 TF/s
+  const double tile_us = 2.0 * bm * bn * (double)bk * KT / (115e6 / cus);   // one tile on a whole CU at 115 TF/s
   const long long full_rounds = tiles / S, rem = tiles - full_rounds * S;
   double t_dp = full_rounds * occ * tile_us;
   if (rem > 0) {
@@ -1407,13 +1421,13 @@ static int plan_streamk(long long tiles, int KT, int bm, int bn, int occ) {
 // Tile choice over the classes of one launch (rows_c, ktotal_c).  The largest tile the column count
 // allows when stream-K will balance it over the CUs; otherwise the largest tile that still gives
 // >= 2 workgroups per CU (else the smallest).
-static void count_tiles(const long long *rows, const int *ktotal, int ncls, int groups, int ncols, TileChoice t,
+static void count_tiles(const long long *rows, const int *ktotal, int ncls, int groups, int ncols, TileChoice t, int bk,
                         long long &tiles, long long &units) {
   tiles = units = 0;
   for (int i = 0; i < ncls; ++i) {
     const long long ti = (long long)groups * ceil_div(rows[i], t.bm) * ceil_div(ncols, t.bn);
     tiles += ti;
-    units += ti * (ktotal[i] > 0 ? ceil_div(ktotal[i], 16) : 1);
+    units += ti * (ktotal[i] > 0 ? ceil_div(ktotal[i], bk) : 1);
   }
 }
 static TileChoice choose_tile_multi(const long long *rows, const int *ktotal, int ncls, int groups, int ncols, bool dgrad) {
@@ -1426,14 +1440,15 @@ static TileChoice choose_tile_multi(const long long *rows, const int *ktotal, in
   long long tiles, units;
   {
     const TileChoice big = ncols >= 128 ? TileChoice{128, 128} : TileChoice{128, 64};
-    count_tiles(rows, ktotal, ncls, groups, ncols, big, tiles, units);
-    if (tiles > 0 && plan_streamk(tiles, (int)(units / tiles), big.bm, big.bn, tile_occupancy(big.bm, big.bn, dgrad)) > 0)
+    const int bk = tile_bk(big.bm, big.bn, dgrad);
+    count_tiles(rows, ktotal, ncls, groups, ncols, big, bk, tiles, units);
+    if (tiles > 0 && plan_streamk(tiles, (int)(units / tiles), big.bm, big.bn, tile_occupancy(big.bm, big.bn, dgrad), bk) > 0)
       return big;
   }
   const TileChoice cand[3] = {{128, 128}, {128, 64}, {64, 64}};
   for (int i = 0; i < 3; ++i) {
     if (cand[i].bn > 64 && ncols < 128) continue;
-    count_tiles(rows, ktotal, ncls, groups, ncols, cand[i], tiles, units);
+    count_tiles(rows, ktotal, ncls, groups, ncols, cand[i], 16, tiles, units);
     if (tiles >= 2LL * cus) return cand[i];
   }
   return (ncols >= 64) ? TileChoice{64, 64} : TileChoice{128, 32};
@@ -1442,11 +1457,11 @@ static TileChoice choose_tile(long long rows_per_group, int groups, int ncols, i
   return choose_tile_multi(&rows_per_group, &ktotal, 1, groups, ncols, dgrad);
 }
 
-template <int BM, int BN, int WGM, int WGN, bool DGRAD>
+template <int BM, int BN, int BK, int WGM, int WGN, bool DGRAD>
 static int launch_igemm_tile(IgemmParams &p, long long tiles, long long units, hipStream_t st) {
   int P = 0;
   if (p.splits == 1 && units > tiles)
-    P = plan_streamk(tiles, (int)(units / tiles), BM, BN, igemm_occupancy<BM, BN, WGM, WGN, DGRAD>());
+    P = plan_streamk(tiles, (int)(units / tiles), BM, BN, igemm_occupancy<BM, BN, BK, WGM, WGN, DGRAD>(), BK);
   if (P > 0) {
     float *scratch = stream_scratch(st, (size_t)P * 2 * BM * BN);
     if (!scratch) P = 0;                                   // no scratch: plain launch
@@ -1454,13 +1469,13 @@ static int launch_igemm_tile(IgemmParams &p, long long tiles, long long units, h
   }
   if (P > 0) {
     p.sk_tiles = (int)tiles;
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, 16, WGM, WGN, DGRAD>), dim3((unsigned)P), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, BK, WGM, WGN, DGRAD>), dim3((unsigned)P), dim3(256), 0, st, p);
     if (check_launch(DGRAD ? "conv_dgrad(stream-K)" : "conv_fprop(stream-K)")) return 1;
-    hipLaunchKernelGGL((igemm_fixup_kernel<BM, BN, 16, WGM, WGN, DGRAD>), dim3((unsigned)(P - 1)), dim3(256), 0, st, p, P);
+    hipLaunchKernelGGL((igemm_fixup_kernel<BM, BN, BK, WGM, WGN, DGRAD>), dim3((unsigned)(P - 1)), dim3(256), 0, st, p, P);
     return check_launch("conv stream-K fix-up");
   }
   p.sk_tiles = 0;
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, 16, WGM, WGN, DGRAD>), dim3((unsigned)(tiles * p.splits)), dim3(256), 0, st, p);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, BK, WGM, WGN, DGRAD>), dim3((unsigned)(tiles * p.splits)), dim3(256), 0, st, p);
   return check_launch(DGRAD ? "conv_dgrad" : "conv_fprop");
 }
 
@@ -1470,11 +1485,13 @@ static int launch_igemm(IgemmParams &p, TileChoice t, hipStream_t st) {
   p.ntiles = ceil_div(p.ncols, t.bn);
   if (p.splits < 1) p.splits = 1;
   if (p.splits == 1) p.ktiles_per_split = 1 << 30;
+  const int bk = tile_bk(t.bm, t.bn, DGRAD);
   long long tiles = 0, units = 0;
   for (int i = 0; i < p.ncls; ++i) {
     IgemmClass &c = p.cls[i];
     c.mtiles_per_group = ceil_div(c.rows_per_group, t.bm);
-    c.KT = c.ktotal > 0 ? ceil_div(c.ktotal, 16) : 1;
+    c.KT = c.ktotal > 0 ? ceil_div(c.ktotal, bk) : 1;
+    c.per_div = make_fastdiv((unsigned)(c.ntaps > 0 ? c.ntaps * (32 / bk) : 1));
     c.tile0 = (int)tiles;
     c.unit0 = units;
     const long long ti = (long long)p.groups * c.mtiles_per_group * p.ntiles;
@@ -1484,10 +1501,13 @@ static int launch_igemm(IgemmParams &p, TileChoice t, hipStream_t st) {
   MVG_REQUIRE(tiles * p.splits < (1LL << 31), "conv: grid too large");
   MVG_REQUIRE(p.splits == 1 || p.ncls == 1, "conv: split-K with several classes");
   if (tiles <= 0) return 0;
-  if (t.bm == 128 && t.bn == 128) return launch_igemm_tile<128, 128, 2, 2, DGRAD>(p, tiles, units, st);
-  if (t.bm == 128 && t.bn == 64) return launch_igemm_tile<128, 64, 2, 2, DGRAD>(p, tiles, units, st);
-  if (t.bm == 64 && t.bn == 64) return launch_igemm_tile<64, 64, 2, 2, DGRAD>(p, tiles, units, st);
-  return launch_igemm_tile<128, 32, 4, 1, DGRAD>(p, tiles, units, st);
+  if (t.bm == 128 && t.bn == 128) {
+    if (bk == 32) return launch_igemm_tile<128, 128, 32, 2, 2, DGRAD>(p, tiles, units, st);
+    return launch_igemm_tile<128, 128, 16, 2, 2, DGRAD>(p, tiles, units, st);
+  }
+  if (t.bm == 128 && t.bn == 64) return launch_igemm_tile<128, 64, 16, 2, 2, DGRAD>(p, tiles, units, st);
+  if (t.bm == 64 && t.bn == 64) return launch_igemm_tile<64, 64, 16, 2, 2, DGRAD>(p, tiles, units, st);
+  return launch_igemm_tile<128, 32, 16, 4, 1, DGRAD>(p, tiles, units, st);
 }
 
 // conv math: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = bf16x6 split on the bf16 MFMA

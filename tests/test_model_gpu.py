@@ -217,6 +217,23 @@ def test_backward_strict_with_imposed_relu_pattern(depth, batch, hw, gtol):
     rel_close(data["img_1"].grad, od["img_1"].grad.numpy(), gtol, "grad img_1")
 
 
+def test_run_to_run_determinism():
+    """Stream-K pieces, wgrad slabs and BN partials are all summed in a fixed order: two runs of the
+    same step give bit-identical loss and gradients (batch large enough for stream-K to engage)."""
+    m = build(18)
+    runs = []
+    for _ in range(2):
+        m.zero_grad(set_to_none=False)
+        data = m(inputs(16, 224, seed=5))
+        loss = metrics()(data)
+        loss.backward()
+        runs.append((loss.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters()
+                                             if p.grad is not None}))
+    assert torch.equal(runs[0][0], runs[1][0])
+    for k, g in runs[0][1].items():
+        assert torch.equal(g, runs[1][1][k]), k
+
+
 def test_gradient_accumulation_and_zero_grad():
     m = build(18)
     d = m(inputs(3, 64))
