@@ -151,20 +151,64 @@ def fuse(sd: SD, it: int, img_feat: Tensor, rotated: Tensor, mask=None) -> Tenso
     return mlp(sd, f"_img_fusers.{it}._fuser.", x, 2, _one(mask)).reshape(-1, 3, NUM_FEAT_VEC)
 
 
+def fuse_rotmat(sd: SD, it: int, img_feat: Tensor, feat: Tensor, rot: Tensor) -> Tensor:
+    """ImageRotmatFeatFuser (encode_rotmat): the partner's feature is NOT rotated; the relative
+    rotation is appended as 9 more inputs of a 3-layer Mlp.  /root/reference/models/rot_mv.py:53-69,219-225."""
+    x = torch.cat([img_feat, feat.flatten(-2, -1), rot.flatten(-2, -1)], dim=-1)
+    return mlp(sd, f"_img_fusers.{it}._fuser.", x, 3).reshape(-1, 3, NUM_FEAT_VEC)
+
+
+def intensity_batchnorm(sd: SD, prefix: str, x: Tensor, training: bool, momentum: float = 0.05,
+                        eps: float = 1e-4) -> Tensor:
+    """IntensityBatchNorm: x [B,3,F] divided by a running mean of the batch std of the column
+    norms; the running buffer is updated BEFORE it is used (train).  /root/reference/models/rot_mv.py:13-32."""
+    key = prefix + "running_mean"
+    intensity = torch.norm(x, dim=-2, keepdim=True).detach()
+    var = torch.var(intensity, unbiased=False, dim=0, keepdim=True)
+    std = torch.sqrt(var.clamp_min(eps))
+    if training:
+        sd[key] = sd[key] * (1 - momentum) + std * momentum
+    return x / (sd[key] + eps)
+
+
+def fuse_rotfeat(sd: SD, it: int, feat_0: Tensor, feat_1: Tensor, training: bool) -> Tensor:
+    """RotFeatFuser (share_feature): both [B,3,F] inputs pass the fuser's ONE IntensityBatchNorm
+    (feat_0 first), are concatenated along F, flattened axis-major and go through a 3-layer Mlp.
+    /root/reference/models/rot_mv.py:72-86."""
+    pre = f"_img_fusers.{it}._batchnorm."
+    n0 = intensity_batchnorm(sd, pre, feat_0, training)
+    n1 = intensity_batchnorm(sd, pre, feat_1, training)
+    x = torch.cat([n0, n1], dim=-1).flatten(-2, -1)
+    return mlp(sd, f"_img_fusers.{it}._fuser.", x, 3).reshape(-1, 3, NUM_FEAT_VEC)
+
+
 def gaze_head(sd: SD, it: int, img_feat: Tensor, feat: Tensor, mask=None) -> Tensor:
-    """Mlp(K_in,[512,2]) on cat([img_feat, feat.flatten(1)]).  /root/reference/models/rot_mv.py:179-184,249-254."""
-    x = torch.cat([img_feat, feat.flatten(1, -1)], dim=-1)
+    """Mlp(K_in,[512,2]) on cat([img_feat, feat.flatten(1)]).  /root/reference/models/rot_mv.py:179-184,249-254.
+    share_feature (img_feat is [B,3,F]): cat along F, then flatten (:241-247)."""
+    if img_feat.dim() == 3:
+        x = torch.cat([img_feat, feat], dim=-1).flatten(1, -1)
+    else:
+        x = torch.cat([img_feat, feat.flatten(1, -1)], dim=-1)
     return mlp(sd, f"_gaze_estimators.{it}.", x, 2, _one(mask))
 
 
 def fuse_pair(sd: SD, num_iter: int, img_feat_0: Tensor, img_feat_1: Tensor, f0: Tensor, f1: Tensor,
-              rot_0: Tensor, rot_1: Tensor, masks: Optional[Dict[Any, Any]] = None) -> Dict[str, Any]:
+              rot_0: Tensor, rot_1: Tensor, masks: Optional[Dict[Any, Any]] = None, variant=None,
+              training: bool = False) -> Dict[str, Any]:
     """The two-view recurrence of /root/reference/models/rot_mv.py:193-194,205-265 given the
-    per-view pooled and lifted features.  ``masks`` (test aid, see _relu): {("fuse", it): [m0, m1],
-    ("head", it): [m0, m1]} imposed hidden-layer ReLU patterns."""
+    per-view pooled and lifted features.  ``masks`` (test aid, see _relu, default variant only):
+    {("fuse", it): [m0, m1], ("head", it): [m0, m1]} imposed hidden-layer ReLU patterns.
+    ``variant``: arch.Variant (ablations, :136-171,219-247); share_weights needs nothing here -
+    the state_dict holds the same tensors under every iteration's names."""
     mk = (lambda kind, it, v: masks[(kind, it)][v]) if masks is not None else (lambda kind, it, v: None)
+    enc = variant is not None and variant.encode_rotmat
+    ign = variant is not None and variant.ignore_rotmat
+    shf = variant is not None and variant.share_feature
+    assert masks is None or not (enc or shf)
     rot_10 = rot_0 @ rot_1.transpose(-1, -2)
     rot_01 = rot_1 @ rot_0.transpose(-1, -2)
+    if shf:                                            # :199-201
+        img_feat_0, img_feat_1 = f0, f1
     pred: Dict[str, Any] = {
         "num_iter": num_iter,
         "img_feat_0": img_feat_0, "img_feat_1": img_feat_1,
@@ -172,8 +216,18 @@ def fuse_pair(sd: SD, num_iter: int, img_feat_0: Tensor, img_feat_1: Tensor, f0:
     }
     for it in range(num_iter):
         f0_prev = f0                                   # rot_mv.py:217 - view 1 reads view 0's OLD feature
-        f0 = fuse(sd, it, img_feat_0, rot_10 @ f1, mk("fuse", it, 0))
-        f1 = fuse(sd, it, img_feat_1, rot_01 @ f0_prev, mk("fuse", it, 1))
+        if enc:
+            f0 = fuse_rotmat(sd, it, img_feat_0, f1, rot_10)
+            f1 = fuse_rotmat(sd, it, img_feat_1, f0_prev, rot_01)
+        elif ign:
+            f0 = fuse(sd, it, img_feat_0, f1, mk("fuse", it, 0))
+            f1 = fuse(sd, it, img_feat_1, f0_prev, mk("fuse", it, 1))
+        elif shf:
+            f0 = fuse_rotfeat(sd, it, img_feat_0, rot_10 @ f1, training)
+            f1 = fuse_rotfeat(sd, it, img_feat_1, rot_01 @ f0_prev, training)
+        else:
+            f0 = fuse(sd, it, img_feat_0, rot_10 @ f1, mk("fuse", it, 0))
+            f1 = fuse(sd, it, img_feat_1, rot_01 @ f0_prev, mk("fuse", it, 1))
         pred[f"iter_{it}"] = {
             "feat_0": f0, "feat_1": f1,
             "pred_gaze_0": gaze_head(sd, it, img_feat_0, f0, mk("head", it, 0)),
@@ -184,8 +238,8 @@ def fuse_pair(sd: SD, num_iter: int, img_feat_0: Tensor, img_feat_1: Tensor, f0:
 
 
 def model_forward(sd: SD, data: Dict[str, Any], depth: int, num_iter: int = 3,
-                  training: bool = False, masks: Optional[Dict[Any, Any]] = None) -> Dict[str, Any]:
-    """FeatRotationSymm.forward (default variant) - /root/reference/models/rot_mv.py:187-269.
+                  training: bool = False, masks: Optional[Dict[Any, Any]] = None, variant=None) -> Dict[str, Any]:
+    """FeatRotationSymm.forward - /root/reference/models/rot_mv.py:187-269.
     Mutates and returns ``data`` like the reference (:266).  ``masks`` (test aid, see _relu):
     {"backbone": [iter_view0, iter_view1], "lift": [m0, m1], ("fuse", it): ..., ("head", it): ...}."""
     spec = backbone_spec(depth)
@@ -194,7 +248,8 @@ def model_forward(sd: SD, data: Dict[str, Any], depth: int, num_iter: int = 3,
     img_feat_0 = backbone_forward(sd, data["img_0"], spec, training, None, bm[0])   # view 0 first: BN running
     img_feat_1 = backbone_forward(sd, data["img_1"], spec, training, None, bm[1])   # stats update order :196-197
     f0, f1 = lift(sd, img_feat_0, lm[0]), lift(sd, img_feat_1, lm[1])
-    data.update(fuse_pair(sd, num_iter, img_feat_0, img_feat_1, f0, f1, data["rot_0"], data["rot_1"], masks))
+    data.update(fuse_pair(sd, num_iter, img_feat_0, img_feat_1, f0, f1, data["rot_0"], data["rot_1"], masks, variant,
+                          training))
     return data
 
 

@@ -50,7 +50,7 @@ def normal(n: int, seed: int, tag: str) -> np.ndarray:
     return np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
 
 
-def make_state_dict(depth: int, seed: int = 0, num_iter: int = 3, perturb_bn: bool = False):
+def make_state_dict(depth: int, seed: int = 0, num_iter: int = 3, perturb_bn: bool = False, variant=None):
     """name -> numpy array, keys/shapes = the reference checkpoint contract.
 
     perturb_bn=True draws BN gamma in U(0.5,1.5), beta in U(-0.2,0.2), running_mean in
@@ -58,7 +58,11 @@ def make_state_dict(depth: int, seed: int = 0, num_iter: int = 3, perturb_bn: bo
     parity tests; False gives the reference's init (gamma=1, beta=0, mean=0, var=1).
     """
     sd = OrderedDict()
-    for name, shape, kind in state_dict_shapes(depth, num_iter):
+    from .arch import DEFAULT_VARIANT
+    variant = variant or DEFAULT_VARIANT
+    shapes = state_dict_shapes(depth, num_iter, variant)
+    fan_ins = dict((nm, sh) for nm, sh, _ in shapes)
+    for name, shape, kind in shapes:
         n = int(np.prod(shape)) if len(shape) else 1
         if kind == "conv":
             cout, _cin, kh, kw = shape
@@ -68,8 +72,7 @@ def make_state_dict(depth: int, seed: int = 0, num_iter: int = 3, perturb_bn: bo
             bound = 1.0 / np.sqrt(shape[1])            # nn.Linear default: U(-1/sqrt(fan_in), +)
             a = ((uniform01(n, seed, name) * 2.0 - 1.0) * bound).astype(np.float32).reshape(shape)
         elif kind == "lin_bias":
-            fan_in = dict((nm, sh) for nm, sh, _ in state_dict_shapes(depth, num_iter))[
-                name[: -len("bias")] + "weight"][1]
+            fan_in = fan_ins[name[: -len("bias")] + "weight"][1]
             bound = 1.0 / np.sqrt(fan_in)
             a = ((uniform01(n, seed, name) * 2.0 - 1.0) * bound).astype(np.float32)
         elif kind == "bn_weight":
@@ -82,6 +85,10 @@ def make_state_dict(depth: int, seed: int = 0, num_iter: int = 3, perturb_bn: bo
             a = (0.5 + uniform01(n, seed, name)).astype(np.float32) if perturb_bn else np.ones(n, np.float32)
         elif kind == "bn_count":
             a = np.array(0, dtype=np.int64)
+        elif kind == "ibn_mean":          # IntensityBatchNorm.running_mean, init ones (rot_mv.py:16)
+            a = ((0.5 + uniform01(n, seed, name)) if perturb_bn else np.ones(n)).astype(np.float32).reshape(shape)
+        elif kind.startswith("alias:"):   # share_weights: the same array under a second name
+            a = sd[kind[len("alias:"):]]
         else:
             raise AssertionError(kind)
         sd[name] = a

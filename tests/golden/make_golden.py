@@ -168,10 +168,13 @@ STAT_SAMPLES = ["_feat_extractor.0.bn1", "_feat_extractor.0.layer1.0.bn2", "_fea
                 "_feat_extractor.0.layer4.1.bn1"]
 
 
-def build_ref(depth, seed, perturb_bn=True):
-    model = ref_rot_mv.FeatRotationSymm(backbone_depth=depth, num_iter=3, share_weights=False,
-                                        encode_rotmat=False, share_feature=False, ignore_rotmat=False)
-    sd_np = synth.make_state_dict(depth, seed, 3, perturb_bn=perturb_bn)
+def build_ref(depth, seed, perturb_bn=True, variant=None):
+    from rot_mvgaze_amd.arch import DEFAULT_VARIANT
+    v = variant or DEFAULT_VARIANT
+    model = ref_rot_mv.FeatRotationSymm(backbone_depth=depth, num_iter=3, share_weights=v.share_weights,
+                                        encode_rotmat=v.encode_rotmat, share_feature=v.share_feature,
+                                        ignore_rotmat=v.ignore_rotmat)
+    sd_np = synth.make_state_dict(depth, seed, 3, perturb_bn=perturb_bn, variant=v)
     ref_keys = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     my_keys = {k: tuple(v.shape) for k, v in sd_np.items()}
     assert ref_keys == my_keys, "state_dict contract mismatch"
@@ -196,6 +199,49 @@ def collect_outputs(data, out):
     for i in range(3):
         for k in ("feat_0", "feat_1", "pred_gaze_0", "pred_gaze_1"):
             out[f"iter_{i}.{k}"] = t2n(data[f"iter_{i}"][k])
+
+
+VARIANT_GRAD_SAMPLES = ["_img_fusers.0._fuser.blocks.0.0.weight", "_img_fusers.0._fuser.blocks.0.0.bias",
+                        "_img_fusers.2._fuser.blocks.1.0.weight", "_gaze_estimators.1.blocks.0.0.weight",
+                        "_lifter._lifter.blocks.1.0.weight", "_feat_extractor.0.layer4.1.conv2.weight",
+                        "_feat_extractor.0.conv1.weight"]
+
+
+def gen_variant(name, variant, depth=18, batch=3, hw=64, seed_w=0, seed_in=1234):
+    """Ablation variants (rot_mv.py:136-171): eval outputs, one train step (outputs, loss, gradient
+    samples + norms, IntensityBatchNorm buffers)."""
+    tag = f"variant_{name}_r{depth}_b{batch}_hw{hw}"
+    metrics = ref_stereo_loss.IterationLoss(
+        loss=ref_stereo_loss.StereoL1Loss(rel_weight=0.01, reference_decay=1.0,
+                                          distance_metric="angular_error", pred_gaze_key="pred_gaze"),
+        iter_decay=0.5)
+    out = {}
+    model = build_ref(depth, seed_w, True, variant)
+    model.eval()
+    with torch.no_grad():
+        data = model(ref_inputs(batch, seed_in, hw))
+    ev = {}
+    collect_outputs(data, ev)
+    out.update({"eval." + k: v for k, v in ev.items()})
+    model = build_ref(depth, seed_w, True, variant)
+    model.train()
+    data = model(ref_inputs(batch, seed_in, hw))
+    loss = metrics(data)
+    loss.backward()
+    tr = {}
+    collect_outputs(data, tr)
+    out.update({"train." + k: v for k, v in tr.items()})
+    out["train.loss"] = t2n(loss)
+    params = dict(model.named_parameters(remove_duplicate=False))
+    for key in VARIANT_GRAD_SAMPLES:
+        g = params[key].grad
+        out["grad." + key] = t2n(g).reshape(-1)[:4096].copy()
+        out["gradnorm." + key] = np.array(float(g.double().norm()))
+    for k, v in model.state_dict().items():
+        if k.endswith("_batchnorm.running_mean"):
+            out["stat." + k] = t2n(v)
+    np.savez_compressed(os.path.join(HERE, tag + ".npz"), **out)
+    print(tag, "loss", float(loss), "pred_gaze[0]", out["train.pred_gaze"][0])
 
 
 def gen_model(depth, batch, hw, seed_w=0, seed_in=1234):
@@ -244,10 +290,23 @@ def gen_model(depth, batch, hw, seed_w=0, seed_in=1234):
     print(tag, "loss", float(loss), "pred_gaze[0]", out["train.pred_gaze"][0])
 
 
+def gen_variants():
+    from rot_mvgaze_amd.arch import Variant
+    gen_variant("share_weights", Variant(share_weights=True))
+    gen_variant("ignore_rotmat", Variant(ignore_rotmat=True))
+    gen_variant("encode_rotmat", Variant(encode_rotmat=True))
+    gen_variant("share_feature", Variant(share_feature=True))
+    gen_variant("share_weights_encode_rotmat", Variant(share_weights=True, encode_rotmat=True))
+
+
 if __name__ == "__main__":
+    if "--variants" in sys.argv:
+        gen_variants()
+        sys.exit(0)
     gen_geometry()
     gen_pair_index()
     gen_model(18, 2, 224)
     gen_model(50, 2, 224)
     gen_model(18, 3, 64)
     gen_model(50, 3, 64)
+    gen_variants()

@@ -132,6 +132,61 @@ def test_model_forward_backward_vs_reference(golden_dir, depth, batch, hw):
     assert int(sd["_feat_extractor.0.bn1.num_batches_tracked"]) == 2
 
 
+VARIANTS = {
+    "share_weights": dict(share_weights=True),
+    "ignore_rotmat": dict(ignore_rotmat=True),
+    "encode_rotmat": dict(encode_rotmat=True),
+    "share_feature": dict(share_feature=True),
+    "share_weights_encode_rotmat": dict(share_weights=True, encode_rotmat=True),
+}
+
+
+def _variant_sd(variant, depth=18, seed=0):
+    """state_dict as torch tensors; share_weights names map to ONE tensor object (one autograd leaf)."""
+    raw = synth.make_state_dict(depth, seed, 3, perturb_bn=True, variant=variant)
+    cache, sd = {}, {}
+    for k, v in raw.items():
+        if id(v) not in cache:
+            cache[id(v)] = torch.from_numpy(np.array(v))
+        sd[k] = cache[id(v)]
+    return sd
+
+
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+def test_variants_vs_reference(golden_dir, name):
+    """The four ablation variants (and one combination) of /root/reference/models/rot_mv.py:136-171
+    against fixtures produced by the reference itself (tests/golden/make_golden.py --variants)."""
+    from rot_mvgaze_amd.arch import Variant
+    variant = Variant(**VARIANTS[name]).check()
+    g = _load(golden_dir, f"variant_{name}_r18_b3_hw64.npz")
+    sd = _variant_sd(variant)
+    with torch.no_grad():
+        data = R.model_forward(sd, _data(3, 64), 18, 3, training=False, variant=variant)
+    _check_outputs(data, g, "eval", 1e-6)
+    sd = _variant_sd(variant)
+    leaves = {k: v.requires_grad_(True) for k, v in sd.items() if v.dtype == torch.float32 and "running" not in k}
+    data = R.model_forward(sd, _data(3, 64), 18, 3, training=True, variant=variant)
+    loss = R.iteration_loss(data)
+    loss.backward()
+    _check_outputs(data, g, "train", 1e-6)
+    np.testing.assert_allclose(loss.item(), g["train.loss"], rtol=1e-6)
+    for key in [k[5:] for k in g.files if k.startswith("grad._")]:
+        ref = g["grad." + key]
+        got = leaves[key].grad.reshape(-1)[: ref.size].numpy()
+        np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max() + 1e-12)
+        np.testing.assert_allclose(float(leaves[key].grad.double().norm()), g["gradnorm." + key], rtol=1e-5)
+    for k in [k for k in g.files if k.startswith("stat.")]:
+        np.testing.assert_allclose(sd[k[5:]].detach().numpy(), g[k], rtol=1e-6, atol=1e-7)
+
+
+def test_invalid_variant_combinations_raise():
+    from rot_mvgaze_amd.arch import Variant
+    with pytest.raises(AssertionError):
+        Variant(ignore_rotmat=True, encode_rotmat=True).check()
+    with pytest.raises(ValueError):
+        Variant(share_feature=True, share_weights=True).check()
+
+
 def test_view_swap_symmetry_is_bit_exact():
     """swapping the two views swaps the outputs bit-exactly in eval mode."""
     sd = _torch_sd(18)
