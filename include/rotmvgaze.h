@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MVG_ABI_VERSION 2
+#define MVG_ABI_VERSION 3
 
 /* ---------------------------------------------------------------- library */
 int mvg_abi_version(void);
@@ -232,6 +232,32 @@ int mvg_rotcat_fwd(const float *img_feat /*[views][batch][cf]*/, const float *fe
 /* dfeat[src_of[d]][b] = rel[d][b]^T @ dx_rot  (src_of must be injective: every slot written once). */
 int mvg_rotcat_bwd(const float *dx, const float *rel, const int32_t *src_of, float *dfeat, int batch,
                    int dirs, int cf, int nvec, void *stream);
+/* ---------------------------------------------------------------- ablation variants
+ * encode_rotmat, ImageRotmatFeatFuser.forward rot_mv.py:62-69: row (d, b) of x (row length ld,
+ * zero-padded) = [ img_feat[view_of[d]][b] | (rel_apply[d][b] @) feat[src_of[d]][b] | rel_append[d][b]
+ * flattened (9) ]; either rel may be NULL (no rotation applied / nothing appended). */
+int mvg_rotcat_ext_fwd(const float *img_feat, const float *feat, const float *rel_apply,
+                       const float *rel_append, const int32_t *view_of, const int32_t *src_of,
+                       float *x, int ld, int batch, int dirs, int cf, int nvec, void *stream);
+int mvg_rotcat_ext_bwd(const float *dx, int ld, const float *rel, const int32_t *src_of, float *dfeat,
+                       int batch, int dirs, int cf, int nvec, void *stream);
+/* share_feature: IntensityBatchNorm rot_mv.py:13-32 as used by RotFeatFuser.forward :82-86.  The
+ * 2*dirs calls of one iteration (direction d: a[view_of[d]] then feat[src_of[d]]) run in order on
+ * the fuser's running_mean [nvec] (updated in place when training); scales [2*dirs][nvec] =
+ * 1 / (running_mean + eps) as each call saw it. */
+int mvg_ibn_scales(const float *a /*[views][batch][3][nvec]*/, const float *feat /*[srcs][batch][3][nvec]*/,
+                   const int32_t *view_of, const int32_t *src_of, float *running_mean, int training,
+                   float momentum, float eps, float *scales, int batch, int dirs, int nvec,
+                   void *stream);
+/* x[(d,b)][axis][0:nvec] = scales[2d] * a[view_of[d]][b][axis], [nvec:2nvec] = scales[2d+1] * (rel[d][b] @
+ * feat[src_of[d]][b])[axis]: cat([.,.], dim=-1).flatten(-2,-1) of rot_mv.py:85 (scales) and :241-247
+ * (gaze head input, scales == NULL, rel == NULL).  Backward: da_dir [(d,b)][3][nvec] (sum it over
+ * directions with mvg_segment_sum) and dfeat[src_of[d]][b] = rel^T @ (...). */
+int mvg_paircat_fwd(const float *a, const float *feat, const float *rel, const float *scales,
+                    const int32_t *view_of, const int32_t *src_of, float *x, int batch, int dirs,
+                    int nvec, void *stream);
+int mvg_paircat_bwd(const float *dx, const float *rel, const float *scales, const int32_t *src_of,
+                    float *da_dir, float *dfeat, int batch, int dirs, int nvec, void *stream);
 /* out[v][b][0:width] (+)= sum over d with seg_of[d] == v, ascending d (reproducible), of
  * x[(d*batch + b)*row_stride + 0:width].  Gradient fan-in of the per-view features that several
  * directed pairs read (img_feat in every fuser/head input, the lifted feature at iteration 0). */

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "librotmvgaze_hip.so")
 
 K_FAMILIES = 18
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class ConvDesc(C.Structure):
@@ -86,6 +86,11 @@ SIGNATURES = {
     "mvg_relative_rotation": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "mvg_rotcat_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "mvg_rotcat_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "mvg_rotcat_ext_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "mvg_rotcat_ext_bwd": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "mvg_ibn_scales": (_I, [_P, _P, _P, _P, _P, _I, _F, _F, _P, _I, _I, _I, _P]),
+    "mvg_paircat_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "mvg_paircat_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "mvg_segment_sum": (_I, [_P, _I64, _I, _P, _P, _I, _I, _I, _I, _P]),
     "mvg_colsum": (_I, [_P, _P, _I64, _I, _I, _P]),
     "mvg_axpby": (_I, [_P, _P, _F, _F, _I64, _P]),

@@ -238,10 +238,10 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams &p, const Igemm
 }
 
 // resident workgroups per CU the register budget is held to (LDS allows 4 / 5 / 8 / 5)
-constexpr int igemm_min_blocks(int bm, int bn, bool dgrad) { return (bm == 128 && bn == 128 && dgrad) ? 3 : 2; }
+constexpr int igemm_min_blocks(int bm, int bn, int bk, bool dgrad) { return (bm == 128 && bn == 128 && bk == 16 && dgrad) ? 3 : 2; }
 
 template <int BM, int BN, int BK, int WGM, int WGN, bool DGRAD>
-__global__ __launch_bounds__(256, igemm_min_blocks(BM, BN, DGRAD)) void igemm_kernel(IgemmParams p) {
+__global__ __launch_bounds__(256, igemm_min_blocks(BM, BN, BK, DGRAD)) void igemm_kernel(IgemmParams p) {
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int KV = BK / 4;                 // float4 per k-contiguous row

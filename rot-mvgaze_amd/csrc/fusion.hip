@@ -88,6 +88,154 @@ __global__ __launch_bounds__(256) void rotcat_bwd_feat_kernel(const float *__res
   }
 }
 
+// ---- ablation variants (rot_mv.py:53-86,136-171) -------------------------------------------------
+// encode_rotmat: x[(d,b)] = [ img_feat | feat (NOT rotated) | rel flattened (9) | zeros to ld ]
+__global__ __launch_bounds__(256) void rotcat_ext_fwd_kernel(const float *__restrict__ img_feat,
+                                                             const float *__restrict__ feat,
+                                                             const float *__restrict__ rel_apply,
+                                                             const float *__restrict__ rel_append,
+                                                             const int *__restrict__ view_of, const int *__restrict__ src_of,
+                                                             float *__restrict__ x, int ld, int batch, int cf, int nvec) {
+  const int row = blockIdx.x;            // d*batch + b
+  const int d = row / batch, b = row - d * batch;
+  float *xo = x + (long long)row * ld;
+  const float4 *src = reinterpret_cast<const float4 *>(img_feat + ((long long)view_of[d] * batch + b) * cf);
+  for (int i = threadIdx.x; i < cf / 4; i += 256) reinterpret_cast<float4 *>(xo)[i] = src[i];
+  const float *f = feat + ((long long)src_of[d] * batch + b) * 3 * nvec;
+  float r[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
+  if (rel_apply) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r[k] = rel_apply[(long long)row * 9 + k];
+  }
+  for (int k = threadIdx.x; k < nvec; k += 256) {
+    const float f0 = f[k], f1 = f[nvec + k], f2 = f[2 * nvec + k];
+    xo[cf + k] = r[0] * f0 + r[1] * f1 + r[2] * f2;
+    xo[cf + nvec + k] = r[3] * f0 + r[4] * f1 + r[5] * f2;
+    xo[cf + 2 * nvec + k] = r[6] * f0 + r[7] * f1 + r[8] * f2;
+  }
+  const int tail = cf + 3 * nvec;
+  for (int k = threadIdx.x; tail + k < ld; k += 256)
+    xo[tail + k] = (rel_append && k < 9) ? rel_append[(long long)row * 9 + k] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void rotcat_ext_bwd_kernel(const float *__restrict__ dx, int ld,
+                                                             const float *__restrict__ rel, const int *__restrict__ src_of,
+                                                             float *__restrict__ dfeat, int batch, int cf, int nvec) {
+  const int row = blockIdx.x;
+  const int d = row / batch, b = row - d * batch;
+  const float *g = dx + (long long)row * ld + cf;
+  float *o = dfeat + ((long long)src_of[d] * batch + b) * 3 * nvec;
+  float r[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
+  if (rel) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r[k] = rel[(long long)row * 9 + k];
+  }
+  for (int k = threadIdx.x; k < nvec; k += 256) {
+    const float g0 = g[k], g1 = g[nvec + k], g2 = g[2 * nvec + k];
+    o[k] = r[0] * g0 + r[3] * g1 + r[6] * g2;
+    o[nvec + k] = r[1] * g0 + r[4] * g1 + r[7] * g2;
+    o[2 * nvec + k] = r[2] * g0 + r[5] * g1 + r[8] * g2;
+  }
+}
+
+// share_feature: the IntensityBatchNorm scales of one iteration.  The reference calls the fuser's ONE
+// normaliser 2*dirs times in sequence (direction 0: feat_0 then feat_1, direction 1: ...); in training
+// every call first moves running_mean towards the batch std of the column norms, then divides by
+// (running_mean + eps).  One thread per column k walks the calls in that order.  The norm of a
+// rotated column equals the norm of the column (rel is orthonormal), so feat is read unrotated.
+__global__ __launch_bounds__(256) void ibn_scales_kernel(const float *__restrict__ a, const float *__restrict__ feat,
+                                                         const int *__restrict__ view_of, const int *__restrict__ src_of,
+                                                         float *__restrict__ running_mean, int training, float momentum,
+                                                         float eps, float *__restrict__ scales, int batch, int dirs,
+                                                         int nvec) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= nvec) return;
+  float rm = running_mean[k];
+  for (int call = 0; call < 2 * dirs; ++call) {
+    const int d = call >> 1;
+    const float *src = (call & 1) ? feat + (long long)src_of[d] * batch * 3 * nvec : a + (long long)view_of[d] * batch * 3 * nvec;
+    if (training) {
+      // biased variance over the batch of the column norm (two passes, like torch.var)
+      double sum = 0.0;
+      for (int b = 0; b < batch; ++b) {
+        const float *x = src + (long long)b * 3 * nvec + k;
+        const float x0 = x[0], x1 = x[nvec], x2 = x[2 * nvec];
+        sum += (double)sqrtf(x0 * x0 + x1 * x1 + x2 * x2);
+      }
+      const double mean = sum / batch;
+      double m2 = 0.0;
+      for (int b = 0; b < batch; ++b) {
+        const float *x = src + (long long)b * 3 * nvec + k;
+        const float x0 = x[0], x1 = x[nvec], x2 = x[2 * nvec];
+        const double dlt = (double)sqrtf(x0 * x0 + x1 * x1 + x2 * x2) - mean;
+        m2 += dlt * dlt;
+      }
+      const float var = (float)(m2 / batch);
+      const float sd = sqrtf(fmaxf(var, eps));
+      rm = rm * (1.f - momentum) + sd * momentum;
+    }
+    scales[(long long)call * nvec + k] = 1.f / (rm + eps);
+  }
+  if (training) running_mean[k] = rm;
+}
+
+// x[(d,b)][axis][0:nvec] = s0 * a[view_of[d]][b][axis][:],  [nvec:2nvec] = s1 * (rel @ feat[src_of[d]][b])[axis][:]
+__global__ __launch_bounds__(256) void paircat_fwd_kernel(const float *__restrict__ a, const float *__restrict__ feat,
+                                                          const float *__restrict__ rel, const float *__restrict__ scales,
+                                                          const int *__restrict__ view_of, const int *__restrict__ src_of,
+                                                          float *__restrict__ x, int batch, int nvec) {
+  const int row = blockIdx.x;
+  const int d = row / batch, b = row - d * batch;
+  float *xo = x + (long long)row * 6 * nvec;
+  const float *pa = a + ((long long)view_of[d] * batch + b) * 3 * nvec;
+  const float *f = feat + ((long long)src_of[d] * batch + b) * 3 * nvec;
+  float r[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
+  if (rel) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r[k] = rel[(long long)row * 9 + k];
+  }
+  for (int k = threadIdx.x; k < nvec; k += 256) {
+    const float s0 = scales ? scales[(long long)(2 * d) * nvec + k] : 1.f;
+    const float s1 = scales ? scales[(long long)(2 * d + 1) * nvec + k] : 1.f;
+    const float f0 = f[k], f1 = f[nvec + k], f2 = f[2 * nvec + k];
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+      xo[ax * 2 * nvec + k] = pa[ax * nvec + k] * s0;
+      xo[ax * 2 * nvec + nvec + k] = (r[3 * ax] * f0 + r[3 * ax + 1] * f1 + r[3 * ax + 2] * f2) * s1;
+    }
+  }
+}
+
+// da_dir[(d,b)][axis][k] = s0 * dx[..][axis][k];   dfeat[src_of[d]][b] = rel^T @ (s1 * dx[..][axis][nvec + k])
+__global__ __launch_bounds__(256) void paircat_bwd_kernel(const float *__restrict__ dx, const float *__restrict__ rel,
+                                                          const float *__restrict__ scales, const int *__restrict__ src_of,
+                                                          float *__restrict__ da_dir, float *__restrict__ dfeat, int batch,
+                                                          int nvec) {
+  const int row = blockIdx.x;
+  const int d = row / batch, b = row - d * batch;
+  const float *g = dx + (long long)row * 6 * nvec;
+  float *oa = da_dir + (long long)row * 3 * nvec;
+  float *of = dfeat + ((long long)src_of[d] * batch + b) * 3 * nvec;
+  float r[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
+  if (rel) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r[k] = rel[(long long)row * 9 + k];
+  }
+  for (int k = threadIdx.x; k < nvec; k += 256) {
+    const float s0 = scales ? scales[(long long)(2 * d) * nvec + k] : 1.f;
+    const float s1 = scales ? scales[(long long)(2 * d + 1) * nvec + k] : 1.f;
+    float gr[3];
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+      oa[ax * nvec + k] = g[ax * 2 * nvec + k] * s0;
+      gr[ax] = g[ax * 2 * nvec + nvec + k] * s1;
+    }
+    of[k] = r[0] * gr[0] + r[3] * gr[1] + r[6] * gr[2];
+    of[nvec + k] = r[1] * gr[0] + r[4] * gr[1] + r[7] * gr[2];
+    of[2 * nvec + k] = r[2] * gr[0] + r[5] * gr[1] + r[8] * gr[2];
+  }
+}
+
 // out[v][b][0:width] (+)= sum over d with seg_of[d] == v (ascending d: reproducible) of x rows
 __global__ __launch_bounds__(256) void segment_sum_kernel(const float *__restrict__ x, long long row_stride, int w4n,
                                                           const int *__restrict__ seg_of, float *__restrict__ out,
@@ -309,6 +457,54 @@ int mvg_rotcat_bwd(const float *dx, const float *rel, const int32_t *src_of, flo
   ProfScope ps(MVG_K_ROTCAT, st, 18.0 * dirs * batch * nvec, 24.0 * dirs * (double)batch * nvec);
   hipLaunchKernelGGL(rotcat_bwd_feat_kernel, dim3(dirs * batch), dim3(256), 0, st, dx, rel, src_of, dfeat, batch, cf, nvec);
   return check_launch("rotcat_bwd");
+}
+
+int mvg_rotcat_ext_fwd(const float *img_feat, const float *feat, const float *rel_apply, const float *rel_append,
+                       const int32_t *view_of, const int32_t *src_of, float *x, int ld, int batch, int dirs, int cf, int nvec,
+                       void *stream) {
+  MVG_REQUIRE(cf % 4 == 0 && ld % 4 == 0, "rotcat_ext: cf / ld %% 4 != 0");
+  MVG_REQUIRE(ld >= cf + 3 * nvec + (rel_append ? 9 : 0), "rotcat_ext: ld too small");
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(MVG_K_ROTCAT, st, 18.0 * dirs * batch * nvec, 8.0 * dirs * (double)batch * ld);
+  hipLaunchKernelGGL(rotcat_ext_fwd_kernel, dim3(dirs * batch), dim3(256), 0, st, img_feat, feat, rel_apply, rel_append, view_of,
+                     src_of, x, ld, batch, cf, nvec);
+  return check_launch("rotcat_ext_fwd");
+}
+
+int mvg_rotcat_ext_bwd(const float *dx, int ld, const float *rel, const int32_t *src_of, float *dfeat, int batch, int dirs,
+                       int cf, int nvec, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(MVG_K_ROTCAT, st, 18.0 * dirs * batch * nvec, 24.0 * dirs * (double)batch * nvec);
+  hipLaunchKernelGGL(rotcat_ext_bwd_kernel, dim3(dirs * batch), dim3(256), 0, st, dx, ld, rel, src_of, dfeat, batch, cf, nvec);
+  return check_launch("rotcat_ext_bwd");
+}
+
+int mvg_ibn_scales(const float *a, const float *feat, const int32_t *view_of, const int32_t *src_of, float *running_mean,
+                   int training, float momentum, float eps, float *scales, int batch, int dirs, int nvec, void *stream) {
+  MVG_REQUIRE(batch > 0 && dirs > 0 && nvec > 0, "ibn_scales: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(MVG_K_ELEMENTWISE, st, 0.0, 24.0 * dirs * (double)batch * nvec * 2);
+  hipLaunchKernelGGL(ibn_scales_kernel, dim3(ceil_div(nvec, 256)), dim3(256), 0, st, a, feat, view_of, src_of, running_mean,
+                     training, momentum, eps, scales, batch, dirs, nvec);
+  return check_launch("ibn_scales");
+}
+
+int mvg_paircat_fwd(const float *a, const float *feat, const float *rel, const float *scales, const int32_t *view_of,
+                    const int32_t *src_of, float *x, int batch, int dirs, int nvec, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(MVG_K_ROTCAT, st, 18.0 * dirs * batch * nvec, 48.0 * dirs * (double)batch * nvec);
+  hipLaunchKernelGGL(paircat_fwd_kernel, dim3(dirs * batch), dim3(256), 0, st, a, feat, rel, scales, view_of, src_of, x, batch,
+                     nvec);
+  return check_launch("paircat_fwd");
+}
+
+int mvg_paircat_bwd(const float *dx, const float *rel, const float *scales, const int32_t *src_of, float *da_dir, float *dfeat,
+                    int batch, int dirs, int nvec, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(MVG_K_ROTCAT, st, 18.0 * dirs * batch * nvec, 48.0 * dirs * (double)batch * nvec);
+  hipLaunchKernelGGL(paircat_bwd_kernel, dim3(dirs * batch), dim3(256), 0, st, dx, rel, scales, src_of, da_dir, dfeat, batch,
+                     nvec);
+  return check_launch("paircat_bwd");
 }
 
 int mvg_segment_sum(const float *x, int64_t row_stride, int width, const int32_t *seg_of, float *out, int batch, int dirs,

@@ -1,11 +1,16 @@
-"""Lifter + rotation-constrained cross-view fusion + gaze heads, forward and backward, on the HIP
-kernels - generalised from the reference's two views to V views (every unordered pair runs the
-reference's two-view recurrence).
+"""Lifter + cross-view fusion + gaze heads, forward and backward, on the HIP kernels - generalised
+from the reference's two views to V views (every unordered pair runs the reference's two-view
+recurrence) and covering the constructor variants of the reference model.
 
 What it replaces (for V = 2 exactly):
   * Feat3dLifter.forward ............ /root/reference/models/rot_mv.py:91-98
   * rot_10 / rot_01 .................. :193-194
-  * the fusion loop .................. :213-263 (ImageFeatFuser.forward :44-50, heads :249-254)
+  * the fusion loop .................. :205-263 with, per variant,
+      default        ImageFeatFuser on rot @ F_partner ............ :35-50, :234-239
+      ignore_rotmat  ImageFeatFuser on F_partner ................... :226-232
+      encode_rotmat  ImageRotmatFeatFuser(img, F_partner, rot) ..... :53-69, :219-225
+      share_feature  RotFeatFuser + IntensityBatchNorm on the lifted features :13-32, :72-86, :199-201, :241-247
+      share_weights  one fuser / head reused by every iteration .... :148-156
 
 Row space: D = V(V-1) *directed* pairs d = 2p (i<-j), 2p+1 (j<-i) for the p-th unordered pair
 (i<j) in lexicographic order; every GEMM of an iteration runs over all D*B rows at once because
@@ -13,16 +18,17 @@ the two directions (and all pairs) share the iteration's weights.
 """
 from __future__ import annotations
 
-from typing import Callable, Dict, List, Optional, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import torch
 
 from . import ops
 from ._lib import ConvDesc
-from .arch import NUM_FEAT_VEC, ROT_DIM
+from .arch import DEFAULT_VARIANT, NUM_FEAT_VEC, ROT_DIM, Variant
 from .backbone import GradSink
 
 Tensor = torch.Tensor
+IBN_MOMENTUM, IBN_EPS = 0.05, 1e-4          # IntensityBatchNorm defaults, rot_mv.py:14
 
 
 def directed_pairs(views: int) -> Tuple[List[int], List[int]]:
@@ -34,61 +40,147 @@ def directed_pairs(views: int) -> Tuple[List[int], List[int]]:
     return vi, vj
 
 
-class _Mlp2:
-    """Linear+ReLU -> Linear (every Mlp on the path has exactly two layers,
-    /root/reference/models/backbones/blocks.py:27-60 with rot_mv.py:95,41-43,179-184)."""
+def _pad4(n: int) -> int:
+    return (n + 3) // 4 * 4
 
-    def __init__(self, params: Dict[str, Tensor], prefix: str):
-        self.w0, self.b0 = params[prefix + "blocks.0.0.weight"], params[prefix + "blocks.0.0.bias"]
-        self.w1, self.b1 = params[prefix + "blocks.1.0.weight"], params[prefix + "blocks.1.0.bias"]
-        self.fin, self.hid, self.fout = self.w0.shape[1], self.w0.shape[0], self.w1.shape[0]
+
+class _Written:
+    """Parameters whose gradient this backward has already written: a second write (weights shared
+    between iterations) must accumulate whatever ``sink.accumulate`` said at the start."""
+
+    def __init__(self, sink: GradSink):
+        self.sink = sink
+        self.seen = set()
+
+    def acc(self, p) -> bool:
+        a = self.sink.accumulate(p) or id(p) in self.seen
+        self.seen.add(id(p))
+        return a
+
+
+class _Mlp:
+    """[Linear + ReLU] * (n - 1), Linear  (/root/reference/models/backbones/blocks.py:27-60; two layers
+    for the lifter, ImageFeatFuser and the heads, three for ImageRotmatFeatFuser / RotFeatFuser).
+
+    Feature widths that are not multiples of 4 (encode_rotmat: K_in + 9 = 2057 / 3593) run on
+    zero-padded copies of the weights: the GEMM kernels move 16-byte vectors along K.  The copies are
+    refreshed from the parameters every forward; padded hidden units are relu(0) = 0."""
+
+    def __init__(self, params: Dict[str, Tensor], prefix: str, n_layers: int = 2):
+        self.w = [params[f"{prefix}blocks.{l}.0.weight"] for l in range(n_layers)]
+        self.b = [params[f"{prefix}blocks.{l}.0.bias"] for l in range(n_layers)]
+        self.n = n_layers
+        self.fin = [w.shape[1] for w in self.w]
+        self.fout = [w.shape[0] for w in self.w]
+        self.fin_p = [_pad4(f) for f in self.fin]
+        self.fout_p = [f if (l == n_layers - 1 and f <= 4) else _pad4(f) for l, f in enumerate(self.fout)]
+        self.padded = [self.fin_p[l] != self.fin[l] or self.fout_p[l] != self.fout[l] for l in range(n_layers)]
+        self._wp: List[Optional[Tensor]] = [None] * n_layers
+        self._bp: List[Optional[Tensor]] = [None] * n_layers
+        self.in_width = self.fin_p[0]
 
     def parameters(self):
-        return [self.w0, self.b0, self.w1, self.b1]
+        out = []
+        for w, b in zip(self.w, self.b):
+            out += [w, b]
+        return out
+
+    def _weights(self, l: int):
+        if not self.padded[l]:
+            return self.w[l].detach(), self.b[l].detach()
+        if self._wp[l] is None or self._wp[l].device != self.w[l].device:
+            self._wp[l] = torch.zeros(self.fout_p[l], self.fin_p[l], dtype=torch.float32, device=self.w[l].device)
+            self._bp[l] = torch.zeros(self.fout_p[l], dtype=torch.float32, device=self.w[l].device)
+        self._wp[l][: self.fout[l], : self.fin[l]].copy_(self.w[l].detach())       # layout plumbing
+        self._bp[l][: self.fout[l]].copy_(self.b[l].detach())
+        return self._wp[l], self._bp[l]
 
     def forward(self, x: Tensor, out: Optional[Tensor] = None):
-        rows = x.shape[0]
-        dev = x.device
-        h = torch.empty(rows, self.hid, dtype=torch.float32, device=dev)
-        ops.linear_fprop(x, self.w0.detach(), self.b0.detach(), True, h, rows, self.fin, self.hid)
-        y = out if out is not None else torch.empty(rows, self.fout, dtype=torch.float32, device=dev)
-        if self.fout <= 4:
-            ops.linear_skinny_fwd(h, self.w1.detach(), self.b1.detach(), y, rows, self.hid, self.fout)
-        else:
-            ops.linear_fprop(h, self.w1.detach(), self.b1.detach(), False, y, rows, self.hid, self.fout)
-        return h, y
+        """x [rows, in_width] -> (hidden activations [h_0 .. h_{n-2}], y [rows, fout_last])."""
+        rows, dev = x.shape[0], x.device
+        assert x.shape[1] == self.fin_p[0], (x.shape, self.fin_p[0])
+        hs: List[Tensor] = []
+        cur = x
+        for l in range(self.n):
+            w, b = self._weights(l)
+            last = l == self.n - 1
+            y = out if (last and out is not None) else torch.empty(rows, self.fout_p[l], dtype=torch.float32, device=dev)
+            if last and self.fout[l] <= 4:
+                ops.linear_skinny_fwd(cur, w, b, y, rows, self.fin_p[l], self.fout[l])
+            else:
+                ops.linear_fprop(cur, w, b, not last, y, rows, self.fin_p[l], self.fout_p[l])
+            if not last:
+                hs.append(y)
+            cur = y
+        return hs, cur
 
-    def backward(self, x: Tensor, h: Tensor, gy: Tensor, sink: GradSink, dx_addend: Optional[Tensor] = None,
-                 dx_out: Optional[Tensor] = None) -> Tensor:
+    def backward(self, x: Tensor, hs: List[Tensor], gy: Tensor, sink: GradSink, wr: _Written,
+                 dx_addend: Optional[Tensor] = None, dx_out: Optional[Tensor] = None) -> Tensor:
         """gy = grad wrt the output; returns grad wrt x (optionally fused `+ dx_addend`)."""
-        rows = x.shape[0]
-        dev = x.device
-        dh = torch.empty(rows, self.hid, dtype=torch.float32, device=dev)
-        if self.fout <= 4:
-            acc = sink.accumulate(self.w1)
-            ops.linear_skinny_bwd(gy, h, self.w1.detach(), h, dh, sink.view(self.w1), sink.view(self.b1), rows,
-                                  self.hid, self.fout, acc)
-        else:
-            d1 = ConvDesc.linear(rows, self.hid, self.fout)
-            ops.linear_dgrad(gy, self.w1.detach(), h, None, dh, rows, self.hid, self.fout)   # (gy @ W1) * (h > 0)
-            ops.conv_wgrad(d1, h, gy, sink.view(self.w1), sink.accumulate(self.w1))
-            ops.colsum(gy, sink.view(self.b1), rows, self.fout, sink.accumulate(self.b1))
-        d0 = ConvDesc.linear(rows, self.fin, self.hid)
-        ops.conv_wgrad(d0, x, dh, sink.view(self.w0), sink.accumulate(self.w0))
-        ops.colsum(dh, sink.view(self.b0), rows, self.hid, sink.accumulate(self.b0))
-        dx = dx_out if dx_out is not None else torch.empty(rows, self.fin, dtype=torch.float32, device=dev)
-        ops.linear_dgrad(dh, self.w0.detach(), None, dx_addend, dx, rows, self.fin, self.hid)
-        return dx
+        rows, dev = x.shape[0], x.device
+        g = gy
+        for l in range(self.n - 1, -1, -1):
+            inp = x if l == 0 else hs[l - 1]
+            w, _ = self._weights(l) if self.padded[l] else (self.w[l].detach(), None)
+            last = l == self.n - 1
+            fin, fout = self.fin_p[l], self.fout_p[l]
+            # ---- weight / bias gradients
+            if self.padded[l]:
+                dwp = torch.empty(fout, fin, dtype=torch.float32, device=dev)
+                dbp = torch.empty(fout, dtype=torch.float32, device=dev)
+                ops.conv_wgrad(ConvDesc.linear(rows, fin, fout), inp, g, dwp, False)
+                ops.colsum(g, dbp, rows, fout, False)
+                for p, src in ((self.w[l], dwp[: self.fout[l], : self.fin[l]]), (self.b[l], dbp[: self.fout[l]])):
+                    if wr.acc(p):
+                        sink.view(p).add_(src)
+                    else:
+                        sink.view(p).copy_(src)
+            elif last and self.fout[l] <= 4:
+                aw, ab = wr.acc(self.w[l]), wr.acc(self.b[l])
+                assert aw == ab
+                dh = torch.empty(rows, fin, dtype=torch.float32, device=dev)
+                ops.linear_skinny_bwd(g, inp, w, inp, dh, sink.view(self.w[l]), sink.view(self.b[l]), rows, fin, self.fout[l], aw)
+                g = dh                               # skinny_bwd already applied the ReLU mask of its input
+                continue
+            else:
+                ops.conv_wgrad(ConvDesc.linear(rows, fin, fout), inp, g, sink.view(self.w[l]), wr.acc(self.w[l]))
+                ops.colsum(g, sink.view(self.b[l]), rows, fout, wr.acc(self.b[l]))
+            # ---- input gradient
+            if l == 0:
+                dx = dx_out if dx_out is not None else torch.empty(rows, fin, dtype=torch.float32, device=dev)
+                ops.linear_dgrad(g, w, None, dx_addend, dx, rows, fin, fout)
+                return dx
+            dh = torch.empty(rows, fin, dtype=torch.float32, device=dev)
+            ops.linear_dgrad(g, w, hs[l - 1], None, dh, rows, fin, fout)            # (g @ W) * (h > 0)
+            g = dh
+        raise AssertionError("unreachable")
 
 
 class FusionHead:
-    def __init__(self, params: Dict[str, Tensor], fc_dim: int, num_iter: int):
-        self.cf, self.I = fc_dim, num_iter
-        self.kin = fc_dim + ROT_DIM
-        self.lifter = _Mlp2(params, "_lifter._lifter.")
-        self.fusers = [_Mlp2(params, f"_img_fusers.{i}._fuser.") for i in range(num_iter)]
-        self.heads = [_Mlp2(params, f"_gaze_estimators.{i}.") for i in range(num_iter)]
+    def __init__(self, params: Dict[str, Tensor], fc_dim: int, num_iter: int, variant: Variant = DEFAULT_VARIANT):
+        self.cf, self.I, self.v = fc_dim, num_iter, variant
+        self.lifter = _Mlp(params, "_lifter._lifter.", 2)
+        three = variant.encode_rotmat or variant.share_feature
+        self.fusers = [_Mlp(params, f"_img_fusers.{i}._fuser.", 3 if three else 2) for i in range(num_iter)]
+        self.heads = [_Mlp(params, f"_gaze_estimators.{i}.", 2) for i in range(num_iter)]
+        if variant.share_weights:                     # nn.ModuleList([module] * num_iter): one module
+            self.fusers = [self.fusers[0]] * num_iter
+            self.heads = [self.heads[0]] * num_iter
+        self.ibn = [params[f"_img_fusers.{i}._batchnorm.running_mean"] for i in range(num_iter)] \
+            if variant.share_feature else None
+        self.kin = self.fusers[0].in_width            # row length of the fuser input (zero-padded)
+        self.hin = self.heads[0].in_width
         self._idx_cache: Dict[Tuple[int, str], dict] = {}
+
+    def unique_modules(self) -> List[_Mlp]:
+        """Heads and fusers in grad-ready order (last iteration first), each module once."""
+        out, seen = [], set()
+        for it in range(self.I - 1, -1, -1):
+            for m in (self.heads[it], self.fusers[it]):
+                if id(m) not in seen:
+                    seen.add(id(m))
+                    out.append(m)
+        return out
 
     def _indices(self, views: int, dev) -> dict:
         key = (views, str(dev))
@@ -100,8 +192,30 @@ class FusionHead:
                                     "ident": mk(list(range(D))), "D": D}
         return self._idx_cache[key]
 
+    # ---------------------------------------------------------------- operand builders
+    def _fuser_input(self, a: Tensor, src: Tensor, rel: Tensor, vi, src_idx, B: int, D: int, scales):
+        """Rows (d, b) of the fuser's input.  a = image features [V,B,Cf] (lifted features [V,B,3,512]
+        for share_feature); src = the partner features, addressed through src_idx."""
+        dev, v = a.device, self.v
+        X = torch.empty(D * B, self.kin, dtype=torch.float32, device=dev)
+        if v.share_feature:
+            ops.paircat_fwd(a, src, rel, scales, vi, src_idx, X, B, D, NUM_FEAT_VEC)
+        elif v.encode_rotmat:
+            ops.rotcat_ext_fwd(a, src, None, rel, vi, src_idx, X, self.kin, B, D, self.cf, NUM_FEAT_VEC)
+        else:
+            ops.rotcat_fwd(a, src, None if v.ignore_rotmat else rel, vi, src_idx, X, B, D, self.cf, NUM_FEAT_VEC)
+        return X
+
+    def _head_input(self, a: Tensor, feat: Tensor, vi, ident, B: int, D: int):
+        Xh = torch.empty(D * B, self.hin, dtype=torch.float32, device=a.device)
+        if self.v.share_feature:
+            ops.paircat_fwd(a, feat, None, None, vi, ident, Xh, B, D, NUM_FEAT_VEC)
+        else:
+            ops.rotcat_fwd(a, feat, None, vi, ident, Xh, B, D, self.cf, NUM_FEAT_VEC)
+        return Xh
+
     # ---------------------------------------------------------------- forward
-    def forward(self, img_feat: Tensor, rot: Tensor, keep_tape: bool):
+    def forward(self, img_feat: Tensor, rot: Tensor, keep_tape: bool, training: bool = True):
         """img_feat [V,B,Cf]; rot [B,V,3,3].  Returns (lifted [V,B,3,512], feats [I,D,B,3,512],
         preds [I,D,B,2], tape)."""
         V, B, cf = img_feat.shape
@@ -113,38 +227,63 @@ class FusionHead:
         ops.relative_rotation(rot.detach().to(torch.float32).contiguous(), ix["vi"], ix["vj"], rel, B, V, D)
         feats = torch.empty(I, D * B, ROT_DIM, dtype=torch.float32, device=dev)
         preds = torch.empty(I, D * B, 2, dtype=torch.float32, device=dev)
+        a = lifted if self.v.share_feature else img_feat       # rot_mv.py:199-201
         saved = []
         src, src_idx = lifted, ix["vj"]                  # iteration 0 reads the partner VIEW's lifted feature
         for it in range(I):
-            X = torch.empty(D * B, self.kin, dtype=torch.float32, device=dev)
-            ops.rotcat_fwd(img_feat, src, rel, ix["vi"], src_idx, X, B, D, cf, NV)
-            H1, Fn = self.fusers[it].forward(X, feats[it])
-            Xh = torch.empty(D * B, self.kin, dtype=torch.float32, device=dev)
-            ops.rotcat_fwd(img_feat, Fn, None, ix["vi"], ix["ident"], Xh, B, D, cf, NV)
+            scales = None
+            if self.v.share_feature:
+                scales = torch.empty(2 * D, NV, dtype=torch.float32, device=dev)
+                ops.ibn_scales(a, src, ix["vi"], src_idx, self.ibn[it], training, IBN_MOMENTUM, IBN_EPS, scales, B, D, NV)
+            X = self._fuser_input(a, src, rel, ix["vi"], src_idx, B, D, scales)
+            Hf, Fn = self.fusers[it].forward(X, feats[it])
+            Xh = self._head_input(a, Fn, ix["vi"], ix["ident"], B, D)
             Hh, _ = self.heads[it].forward(Xh, preds[it])
             if keep_tape:
-                saved.append((X, H1, Xh, Hh))
+                saved.append((X, Hf, Xh, Hh, scales))
             src, src_idx = Fn, ix["partner"]             # view j's feature of the SAME pair, previous iteration
-        tape = {"img_feat": img_feat, "hl": hl, "rel": rel, "saved": saved, "V": V, "B": B} if keep_tape else None
+        tape = {"img_feat": img_feat, "lifted": lifted, "hl": hl, "rel": rel, "saved": saved, "V": V, "B": B} \
+            if keep_tape else None
         return lifted.view(V, B, 3, NV), feats.view(I, D, B, 3, NV), preds.view(I, D, B, 2), tape
 
     # ---------------------------------------------------------------- backward
     def backward(self, tape: dict, d_lifted: Optional[Tensor], d_feats: Optional[Tensor], d_preds: Optional[Tensor],
                  sink: GradSink) -> Tensor:
         """Gradients wrt the three outputs (None = zero) -> d(img_feat) [V,B,Cf]; parameter gradients
-        go to ``sink`` and are published iteration I-1 ... 0, then the lifter."""
-        V, B, cf = tape["V"], tape["B"], self.cf
+        go to ``sink`` and are published iteration I-1 ... 0 (shared weights: once, after iteration 0),
+        then the lifter."""
+        V, B, cf, v = tape["V"], tape["B"], self.cf, self.v
         img_feat, rel = tape["img_feat"], tape["rel"]
         dev = img_feat.device
         ix = self._indices(V, dev)
         D, NV = ix["D"], NUM_FEAT_VEC
-        dimg = torch.empty(V, B, cf, dtype=torch.float32, device=dev)
-        dimg_live = False
+        wr = _Written(sink)
+        # "a" = what every fuser / head input starts with: image features, or (share_feature) the lifted ones
+        aw = ROT_DIM if v.share_feature else cf
+        da = torch.empty(V, B, aw, dtype=torch.float32, device=dev)
+        da_live = False
         dF_next: Optional[Tensor] = None
         dlift = torch.empty(V * B, ROT_DIM, dtype=torch.float32, device=dev)
         dlift_live = False
+        rel_fuse = None if (v.ignore_rotmat or v.encode_rotmat) else rel
+
+        def split_input_grad(dX: Tensor, ld: int, rel_b, scales, src_idx, dsrc: Tensor):
+            """dX of a fuser / head input -> da (+= over directions) and the gradient of the feature operand."""
+            nonlocal da_live
+            if v.share_feature:
+                da_dir = torch.empty(D * B, ROT_DIM, dtype=torch.float32, device=dev)
+                ops.paircat_bwd(dX, rel_b, scales, src_idx, da_dir, dsrc, B, D, NV)
+                ops.segment_sum(da_dir, ROT_DIM, ROT_DIM, ix["vi"], da, B, D, V, da_live)
+            else:
+                ops.segment_sum(dX, ld, cf, ix["vi"], da, B, D, V, da_live)
+                if ld == cf + ROT_DIM:
+                    ops.rotcat_bwd(dX, rel_b, src_idx, dsrc, B, D, cf, NV)
+                else:
+                    ops.rotcat_ext_bwd(dX, ld, rel_b, src_idx, dsrc, B, D, cf, NV)
+            da_live = True
+
         for it in range(self.I - 1, -1, -1):
-            X, H1, Xh, Hh = tape["saved"][it]
+            X, Hf, Xh, Hh, scales = tape["saved"][it]
             dF = dF_next
             if d_feats is not None:
                 ext = d_feats[it].reshape(D * B, ROT_DIM).contiguous()
@@ -154,53 +293,58 @@ class FusionHead:
                     ops.axpby(ext, dF, 1.0, 1.0)
             if d_preds is not None:
                 gp = d_preds[it].reshape(D * B, 2).contiguous()
-                dXh = self.heads[it].backward(Xh, Hh, gp, sink)
-                ops.segment_sum(dXh, self.kin, cf, ix["vi"], dimg, B, D, V, dimg_live)
-                dimg_live = True
+                dXh = self.heads[it].backward(Xh, Hh, gp, sink, wr)
+                dFh = torch.empty(D * B, ROT_DIM, dtype=torch.float32, device=dev)
+                split_input_grad(dXh, self.hin, None, None, ix["ident"], dFh)
                 if dF is None:
-                    dF = torch.empty(D * B, ROT_DIM, dtype=torch.float32, device=dev)
-                    ops.rotcat_bwd(dXh, None, ix["ident"], dF, B, D, cf, NV)
+                    dF = dFh
                 else:
-                    dFh = torch.empty(D * B, ROT_DIM, dtype=torch.float32, device=dev)
-                    ops.rotcat_bwd(dXh, None, ix["ident"], dFh, B, D, cf, NV)
                     ops.axpby(dFh, dF, 1.0, 1.0)
             else:
-                self._zero_grads(self.heads[it], sink)
+                self._zero_grads(self.heads[it], sink, wr)
             dF_next = None
             if dF is None:
-                self._zero_grads(self.fusers[it], sink)
+                self._zero_grads(self.fusers[it], sink, wr)
             else:
-                dX = self.fusers[it].backward(X, H1, dF, sink)
-                ops.segment_sum(dX, self.kin, cf, ix["vi"], dimg, B, D, V, dimg_live)
-                dimg_live = True
+                dX = self.fusers[it].backward(X, Hf, dF, sink, wr)
                 if it > 0:
                     dF_next = torch.empty(D * B, ROT_DIM, dtype=torch.float32, device=dev)
-                    ops.rotcat_bwd(dX, rel, ix["partner"], dF_next, B, D, cf, NV)
+                    split_input_grad(dX, self.kin, rel_fuse, scales, ix["partner"], dF_next)
                 else:
                     tmp = torch.empty(D * B, ROT_DIM, dtype=torch.float32, device=dev)
-                    ops.rotcat_bwd(dX, rel, ix["ident"], tmp, B, D, cf, NV)
+                    split_input_grad(dX, self.kin, rel_fuse, scales, ix["ident"], tmp)
                     ops.segment_sum(tmp, ROT_DIM, ROT_DIM, ix["vj"], dlift, B, D, V, False)
                     dlift_live = True
-            sink.publish(self.heads[it].parameters() + self.fusers[it].parameters())
+            if not v.share_weights:
+                sink.publish(self.heads[it].parameters() + self.fusers[it].parameters())
+        if v.share_weights:
+            sink.publish(self.heads[0].parameters() + self.fusers[0].parameters())
         if d_lifted is not None:
             ext = d_lifted.reshape(V * B, ROT_DIM).contiguous()
             if dlift_live:
                 ops.axpby(ext, dlift, 1.0, 1.0)
             else:
                 dlift, dlift_live = ext.clone(), True
+        if v.share_feature and da_live:                  # the lifted features ARE the "image features" here
+            if dlift_live:
+                ops.axpby(da.view(V * B, ROT_DIM), dlift, 1.0, 1.0)
+            else:
+                dlift, dlift_live = da.view(V * B, ROT_DIM), True
+        dimg = da if not v.share_feature else torch.empty(V, B, cf, dtype=torch.float32, device=dev)
+        dimg_live = da_live and not v.share_feature
         if dlift_live:
-            self.lifter.backward(img_feat.reshape(V * B, cf), tape["hl"], dlift, sink,
+            self.lifter.backward(img_feat.reshape(V * B, cf), tape["hl"], dlift, sink, wr,
                                  dx_addend=dimg.view(V * B, cf) if dimg_live else None, dx_out=dimg.view(V * B, cf))
             dimg_live = True
         else:
-            self._zero_grads(self.lifter, sink)
+            self._zero_grads(self.lifter, sink, wr)
         sink.publish(self.lifter.parameters())
         if not dimg_live:
             dimg.zero_()
         return dimg
 
     @staticmethod
-    def _zero_grads(m: _Mlp2, sink: GradSink):
+    def _zero_grads(m: _Mlp, sink: GradSink, wr: _Written):
         for p in m.parameters():
-            if not sink.accumulate(p):
+            if not wr.acc(p):
                 sink.view(p).zero_()

@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .arch import NUM_FEAT_VEC, backbone_spec, state_dict_shapes
+from .arch import DEFAULT_VARIANT, NUM_FEAT_VEC, Variant, backbone_spec, state_dict_shapes
 from .backbone import Backbone, GradSink
 from .heads import FusionHead, directed_pairs
 
@@ -129,7 +129,7 @@ class _HeadFn(torch.autograd.Function):
     def forward(ctx, model: "MultiViewGaze", img_feat: Tensor, rot: Tensor, *params: Tensor):
         ctx.set_materialize_grads(False)
         keep = any(ctx.needs_input_grad)
-        lifted, feats, preds, tape = model._head.forward(img_feat.detach().contiguous(), rot, keep)
+        lifted, feats, preds, tape = model._head.forward(img_feat.detach().contiguous(), rot, keep, model.training)
         ctx.model, ctx.tape = model, tape
         if model._debug_keep_tapes:
             model._last_head_tape = tape
@@ -150,17 +150,19 @@ class _HeadFn(torch.autograd.Function):
 class MultiViewGaze(nn.Module):
     """V-view engine (V >= 2).  ``FeatRotationSymm`` below is its two-view, reference-shaped face."""
 
-    def __init__(self, backbone_depth: int = 50, num_iter: int = 3) -> None:
+    def __init__(self, backbone_depth: int = 50, num_iter: int = 3, variant: Variant = DEFAULT_VARIANT) -> None:
         super().__init__()
         if backbone_depth not in (18, 50):
             raise ValueError("backbone_depth must be 18 or 50 (rot_mv.py:119-122)")
+        self._variant = variant.check()
         self._num_iter = num_iter
         self._output_index = num_iter - 1
         self._num_feat_vec = NUM_FEAT_VEC
         self._depth = backbone_depth
         self._fc_dim = backbone_spec(backbone_depth).fc_dim
-        shapes = state_dict_shapes(backbone_depth, num_iter)
+        shapes = state_dict_shapes(backbone_depth, num_iter, self._variant)
         fan_in = {n: s[1] for n, s, k in shapes if k == "lin_weight"}
+        made: Dict[str, nn.Parameter] = {}
         for name, shape, kind in shapes:
             node: nn.Module = self
             parts = name.split(".")
@@ -168,6 +170,12 @@ class MultiViewGaze(nn.Module):
                 if part not in node._modules:
                     node.add_module(part, _Node())
                 node = node._modules[part]
+            if kind.startswith("alias:"):             # share_weights: the same Parameter under a second name
+                node.register_parameter(parts[-1], made[kind[len("alias:"):]])
+                continue
+            if kind == "ibn_mean":                    # IntensityBatchNorm.running_mean (rot_mv.py:16)
+                node.register_buffer(parts[-1], torch.ones(shape))
+                continue
             t = _init_tensor(shape, kind)
             if kind == "lin_bias":
                 bound = 1.0 / fan_in[name[:-4] + "weight"] ** 0.5
@@ -175,7 +183,8 @@ class MultiViewGaze(nn.Module):
             if kind in ("bn_mean", "bn_var", "bn_count"):
                 node.register_buffer(parts[-1], t)
             else:
-                node.register_parameter(parts[-1], nn.Parameter(t))
+                made[name] = nn.Parameter(t)
+                node.register_parameter(parts[-1], made[name])
         owner = weakref.ref(self)
         for prm in self.parameters():
             prm._mvg_owner = owner            # lets rot_mvgaze_amd.optim.Adam find the arenas
@@ -188,7 +197,7 @@ class MultiViewGaze(nn.Module):
 
     # ---------------------------------------------------------------- plumbing
     def _named_tensors(self) -> Dict[str, Tensor]:
-        d: Dict[str, Tensor] = dict(self.named_parameters())
+        d: Dict[str, Tensor] = dict(self.named_parameters(remove_duplicate=False))
         d.update(dict(self.named_buffers()))
         return d
 
@@ -210,11 +219,11 @@ class MultiViewGaze(nn.Module):
             if p.dtype != torch.float32:
                 raise RuntimeError("fp32 parameters only")
         self._backbone = Backbone(self._depth, named)
-        self._head = FusionHead(named, self._fc_dim, self._num_iter)
-        # grad-ready order: heads+fusers I-1..0, lifter, backbone blocks last..first, stem
+        self._head = FusionHead(named, self._fc_dim, self._num_iter, self._variant)
+        # grad-ready order: heads+fusers I-1..0 (shared weights: once), lifter, backbone blocks last..first, stem
         order: List[nn.Parameter] = []
-        for it in range(self._num_iter - 1, -1, -1):
-            order += self._head.heads[it].parameters() + self._head.fusers[it].parameters()
+        for m in self._head.unique_modules():
+            order += m.parameters()
         order += self._head.lifter.parameters()
         self._head_params = list(order)
         bb: List[nn.Parameter] = []
@@ -317,11 +326,7 @@ class FeatRotationSymm(MultiViewGaze):
         ignore_rotmat: bool = False,
     ) -> None:
         assert not (ignore_rotmat and encode_rotmat)                       # rot_mv.py:133
-        if share_weights or encode_rotmat or share_feature or ignore_rotmat:
-            raise NotImplementedError(
-                "only the default variant (share_weights=encode_rotmat=share_feature=ignore_rotmat=False, "
-                "main.py:231-236) is on the MI355X hot path; the ablation variants are SURVEY.md §8(f) rank 4")
-        super().__init__(backbone_depth, num_iter)
+        super().__init__(backbone_depth, num_iter, Variant(share_weights, encode_rotmat, share_feature, ignore_rotmat))
 
     def forward(self, data: Dict[str, Any]) -> Dict[str, Any]:
         img_0: Tensor = data["img_0"]
@@ -333,6 +338,8 @@ class FeatRotationSymm(MultiViewGaze):
             "img_feat_0": img_feat[0], "img_feat_1": img_feat[1],
             "initial_rot_feat_0": lifted[0], "initial_rot_feat_1": lifted[1],
         }
+        if self._variant.share_feature:                                    # rot_mv.py:199-201
+            pred["img_feat_0"], pred["img_feat_1"] = lifted[0], lifted[1]
         for it in range(self._num_iter):
             pred[f"iter_{it}"] = {"feat_0": feats[it, 0], "feat_1": feats[it, 1],
                                   "pred_gaze_0": preds[it, 0], "pred_gaze_1": preds[it, 1]}

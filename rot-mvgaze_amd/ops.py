@@ -221,6 +221,30 @@ def rotcat_bwd(dx, rel, src_of, dfeat, batch, dirs, cf, nvec):
     check(lib().mvg_rotcat_bwd(_p(dx), _p(rel), _p(src_of), _p(dfeat), batch, dirs, cf, nvec, _s()), "rotcat_bwd")
 
 
+def rotcat_ext_fwd(img_feat, feat, rel_apply, rel_append, view_of, src_of, x, ld, batch, dirs, cf, nvec):
+    check(lib().mvg_rotcat_ext_fwd(_p(img_feat), _p(feat), _p(rel_apply), _p(rel_append), _p(view_of), _p(src_of), _p(x), ld,
+                                   batch, dirs, cf, nvec, _s()), "rotcat_ext_fwd")
+
+
+def rotcat_ext_bwd(dx, ld, rel, src_of, dfeat, batch, dirs, cf, nvec):
+    check(lib().mvg_rotcat_ext_bwd(_p(dx), ld, _p(rel), _p(src_of), _p(dfeat), batch, dirs, cf, nvec, _s()), "rotcat_ext_bwd")
+
+
+def ibn_scales(a, feat, view_of, src_of, running_mean, training, momentum, eps, scales, batch, dirs, nvec):
+    check(lib().mvg_ibn_scales(_p(a), _p(feat), _p(view_of), _p(src_of), _p(running_mean), int(training), momentum, eps,
+                               _p(scales), batch, dirs, nvec, _s()), "ibn_scales")
+
+
+def paircat_fwd(a, feat, rel, scales, view_of, src_of, x, batch, dirs, nvec):
+    check(lib().mvg_paircat_fwd(_p(a), _p(feat), _p(rel), _p(scales), _p(view_of), _p(src_of), _p(x), batch, dirs, nvec, _s()),
+          "paircat_fwd")
+
+
+def paircat_bwd(dx, rel, scales, src_of, da_dir, dfeat, batch, dirs, nvec):
+    check(lib().mvg_paircat_bwd(_p(dx), _p(rel), _p(scales), _p(src_of), _p(da_dir), _p(dfeat), batch, dirs, nvec, _s()),
+          "paircat_bwd")
+
+
 def segment_sum(x, row_stride, width, seg_of, out, batch, dirs, segments, accumulate):
     check(lib().mvg_segment_sum(_p(x), row_stride, width, _p(seg_of), _p(out), batch, dirs, segments, int(accumulate),
                                 _s()), "segment_sum")

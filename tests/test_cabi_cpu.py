@@ -33,7 +33,7 @@ def test_header_symbols_exported(built_lib):
     for name in declared:
         assert hasattr(built_lib, name), f"{name} declared in include/rotmvgaze.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert built_lib.mvg_abi_version() == _lib.ABI_VERSION == 2
+    assert built_lib.mvg_abi_version() == _lib.ABI_VERSION == 3
 
 
 def test_pair_index_bit_exact(built_lib, golden_dir):
@@ -81,12 +81,12 @@ def test_state_dict_contract(depth):
     assert w.is_contiguous(memory_format=torch.channels_last)                # KRSC in memory
 
 
-def test_unsupported_variants_and_cpu_inputs_fail_loudly():
+def test_invalid_variants_and_cpu_inputs_fail_loudly():
     from rot_mvgaze_amd.model import FeatRotationSymm
-    with pytest.raises(NotImplementedError):
-        FeatRotationSymm(18, 3, encode_rotmat=True)
-    with pytest.raises(AssertionError):
+    with pytest.raises(AssertionError):                                   # rot_mv.py:133
         FeatRotationSymm(18, 3, encode_rotmat=True, ignore_rotmat=True)
+    with pytest.raises(ValueError):                                       # combinations the reference cannot run either
+        FeatRotationSymm(18, 3, share_feature=True, share_weights=True)
     m = FeatRotationSymm(18, 3)
     d = {"img_0": torch.zeros(1, 3, 32, 32), "img_1": torch.zeros(1, 3, 32, 32),
          "rot_0": torch.eye(3)[None], "rot_1": torch.eye(3)[None]}

@@ -117,6 +117,56 @@ def test_against_reference_golden(golden_dir, depth, batch, hw):
             rel_close(sd[k[5:]], g[k], TOL, k)
 
 
+VARIANTS = {
+    "share_weights": dict(share_weights=True),
+    "ignore_rotmat": dict(ignore_rotmat=True),
+    "encode_rotmat": dict(encode_rotmat=True),
+    "share_feature": dict(share_feature=True),
+    "share_weights_encode_rotmat": dict(share_weights=True, encode_rotmat=True),
+}
+
+
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+def test_variants_against_reference_golden(golden_dir, name):
+    """Constructor variants of the reference model (rot_mv.py:136-171) against
+    fixtures the reference produced: eval outputs, train outputs, loss, gradients, IntensityBatchNorm buffers."""
+    from rot_mvgaze_amd.arch import Variant
+    from rot_mvgaze_amd.model import FeatRotationSymm
+    kw = VARIANTS[name]
+    g = np.load(os.path.join(golden_dir, f"variant_{name}_r18_b3_hw64.npz"))
+
+    def make(train):
+        m = FeatRotationSymm(backbone_depth=18, num_iter=3, **kw)
+        sd = synth.make_state_dict(18, 0, 3, perturb_bn=True, variant=Variant(**kw))
+        m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
+        m.to(dev())
+        return m.train() if train else m.eval()
+    m = make(False)
+    with torch.no_grad():
+        data = m(inputs(3, 64))
+    check_outputs(data, g, "eval", TOL)
+    m = make(True)
+    data = m(inputs(3, 64))
+    loss = metrics()(data)
+    loss.backward()
+    check_outputs(data, g, "train", TOL)
+    rel_close(loss, g["train.loss"], TOL, "loss")
+    params = dict(m.named_parameters(remove_duplicate=False))
+    for key in [k[5:] for k in g.files if k.startswith("grad._")]:
+        ref = g["grad." + key]
+        gr = params[key].grad
+        if gr.dim() == 4:
+            gr = gr.contiguous()
+        l2_close(gr.reshape(-1)[: ref.size], ref, GTOL_L2_FLIPS, "grad " + key)
+        rel_close(gr.double().norm().item(), g["gradnorm." + key], GTOL_L2_FLIPS, "gradnorm " + key)
+    sd = m.state_dict()
+    for k in [k for k in g.files if k.startswith("stat.")]:
+        rel_close(sd[k[5:]], g[k], TOL, k)
+    if kw.get("share_weights"):
+        assert params["_img_fusers.2._fuser.blocks.0.0.weight"] is params["_img_fusers.0._fuser.blocks.0.0.weight"]
+    torch.optim.Adam(m.parameters(), lr=1e-4).step()
+
+
 def test_against_oracle_and_generic_loss_path():
     """Same step as the CPU oracle; the generic (per-call) loss path and the fused one agree."""
     from oracle import restatement as R
@@ -166,10 +216,10 @@ def _captured_masks(m, V=2):
         return (u.y[v].double() * scale[v].double() + shift[v].double()) > 0
     masks = {"backbone": [iter([unit_mask(u, v).permute(0, 3, 1, 2).cpu() for u in relu_units]) for v in range(V)]}
     B = bt["B"]
-    hl = (ht["hl"] > 0).cpu()
+    hl = (ht["hl"][0] > 0).cpu()                 # hidden activations are lists (one entry per hidden layer)
     masks["lift"] = [hl[v * B:(v + 1) * B] for v in range(V)]
-    for it, (X, H1, Xh, Hh) in enumerate(ht["saved"]):
-        h1, hh = (H1 > 0).cpu(), (Hh > 0).cpu()
+    for it, (X, H1, Xh, Hh, _scales) in enumerate(ht["saved"]):
+        h1, hh = (H1[0] > 0).cpu(), (Hh[0] > 0).cpu()
         masks[("fuse", it)] = [h1[d * B:(d + 1) * B] for d in range(2)]
         masks[("head", it)] = [hh[d * B:(d + 1) * B] for d in range(2)]
     return masks
