@@ -212,6 +212,12 @@ int mvg_nhwc4_to_nchw(const float *src, float *dst, int n, int c, int h, int w, 
  * (x - mean)/std (Normalize, main.py:38-39,54) -> NHWC4 fp32, the backbone's input layout. */
 int mvg_preprocess_u8hwc(const uint8_t *src, float *dst, int n, int h, int w, float mean0, float mean1,
                          float mean2, float std0, float std1, float std2, int swap_rb, void *stream);
+/* RandomMultiErasing.__call__ utils/augment.py:38-47 on a device batch: img [n][c][h][w] *= the
+ * nearest-neighbour upsampling (F.interpolate default, augment.py:21) of masks[n] (grid[n] x grid[n]
+ * floats in a gmax*gmax slot); grid[n] == 0 leaves image n untouched.  The random draws stay on the
+ * host (rot_mvgaze_amd/augment.py replays the reference's RNG calls). */
+int mvg_multi_erase_nchw(float *img, const float *masks, const int32_t *grid, int gmax, int n, int c,
+                         int h, int w, void *stream);
 
 /* ---------------------------------------------------------------- geometry
  * rotation_matrix_2d utils/math.py:188-219; relative rotations rot_mv.py:193-194. */

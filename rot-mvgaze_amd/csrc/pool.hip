@@ -147,6 +147,27 @@ __global__ __launch_bounds__(256) void preprocess_u8_kernel(const unsigned char 
   dst[i] = make_float4(c0, c1, c2, 0.f);
 }
 
+// RandomMultiErasing (utils/augment.py:10-47): img *= nearest-neighbour upsampling of a per-image
+// g x g keep-mask (F.interpolate default mode: src = min(int(floorf(dst * (float)g / size)), g - 1)).
+// grid[n] == 0: this image is not erased.  NCHW in place.
+__global__ __launch_bounds__(256) void multi_erase_kernel(float *__restrict__ img, const float *__restrict__ masks,
+                                                          const int *__restrict__ grid, int gmax, int c, int h, int w) {
+  const int n = blockIdx.y;
+  const int g = grid[n];
+  if (g <= 0) return;
+  const long long hw = (long long)h * w;
+  const float sy = (float)g / (float)h, sx = (float)g / (float)w;
+  const float *m = masks + (long long)n * gmax * gmax;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < hw; i += (long long)gridDim.x * 256) {
+    const int y = (int)(i / w), x = (int)(i - (long long)y * w);
+    int my = (int)floorf((float)y * sy), mx = (int)floorf((float)x * sx);
+    my = my < g - 1 ? my : g - 1;
+    mx = mx < g - 1 ? mx : g - 1;
+    const float keep = m[my * g + mx];
+    for (int ch = 0; ch < c; ++ch) img[((long long)n * c + ch) * hw + i] *= keep;
+  }
+}
+
 }  // namespace mvg
 
 using namespace mvg;
@@ -214,6 +235,17 @@ int mvg_preprocess_u8hwc(const uint8_t *src, float *dst, int n, int h, int w, fl
   hipLaunchKernelGGL(preprocess_u8_kernel, dim3(ceil_div(pixels, 256)), dim3(256), 0, st, src, (float4 *)dst, pixels, mean0,
                      mean1, mean2, std0, std1, std2, swap_rb);
   return check_launch("preprocess_u8hwc");
+}
+
+int mvg_multi_erase_nchw(float *img, const float *masks, const int32_t *grid, int gmax, int n, int c, int h, int w,
+                         void *stream) {
+  MVG_REQUIRE(n > 0 && c > 0 && h > 0 && w > 0 && gmax > 0, "multi_erase: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(MVG_K_LAYOUT, st, 0.0, 8.0 * (double)n * c * h * w);
+  long long bx = ((long long)h * w + 255) / 256;
+  if (bx > 64) bx = 64;
+  hipLaunchKernelGGL(multi_erase_kernel, dim3((unsigned)bx, n), dim3(256), 0, st, img, masks, grid, gmax, c, h, w);
+  return check_launch("multi_erase");
 }
 
 int mvg_nhwc4_to_nchw(const float *src, float *dst, int n, int c, int h, int w, void *stream) {

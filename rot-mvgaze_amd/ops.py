@@ -198,6 +198,10 @@ def nhwc4_to_nchw(src, dst, n, c, h, w):
     check(lib().mvg_nhwc4_to_nchw(_p(src), _p(dst), n, c, h, w, _s()), "nhwc4_to_nchw")
 
 
+def multi_erase_nchw(img, masks, grid, gmax, n, c, h, w):
+    check(lib().mvg_multi_erase_nchw(_p(img), _p(masks), _p(grid), gmax, n, c, h, w, _s()), "multi_erase_nchw")
+
+
 def preprocess_u8hwc(src, dst, n, h, w, mean, std, swap_rb):
     check(lib().mvg_preprocess_u8hwc(_p(src), _p(dst), n, h, w, mean[0], mean[1], mean[2], std[0], std[1], std[2],
                                      int(swap_rb), _s()), "preprocess_u8hwc")

@@ -290,6 +290,20 @@ def gen_model(depth, batch, hw, seed_w=0, seed_in=1234):
     print(tag, "loss", float(loss), "pred_gaze[0]", out["train.pred_gaze"][0])
 
 
+def gen_multi_erase():
+    """RandomMultiErasing of the reference (utils/augment.py:10-47), seeded: which images are erased and
+    the resulting images (input = seeded noise), for the RNG-order and kernel parity tests."""
+    import utils.augment as ref_aug
+    random.seed(7)
+    np.random.seed(7)
+    torch.manual_seed(7)
+    aug = ref_aug.RandomMultiErasing(p=0.5, proportion=[0.5, 0.6], dot_size=[0.05, 0.3])     # main.py:48
+    imgs = torch.from_numpy(synth.normal(10 * 3 * 40 * 56, 77, "erase").reshape(10, 3, 40, 56).astype(np.float32))
+    out = torch.stack([aug(imgs[i].clone()) for i in range(10)])
+    np.savez_compressed(os.path.join(HERE, "multi_erase.npz"), out=out.numpy())
+    print("multi_erase: erased images", int((out != imgs).flatten(1).any(1).sum()), "of 10")
+
+
 def gen_variants():
     from rot_mvgaze_amd.arch import Variant
     gen_variant("share_weights", Variant(share_weights=True))
@@ -303,6 +317,9 @@ if __name__ == "__main__":
     if "--variants" in sys.argv:
         gen_variants()
         sys.exit(0)
+    if "--erase" in sys.argv:
+        gen_multi_erase()
+        sys.exit(0)
     gen_geometry()
     gen_pair_index()
     gen_model(18, 2, 224)
@@ -310,3 +327,4 @@ if __name__ == "__main__":
     gen_model(18, 3, 64)
     gen_model(50, 3, 64)
     gen_variants()
+    gen_multi_erase()

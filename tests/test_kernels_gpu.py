@@ -1,5 +1,7 @@
 """Per-kernel parity: every C-ABI entry point against the same op of the CPU oracle vocabulary
 (torch-CPU functional ops, fp32/fp64) on seeded inputs.  Runs on a real MI355X only."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -422,3 +424,19 @@ def test_rotcat_and_relative_rotation():
     b0 = b.clone()
     ops.axpby(a, b, 2.0, 0.5)
     close(b, 2 * a + 0.5 * b0, 1e-6, "axpby")
+
+
+def test_multi_erase_kernel_matches_reference_fixture(golden_dir):
+    """mvg_multi_erase_nchw against images the reference's RandomMultiErasing produced (bit-exact:
+    the kernel only multiplies by 0/1 with the reference's nearest-neighbour index rule)."""
+    import random
+    from rot_mvgaze_amd.augment import RandomMultiErasing
+    from rot_mvgaze_amd import synth
+    g = np.load(os.path.join(golden_dir, "multi_erase.npz"))
+    random.seed(7)
+    np.random.seed(7)
+    torch.manual_seed(7)
+    aug = RandomMultiErasing(p=0.5, proportion=[0.5, 0.6], dot_size=[0.05, 0.3])
+    imgs = torch.from_numpy(synth.normal(10 * 3 * 40 * 56, 77, "erase").reshape(10, 3, 40, 56).astype(np.float32))
+    out = aug(imgs.to(dev()))
+    assert np.array_equal(out.cpu().numpy(), g["out"])

@@ -228,3 +228,30 @@ def test_iteration_loss_weights():
         data[f"iter_{i}"] = {"pred_gaze_0": preds[i], "pred_gaze_1": preds[i]}
     Ls = [R.stereo_loss(preds[i], preds[i], gt, gt) for i in range(3)]
     np.testing.assert_allclose(R.iteration_loss(data).item(), (0.25 * Ls[0] + 0.5 * Ls[1] + Ls[2]).item(), rtol=1e-6)
+
+
+def _erase_inputs():
+    return torch.from_numpy(synth.normal(10 * 3 * 40 * 56, 77, "erase").reshape(10, 3, 40, 56).astype(np.float32))
+
+
+def test_multi_erase_draws_match_reference(golden_dir):
+    """rot_mvgaze_amd.augment.RandomMultiErasing.draw replays the reference's RNG calls
+    (utils/augment.py:38-45): seeded alike, the same images get the same keep-masks.  The masks are
+    applied here with F.interpolate (the reference's own upsampling) - the HIP kernel is checked
+    against the same fixture in tests/test_kernels_gpu.py."""
+    import random
+    import torch.nn.functional as F
+    from rot_mvgaze_amd.augment import RandomMultiErasing
+    g = _load(golden_dir, "multi_erase.npz")
+    random.seed(7)
+    np.random.seed(7)
+    torch.manual_seed(7)
+    aug = RandomMultiErasing(p=0.5, proportion=[0.5, 0.6], dot_size=[0.05, 0.3])
+    imgs = _erase_inputs()
+    # the reference draws image by image, interleaving the three generators: draw() keeps that order
+    draws = aug.draw(10)
+    out = imgs.clone()
+    for i, (gs, m) in enumerate(draws):
+        if gs:
+            out[i] *= F.interpolate(m[None, None], (40, 56)).squeeze()
+    assert np.array_equal(out.numpy(), g["out"])
