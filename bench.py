@@ -127,6 +127,9 @@ def main():
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
+        # the gradient stream is ~160-360 MB per step: 8 RCCL channels move it inside backward and leave
+        # the CUs to the persistent conv kernels (see rot_mvgaze_amd/dp.py)
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "8")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)

@@ -16,6 +16,15 @@ void set_error(const char *fmt, ...) {
   va_end(ap);
 }
 
+// CUs the work-distribution planners leave to someone else (the RCCL kernels of a data-parallel run)
+static int g_reserved_cus = 0;
+int compute_cus() {
+  int cus = mvg_device_cus();
+  if (cus <= 0) cus = 256;
+  cus -= g_reserved_cus;
+  return cus > 8 ? cus : 8;
+}
+
 struct Scratch {
   int dev;
   hipStream_t st;
@@ -104,6 +113,12 @@ extern "C" {
 
 int mvg_abi_version(void) { return MVG_ABI_VERSION; }
 const char *mvg_last_error(void) { return mvg::g_err; }
+
+int mvg_set_reserved_cus(int n) {
+  MVG_REQUIRE(n >= 0 && n < 4096, "reserved CUs must be >= 0");
+  mvg::g_reserved_cus = n;
+  return 0;
+}
 
 int mvg_device_cus(void) {
   int dev = 0, cus = 0;

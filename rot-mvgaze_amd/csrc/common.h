@@ -19,6 +19,8 @@ void prof_end(int family, hipStream_t s);
 // ordered by the stream, so every kernel sequence that finishes with its scratch before the next
 // launch on that stream may share it (stream-K pieces, bn_finalize slices).  nullptr = no memory.
 float *stream_scratch(hipStream_t st, size_t floats);
+// device CUs minus mvg_set_reserved_cus(): what stream-K grids, wgrad splits and split-K plan for
+int compute_cus();
 
 struct ProfScope {
   int fam;

@@ -1398,8 +1398,7 @@ static int tile_occupancy(int bm, int bn, bool dgrad) {
 // piece twice at ~4 TB/s (128-wide tiles) / ~2.5 TB/s (64-wide: more, smaller pieces).
 static int plan_streamk(long long tiles, int KT, int bm, int bn, int occ, int bk = 16) {
   if (!streamk_enabled() || tiles <= 0 || bm != 128 || bn < 64) return 0;
-  int cus = mvg_device_cus();
-  if (cus <= 0) cus = 256;
+  const int cus = compute_cus();
   const long long S = (long long)occ * cus;
   if (tiles * KT < 8 * S) return 0;                       // < 8 K-steps per workgroup: overheads dominate
   const double solo = bn >= 128 ? 0.62 : 0.40;
@@ -1431,11 +1430,7 @@ static void count_tiles(const long long *rows, const int *ktotal, int ncls, int 
   }
 }
 static TileChoice choose_tile_multi(const long long *rows, const int *ktotal, int ncls, int groups, int ncols, bool dgrad) {
-  static int cus = 0;
-  if (cus <= 0) {
-    cus = mvg_device_cus();
-    if (cus <= 0) cus = 256;
-  }
+  const int cus = compute_cus();
   if (ncols <= 32) return {128, 32};
   long long tiles, units;
   {
@@ -1544,8 +1539,7 @@ static int launch_igemm6(IgemmParams &p, TileChoice t, hipStream_t st) {
 // tile for the bf16x6 kernels: one workgroup per CU is resident (LDS), so prefer the biggest tile
 // that still gives every CU >= ~2 tiles.
 static TileChoice choose_tile6(long long rows_per_group, int groups, int ncols) {
-  int cus = mvg_device_cus();
-  if (cus <= 0) cus = 256;
+  const int cus = compute_cus();
   // BM is always 128 in this mode, so that BN partial statistics have one geometry (64-row partials)
   if (ncols >= 128) {
     const long long blocks = (long long)groups * ceil_div(rows_per_group, 128) * ceil_div(ncols, 128);
@@ -1579,8 +1573,7 @@ static int launch_igemm6p(IgemmParams &p, TileChoice t, hipStream_t st) {
 static int plan_splitk(IgemmParams &p, TileChoice t, size_t ws_floats) {
   p.splits = 1;
   if (ws_floats == 0 || p.ncols % 4 != 0) return 1;
-  int cus = mvg_device_cus();
-  if (cus <= 0) cus = 256;
+  const int cus = compute_cus();
   const long long tiles = (long long)p.groups * ceil_div(p.rows_per_group, t.bm) * ceil_div(p.ncols, t.bn);
   if (tiles >= cus) return 1;
   const int KT = ceil_div(p.ktotal, 16);
@@ -1964,8 +1957,7 @@ int mvg_conv_wgrad_splits(const mvg_conv_desc *d) {
   const int ncols = d->r * d->s * d->cin;
   const long long tiles = (long long)ceil_div(d->cout, t.bm) * ceil_div(ncols, t.bn);
   const long long pixels = (long long)d->groups * d->n * d->ho * d->wo;
-  int cus = mvg_device_cus();
-  if (cus <= 0) cus = 256;
+  const int cus = compute_cus();
   // one resident round: tiles x splits <= CUs x workgroups-per-CU (rounding the split count UP puts a
   // handful of workgroups into a second round that costs as much as the first)
   static int wpc_env = -1;

@@ -12,6 +12,7 @@ parameter is published, on a side stream that waits on an event recorded on the 
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -52,6 +53,13 @@ class GradAllReducer:
         self._param_end = {id(p): off + n for (p, off, n) in entries}
         self._next = 0
         self._done_upto = 0
+        if arena.is_cuda and (self.world > 1 or self.force):
+            # The conv kernels run as persistent stream-K grids sized to fill every CU; an RCCL kernel that
+            # is resident when one starts would push part of that grid into a second round (2x the kernel
+            # time).  Plan the grids for a few CUs less and keep RCCL to a few channels (the gradient
+            # stream needs ~15 GB/s of bus bandwidth at C2 / C4, a fraction of what 8 channels move).
+            from . import ops
+            ops.set_reserved_cus(int(os.environ.get("MVG_RESERVED_CUS", "12")))
         if arena.is_cuda and self._side is None:
             self._side = torch.cuda.Stream(device=arena.device)
         self._built_for = arena.data_ptr()

@@ -198,6 +198,10 @@ def nhwc4_to_nchw(src, dst, n, c, h, w):
     check(lib().mvg_nhwc4_to_nchw(_p(src), _p(dst), n, c, h, w, _s()), "nhwc4_to_nchw")
 
 
+def set_reserved_cus(n: int):
+    check(lib().mvg_set_reserved_cus(int(n)), "set_reserved_cus")
+
+
 def multi_erase_nchw(img, masks, grid, gmax, n, c, h, w):
     check(lib().mvg_multi_erase_nchw(_p(img), _p(masks), _p(grid), gmax, n, c, h, w, _s()), "multi_erase_nchw")
 
