@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=64.0)
     ap.add_argument("--no-optimizer", action="store_true", help="time forward+loss+backward only (no Adam step)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="run the backward-weight kernels on the compute stream (per-kernel profiling: rocprofv3 --stats)")
     ap.add_argument("--mode", default="train", choices=["train", "eval"],
                     help="eval = inference forward only (model.eval(), BN folded into the convs; SURVEY §8(f) rank 2)")
     args = ap.parse_args()
@@ -154,6 +156,9 @@ def main():
     if args.mode == "eval":
         model.eval()
         optimizer = None
+    if args.no_overlap:
+        model.ensure_layout()
+        model._backbone.overlap_wgrad = False
 
     def step():
         if args.mode == "eval":
@@ -193,12 +198,21 @@ def main():
     roofline, families = None, None
     if not args.no_roofline:
         nprof = min(args.steps, 3)
+        # per-kernel durations are taken with the kernels alone on the GPU: the timed region overlaps the
+        # backward-weight kernels (side stream) with the rest of backward, which stretches every
+        # overlapped kernel's own start-to-end time without saying anything about the kernel
+        bb = getattr(model, "_backbone", None)
+        was = bb.overlap_wgrad if bb is not None else None
+        if bb is not None:
+            bb.overlap_wgrad = False
         ops.prof_reset()
         ops.prof_enable(True)
         for _ in range(nprof):
             step()
         torch.cuda.synchronize()
         ops.prof_enable(False)
+        if bb is not None:
+            bb.overlap_wgrad = was
         prof = ops.prof_collect()
         conv = [prof[k] for k in ("conv_fprop", "conv_dgrad", "conv_wgrad") if k in prof]
         flops = sum(e["flops"] for e in conv)

@@ -37,6 +37,10 @@ int mvg_abi_version(void);
 const char *mvg_last_error(void);
 /* number of CUs of the current device (used by the host to size split-K). */
 int mvg_device_cus(void);
+/* A HIP stream of the device's LOWEST priority (hipStreamNonBlocking) for work that should only fill
+ * what the caller's stream leaves idle - the backward-weight kernels, which are off the critical
+ * path of backward.  NULL on failure.  The stream lives until process exit. */
+void *mvg_stream_create_low_priority(void);
 /* Data-parallel runs: leave n CUs out of the stream-K grids / wgrad and split-K plans so that the
  * RCCL kernels of the gradient all-reduce (side stream) find room next to the persistent conv
  * kernels instead of pushing part of their grid into a second round.  0 = use every CU. */

@@ -46,6 +46,7 @@ SIGNATURES = {
     "mvg_last_error": (C.c_char_p, []),
     "mvg_device_cus": (_I, []),
     "mvg_set_reserved_cus": (_I, [_I]),
+    "mvg_stream_create_low_priority": (_P, []),
     "mvg_prof_enable": (_I, [_I]),
     "mvg_prof_reset": (_I, []),
     "mvg_prof_collect": (_I, [C.POINTER(ProfEntry)]),

@@ -12,6 +12,7 @@ input, ReLU mask); weights are the PyTorch parameters themselves in channels_las
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Dict, List, Optional
 
 import torch
@@ -51,6 +52,14 @@ class Backbone:
         self.spec: BackboneSpec = backbone_spec(depth, prefix)
         self.p = params                      # name -> Parameter / buffer (live objects)
         self.fc_dim = self.spec.fc_dim
+        # Backward-weight kernels are off the critical path (bn_bwd -> dgrad -> bn_bwd ...): they run on a
+        # side stream, where their MFMA work overlaps the HBM-bound BatchNorm-backward passes and the
+        # stream-K fix-ups of the main stream.  grad_streams lists every stream that writes gradients
+        # besides the caller's (the data-parallel reducer waits on them too).
+        self.overlap_wgrad = os.environ.get("MVG_WGRAD_OVERLAP", "1") != "0"
+        self.overlap_head = os.environ.get("MVG_HEAD_OVERLAP", "0") != "0"      # the fusion block's weight gradients too
+        self.grad_streams: List[torch.cuda.Stream] = []
+        self._wg_stream: Optional[torch.cuda.Stream] = None
 
     # ---------------------------------------------------------------- helpers
     def _weight(self, c: ConvSpec) -> Tensor:
@@ -209,7 +218,29 @@ class Backbone:
         ops.bn_bwd_apply(g, act, u.y, u.mean, u.invstd, gp.detach(), s12[0], s12[1], G, u.rows, c.cout, g, None, ra)
         return g, None
 
+    def _side(self, dev) -> "torch.cuda.Stream":
+        if self._wg_stream is None or self._wg_stream.device != dev:
+            self._wg_stream = ops.low_priority_stream(dev)       # fills what the critical path leaves idle
+            self.grad_streams[:] = [self._wg_stream]
+        return self._wg_stream
+
     def _conv_bwd(self, u: _Unit, dy: Tensor, need_dx: bool, addend: Optional[Tensor], sink: GradSink):
+        if self.overlap_wgrad and dy.is_cuda:
+            side = self._side(dy.device)
+            side.wait_stream(torch.cuda.current_stream())         # dy (and everything before it) is ready
+            with torch.cuda.stream(side):
+                self._wgrad(u, dy, sink)
+            dy.record_stream(side)                                # the allocator must not recycle these while
+            u.x_in.record_stream(side)                            # the side stream still reads them
+        else:
+            self._wgrad(u, dy, sink)
+        dx = None
+        if need_dx:
+            dx = torch.empty_like(u.x_in)
+            self._dgrad(u, dy, dx, addend)
+        return dx
+
+    def _wgrad(self, u: _Unit, dy: Tensor, sink: GradSink):
         c = u.spec
         wp = self.p[c.name + ".weight"]
         if c.cin == 3:
@@ -222,11 +253,6 @@ class Backbone:
                 gv.copy_(dw4[..., :3])
         else:
             ops.conv_wgrad(u.desc, u.x_in, dy, sink.view(wp), sink.accumulate(wp))
-        dx = None
-        if need_dx:
-            dx = torch.empty_like(u.x_in)
-            self._dgrad(u, dy, dx, addend)
-        return dx
 
     @staticmethod
     def _dgrad(u: _Unit, dy: Tensor, dx: Tensor, addend: Optional[Tensor]):
@@ -264,8 +290,7 @@ class Backbone:
             if ds_idx is not None:
                 ud = units[ds_idx]
                 dyd, _ = self._bn_bwd(ud, dz, False, sink)
-                ops.conv_wgrad(ud.desc, ud.x_in, dyd, sink.view(P[ud.spec.name + ".weight"]),
-                               sink.accumulate(P[ud.spec.name + ".weight"]))
+                self._conv_bwd(ud, dyd, False, None, sink)                # wgrad only
                 self._dgrad(ud, dyd, d, d)                                # d += dgrad (aliasing addend)
                 done += [P[ud.spec.name + ".weight"], P[ud.spec.bn + ".weight"], P[ud.spec.bn + ".bias"]]
                 ud.y = ud.out = None
@@ -288,6 +313,8 @@ class Backbone:
                                       V, B, H1, W1, sc.cout, Hp, Wp, dy)
         dx0 = self._conv_bwd(stem, dy, need_dimg, None, sink)
         sink.publish([P[stem.spec.name + ".weight"], P[stem.spec.bn + ".weight"], P[stem.spec.bn + ".bias"]])
+        if self._wg_stream is not None and dy.is_cuda:
+            torch.cuda.current_stream().wait_stream(self._wg_stream)      # gradients complete for the optimizer
         if not need_dimg:
             return None
         H, W = dx0.shape[2], dx0.shape[3]

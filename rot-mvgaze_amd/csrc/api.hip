@@ -114,6 +114,21 @@ extern "C" {
 int mvg_abi_version(void) { return MVG_ABI_VERSION; }
 const char *mvg_last_error(void) { return mvg::g_err; }
 
+void *mvg_stream_create_low_priority(void) {
+  int least = 0, greatest = 0;
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) {
+    (void)hipGetLastError();
+    least = 0;
+  }
+  hipStream_t st = nullptr;
+  if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, least) != hipSuccess) {
+    (void)hipGetLastError();
+    mvg::set_error("hipStreamCreateWithPriority failed");
+    return nullptr;
+  }
+  return (void *)st;
+}
+
 int mvg_set_reserved_cus(int n) {
   MVG_REQUIRE(n >= 0 && n < 4096, "reserved CUs must be >= 0");
   mvg::g_reserved_cus = n;

@@ -1,5 +1,7 @@
 // BatchNorm2d (train + eval) forward / backward around the conv kernels.  All HBM-bound passes:
 // float4 accesses, channel index carried incrementally (no per-element division).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace mvg {
@@ -566,8 +568,14 @@ static int bwd_chunks(int groups, long long rows, int c) {
 }
 
 static int grid_for(long long n4) {
+  static int cap = 0;
+  if (cap <= 0) {
+    const char *e = getenv("MVG_BN_GRID");
+    cap = e ? atoi(e) : 4096;
+    if (cap <= 0) cap = 4096;
+  }
   long long b = (n4 + 255) / 256;
-  if (b > 4096) b = 4096;
+  if (b > cap) b = cap;
   if (b < 1) b = 1;
   return (int)b;
 }

@@ -70,9 +70,12 @@ class GradAllReducer:
         if self.world == 1 and not self.force:
             return
         if self.arena.is_cuda:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-            self._side.wait_event(ev)
+            # gradients of this bucket are complete once the compute stream AND the model's other gradient
+            # streams (backward-weight kernels run on their own) reach this point
+            for st in [torch.cuda.current_stream()] + list(getattr(self.model, "_grad_streams", [])):
+                ev = torch.cuda.Event()
+                ev.record(st)
+                self._side.wait_event(ev)
             with torch.cuda.stream(self._side):
                 dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg)
                 if self.average:

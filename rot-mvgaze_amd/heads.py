@@ -48,9 +48,22 @@ class _Written:
     """Parameters whose gradient this backward has already written: a second write (weights shared
     between iterations) must accumulate whatever ``sink.accumulate`` said at the start."""
 
-    def __init__(self, sink: GradSink):
+    def __init__(self, sink: GradSink, side=None):
         self.sink = sink
         self.seen = set()
+        self.side = side          # low-priority stream for the weight / bias gradients (off the critical path)
+
+    def off_path(self, fn, *tensors):
+        """Run fn (kernels that only produce parameter gradients) on the side stream, after everything
+        queued so far; `tensors` are its inputs (kept from the allocator until the side stream is done)."""
+        if self.side is None:
+            fn()
+            return
+        self.side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side):
+            fn()
+        for t in tensors:
+            t.record_stream(self.side)
 
     def acc(self, p) -> bool:
         a = self.sink.accumulate(p) or id(p) in self.seen
@@ -126,15 +139,20 @@ class _Mlp:
             fin, fout = self.fin_p[l], self.fout_p[l]
             # ---- weight / bias gradients
             if self.padded[l]:
-                dwp = torch.empty(fout, fin, dtype=torch.float32, device=dev)
-                dbp = torch.empty(fout, dtype=torch.float32, device=dev)
-                ops.conv_wgrad(ConvDesc.linear(rows, fin, fout), inp, g, dwp, False)
-                ops.colsum(g, dbp, rows, fout, False)
-                for p, src in ((self.w[l], dwp[: self.fout[l], : self.fin[l]]), (self.b[l], dbp[: self.fout[l]])):
-                    if wr.acc(p):
-                        sink.view(p).add_(src)
-                    else:
-                        sink.view(p).copy_(src)
+                accs = (wr.acc(self.w[l]), wr.acc(self.b[l]))
+
+                def padded_grads(inp=inp, g=g, l=l, fin=fin, fout=fout, accs=accs):
+                    dwp = torch.empty(fout, fin, dtype=torch.float32, device=dev)
+                    dbp = torch.empty(fout, dtype=torch.float32, device=dev)
+                    ops.conv_wgrad(ConvDesc.linear(rows, fin, fout), inp, g, dwp, False)
+                    ops.colsum(g, dbp, rows, fout, False)
+                    for p, src, a in ((self.w[l], dwp[: self.fout[l], : self.fin[l]], accs[0]),
+                                      (self.b[l], dbp[: self.fout[l]], accs[1])):
+                        if a:
+                            sink.view(p).add_(src)
+                        else:
+                            sink.view(p).copy_(src)
+                wr.off_path(padded_grads, inp, g)
             elif last and self.fout[l] <= 4:
                 aw, ab = wr.acc(self.w[l]), wr.acc(self.b[l])
                 assert aw == ab
@@ -143,8 +161,12 @@ class _Mlp:
                 g = dh                               # skinny_bwd already applied the ReLU mask of its input
                 continue
             else:
-                ops.conv_wgrad(ConvDesc.linear(rows, fin, fout), inp, g, sink.view(self.w[l]), wr.acc(self.w[l]))
-                ops.colsum(g, sink.view(self.b[l]), rows, fout, wr.acc(self.b[l]))
+                aw, ab = wr.acc(self.w[l]), wr.acc(self.b[l])
+
+                def grads(inp=inp, g=g, l=l, fin=fin, fout=fout, aw=aw, ab=ab):
+                    ops.conv_wgrad(ConvDesc.linear(rows, fin, fout), inp, g, sink.view(self.w[l]), aw)
+                    ops.colsum(g, sink.view(self.b[l]), rows, fout, ab)
+                wr.off_path(grads, inp, g)
             # ---- input gradient
             if l == 0:
                 dx = dx_out if dx_out is not None else torch.empty(rows, fin, dtype=torch.float32, device=dev)
@@ -248,7 +270,7 @@ class FusionHead:
 
     # ---------------------------------------------------------------- backward
     def backward(self, tape: dict, d_lifted: Optional[Tensor], d_feats: Optional[Tensor], d_preds: Optional[Tensor],
-                 sink: GradSink) -> Tensor:
+                 sink: GradSink, side=None) -> Tensor:
         """Gradients wrt the three outputs (None = zero) -> d(img_feat) [V,B,Cf]; parameter gradients
         go to ``sink`` and are published iteration I-1 ... 0 (shared weights: once, after iteration 0),
         then the lifter."""
@@ -257,7 +279,7 @@ class FusionHead:
         dev = img_feat.device
         ix = self._indices(V, dev)
         D, NV = ix["D"], NUM_FEAT_VEC
-        wr = _Written(sink)
+        wr = _Written(sink, side)
         # "a" = what every fuser / head input starts with: image features, or (share_feature) the lifted ones
         aw = ROT_DIM if v.share_feature else cf
         da = torch.empty(V, B, aw, dtype=torch.float32, device=dev)

@@ -143,7 +143,11 @@ class _HeadFn(torch.autograd.Function):
             return (None, None, None) + (None,) * nparam
         ctx.tape = None
         model._sink.begin()                       # the head's backward is the first node to run
-        dimg = model._head.backward(tape, d_lifted, d_feats, d_preds, model._sink)
+        bb = model._backbone
+        side = bb._side(tape["img_feat"].device) if (bb.overlap_wgrad and bb.overlap_head and tape["img_feat"].is_cuda) else None
+        dimg = model._head.backward(tape, d_lifted, d_feats, d_preds, model._sink, side)
+        if side is not None and not ctx.needs_input_grad[1]:
+            torch.cuda.current_stream().wait_stream(side)     # no backbone backward will follow to join it
         return (None, dimg, None) + (None,) * nparam
 
 
@@ -219,6 +223,7 @@ class MultiViewGaze(nn.Module):
             if p.dtype != torch.float32:
                 raise RuntimeError("fp32 parameters only")
         self._backbone = Backbone(self._depth, named)
+        self._grad_streams = self._backbone.grad_streams   # streams besides the caller's that write gradients
         self._head = FusionHead(named, self._fc_dim, self._num_iter, self._variant)
         # grad-ready order: heads+fusers I-1..0 (shared weights: once), lifter, backbone blocks last..first, stem
         order: List[nn.Parameter] = []

@@ -198,6 +198,15 @@ def nhwc4_to_nchw(src, dst, n, c, h, w):
     check(lib().mvg_nhwc4_to_nchw(_p(src), _p(dst), n, c, h, w, _s()), "nhwc4_to_nchw")
 
 
+def low_priority_stream(device) -> "torch.cuda.Stream":
+    """A lowest-priority HIP stream wrapped for torch (work queued on it yields the CUs to the caller's stream)."""
+    with torch.cuda.device(device):
+        ptr = lib().mvg_stream_create_low_priority()
+    if not ptr:
+        check(1, "stream_create_low_priority")
+    return torch.cuda.ExternalStream(ptr, device=device)
+
+
 def set_reserved_cus(n: int):
     check(lib().mvg_set_reserved_cus(int(n)), "set_reserved_cus")
 
