@@ -568,14 +568,8 @@ static int bwd_chunks(int groups, long long rows, int c) {
 }
 
 static int grid_for(long long n4) {
-  static int cap = 0;
-  if (cap <= 0) {
-    const char *e = getenv("MVG_BN_GRID");
-    cap = e ? atoi(e) : 4096;
-    if (cap <= 0) cap = 4096;
-  }
   long long b = (n4 + 255) / 256;
-  if (b > cap) b = cap;
+  if (b > 4096) b = 4096;      // thinner grids (1024 / 2048) were tried to leave wave slots to the wgrad stream: no gain
   if (b < 1) b = 1;
   return (int)b;
 }
