@@ -284,6 +284,40 @@ def test_run_to_run_determinism():
         assert torch.equal(g, runs[1][1][k]), k
 
 
+def test_dp_reducer_one_rank_over_rccl(monkeypatch):
+    """The data-parallel path with one rank: RCCL all-reduce of the arena buckets on the reducer's side
+    stream, fed by the compute stream AND the low-priority backward-weight stream.  With world size 1
+    the averaged gradients must equal the plain ones bit for bit."""
+    import socket
+    import torch.distributed as dist
+    from rot_mvgaze_amd import ops
+    from rot_mvgaze_amd.dp import GradAllReducer
+    monkeypatch.setenv("MVG_RESERVED_CUS", "0")       # same work split (= summation order) as the plain run
+    m = build(18)
+    data = m(inputs(4, 96, seed=11))
+    metrics()(data).backward()
+    plain = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=dev())
+    try:
+        m2 = build(18)
+        red = GradAllReducer(m2, bucket_mb=8.0, force=True)
+        data = m2(inputs(4, 96, seed=11))
+        metrics()(data).backward()
+        torch.cuda.synchronize()
+        assert len(red.buckets) > 3
+        for k, p in m2.named_parameters():
+            if p.grad is not None:
+                assert torch.equal(p.grad, plain[k]), k
+    finally:
+        dist.destroy_process_group()
+        ops.set_reserved_cus(0)
+
+
 def test_gradient_accumulation_and_zero_grad():
     m = build(18)
     d = m(inputs(3, 64))
