@@ -524,6 +524,7 @@ __global__ __launch_bounds__(256) void igemm_fixup_kernel(IgemmParams p, int P) 
   for (int b = cut; b < P; ++b) {
     const long long ub = (long long)b * U / P;
     if (ub >= t1) break;
+    if ((long long)(b + 1) * U / P == ub) continue;       // an empty share stored nothing (P > U; not planned, but safe)
     const float4 *src = reinterpret_cast<const float4 *>(p.slab) + ((long long)b * 2 + (ub > t0 ? 0 : 1)) * (BM * BN / 4);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
