@@ -267,6 +267,34 @@ def test_backward_strict_with_imposed_relu_pattern(depth, batch, hw, gtol):
     rel_close(data["img_1"].grad, od["img_1"].grad.numpy(), gtol, "grad img_1")
 
 
+@pytest.mark.parametrize("depth,batch,hw", [(18, 1, 64), (50, 1, 96), (18, 5, 40)])
+def test_small_and_odd_shapes_against_oracle(depth, batch, hw):
+    """Edge shapes: a single sample (4-value BatchNorm in layer4), odd batch, maps whose sizes are not
+    multiples of any tile (40 -> 20 -> 10 -> 5 -> 3 -> 2): forward, loss and gradient norms vs the oracle."""
+    from oracle import restatement as R
+    m = build(depth)
+    data = m(inputs(batch, hw, seed=21))
+    loss = metrics()(data)
+    loss.backward()
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in synth.make_state_dict(depth, 0, 3, perturb_bn=True).items()}
+    leaves = {k: v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running" not in k}
+    inp = synth.make_inputs(batch, 2, 21, hw)
+    img, hp, gt = (torch.from_numpy(inp[k]) for k in ("img", "head_pose", "gt_gaze"))
+    od = {"img_0": img[:, 0].contiguous(), "img_1": img[:, 1].contiguous(),
+          "rot_0": R.rotation_matrix_2d(hp[:, 0]), "rot_1": R.rotation_matrix_2d(hp[:, 1]),
+          "gt_gaze": gt[:, 0], "gt_gaze_1": gt[:, 1]}
+    od = R.model_forward(sd, od, depth, 3, True)
+    ol = R.iteration_loss(od)
+    ol.backward()
+    # tiny BatchNorm populations amplify fp32 reduction-order noise: 5x the fixture tolerances
+    rel_close(loss, ol.item(), 5 * TOL, "loss")
+    for i in range(3):
+        rel_close(data[f"iter_{i}"]["pred_gaze_0"], od[f"iter_{i}"]["pred_gaze_0"].detach().numpy(), 5 * TOL, "pred")
+    for k, p in m.named_parameters():
+        if leaves[k].grad is not None:
+            l2_close(p.grad.contiguous() if p.grad.dim() == 4 else p.grad, leaves[k].grad.numpy(), GTOL_L2_FLIPS, "grad " + k)
+
+
 def test_run_to_run_determinism():
     """Stream-K pieces, wgrad slabs and BN partials are all summed in a fixed order: two runs of the
     same step give bit-identical loss and gradients (batch large enough for stream-K to engage)."""
