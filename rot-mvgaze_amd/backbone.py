@@ -220,7 +220,10 @@ class Backbone:
 
     def _side(self, dev) -> "torch.cuda.Stream":
         if self._wg_stream is None or self._wg_stream.device != dev:
-            self._wg_stream = ops.low_priority_stream(dev)       # fills what the critical path leaves idle
+            try:
+                self._wg_stream = ops.low_priority_stream(dev)   # fills what the critical path leaves idle
+            except RuntimeError:                                 # no priority support: an ordinary side stream
+                self._wg_stream = torch.cuda.Stream(device=dev)
             self.grad_streams[:] = [self._wg_stream]
         return self._wg_stream
 
