@@ -346,6 +346,51 @@ def test_dp_reducer_one_rank_over_rccl(monkeypatch):
         ops.set_reserved_cus(0)
 
 
+def _dp_rank(rank, port, out_dir):
+    import torch.distributed as dist
+    from rot_mvgaze_amd.dp import GradAllReducer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["MVG_RESERVED_CUS"] = "0"
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    try:
+        m = build(18)
+        GradAllReducer(m, bucket_mb=16.0)
+        data = m(inputs(3, 64, seed=300 + rank))
+        metrics()(data).backward()
+        torch.cuda.synchronize()
+        torch.save({k: p.grad.detach().cpu() for k, p in m.named_parameters() if p.grad is not None},
+                   os.path.join(out_dir, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_two_ranks_equals_average_of_independent_steps(tmp_path):
+    """N ranks with averaged gradients == the average of N independent steps (BatchNorm
+    statistics rank-local).  Two processes share this GPU and reduce over gloo (RCCL needs one GPU per
+    rank); everything else - arena buckets, grad-ready order, side streams - is the production path."""
+    import socket
+    import torch.multiprocessing as mp
+    want = None
+    for r in range(2):
+        m = build(18)
+        data = m(inputs(3, 64, seed=300 + r))
+        metrics()(data).backward()
+        g = {k: p.grad.detach().cpu() for k, p in m.named_parameters() if p.grad is not None}
+        want = g if want is None else {k: want[k] + g[k] for k in g}
+    want = {k: v * 0.5 for k, v in want.items()}
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_dp_rank, args=(port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        got = torch.load(tmp_path / f"rank{r}.pt", weights_only=True)
+        assert set(got) == set(want)
+        for k in want:
+            assert torch.equal(got[k], want[k]), (r, k)
+
+
 def test_gradient_accumulation_and_zero_grad():
     m = build(18)
     d = m(inputs(3, 64))
