@@ -460,10 +460,13 @@ __device__ __forceinline__ float4 pool_gather(const float4 *__restrict__ gp, con
   return acc;
 }
 
-// grid = (chunks, column blocks, groups) and the partial layout of bn_bwd_reduce_kernel; a chunk is a
-// range of image lines (image, iy), the 256/cw row lanes stride along ix - no per-element division.
+// grid = (chunks, column blocks, groups) and the partial layout of bn_bwd_reduce_kernel.  The sums run
+// over POOLED elements: sum_pixels d = sum_windows g_w * mask(winner pixel of w), so every window
+// fetches y only at its argmax pixel (one scalar per channel) - a quarter of the elements and a tenth
+// of the instructions of the per-pixel gather.  A chunk is a range of pooled lines (image, oy); the
+// 256/cw row lanes stride along ox.
 __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const float4 *__restrict__ gp, const uchar4 *__restrict__ am,
-                                                                 const float4 *__restrict__ y, const float *__restrict__ mean,
+                                                                 const float *__restrict__ y, const float *__restrict__ mean,
                                                                  const float *__restrict__ invstd,
                                                                  const float *__restrict__ scale,
                                                                  const float *__restrict__ shift, int lines_per_chunk,
@@ -475,49 +478,52 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const float4 *_
   const int nrl = 256 / cw;
   const int cq = blockIdx.y * cw + cl;
   const bool cok = cq < c4n;
-  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   if (cok) {
-    const float4 mu = reinterpret_cast<const float4 *>(mean + (long long)grp * c)[cq];
-    const float4 is = reinterpret_cast<const float4 *>(invstd + (long long)grp * c)[cq];
-    const float4 sa = reinterpret_cast<const float4 *>(scale + (long long)grp * c)[cq];
-    const float4 sb = reinterpret_cast<const float4 *>(shift + (long long)grp * c)[cq];
-    const int lines = n_per_group * h;
+    const float4 mu4 = reinterpret_cast<const float4 *>(mean + (long long)grp * c)[cq];
+    const float4 is4 = reinterpret_cast<const float4 *>(invstd + (long long)grp * c)[cq];
+    const float4 sa4 = reinterpret_cast<const float4 *>(scale + (long long)grp * c)[cq];
+    const float4 sb4 = reinterpret_cast<const float4 *>(shift + (long long)grp * c)[cq];
+    const float mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, is[4] = {is4.x, is4.y, is4.z, is4.w};
+    const float sa[4] = {sa4.x, sa4.y, sa4.z, sa4.w}, sb[4] = {sb4.x, sb4.y, sb4.z, sb4.w};
+    const int lines = n_per_group * ho;
     const int l0 = blockIdx.x * lines_per_chunk;
     const int l1 = l0 + lines_per_chunk < lines ? l0 + lines_per_chunk : lines;
     for (int l = l0; l < l1; ++l) {
-      const int img = l / h, iy = l - img * h;
+      const int img = l / ho, oy = l - img * ho;
       const long long n = (long long)grp * n_per_group + img;
-      const float4 *yl = y + ((n * h + iy) * w) * c4n + cq;
-      for (int ix = rl; ix < w; ix += nrl) {
-        const float4 v = yl[(long long)ix * c4n];
-        float4 d = pool_gather(gp, am, n, iy, ix, cq, c4n, ho, wo);
-        d.x = __builtin_fmaf(v.x, sa.x, sb.x) > 0.f ? d.x : 0.f;
-        d.y = __builtin_fmaf(v.y, sa.y, sb.y) > 0.f ? d.y : 0.f;
-        d.z = __builtin_fmaf(v.z, sa.z, sb.z) > 0.f ? d.z : 0.f;
-        d.w = __builtin_fmaf(v.w, sa.w, sb.w) > 0.f ? d.w : 0.f;
-        s1.x += d.x;
-        s1.y += d.y;
-        s1.z += d.z;
-        s1.w += d.w;
-        s2.x += d.x * ((v.x - mu.x) * is.x);
-        s2.y += d.y * ((v.y - mu.y) * is.y);
-        s2.z += d.z * ((v.z - mu.z) * is.z);
-        s2.w += d.w * ((v.w - mu.w) * is.w);
+      const long long prow = ((n * ho + oy) * wo) * c4n + cq;
+      const float *yimg = y + n * h * w * c + cq * 4;
+      for (int ox = rl; ox < wo; ox += nrl) {
+        const float4 g4 = gp[prow + (long long)ox * c4n];
+        const uchar4 k4 = am[prow + (long long)ox * c4n];
+        const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+        const int k[4] = {k4.x, k4.y, k4.z, k4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int kh = (k[j] * 11) >> 5, kw = k[j] - 3 * kh;          // k / 3, k % 3 for k < 9
+          const int iy = 2 * oy - 1 + kh, ix = 2 * ox - 1 + kw;          // the winner is an in-bounds pixel
+          const float v = yimg[((long long)iy * w + ix) * c + j];
+          const float d = __builtin_fmaf(v, sa[j], sb[j]) > 0.f ? g[j] : 0.f;
+          s1[j] += d;
+          s2[j] += d * ((v - mu[j]) * is[j]);
+        }
       }
     }
   }
-  sh[0][threadIdx.x] = s1;
-  sh[1][threadIdx.x] = s2;
+  sh[0][threadIdx.x] = make_float4(s1[0], s1[1], s1[2], s1[3]);
+  sh[1][threadIdx.x] = make_float4(s2[0], s2[1], s2[2], s2[3]);
   __syncthreads();
   if (rl == 0 && cok) {
+    float4 t1 = sh[0][threadIdx.x], t2 = sh[1][threadIdx.x];
     for (int k = 1; k < nrl; ++k) {
       const float4 a = sh[0][k * cw + cl], b = sh[1][k * cw + cl];
-      s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
-      s2.x += b.x; s2.y += b.y; s2.z += b.z; s2.w += b.w;
+      t1.x += a.x; t1.y += a.y; t1.z += a.z; t1.w += a.w;
+      t2.x += b.x; t2.y += b.y; t2.z += b.z; t2.w += b.w;
     }
     float4 *p = reinterpret_cast<float4 *>(partial + (((long long)grp * chunks + blockIdx.x) * 2) * c);
-    p[cq] = s1;
-    p[c4n + cq] = s2;
+    p[cq] = t1;
+    p[c4n + cq] = t2;
   }
 }
 
@@ -694,7 +700,7 @@ int mvg_bn_relu_maxpool_bwd_reduce(const float *g_pooled, const uint8_t *argmax,
   const int cw = c4n < 256 ? c4n : 256;
   MVG_REQUIRE(256 % cw == 0, "bn_relu_maxpool_bwd_reduce: c/4 must divide 256 or be a multiple of it (c=%d)", c);
   // chunk = whole image lines; never more chunks than mvg_bn_bwd_workspace_floats(groups, rows, c) sizes
-  const int lines = n_per_group * h;
+  const int lines = n_per_group * ho;                 // pooled lines
   int chunks = bwd_chunks(groups, rows, c);
   if (chunks > lines) chunks = lines;
   const int lpc = (lines + chunks - 1) / chunks;
@@ -702,7 +708,7 @@ int mvg_bn_relu_maxpool_bwd_reduce(const float *g_pooled, const uint8_t *argmax,
   ProfScope ps(MVG_K_BN_BWD_REDUCE, st, 0.0,
                4.0 * groups * ((double)rows * c + (double)n_per_group * ho * wo * c * 1.25));
   hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3(chunks, ceil_div(c4n, cw), groups), dim3(256), 0, st,
-                     (const float4 *)g_pooled, (const uchar4 *)argmax, (const float4 *)y, mean, invstd, scale, shift, lpc,
+                     (const float4 *)g_pooled, (const uchar4 *)argmax, y, mean, invstd, scale, shift, lpc,
                      n_per_group, h, w, ho, wo, c, c4n, cw, workspace, chunks);
   if (check_launch("bn_relu_maxpool_bwd_reduce")) return 1;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(c, 16)), dim3(1024), 0, st, workspace, groups, chunks, c, s1, s2,
