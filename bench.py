@@ -95,7 +95,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--bucket-mb", type=float, default=64.0)
+    ap.add_argument("--bucket-mb", type=float, default=25.0)
     ap.add_argument("--no-optimizer", action="store_true", help="time forward+loss+backward only (no Adam step)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the backward-weight kernels on the compute stream (per-kernel profiling: rocprofv3 --stats)")

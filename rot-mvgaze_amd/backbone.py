@@ -58,8 +58,10 @@ class Backbone:
         # besides the caller's (the data-parallel reducer waits on them too).
         self.overlap_wgrad = os.environ.get("MVG_WGRAD_OVERLAP", "1") != "0"
         self.overlap_head = os.environ.get("MVG_HEAD_OVERLAP", "0") != "0"      # the fusion block's weight gradients too
+        self.wgrad_low_priority = True      # data-parallel runs use an ordinary stream: gradients must not finish last
         self.grad_streams: List[torch.cuda.Stream] = []
         self._wg_stream: Optional[torch.cuda.Stream] = None
+        self._wg_low = True
 
     # ---------------------------------------------------------------- helpers
     def _weight(self, c: ConvSpec) -> Tensor:
@@ -219,10 +221,13 @@ class Backbone:
         return g, None
 
     def _side(self, dev) -> "torch.cuda.Stream":
-        if self._wg_stream is None or self._wg_stream.device != dev:
+        if self._wg_stream is None or self._wg_stream.device != dev or self._wg_low != self.wgrad_low_priority:
+            self._wg_low = self.wgrad_low_priority
             try:
+                if not self._wg_low:
+                    raise RuntimeError
                 self._wg_stream = ops.low_priority_stream(dev)   # fills what the critical path leaves idle
-            except RuntimeError:                                 # no priority support: an ordinary side stream
+            except RuntimeError:                                 # ordinary side stream (also: no priority support)
                 self._wg_stream = torch.cuda.Stream(device=dev)
             self.grad_streams[:] = [self._wg_stream]
         return self._wg_stream

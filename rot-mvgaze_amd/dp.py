@@ -60,6 +60,12 @@ class GradAllReducer:
             # stream needs ~15 GB/s of bus bandwidth at C2 / C4, a fraction of what 8 channels move).
             from . import ops
             ops.set_reserved_cus(int(os.environ.get("MVG_RESERVED_CUS", "12")))
+            # backward-weight kernels on a LOWEST-priority stream finish last, which would hold every
+            # backbone bucket back until the end of backward; with ranks to feed they run on an ordinary
+            # side stream (still off the critical path, +3 % instead of +4 %)
+            bb = getattr(self.model, "_backbone", None)
+            if bb is not None and os.environ.get("MVG_DP_LOW_PRIORITY_WGRAD", "0") == "0":
+                bb.wgrad_low_priority = False
         if arena.is_cuda and self._side is None:
             self._side = torch.cuda.Stream(device=arena.device)
         self._built_for = arena.data_ptr()
