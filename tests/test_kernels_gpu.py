@@ -440,3 +440,26 @@ def test_multi_erase_kernel_matches_reference_fixture(golden_dir):
     imgs = torch.from_numpy(synth.normal(10 * 3 * 40 * 56, 77, "erase").reshape(10, 3, 40, 56).astype(np.float32))
     out = aug(imgs.to(dev()))
     assert np.array_equal(out.cpu().numpy(), g["out"])
+
+
+def test_bad_arguments_fail_with_a_message():
+    """Error convention of the C ABI: non-zero return code + mvg_last_error() text, surfaced
+    by the host layer as RuntimeError - never a silent wrong answer or a device fault."""
+    from rot_mvgaze_amd import ops
+    from rot_mvgaze_amd._lib import ConvDesc
+    x = torch.zeros(1, 1, 8, 8, 6, device=dev())
+    with pytest.raises(RuntimeError, match="c %% 4|c % 4"):
+        ops.bn_apply(x.view(1, 64, 6), torch.ones(1, 6, device=dev()), torch.zeros(1, 6, device=dev()), None, True,
+                     torch.empty(1, 64, 6, device=dev()), 1, 64, 6)
+    d = ConvDesc.make(1, 1, 8, 8, 8, 6, 3, 1, 1)                       # cout = 6: not a multiple of 4
+    with pytest.raises(RuntimeError, match="power-of-two|cout"):
+        ops.conv_dgrad(d, torch.zeros(1, 1, 8, 8, 6, device=dev()), torch.zeros(6, 3, 3, 8, device=dev()),
+                       torch.empty(1, 1, 8, 8, 8, device=dev()), None, None)
+    with pytest.raises(RuntimeError, match="out_features"):
+        ops.linear_skinny_fwd(torch.zeros(4, 8, device=dev()), torch.zeros(5, 8, device=dev()), torch.zeros(5, device=dev()),
+                              torch.empty(4, 5, device=dev()), 4, 8, 5)
+    bad = ConvDesc.make(1, 1, 8, 8, 8, 8, 3, 1, 1)
+    bad.ho = 3                                                          # inconsistent output size
+    with pytest.raises(RuntimeError):
+        ops.conv_fprop(bad, torch.zeros(1, 1, 8, 8, 8, device=dev()), torch.zeros(8, 3, 3, 8, device=dev()),
+                       torch.empty(1, 1, 3, 8, 8, device=dev()), None, False, None)
