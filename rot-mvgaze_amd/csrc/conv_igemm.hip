@@ -240,7 +240,12 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams &p, const Igemm
 // resident workgroups per CU the register budget is held to (LDS allows 4 / 5 / 8 / 5)
 constexpr int igemm_min_blocks(int bm, int bn, int bk, bool dgrad) { return (bm == 128 && bn == 128 && bk == 16 && dgrad) ? 3 : 2; }
 
-template <int BM, int BN, int BK, int WGM, int WGN, bool DGRAD>
+// FASTA (host: every class has >= 16 channels per tap and <= 32 taps): the 16 k of a K-step lie inside
+// ONE tap, so the tap decode, the tap's pixel displacement and the channel base are wave-uniform
+// (scalar unit) and each row's bounds checks collapse to one bit of a per-segment tap mask.  PMC on the
+// 64-column kernel: VALU active 22 % + MFMA busy 71 % of the cycles - the vector ALU work of the loader
+// does not hide under the MFMAs, it displaces them.
+template <int BM, int BN, int BK, int WGM, int WGN, bool DGRAD, bool FASTA = false>
 __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN, BK, DGRAD)) void igemm_kernel(IgemmParams p) {
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -330,6 +335,40 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN, BK, DGRAD)) void igem
     }
     a_img[i] = (unsigned)(img * p.src_img_stride * 4);
   }
+  // FASTA: per row, byte offset of (image, y0, x0, channel 0) and the mask of in-bounds taps
+  unsigned a_base[A_PASSES], a_vmask[A_PASSES];
+  unsigned b_base[DGRAD ? B_PASSES_D : B_PASSES_F];
+  bool b_ok[DGRAD ? B_PASSES_D : B_PASSES_F];
+  if (FASTA) {
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+      a_base[i] = a_img[i] + (unsigned)((a_y0[i] * p.src_w + a_x0[i]) * p.src_c) * 4u + (unsigned)a_kv * 16u;
+      unsigned m = 0;
+      for (int t = 0; t < c.ntaps; ++t) {
+        const int fr = (int)fdiv((unsigned)t, c.tap_ns_div), fs = t - fr * c.tap_ns;
+        const int iy = DGRAD ? a_y0[i] - fr : a_y0[i] + fr;
+        const int ix = DGRAD ? a_x0[i] - fs : a_x0[i] + fs;
+        m |= (unsigned)(((unsigned)iy < (unsigned)p.src_h) & ((unsigned)ix < (unsigned)p.src_w)) << t;
+      }
+      a_vmask[i] = a_ok[i] ? m : 0u;
+    }
+    if (!DGRAD) {
+#pragma unroll
+      for (int i = 0; i < B_PASSES_F; ++i) {
+        const int n = ntile * BN + a_r0 + i * RPP;
+        b_ok[i] = n < p.ncols;
+        b_base[i] = ((unsigned)n * (unsigned)c.ktotal + (unsigned)a_kv * 4u) * 4u;
+      }
+    } else {
+      const int ncol = ntile * BN + (tid % NV) * 4;
+#pragma unroll
+      for (int i = 0; i < B_PASSES_D; ++i) {
+        const int krow = tid / NV + i * KRPP;
+        b_ok[i] = ncol < p.ncols;
+        b_base[i] = ((unsigned)krow * (unsigned)p.rs * (unsigned)p.cin + (unsigned)ncol) * 4u;
+      }
+    }
+  }
   const __amdgpu_buffer_rsrc_t rs_a =
       make_rsrc(p.a + (long long)g * p.imgs_per_group * p.src_img_stride, p.a_group_bytes);
 
@@ -349,6 +388,32 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN, BK, DGRAD)) void igem
     if (c.korder) {
       const int cblk = (int)fdiv((unsigned)kt, c.per_div), rem = kt - cblk * (c.ntaps * (32 / BK));
       kstart = BK == 32 ? (rem << p.src_c_shift) + cblk * 32 : ((rem >> 1) << p.src_c_shift) + cblk * 32 + (rem & 1) * 16;
+    }
+    if constexpr (FASTA) {
+      const int ks = __builtin_amdgcn_readfirstlane(kstart);
+      const int tap_u = c.ntaps > 1 ? (ks >> p.src_c_shift) : 0;
+      const int chb = ks - (tap_u << p.src_c_shift);                                 // first channel of the step
+      const int fru = (int)fdiv((unsigned)tap_u, c.tap_ns_div), fsu = tap_u - fru * c.tap_ns;
+      const int disp = (fru * p.src_w + fsu) * p.src_c;                              // the tap's pixel displacement
+      const unsigned sdelta = (unsigned)(((DGRAD ? -disp : disp) + chb) * 4);
+      const bool kok_u = (kt < KT) & (ks < c.ktotal);
+#pragma unroll
+      for (int i = 0; i < A_PASSES; ++i) {
+        const bool ok = kok_u & (((a_vmask[i] >> tap_u) & 1u) != 0u);
+        a_reg[i] = buf_ld16(rs_a, pred_off(a_base[i] + sdelta, ok));
+      }
+      if (!DGRAD) {
+        const unsigned kb = (unsigned)ks * 4u;
+#pragma unroll
+        for (int i = 0; i < B_PASSES_F; ++i) b_reg[i] = buf_ld16(rs_b, pred_off(b_base[i] + kb, b_ok[i] & kok_u));
+      } else {
+        const int bi = fru, bj = fsu;
+        const int btap = (c.tap_r0 + p.tap_step * bi) * p.s + c.tap_s0 + p.tap_step * bj;
+        const unsigned kb = (unsigned)((chb * p.rs + btap) * p.cin) * 4u;
+#pragma unroll
+        for (int i = 0; i < B_PASSES_D; ++i) b_reg[i] = buf_ld16(rs_b, pred_off(b_base[i] + kb, b_ok[i] & kok_u));
+      }
+      return;
     }
     const int k0 = kstart + a_kv * 4;
     int tap = 0, ch = k0;
@@ -1368,12 +1433,12 @@ static bool streamk_enabled() {
 }
 
 // ---- stream-K planning ---------------------------------------------------------------------
-template <int BM, int BN, int BK, int WGM, int WGN, bool DGRAD>
+template <int BM, int BN, int BK, int WGM, int WGN, bool DGRAD, bool FASTA = false>
 static int igemm_occupancy() {
   static int occ = 0;
   if (occ <= 0) {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<BM, BN, BK, WGM, WGN, DGRAD>, 256, 0) != hipSuccess) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<BM, BN, BK, WGM, WGN, DGRAD, FASTA>, 256, 0) != hipSuccess) {
       (void)hipGetLastError();
       n = 1;
     }
@@ -1453,11 +1518,11 @@ static TileChoice choose_tile(long long rows_per_group, int groups, int ncols, i
   return choose_tile_multi(&rows_per_group, &ktotal, 1, groups, ncols, dgrad);
 }
 
-template <int BM, int BN, int BK, int WGM, int WGN, bool DGRAD>
+template <int BM, int BN, int BK, int WGM, int WGN, bool DGRAD, bool FASTA = false>
 static int launch_igemm_tile(IgemmParams &p, long long tiles, long long units, hipStream_t st) {
   int P = 0;
   if (p.splits == 1 && units > tiles)
-    P = plan_streamk(tiles, (int)(units / tiles), BM, BN, igemm_occupancy<BM, BN, BK, WGM, WGN, DGRAD>(), BK);
+    P = plan_streamk(tiles, (int)(units / tiles), BM, BN, igemm_occupancy<BM, BN, BK, WGM, WGN, DGRAD, FASTA>(), BK);
   if (P > 0) {
     float *scratch = stream_scratch(st, (size_t)P * 2 * BM * BN);
     if (!scratch) P = 0;                                   // no scratch: plain launch
@@ -1465,13 +1530,13 @@ static int launch_igemm_tile(IgemmParams &p, long long tiles, long long units, h
   }
   if (P > 0) {
     p.sk_tiles = (int)tiles;
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, BK, WGM, WGN, DGRAD>), dim3((unsigned)P), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, BK, WGM, WGN, DGRAD, FASTA>), dim3((unsigned)P), dim3(256), 0, st, p);
     if (check_launch(DGRAD ? "conv_dgrad(stream-K)" : "conv_fprop(stream-K)")) return 1;
     hipLaunchKernelGGL((igemm_fixup_kernel<BM, BN, BK, WGM, WGN, DGRAD>), dim3((unsigned)(P - 1)), dim3(256), 0, st, p, P);
     return check_launch("conv stream-K fix-up");
   }
   p.sk_tiles = 0;
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, BK, WGM, WGN, DGRAD>), dim3((unsigned)(tiles * p.splits)), dim3(256), 0, st, p);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, BK, WGM, WGN, DGRAD, FASTA>), dim3((unsigned)(tiles * p.splits)), dim3(256), 0, st, p);
   return check_launch(DGRAD ? "conv_dgrad" : "conv_fprop");
 }
 
@@ -1497,11 +1562,29 @@ static int launch_igemm(IgemmParams &p, TileChoice t, hipStream_t st) {
   MVG_REQUIRE(tiles * p.splits < (1LL << 31), "conv: grid too large");
   MVG_REQUIRE(p.splits == 1 || p.ncls == 1, "conv: split-K with several classes");
   if (tiles <= 0) return 0;
+  // uniform-tap loader: every class has whole K-steps inside one tap and at most 32 taps
+  static int fasta_env = -1;
+  if (fasta_env < 0) {
+    const char *e = getenv("MVG_FASTA");
+    fasta_env = (e && !strcmp(e, "0")) ? 0 : 1;
+  }
+  bool fasta = fasta_env == 1;
+  for (int i = 0; i < p.ncls; ++i) {
+    const IgemmClass &c = p.cls[i];
+    fasta = fasta && c.ntaps >= 1 && c.ntaps <= 32 && c.ktotal % bk == 0 && p.src_c % bk == 0;
+  }
   if (t.bm == 128 && t.bn == 128) {
-    if (bk == 32) return launch_igemm_tile<128, 128, 32, 2, 2, DGRAD>(p, tiles, units, st);
+    if (bk == 32) {
+      if (fasta) return launch_igemm_tile<128, 128, 32, 2, 2, DGRAD, true>(p, tiles, units, st);
+      return launch_igemm_tile<128, 128, 32, 2, 2, DGRAD>(p, tiles, units, st);
+    }
+    if (fasta) return launch_igemm_tile<128, 128, 16, 2, 2, DGRAD, true>(p, tiles, units, st);
     return launch_igemm_tile<128, 128, 16, 2, 2, DGRAD>(p, tiles, units, st);
   }
-  if (t.bm == 128 && t.bn == 64) return launch_igemm_tile<128, 64, 16, 2, 2, DGRAD>(p, tiles, units, st);
+  if (t.bm == 128 && t.bn == 64) {
+    if (fasta) return launch_igemm_tile<128, 64, 16, 2, 2, DGRAD, true>(p, tiles, units, st);
+    return launch_igemm_tile<128, 64, 16, 2, 2, DGRAD>(p, tiles, units, st);
+  }
   if (t.bm == 64 && t.bn == 64) return launch_igemm_tile<64, 64, 16, 2, 2, DGRAD>(p, tiles, units, st);
   return launch_igemm_tile<128, 32, 16, 4, 1, DGRAD>(p, tiles, units, st);
 }
