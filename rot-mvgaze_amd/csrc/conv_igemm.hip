@@ -1162,7 +1162,12 @@ struct WgradParams {
   FastDiv ohw_div, wo_div, cin_div, s_div;
 };
 
-template <int BM, int BN, int BK, int WGM, int WGN>
+// INCR (host: ho*wo >= 32, every product below fits 24 x 24 bits): the pixel coordinates of a loader
+// row advance by exactly BK pixels per K-step, so (image offset, oy, ox) are carried in registers and
+// stepped with one multiply-shift division instead of being decoded from the pixel index every time
+// (99 VALU instructions per K-step, 26 of them quarter-rate multiplies, against 32 MFMAs - and VALU
+// work displaces MFMAs on this machine; rows beyond the split fall outside the dy descriptor = zeros).
+template <int BM, int BN, int BK, int WGM, int WGN, bool INCR = false>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -1210,8 +1215,54 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   const int b_fr = (int)fdiv((unsigned)b_tap, p.s_div), b_fs = b_tap - b_fr * p.s;
   const int b_dy = b_fr - p.pad, b_dx = b_fs - p.pad;
 
+  // INCR state: per B pass the row's (oy, ox) and image byte offset; per A pass the running byte offset
+  int b_oy[B_PASSES], b_ox[B_PASSES];
+  unsigned b_imgoff[B_PASSES], a_off[A_PASSES];
+  const unsigned b_tconst = (unsigned)(((b_dy * p.w + b_dx) * p.cin + b_c) * 4);
+  const unsigned row_bytes = (unsigned)(p.stride * p.w * p.cin * 4), col_bytes = (unsigned)(p.stride * p.cin * 4);
+  const unsigned img_bytes = (unsigned)(x_img_elems * 4);
+  if (INCR) {
+#pragma unroll
+    for (int i = 0; i < B_PASSES; ++i) {
+      const unsigned pix = rem0 + (unsigned)(b_k0 + i * B_KRPP);
+      const unsigned img = fdiv(pix, p.ohw_div);
+      const unsigned rem = pix - img * (unsigned)ohw;
+      const unsigned oy = fdiv(rem, p.wo_div);
+      b_oy[i] = (int)oy;
+      b_ox[i] = (int)(rem - oy * (unsigned)p.wo);
+      b_imgoff[i] = img * img_bytes;
+    }
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i)
+      a_off[i] = a_cok ? (unsigned)((a_k0 + i * A_KRPP) * p.cout + a_col) * 4u : 0x80000000u;
+  }
   float4 a_reg[A_PASSES], b_reg[B_PASSES];
   auto load_tiles = [&](int kt) {
+    if constexpr (INCR) {
+      // called with kt = 0, 1, 2, ... in order: the state is that of K-step kt on entry
+#pragma unroll
+      for (int i = 0; i < A_PASSES; ++i) {
+        a_reg[i] = buf_ld16(rs_a, a_off[i]);                 // rows >= m_count are beyond the descriptor: zeros
+        a_off[i] += (unsigned)(BK * p.cout * 4);
+      }
+#pragma unroll
+      for (int i = 0; i < B_PASSES; ++i) {
+        const int m = kt * BK + b_k0 + i * B_KRPP;
+        const int iy = b_oy[i] * p.stride + b_dy, ix = b_ox[i] * p.stride + b_dx;
+        const bool ok = (m < m_count) & b_cok & ((unsigned)iy < (unsigned)p.h) & ((unsigned)ix < (unsigned)p.w);
+        const unsigned off = b_imgoff[i] + __umul24((unsigned)b_oy[i], row_bytes) + __umul24((unsigned)b_ox[i], col_bytes) + b_tconst;
+        b_reg[i] = buf_ld16(rs_b, pred_off(off, ok));
+        // advance BK pixels: columns wrap into rows (any number of times), rows into the next image (at most once)
+        const unsigned nx = (unsigned)b_ox[i] + BK;
+        const unsigned q = fdiv(nx, p.wo_div);
+        b_ox[i] = (int)(nx - q * (unsigned)p.wo);
+        int noy = b_oy[i] + (int)q;
+        const bool wrap = noy >= p.ho;
+        b_oy[i] = wrap ? noy - p.ho : noy;
+        b_imgoff[i] += wrap ? img_bytes : 0u;
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
       const int m = kt * BK + a_k0 + i * A_KRPP;
@@ -2017,7 +2068,7 @@ static int wgrad_occupancy_t() {
   static int occ = 0;
   if (occ <= 0) {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wgrad_kernel<BM, BN, 16, WGM, WGN>, 256, 0) != hipSuccess) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wgrad_kernel<BM, BN, 16, WGM, WGN, true>, 256, 0) != hipSuccess) {
       (void)hipGetLastError();
       n = 2;
     }
@@ -2106,16 +2157,26 @@ int mvg_conv_wgrad(const mvg_conv_desc *d, const float *x, const float *dy, floa
     ProfScope ps(lin ? MVG_K_LINEAR_WGRAD : MVG_K_CONV_WGRAD, st, flops, bytes);
     MVG_REQUIRE((long long)p.mtiles * p.ntiles * splits < (1LL << 31), "wgrad: grid too large");
     dim3 grid(p.mtiles * p.ntiles * splits), block(256);
-    if (t.bm == 128 && t.bn == 128)
-      hipLaunchKernelGGL((wgrad_kernel<128, 128, 16, 2, 2>), grid, block, 0, st, p);
-    else if (t.bm == 64 && t.bn == 128)
-      hipLaunchKernelGGL((wgrad_kernel<64, 128, 16, 2, 2>), grid, block, 0, st, p);
-    else if (t.bm == 64 && t.bn == 64)
-      hipLaunchKernelGGL((wgrad_kernel<64, 64, 16, 2, 2>), grid, block, 0, st, p);
-    else if (t.bm == 32 && t.bn == 128)
-      hipLaunchKernelGGL((wgrad_kernel<32, 128, 16, 1, 4>), grid, block, 0, st, p);
-    else
-      hipLaunchKernelGGL((wgrad_kernel<128, 32, 16, 4, 1>), grid, block, 0, st, p);
+    // incremental pixel stepping: needs >= 32 pixels per image (one image wrap per step at most), 24-bit
+    // factors in the offset multiplies and 32-bit x offsets
+    static int incr_env = -1;
+    if (incr_env < 0) {
+      const char *e = getenv("MVG_WGRAD_INCR");
+      incr_env = (e && !strcmp(e, "0")) ? 0 : 1;
+    }
+    const bool incr = incr_env == 1 && (long long)d->ho * d->wo >= 32 && d->ho < (1 << 20) && d->wo < (1 << 20) &&
+                      (long long)d->stride * d->w * d->cin * 4 < (1 << 24);
+#define MVG_WGRAD_LAUNCH(BM_, BN_, WGM_, WGN_)                                                              \
+  do {                                                                                                      \
+    if (incr) hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, 16, WGM_, WGN_, true>), grid, block, 0, st, p);    \
+    else hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, 16, WGM_, WGN_, false>), grid, block, 0, st, p);        \
+  } while (0)
+    if (t.bm == 128 && t.bn == 128) MVG_WGRAD_LAUNCH(128, 128, 2, 2);
+    else if (t.bm == 64 && t.bn == 128) MVG_WGRAD_LAUNCH(64, 128, 2, 2);
+    else if (t.bm == 64 && t.bn == 64) MVG_WGRAD_LAUNCH(64, 64, 2, 2);
+    else if (t.bm == 32 && t.bn == 128) MVG_WGRAD_LAUNCH(32, 128, 1, 4);
+    else MVG_WGRAD_LAUNCH(128, 32, 4, 1);
+#undef MVG_WGRAD_LAUNCH
     if (check_launch("conv_wgrad")) return 1;
   }
   if (splits > 1) {
