@@ -1274,22 +1274,37 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   const int b_fr = (int)fdiv((unsigned)b_tap, p.s_div), b_fs = b_tap - b_fr * p.s;
   const int b_dy = b_fr - p.pad, b_dx = b_fs - p.pad;
 
-  // INCR state: per B pass the row's (oy, ox) and image byte offset; per A pass the running byte offset
-  int b_oy[B_PASSES], b_ox[B_PASSES];
-  unsigned b_imgoff[B_PASSES], a_off[A_PASSES];
-  const unsigned b_tconst = (unsigned)(((b_dy * p.w + b_dx) * p.cin + b_c) * 4);
+  // INCR: a thread's B loads all come from ONE pixel row of the K-step (row = tid / (NVB / B_PASSES)) and
+  // differ in the column group, so the pixel state (oy, ox, image offset) is carried and stepped once per
+  // K-step; per column group only the tap's displacement and bounds differ.
+  constexpr int B_TPR = NVB / B_PASSES;                 // threads per k-row
+  static_assert(!INCR || NVB % B_PASSES == 0, "wgrad loader mapping");
+  const int i_row = tid / B_TPR, i_nv0 = tid % B_TPR;
+  int s_oy = 0, s_ox = 0;
+  unsigned s_imgoff = 0, a_off[A_PASSES];
+  int i_dy[B_PASSES], i_dx[B_PASSES];
+  unsigned i_tconst[B_PASSES];
+  bool i_cok[B_PASSES];
   const unsigned row_bytes = (unsigned)(p.stride * p.w * p.cin * 4), col_bytes = (unsigned)(p.stride * p.cin * 4);
   const unsigned img_bytes = (unsigned)(x_img_elems * 4);
   if (INCR) {
+    const unsigned pix = rem0 + (unsigned)i_row;
+    const unsigned img = fdiv(pix, p.ohw_div);
+    const unsigned rem = pix - img * (unsigned)ohw;
+    const unsigned oy = fdiv(rem, p.wo_div);
+    s_oy = (int)oy;
+    s_ox = (int)(rem - oy * (unsigned)p.wo);
+    s_imgoff = img * img_bytes;
 #pragma unroll
-    for (int i = 0; i < B_PASSES; ++i) {
-      const unsigned pix = rem0 + (unsigned)(b_k0 + i * B_KRPP);
-      const unsigned img = fdiv(pix, p.ohw_div);
-      const unsigned rem = pix - img * (unsigned)ohw;
-      const unsigned oy = fdiv(rem, p.wo_div);
-      b_oy[i] = (int)oy;
-      b_ox[i] = (int)(rem - oy * (unsigned)p.wo);
-      b_imgoff[i] = img * img_bytes;
+    for (int j = 0; j < B_PASSES; ++j) {
+      const int col = ntile * BN + (i_nv0 + j * B_TPR) * 4;
+      i_cok[j] = col < p.ncols;
+      const int tap = (int)fdiv((unsigned)(i_cok[j] ? col : 0), p.cin_div);
+      const int cc = (i_cok[j] ? col : 0) - tap * p.cin;
+      const int fr = (int)fdiv((unsigned)tap, p.s_div), fs = tap - fr * p.s;
+      i_dy[j] = fr - p.pad;
+      i_dx[j] = fs - p.pad;
+      i_tconst[j] = (unsigned)(((i_dy[j] * p.w + i_dx[j]) * p.cin + cc) * 4);
     }
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i)
@@ -1304,22 +1319,29 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
         a_reg[i] = buf_ld16(rs_a, a_off[i]);                 // rows >= m_count are beyond the descriptor: zeros
         a_off[i] += (unsigned)(BK * p.cout * 4);
       }
+      const bool mok = (kt * BK + i_row < m_count) & (i_row < BK);
+      const int iy0 = s_oy * p.stride, ix0 = s_ox * p.stride;
+      const unsigned pixoff = s_imgoff + __umul24((unsigned)s_oy, row_bytes) + __umul24((unsigned)s_ox, col_bytes);
 #pragma unroll
-      for (int i = 0; i < B_PASSES; ++i) {
-        const int m = kt * BK + b_k0 + i * B_KRPP;
-        const int iy = b_oy[i] * p.stride + b_dy, ix = b_ox[i] * p.stride + b_dx;
-        const bool ok = (m < m_count) & b_cok & ((unsigned)iy < (unsigned)p.h) & ((unsigned)ix < (unsigned)p.w);
-        const unsigned off = b_imgoff[i] + __umul24((unsigned)b_oy[i], row_bytes) + __umul24((unsigned)b_ox[i], col_bytes) + b_tconst;
-        b_reg[i] = buf_ld16(rs_b, pred_off(off, ok));
-        // advance BK pixels: columns wrap into rows (any number of times), rows into the next image (at most once)
-        const unsigned nx = (unsigned)b_ox[i] + BK;
-        const unsigned q = fdiv(nx, p.wo_div);
-        b_ox[i] = (int)(nx - q * (unsigned)p.wo);
-        int noy = b_oy[i] + (int)q;
-        const bool wrap = noy >= p.ho;
-        b_oy[i] = wrap ? noy - p.ho : noy;
-        b_imgoff[i] += wrap ? img_bytes : 0u;
+      for (int j = 0; j < B_PASSES; ++j) {
+        const bool ok = mok & i_cok[j] & ((unsigned)(iy0 + i_dy[j]) < (unsigned)p.h) & ((unsigned)(ix0 + i_dx[j]) < (unsigned)p.w);
+        b_reg[j] = buf_ld16(rs_b, pred_off(pixoff + i_tconst[j], ok));
       }
+      // advance BK pixels: columns wrap into rows, rows into the next image (at most once: ho*wo >= 2*BK)
+      unsigned nx = (unsigned)s_ox + BK;
+      unsigned q;
+      if (p.wo >= BK) {                                      // uniform: at most one row wrap
+        q = nx >= (unsigned)p.wo ? 1u : 0u;
+        nx -= q ? (unsigned)p.wo : 0u;
+      } else {
+        q = fdiv(nx, p.wo_div);
+        nx -= q * (unsigned)p.wo;
+      }
+      s_ox = (int)nx;
+      const int noy = s_oy + (int)q;
+      const bool wrap = noy >= p.ho;
+      s_oy = wrap ? noy - p.ho : noy;
+      s_imgoff += wrap ? img_bytes : 0u;
       return;
     }
 #pragma unroll
@@ -1347,8 +1369,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     for (int i = 0; i < A_PASSES; ++i)
       *reinterpret_cast<float4 *>(As + (a_k0 + i * A_KRPP) * LDA + a_mv * 4) = a_reg[i];
 #pragma unroll
-    for (int i = 0; i < B_PASSES; ++i)
-      *reinterpret_cast<float4 *>(Bs + (b_k0 + i * B_KRPP) * LDB + b_nv * 4) = b_reg[i];
+    for (int i = 0; i < B_PASSES; ++i) {
+      if (INCR)
+        *reinterpret_cast<float4 *>(Bs + i_row * LDB + (i_nv0 + i * B_TPR) * 4) = b_reg[i];
+      else
+        *reinterpret_cast<float4 *>(Bs + (b_k0 + i * B_KRPP) * LDB + b_nv * 4) = b_reg[i];
+    }
   };
 
   f32x16 acc[TM][TN];
