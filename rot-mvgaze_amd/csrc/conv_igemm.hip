@@ -149,11 +149,55 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
 template <int BM, int BN, int WGM, int WGN, bool DGRAD>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams &p, const IgemmClass &c, f32x16 (&acc)[BM / WGM / 32][BN / WGN / 32], int g,
                                                int mtile, int ntile, int split, int wm, int wn, int li, int lh,
-                                               int ohw) {
+                                               int ohw, int *row_lds = nullptr) {
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   const long long row_base = (long long)mtile * BM + wm * WTM;
   const long long grow0 = (long long)g * c.rows_per_group;
+  // Stride-2 parity class: a row of the class is the dx pixel (2*y2 + py, 2*x2 + px).  The tile's BM row
+  // offsets are decoded ONCE (one thread per row, two exact divisions) into LDS; the stores then cost a
+  // table read and an add instead of ~40 VALU instructions of division and 64-bit index math per element
+  // (the one-tap classes have 8 K-steps per tile: the old epilogue was longer than their main loop).
+  if (DGRAD && p.cls_step == 2 && p.splits <= 1 && row_lds != nullptr &&
+      (long long)p.groups * p.imgs_per_group * p.full_h * p.full_w * p.ncols < (1ll << 31)) {
+    __syncthreads();                                   // every wave is done with the operand images
+    for (int r = threadIdx.x; r < BM; r += blockDim.x) {
+      const long long m = (long long)mtile * BM + r;
+      int off = -1;
+      if (m < c.rows_per_group) {
+        const int rr = (int)m;
+        const int img = (int)fdiv((unsigned)rr, c.ohw_div), rem = rr - img * ohw;
+        const int y2 = (int)fdiv((unsigned)rem, c.ow_div), x2 = rem - y2 * c.out_w;
+        off = (((g * p.imgs_per_group + img) * p.full_h + 2 * y2 + c.cls_py) * p.full_w + 2 * x2 + c.cls_px) * p.ncols;
+      }
+      row_lds[r] = off;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = ntile * BN + wn * WTN + j * 32 + li;
+      const bool cok = col < p.ncols;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+          const int4 ro = *reinterpret_cast<const int4 *>(row_lds + wm * WTM + i * 32 + 8 * e4 + 4 * lh);
+          const int rov[4] = {ro.x, ro.y, ro.z, ro.w};
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            if (cok && rov[d] >= 0) {
+              const int off = rov[d] + col;
+              float v = acc[i][j][4 * e4 + d];
+              if (p.mask) v = (p.mask[off] > 0.f) ? v : 0.f;
+              if (p.addend) v += p.addend[off];
+              p.out[off] = v;
+            }
+          }
+        }
+      }
+    }
+    return;
+  }
   if (p.splits > 1) {       // raw partial tile -> slab; the epilogue runs in splitk_reduce_kernel
     float *slab = p.slab + (long long)split * p.groups * c.rows_per_group * p.ncols;
 #pragma unroll
@@ -613,7 +657,9 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN, BK, DGRAD)) void igem
           dst[((i * TN + j) * 4 + q) * 256 + tid] =
               make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
   } else {
-    igemm_epilogue<BM, BN, WGM, WGN, DGRAD>(p, c, acc, g, mtile, ntile, split, wm, wn, li, lh, ohw);
+    igemm_epilogue<BM, BN, WGM, WGN, DGRAD>(p, c, acc, g, mtile, ntile, split, wm, wn, li, lh, ohw,
+                                            reinterpret_cast<int *>(smem));
+    if (DGRAD && p.cls_step == 2) __syncthreads();      // the row table lives in the operand buffers of the next segment
   }
   }  // while (u0 < u1)
 }
@@ -668,7 +714,9 @@ __global__ __launch_bounds__(256) void igemm_fixup_kernel(IgemmParams p, int P) 
   const int mt_all = wg / p.ntiles;
   const int g = mt_all / c.mtiles_per_group;
   const int mtile = mt_all - g * c.mtiles_per_group;
-  igemm_epilogue<BM, BN, WGM, WGN, DGRAD>(p, c, acc, g, mtile, ntile, 0, wm, wn, li, lh, c.out_h * c.out_w);
+  __shared__ int row_lds[DGRAD ? BM : 1];
+  igemm_epilogue<BM, BN, WGM, WGN, DGRAD>(p, c, acc, g, mtile, ntile, 0, wm, wn, li, lh, c.out_h * c.out_w,
+                                          DGRAD ? row_lds : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------
