@@ -200,6 +200,20 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams &p, const Igemm
   }
   if (p.splits > 1) {       // raw partial tile -> slab; the epilogue runs in splitk_reduce_kernel
     float *slab = p.slab + (long long)split * p.groups * c.rows_per_group * p.ncols;
+    if (row_base + WTM <= c.rows_per_group && ntile * BN + wn * WTN + WTN <= p.ncols &&
+        c.rows_per_group * (long long)p.ncols < (1ll << 30)) {           // interior block: no predicates
+      float *slab_t = slab + (grow0 + row_base) * p.ncols;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const unsigned lane_off = (unsigned)(4 * lh) * (unsigned)p.ncols + (unsigned)(ntile * BN + wn * WTN + j * 32 + li);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            slab_t[(unsigned)(i * 32 + (e & 3) + 8 * (e >> 2)) * (unsigned)p.ncols + lane_off] = acc[i][j][e];
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = ntile * BN + wn * WTN + j * 32 + li;
