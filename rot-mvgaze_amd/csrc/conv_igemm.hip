@@ -1802,7 +1802,10 @@ static int launch_igemm(IgemmParams &p, TileChoice t, hipStream_t st) {
     if (fasta) return launch_igemm_tile<128, 64, 16, 2, 2, DGRAD, true>(p, tiles, units, st);
     return launch_igemm_tile<128, 64, 16, 2, 2, DGRAD>(p, tiles, units, st);
   }
-  if (t.bm == 64 && t.bn == 64) return launch_igemm_tile<64, 64, 16, 2, 2, DGRAD>(p, tiles, units, st);
+  if (t.bm == 64 && t.bn == 64) {
+    if (fasta) return launch_igemm_tile<64, 64, 16, 2, 2, DGRAD, true>(p, tiles, units, st);     // the fusion block's Linears
+    return launch_igemm_tile<64, 64, 16, 2, 2, DGRAD>(p, tiles, units, st);
+  }
   return launch_igemm_tile<128, 32, 16, 4, 1, DGRAD>(p, tiles, units, st);
 }
 
