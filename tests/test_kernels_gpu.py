@@ -56,6 +56,8 @@ CONV_CASES = [
     (2, 16, 56, 56, 64, 128, 3, 2, 1),    # stride 2: stream-K fprop, parity-class dgrad
     (1, 30, 14, 14, 256, 256, 3, 1, 1),   # ragged last M tile (5880 rows) under stream-K
     (1, 24, 57, 57, 64, 64, 1, 1, 0),     # 1219 BN partials (ragged last one): two-level bn_finalize
+    (1, 4, 20, 20, 16, 64, 3, 1, 1),      # 16 channels per tap: uniform-tap loader with tap-major K order
+    (2, 6, 30, 30, 16, 128, 3, 2, 1),     # same, stride 2 (dgrad classes over 128 channels)
 ]
 
 
