@@ -128,11 +128,19 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
+        # MVG_DIST_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (the
+        # ranks share the devices, gradients travel through the host); never a measurement
+        backend = os.environ.get("MVG_DIST_BACKEND", "nccl")
+        if backend != "nccl":
+            local_rank %= max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
         # the gradient stream is ~160-360 MB per step: 8 RCCL channels move it inside backward and leave
         # the CUs to the persistent conv kernels (see rot_mvgaze_amd/dp.py)
         os.environ.setdefault("NCCL_MAX_NCHANNELS", "8")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
 
@@ -251,7 +259,7 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "backbone": f"ResNet-{depth}", "views": V, "batch_per_gpu": B,
-                       "global_batch": B * world, "image": "3x224x224", "parallelism": f"dp{world}",
+                       "global_batch": B * world, "image": "3x224x224", "parallelism": f"dp{world}" + ("" if os.environ.get("MVG_DIST_BACKEND", "nccl") == "nccl" else " (REHEARSAL: gloo, ranks share devices - not a measurement)"),
                        "timed_region": ("inference forward (BN folded into conv epilogues)" if args.mode == "eval" else
                                         "forward + loss + backward" + (" + RCCL gradient all-reduce" if world > 1 else "") +
                                         ("" if args.no_optimizer else " + fused Adam step")),
