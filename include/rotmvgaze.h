@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MVG_ABI_VERSION 3
+#define MVG_ABI_VERSION 4
 
 /* ---------------------------------------------------------------- library */
 int mvg_abi_version(void);
@@ -220,6 +220,14 @@ int mvg_nhwc4_to_nchw(const float *src, float *dst, int n, int c, int h, int w, 
  * (x - mean)/std (Normalize, main.py:38-39,54) -> NHWC4 fp32, the backbone's input layout. */
 int mvg_preprocess_u8hwc(const uint8_t *src, float *dst, int n, int h, int w, float mean0, float mean1,
                          float mean2, float std0, float std1, float std2, int swap_rb, void *stream);
+/* The same with the Resize((oh, ow), antialias=True) of main.py:46,53 between ToTensor and Normalize, for
+ * patches that are not already oh x ow (h == oh && w == ow is mvg_preprocess_u8hwc: torchvision returns
+ * the input unchanged).  Resize on a float tensor is torch.nn.functional.interpolate(mode="bilinear",
+ * antialias=True, align_corners=False) (ATen _upsample_bilinear2d_aa): width pass, then height.
+ * dst [n][oh][ow][4]. */
+int mvg_preprocess_u8hwc_resize(const uint8_t *src, float *dst, int n, int h, int w, int oh, int ow, float mean0,
+                                float mean1, float mean2, float std0, float std1, float std2, int swap_rb,
+                                void *stream);
 /* RandomMultiErasing.__call__ utils/augment.py:38-47 on a device batch: img [n][c][h][w] *= the
  * nearest-neighbour upsampling (F.interpolate default, augment.py:21) of masks[n] (grid[n] x grid[n]
  * floats in a gmax*gmax slot); grid[n] == 0 leaves image n untouched.  The random draws stay on the

@@ -407,3 +407,74 @@ def build_pair_index(file_rows: Sequence[int], camera_tag: str, rng: MT19937) ->
             if cand:
                 out.append((fi, idx, cand[rng.randbelow(len(cand))]))
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# input pipeline: ToTensor -> Resize((S, S), antialias=True) -> Normalize   (main.py:38-56)
+# --------------------------------------------------------------------------------------------
+def _aa_axis_weights(in_size: int, out_size: int):
+    """Per output index: (first input index, weights) of the antialiased triangle filter that
+    torchvision.transforms.Resize(antialias=True) applies to float tensors.  torchvision is not
+    installed here: its tensor path (transforms/_functional_tensor.py: resize) is one call to
+    torch.nn.functional.interpolate(mode='bilinear', antialias=True, align_corners=False), i.e. ATen
+    `_upsample_bilinear2d_aa` (aten/src/ATen/native/cpu/UpSampleKernel.cpp,
+    `_compute_indices_min_size_weights_aa`), restated here in float32 and pinned against that op's
+    outputs (tests/golden/resize_aa.npz, generated by make_golden.py --resize)."""
+    f32 = np.float32
+    scale = f32(in_size) / f32(out_size)
+    support = scale if scale >= 1.0 else f32(1.0)
+    invscale = f32(1.0) / scale if scale >= 1.0 else f32(1.0)
+    max_k = int(math.ceil(float(support))) * 2 + 1
+    out = []
+    for i in range(out_size):
+        center = scale * f32(i + 0.5)
+        xmin = max(int(center - support + f32(0.5)), 0)
+        xsize = min(int(center + support + f32(0.5)), in_size) - xmin
+        xsize = min(max(xsize, 0), max_k)
+        w = np.zeros(xsize, dtype=f32)
+        for j in range(xsize):
+            t = (f32(j + xmin) - center + f32(0.5)) * invscale
+            w[j] = max(f32(0.0), f32(1.0) - abs(t))
+        tot = f32(0.0)
+        for j in range(xsize):
+            tot = f32(tot + w[j])
+        if tot != 0.0:
+            w = (w / tot).astype(f32)
+        out.append((xmin, w))
+    return out
+
+
+def resize_bilinear_aa(x: np.ndarray, oh: int, ow: int) -> np.ndarray:
+    """x [..., H, W] float32 -> [..., oh, ow]; width pass first, then height (the CPU kernel's order)."""
+    x = np.asarray(x, dtype=np.float32)
+    H, W = x.shape[-2:]
+    if (H, W) == (oh, ow):
+        return x.copy()                                  # torchvision returns the input unchanged
+    wx = _aa_axis_weights(W, ow)
+    tmp = np.zeros(x.shape[:-1] + (ow,), dtype=np.float32)
+    for o, (x0, w) in enumerate(wx):
+        acc = np.zeros(x.shape[:-1], dtype=np.float32)
+        for j in range(len(w)):
+            acc = (acc + w[j] * x[..., x0 + j]).astype(np.float32)
+        tmp[..., o] = acc
+    wy = _aa_axis_weights(H, oh)
+    out = np.zeros(x.shape[:-2] + (oh, ow), dtype=np.float32)
+    for o, (y0, w) in enumerate(wy):
+        acc = np.zeros(tmp.shape[:-2] + (ow,), dtype=np.float32)
+        for j in range(len(w)):
+            acc = (acc + w[j] * tmp[..., y0 + j, :]).astype(np.float32)
+        out[..., o, :] = acc
+    return out
+
+
+def preprocess_u8(img_u8: np.ndarray, size: int, mean, std, swap_rb: bool = False) -> np.ndarray:
+    """uint8 [N,H,W,3] -> float32 [N,3,size,size]: (BGR->RGB, dataset/gaze.py:108-109) -> ToTensor
+    (/255, CHW) -> Resize((size, size), antialias=True) -> Normalize(mean, std)   (main.py:50-55)."""
+    x = np.asarray(img_u8)
+    if swap_rb:
+        x = x[..., ::-1]
+    x = (x.astype(np.float32) / np.float32(255.0)).transpose(0, 3, 1, 2)
+    x = resize_bilinear_aa(x, size, size)
+    m = np.asarray(mean, dtype=np.float32).reshape(1, 3, 1, 1)
+    s = np.asarray(std, dtype=np.float32).reshape(1, 3, 1, 1)
+    return ((x - m) / s).astype(np.float32)

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "librotmvgaze_hip.so")
 
 K_FAMILIES = 18
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class ConvDesc(C.Structure):
@@ -84,6 +84,7 @@ SIGNATURES = {
     "mvg_nchw_to_nhwc4": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "mvg_nhwc4_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "mvg_preprocess_u8hwc": (_I, [_P, _P, _I, _I, _I, _F, _F, _F, _F, _F, _F, _I, _P]),
+    "mvg_preprocess_u8hwc_resize": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _F, _F, _F, _I, _P]),
     "mvg_multi_erase_nchw": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "mvg_rotation_matrix_2d": (_I, [_P, _P, _I, _I, _P]),
     "mvg_relative_rotation": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),

@@ -147,14 +147,17 @@ class Backbone:
         ops.maxpool_fwd(a0, x, argmax, G * N, h, w, c, hp, wp_)
         return x, argmax
 
-    def forward(self, imgs: List[Tensor], training: bool, keep_tape: bool, input_bgr: bool = False):
+    def forward(self, imgs: List[Tensor], training: bool, keep_tape: bool, input_bgr: bool = False,
+                input_size: Optional[int] = None):
         """imgs: V tensors [B,3,H,W] fp32 NCHW (the reference's input format, rot_mv.py:188-189), or
-        V raw uint8 [B,H,W,3] face patches, normalised on the GPU.
-        Returns (img_feat [V,B,fc_dim], tape or None)."""
+        V raw uint8 [B,H,W,3] face patches, put through test_transform of main.py:50-55 on the GPU
+        (ToTensor, Resize((input_size, input_size), antialias=True) when the patch has another size,
+        Normalize).  Returns (img_feat [V,B,fc_dim], tape or None)."""
         V = len(imgs)
         raw = imgs[0].dtype == torch.uint8
         if raw:
-            B, H, W, C = imgs[0].shape
+            B, Hin, Win, C = imgs[0].shape
+            H, W = (input_size, input_size) if input_size else (Hin, Win)
         else:
             B, C, H, W = imgs[0].shape
         assert C == 3
@@ -163,7 +166,7 @@ class Backbone:
         for v, im in enumerate(imgs):
             assert im.shape == imgs[0].shape and im.is_cuda and im.dtype == imgs[0].dtype
             if raw:
-                ops.preprocess_u8hwc(im.contiguous(), x0[v], B, H, W, IMAGE_MEAN, IMAGE_STD, input_bgr)
+                ops.preprocess_u8hwc_resize(im.contiguous(), x0[v], B, Hin, Win, H, W, IMAGE_MEAN, IMAGE_STD, input_bgr)
             else:
                 assert im.dtype == torch.float32
                 ops.nchw_to_nhwc4(im.detach().contiguous(), x0[v], B, 3, H, W)

@@ -147,6 +147,73 @@ __global__ __launch_bounds__(256) void preprocess_u8_kernel(const unsigned char 
   dst[i] = make_float4(c0, c1, c2, 0.f);
 }
 
+// test_transform of main.py:50-55 for patches that are not already S x S: ToTensor (/255) ->
+// Resize((S, S), antialias=True) -> Normalize, fused, NHWC4 out.  torchvision's tensor Resize is
+// torch.nn.functional.interpolate(mode="bilinear", antialias=True, align_corners=False) = ATen
+// _upsample_bilinear2d_aa: per axis a triangle filter of half-width max(scale, 1) input pixels around
+// scale * (i + 0.5), weights normalised by their float32 sum (UpSampleKernel.cpp,
+// _compute_indices_min_size_weights_aa); width pass first, then height.  One thread per output pixel;
+// the weights are recomputed per thread (<= (2*ceil(scale)+1)^2 filter evaluations).
+struct AaAxis {
+  float scale, support, invscale;
+  int in_size, max_k;
+};
+__device__ __forceinline__ void aa_window(const AaAxis &a, int i, float &center, int &x0, int &xs, float &total) {
+  center = a.scale * ((float)i + 0.5f);
+  x0 = (int)(center - a.support + 0.5f);
+  if (x0 < 0) x0 = 0;
+  int hi = (int)(center + a.support + 0.5f);
+  if (hi > a.in_size) hi = a.in_size;
+  xs = hi - x0;
+  xs = xs < 0 ? 0 : (xs > a.max_k ? a.max_k : xs);
+  total = 0.f;
+  for (int j = 0; j < xs; ++j) {
+    const float t = ((float)(j + x0) - center + 0.5f) * a.invscale;
+    total = __fadd_rn(total, fmaxf(0.f, 1.f - fabsf(t)));
+  }
+}
+__device__ __forceinline__ float aa_weight(const AaAxis &a, int j, int x0, float center, float total) {
+  const float t = ((float)(j + x0) - center + 0.5f) * a.invscale;
+  const float w = fmaxf(0.f, 1.f - fabsf(t));
+  return total != 0.f ? w / total : w;
+}
+__global__ __launch_bounds__(256) void preprocess_u8_resize_kernel(const unsigned char *__restrict__ src,
+                                                                   float4 *__restrict__ dst, int n, int h, int w, int oh,
+                                                                   int ow, AaAxis ay, AaAxis ax, float m0, float m1,
+                                                                   float m2, float s0, float s1, float s2, int swap_rb) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)n * oh * ow) return;
+  const int ox = (int)(i % ow);
+  const long long r = i / ow;
+  const int oy = (int)(r % oh), img = (int)(r / oh);
+  float cx, cy, tx, ty;
+  int x0, xs, y0, ys;
+  aa_window(ax, ox, cx, x0, xs, tx);
+  aa_window(ay, oy, cy, y0, ys, ty);
+  const unsigned char *base = src + (long long)img * h * w * 3;
+  float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+  for (int jy = 0; jy < ys; ++jy) {
+    const unsigned char *row = base + ((long long)(y0 + jy) * w + x0) * 3;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+    for (int jx = 0; jx < xs; ++jx) {
+      const float wx = aa_weight(ax, jx, x0, cx, tx);
+      t0 = __fadd_rn(t0, __fmul_rn(wx, (float)row[3 * jx] / 255.0f));
+      t1 = __fadd_rn(t1, __fmul_rn(wx, (float)row[3 * jx + 1] / 255.0f));
+      t2 = __fadd_rn(t2, __fmul_rn(wx, (float)row[3 * jx + 2] / 255.0f));
+    }
+    const float wy = aa_weight(ay, jy, y0, cy, ty);
+    o0 = __fadd_rn(o0, __fmul_rn(wy, t0));
+    o1 = __fadd_rn(o1, __fmul_rn(wy, t1));
+    o2 = __fadd_rn(o2, __fmul_rn(wy, t2));
+  }
+  if (swap_rb) {
+    const float t = o0;
+    o0 = o2;
+    o2 = t;
+  }
+  dst[i] = make_float4((o0 - m0) / s0, (o1 - m1) / s1, (o2 - m2) / s2, 0.f);
+}
+
 // RandomMultiErasing (utils/augment.py:10-47): img *= nearest-neighbour upsampling of a per-image
 // g x g keep-mask (F.interpolate default mode: src = min(int(floorf(dst * (float)g / size)), g - 1)).
 // grid[n] == 0: this image is not erased.  NCHW in place.
@@ -235,6 +302,30 @@ int mvg_preprocess_u8hwc(const uint8_t *src, float *dst, int n, int h, int w, fl
   hipLaunchKernelGGL(preprocess_u8_kernel, dim3(ceil_div(pixels, 256)), dim3(256), 0, st, src, (float4 *)dst, pixels, mean0,
                      mean1, mean2, std0, std1, std2, swap_rb);
   return check_launch("preprocess_u8hwc");
+}
+
+static AaAxis aa_axis(int in_size, int out_size) {
+  AaAxis a;
+  a.scale = (float)in_size / (float)out_size;
+  a.support = a.scale >= 1.f ? a.scale : 1.f;
+  a.invscale = a.scale >= 1.f ? 1.f / a.scale : 1.f;
+  a.in_size = in_size;
+  a.max_k = (int)ceilf(a.support) * 2 + 1;
+  return a;
+}
+
+int mvg_preprocess_u8hwc_resize(const uint8_t *src, float *dst, int n, int h, int w, int oh, int ow, float mean0,
+                                float mean1, float mean2, float std0, float std1, float std2, int swap_rb, void *stream) {
+  MVG_REQUIRE(std0 > 0.f && std1 > 0.f && std2 > 0.f, "preprocess: std must be positive");
+  MVG_REQUIRE(n > 0 && h > 0 && w > 0 && oh > 0 && ow > 0, "preprocess_resize: bad sizes");
+  if (h == oh && w == ow)      // torchvision's resize returns the input unchanged
+    return mvg_preprocess_u8hwc(src, dst, n, h, w, mean0, mean1, mean2, std0, std1, std2, swap_rb, stream);
+  hipStream_t st = (hipStream_t)stream;
+  const long long pixels = (long long)n * oh * ow;
+  ProfScope ps(MVG_K_LAYOUT, st, 0.0, 3.0 * (double)n * h * w + 16.0 * (double)pixels);
+  hipLaunchKernelGGL(preprocess_u8_resize_kernel, dim3(ceil_div(pixels, 256)), dim3(256), 0, st, src, (float4 *)dst, n, h, w,
+                     oh, ow, aa_axis(h, oh), aa_axis(w, ow), mean0, mean1, mean2, std0, std1, std2, swap_rb);
+  return check_launch("preprocess_u8hwc_resize");
 }
 
 int mvg_multi_erase_nchw(float *img, const float *masks, const int32_t *grid, int gmax, int n, int c, int h, int w,

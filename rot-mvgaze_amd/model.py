@@ -102,7 +102,7 @@ class _BackboneFn(torch.autograd.Function):
         imgs = list(tensors[:n_views])
         ctx.set_materialize_grads(False)
         keep = any(ctx.needs_input_grad)          # False under no_grad / when nothing requires grad
-        feat, tape = model._backbone.forward(imgs, training, keep, model.input_bgr)
+        feat, tape = model._backbone.forward(imgs, training, keep, model.input_bgr, model.input_size)
         ctx.model, ctx.tape, ctx.n_views = model, tape, n_views
         if model._debug_keep_tapes:
             model._last_backbone_tape = tape
@@ -197,6 +197,7 @@ class MultiViewGaze(nn.Module):
         self._layout_sig = None
         self._debug_keep_tapes = False            # tests: keep references to the saved activations
         self.input_bgr = False                    # raw uint8 inputs: swap B and R first (dataset color_type 'bgr')
+        self.input_size: Optional[int] = 224      # raw uint8 inputs: Resize((S, S), antialias=True), main.py:40,53; None = keep
         self._sink = _ArenaSink(self)
 
     # ---------------------------------------------------------------- plumbing

@@ -215,6 +215,11 @@ def multi_erase_nchw(img, masks, grid, gmax, n, c, h, w):
     check(lib().mvg_multi_erase_nchw(_p(img), _p(masks), _p(grid), gmax, n, c, h, w, _s()), "multi_erase_nchw")
 
 
+def preprocess_u8hwc_resize(src, dst, n, h, w, oh, ow, mean, std, swap_rb):
+    check(lib().mvg_preprocess_u8hwc_resize(_p(src), _p(dst), n, h, w, oh, ow, mean[0], mean[1], mean[2], std[0], std[1],
+                                            std[2], int(swap_rb), _s()), "preprocess_u8hwc_resize")
+
+
 def preprocess_u8hwc(src, dst, n, h, w, mean, std, swap_rb):
     check(lib().mvg_preprocess_u8hwc(_p(src), _p(dst), n, h, w, mean[0], mean[1], mean[2], std[0], std[1], std[2],
                                      int(swap_rb), _s()), "preprocess_u8hwc")

@@ -304,6 +304,32 @@ def gen_multi_erase():
     print("multi_erase: erased images", int((out != imgs).flatten(1).any(1).sum()), "of 10")
 
 
+RESIZE_CASES = [(2, 37, 41, 24), (1, 100, 90, 64), (1, 50, 60, 96), (1, 96, 96, 48), (1, 64, 64, 64)]   # n, h, w, size
+
+
+def gen_resize():
+    """test_transform of main.py:50-55 on raw uint8 patches of other sizes than 224: ToTensor ->
+    Resize((S, S), antialias=True) -> Normalize.  torchvision is not installed in this image; its
+    tensor Resize is one call to torch.nn.functional.interpolate(mode='bilinear', antialias=True,
+    align_corners=False) (torchvision/transforms/_functional_tensor.py: resize), which is what
+    generates these vectors (small output sizes keep the fixture small; the op is size-generic)."""
+    import torch.nn.functional as F
+    mean = np.array([0.485, 0.456, 0.406], dtype=np.float32).reshape(1, 3, 1, 1)      # main.py:38-39
+    std = np.array([0.229, 0.224, 0.225], dtype=np.float32).reshape(1, 3, 1, 1)
+    out = {}
+    for idx, (n, h, w, size) in enumerate(RESIZE_CASES):
+        rng = np.random.default_rng(100 + idx)
+        u8 = rng.integers(0, 256, size=(n, h, w, 3), dtype=np.uint8)
+        x = torch.from_numpy(u8).permute(0, 3, 1, 2).to(torch.float32).div(255)       # ToTensor
+        if (h, w) != (size, size):
+            x = F.interpolate(x, size=(size, size), mode="bilinear", antialias=True, align_corners=False)
+        y = (x - torch.from_numpy(mean)) / torch.from_numpy(std)                        # Normalize
+        out[f"u8_{idx}"] = u8
+        out[f"y_{idx}"] = y.numpy()
+    np.savez_compressed(os.path.join(HERE, "resize_aa.npz"), **out)
+    print("resize_aa:", len(RESIZE_CASES), "cases")
+
+
 def gen_variants():
     from rot_mvgaze_amd.arch import Variant
     gen_variant("share_weights", Variant(share_weights=True))
@@ -320,6 +346,9 @@ if __name__ == "__main__":
     if "--erase" in sys.argv:
         gen_multi_erase()
         sys.exit(0)
+    if "--resize" in sys.argv:
+        gen_resize()
+        sys.exit(0)
     gen_geometry()
     gen_pair_index()
     gen_model(18, 2, 224)
@@ -328,3 +357,4 @@ if __name__ == "__main__":
     gen_model(50, 3, 64)
     gen_variants()
     gen_multi_erase()
+    gen_resize()

@@ -444,6 +444,38 @@ def test_multi_erase_kernel_matches_reference_fixture(golden_dir):
     assert np.array_equal(out.cpu().numpy(), g["out"])
 
 
+RESIZE_CASES = [(2, 37, 41, 24), (1, 100, 90, 64), (1, 50, 60, 96), (1, 96, 96, 48), (1, 64, 64, 64)]   # n, h, w, size
+IMAGE_MEAN, IMAGE_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+
+def _resize_gpu(u8, size, swap=False):
+    from rot_mvgaze_amd import ops
+    n, h, w, _ = u8.shape
+    dst = torch.empty(n, size, size, 4, device=dev())
+    ops.preprocess_u8hwc_resize(torch.from_numpy(u8).to(dev()), dst, n, h, w, size, size, IMAGE_MEAN, IMAGE_STD, swap)
+    out = dst.cpu().numpy()
+    assert np.all(out[..., 3] == 0)
+    return np.ascontiguousarray(out[..., :3].transpose(0, 3, 1, 2))
+
+
+def test_preprocess_resize_matches_aten_fixture_and_oracle(golden_dir):
+    """mvg_preprocess_u8hwc_resize (ToTensor -> Resize((S, S), antialias=True) -> Normalize of
+    main.py:50-55, NHWC4 out) against the ATen-generated fixture (tests/golden/resize_aa.npz) and, at the
+    benchmark's 224 x 224 output from 256 x 240 and 180 x 200 patches, against the oracle restatement.
+    Tolerance 3e-6 absolute on the normalised values (float32 summation order; values are O(1))."""
+    from oracle import restatement as R
+    g = np.load(os.path.join(golden_dir, "resize_aa.npz"))
+    for idx, (n, h, w, size) in enumerate(RESIZE_CASES):
+        got = _resize_gpu(g[f"u8_{idx}"], size)
+        np.testing.assert_allclose(got, g[f"y_{idx}"], rtol=0, atol=3e-6)
+    rng = np.random.default_rng(5)
+    for (h, w) in ((256, 240), (180, 200), (224, 224)):
+        u8 = rng.integers(0, 256, size=(2, h, w, 3), dtype=np.uint8)
+        for swap in (False, True):
+            np.testing.assert_allclose(_resize_gpu(u8, 224, swap), R.preprocess_u8(u8, 224, IMAGE_MEAN, IMAGE_STD, swap),
+                                       rtol=0, atol=3e-6)
+
+
 def test_bad_arguments_fail_with_a_message():
     """Error convention of the C ABI: non-zero return code + mvg_last_error() text, surfaced
     by the host layer as RuntimeError - never a silent wrong answer or a device fault."""

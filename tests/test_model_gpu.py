@@ -524,11 +524,36 @@ def test_raw_uint8_input_pipeline():
     for bgr in (False, True):
         m = build(18, train=False)
         m.input_bgr = bgr
+        m.input_size = None                       # keep the patch size (the reference resizes to 224: next test)
         with torch.no_grad():
             a = m({"img_0": u8[0].to(dev()), "img_1": u8[1].to(dev()), "rot_0": d["rot_0"], "rot_1": d["rot_1"]})
             b = m({"img_0": host(u8[0], bgr).to(dev()), "img_1": host(u8[1], bgr).to(dev()),
                    "rot_0": d["rot_0"], "rot_1": d["rot_1"]})
         assert torch.equal(a["pred_gaze"], b["pred_gaze"]) and torch.equal(a["img_feat_1"], b["img_feat_1"])
+
+
+def test_raw_uint8_input_is_resized_like_the_reference_transform():
+    """test_transform of main.py:50-55 on the GPU: uint8 patches of another size go through
+    Resize((input_size, input_size), antialias=True) between ToTensor and Normalize.  The float path is
+    fed with the oracle's restatement of that transform (pinned to the ATen op torchvision calls:
+    tests/golden/resize_aa.npz); the resize kernel itself is held to 3e-6 in tests/test_kernels_gpu.py,
+    here the predictions must agree within the model tolerance."""
+    from oracle import restatement as R
+    rng = np.random.default_rng(1)
+    B, size = 3, 64
+    u8 = [rng.integers(0, 256, size=(B, 100, 90, 3), dtype=np.uint8) for _ in range(2)]
+    d = inputs(B, size)
+    m = build(18, train=False)
+    m.input_size = size
+    assert build(18, train=False).input_size == 224          # main.py:40
+    host = [torch.from_numpy(R.preprocess_u8(x, size, (0.485, 0.456, 0.406), (0.229, 0.224, 0.225))) for x in u8]
+    with torch.no_grad():
+        a = m({"img_0": torch.from_numpy(u8[0]).to(dev()), "img_1": torch.from_numpy(u8[1]).to(dev()),
+               "rot_0": d["rot_0"], "rot_1": d["rot_1"]})
+        b = m({"img_0": host[0].to(dev()), "img_1": host[1].to(dev()), "rot_0": d["rot_0"], "rot_1": d["rot_1"]})
+    assert a["pred_gaze"].shape == b["pred_gaze"].shape
+    rel = (a["pred_gaze"] - b["pred_gaze"]).abs().max() / b["pred_gaze"].abs().max()
+    assert rel < 1e-4, rel
 
 
 def test_view_swap_symmetry_eval():

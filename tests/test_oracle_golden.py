@@ -255,3 +255,25 @@ def test_multi_erase_draws_match_reference(golden_dir):
         if gs:
             out[i] *= F.interpolate(m[None, None], (40, 56)).squeeze()
     assert np.array_equal(out.numpy(), g["out"])
+
+
+RESIZE_CASES = [(2, 37, 41, 24), (1, 100, 90, 64), (1, 50, 60, 96), (1, 96, 96, 48), (1, 64, 64, 64)]   # n, h, w, size
+IMAGE_MEAN, IMAGE_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)                                      # main.py:38-39
+
+
+def test_resize_restatement_matches_aten_fixture(golden_dir):
+    """oracle.restatement.preprocess_u8 (ToTensor -> Resize(antialias=True) -> Normalize, main.py:50-55)
+    against vectors produced by the ATen op torchvision's tensor Resize calls (make_golden.py --resize;
+    torchvision itself is not installed: pinned to torch.nn.functional.interpolate(antialias=True)).
+    Tolerance 2e-6 absolute on the normalised values: float32 rounding order of the two passes."""
+    g = _load(golden_dir, "resize_aa.npz")
+    for idx, (n, h, w, size) in enumerate(RESIZE_CASES):
+        u8 = g[f"u8_{idx}"]
+        assert u8.shape == (n, h, w, 3)
+        y = R.preprocess_u8(u8, size, IMAGE_MEAN, IMAGE_STD)
+        np.testing.assert_allclose(y, g[f"y_{idx}"], rtol=0, atol=2e-6)
+    # BGR input: swapping before or after the (per-channel) resize is the same thing
+    u8 = g["u8_1"]
+    a = R.preprocess_u8(u8, 64, IMAGE_MEAN, IMAGE_STD, swap_rb=True)
+    b = R.preprocess_u8(np.ascontiguousarray(u8[..., ::-1]), 64, IMAGE_MEAN, IMAGE_STD)
+    assert np.array_equal(a, b)
