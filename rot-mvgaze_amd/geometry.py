@@ -1,7 +1,8 @@
 """Geometry helpers with the reference's names and argument meaning, computed by HIP kernels.
 
 Mirrors /root/reference/utils/math.py: ``rotation_matrix_2d`` (:188-219), ``pitchyaw_to_vector``
-(:24-60) and ``angular_error`` (:97-136).  Device tensors only - there is no CPU fallback.
+(:24-60), ``vector_to_pitchyaw`` (:62-94) and ``angular_error`` (:97-136).  The functions on the path take
+device tensors only - there is no CPU fallback.
 """
 from __future__ import annotations
 
@@ -36,6 +37,23 @@ def pitchyaw_to_vector(pitchyaws: torch.Tensor) -> torch.Tensor:
     rot = torch.empty(py.shape[0], 3, 3, dtype=torch.float32, device=py.device)
     ops.rotation_matrix_2d(py, rot, False)
     return rot[:, :, 2].contiguous()
+
+
+def vector_to_pitchyaw(vectors):
+    """math.py:62-94: gaze vectors [N,3] (any length) -> (pitch, yaw) = (asin(y/|v|), atan2(x, z)), of the
+    input's type.  The reference imports it next to the functions above (trainer.py:26,
+    losses/gaze_loss.py:6) but never calls it on the training/eval path, so it is plain tensor/array
+    arithmetic here (device tensors stay on the device), not a kernel."""
+    if isinstance(vectors, np.ndarray):
+        v = vectors / np.linalg.norm(vectors, axis=1).reshape(-1, 1)
+        out = np.empty((v.shape[0], 2))
+        out[:, 0] = np.arcsin(v[:, 1])
+        out[:, 1] = np.arctan2(v[:, 0], v[:, 2])
+        return out
+    if isinstance(vectors, torch.Tensor):
+        v = vectors / torch.norm(vectors, dim=1).reshape(-1, 1)
+        return torch.stack([torch.asin(v[:, 1]), torch.atan2(v[:, 0], v[:, 2])], dim=1)
+    raise ValueError("Unsupported input type. Only numpy arrays and torch tensors are supported.")
 
 
 def angular_error(a, b):

@@ -96,6 +96,17 @@ def gen_geometry():
     print("geometry_loss: loss", float(loss), "known-answer", float(l2))
 
 
+def gen_vec2py():
+    """utils/math.py:62-94 (imported by trainer.py:26 and losses/gaze_loss.py:6, not called on the path):
+    vector_to_pitchyaw on un-normalised vectors, torch and numpy branches."""
+    v = torch.tensor(synth.normal(96, 9, "vec2py").reshape(32, 3), dtype=torch.float32)
+    v[0] = torch.tensor([0.0, 0.0, 2.0])
+    out = {"v": t2n(v), "py_torch": t2n(ref_math.vector_to_pitchyaw(v)),
+           "py_numpy": ref_math.vector_to_pitchyaw(t2n(v).astype(np.float64))}
+    np.savez_compressed(os.path.join(HERE, "vector_to_pitchyaw.npz"), **out)
+    print("vector_to_pitchyaw: 32 vectors")
+
+
 def gen_pair_index():
     """A10: run the reference GazeDataset.__init__ against a fake in-memory h5py."""
     import dataset.gaze as ref_gaze
@@ -346,6 +357,9 @@ if __name__ == "__main__":
     if "--erase" in sys.argv:
         gen_multi_erase()
         sys.exit(0)
+    if "--vec2py" in sys.argv:
+        gen_vec2py()
+        sys.exit(0)
     if "--resize" in sys.argv:
         gen_resize()
         sys.exit(0)
@@ -358,3 +372,4 @@ if __name__ == "__main__":
     gen_variants()
     gen_multi_erase()
     gen_resize()
+    gen_vec2py()

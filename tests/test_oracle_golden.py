@@ -277,3 +277,16 @@ def test_resize_restatement_matches_aten_fixture(golden_dir):
     a = R.preprocess_u8(u8, 64, IMAGE_MEAN, IMAGE_STD, swap_rb=True)
     b = R.preprocess_u8(np.ascontiguousarray(u8[..., ::-1]), 64, IMAGE_MEAN, IMAGE_STD)
     assert np.array_equal(a, b)
+
+
+def test_vector_to_pitchyaw_matches_reference(golden_dir):
+    """rot_mvgaze_amd.geometry.vector_to_pitchyaw (utils/math.py:62-94; imported by trainer.py:26, unused
+    on the path) against the reference's own outputs, numpy (float64) and torch (float32) branches."""
+    from rot_mvgaze_amd.geometry import vector_to_pitchyaw
+    g = _load(golden_dir, "vector_to_pitchyaw.npz")
+    np.testing.assert_allclose(vector_to_pitchyaw(g["v"].astype(np.float64)), g["py_numpy"], rtol=0, atol=1e-12)
+    got = vector_to_pitchyaw(torch.from_numpy(g["v"]))
+    assert got.dtype == torch.float32 and got.shape == (32, 2)
+    np.testing.assert_allclose(got.numpy(), g["py_torch"], rtol=0, atol=1e-6)
+    with pytest.raises(ValueError):
+        vector_to_pitchyaw([[0.0, 0.0, 1.0]])
