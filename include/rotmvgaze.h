@@ -316,6 +316,11 @@ int mvg_adam_step(float *param, const float *grad, float *exp_avg, float *exp_av
 int mvg_gaze_angular_loss(const float *pred, const float *gt, int n, float row_weight,
                           float *loss, int accumulate, float *dpred, float *theta_out, void *stream);
 
+/* gaze_l1_loss / gaze_l2_loss losses/gaze_loss.py:56-64 (GazeLoss loss_type 'l1' / 'l2', :21-29; not used by
+ * StereoL1Loss, which fixes 'angular'): loss[0] = mean over the n elements of |pred - label|^p, p in {1, 2};
+ * dpred (optional, n floats) = d loss / d pred (zero where pred == label, like torch.abs). */
+int mvg_gaze_lp_loss(const float *pred, const float *label, int n, int p, float *loss, float *dpred, void *stream);
+
 /* ---------------------------------------------------------------- stereo pair index (HOST)
  * GazeDataset.__init__'s idx_to_kv build, dataset/gaze.py:39-73, driven by CPython's
  * random.seed(int)/random.choice stream (MT19937 + getrandbits rejection).  Pure host integer

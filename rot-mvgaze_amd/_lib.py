@@ -84,6 +84,7 @@ SIGNATURES = {
     "mvg_nchw_to_nhwc4": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "mvg_nhwc4_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "mvg_preprocess_u8hwc": (_I, [_P, _P, _I, _I, _I, _F, _F, _F, _F, _F, _F, _I, _P]),
+    "mvg_gaze_lp_loss": (_I, [_P, _P, _I, _I, _P, _P, _P]),
     "mvg_preprocess_u8hwc_resize": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _F, _F, _F, _I, _P]),
     "mvg_multi_erase_nchw": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "mvg_rotation_matrix_2d": (_I, [_P, _P, _I, _I, _P]),

@@ -370,6 +370,28 @@ __global__ __launch_bounds__(256) void skinny_bwd_dw_kernel(const float *__restr
   }
 }
 
+// ---- L1 / L2 loss of GazeLoss (losses/gaze_loss.py:56-64): mean |a - b|^p over all elements ----------
+__global__ __launch_bounds__(256) void gaze_lp_loss_kernel(const float *__restrict__ pred, const float *__restrict__ label,
+                                                           int n, int p, float *__restrict__ loss,
+                                                           float *__restrict__ dpred) {
+  __shared__ double sh[4];
+  double local = 0.0;
+  const float inv_n = 1.f / (float)n;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float d = pred[i] - label[i];
+    const float a = fabsf(d);
+    local += (double)(p == 1 ? a : a * a);
+    if (dpred) {
+      const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);      // torch.abs: zero gradient at 0
+      dpred[i] = (p == 1 ? sgn : 2.f * a * sgn) * inv_n;
+    }
+  }
+  local = wave_sum_d(local);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) loss[0] = (float)((sh[0] + sh[1] + sh[2] + sh[3]) / (double)n);
+}
+
 // ---- angular loss ------------------------------------------------------------------------------
 // v(p,y) = (cos p sin y, sin p, cos p cos y); sim = <u/|u|, v/|v|> with the norms clamped at 1e-6
 // (ATen cosine_similarity); clamp to [-1,1] (hardtanh: zero gradient AT and beyond the bounds);
@@ -586,6 +608,14 @@ int mvg_linear_skinny_bwd(const float *dy, const float *x, const float *w, const
     if (check_launch("skinny_bwd_dw")) return 1;
   }
   return 0;
+}
+
+int mvg_gaze_lp_loss(const float *pred, const float *label, int n, int p, float *loss, float *dpred, void *stream) {
+  MVG_REQUIRE(n > 0 && (p == 1 || p == 2), "gaze_lp_loss: n > 0 and p in {1, 2}");
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(MVG_K_LOSS, st, 0.0, 12.0 * n);
+  hipLaunchKernelGGL(gaze_lp_loss_kernel, dim3(1), dim3(256), 0, st, pred, label, n, p, loss, dpred);
+  return check_launch("gaze_lp_loss");
 }
 
 int mvg_gaze_angular_loss(const float *pred, const float *gt, int n, float row_weight, float *loss, int accumulate,

@@ -45,18 +45,52 @@ def gaze_angular_loss(y_hat: Tensor, y: Tensor) -> Tensor:
     return _AngularLossFn.apply(y_hat, y)
 
 
+class _LpLossFn(torch.autograd.Function):
+    """mean |pred - label|^p over all elements (gaze_loss.py:56-64); the gradient comes out of the same launch."""
+
+    @staticmethod
+    def forward(ctx, pred: Tensor, label: Tensor, p: int):
+        if not pred.is_cuda:
+            raise RuntimeError("GazeLoss: the MI355X path needs device tensors (no CPU fallback)")
+        a = pred.detach().to(torch.float32).contiguous()
+        b = label.detach().to(torch.float32).expand_as(a).contiguous()
+        loss = torch.empty(1, dtype=torch.float32, device=a.device)
+        dpred = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        ops.gaze_lp_loss(a, b, a.numel(), p, loss, dpred)
+        ctx.dpred = dpred
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.dpred is None:
+            return None, None, None
+        out = torch.empty_like(ctx.dpred)
+        ops.scale_by(ctx.dpred, g.reshape(1).to(torch.float32).contiguous(), out)
+        return out, None, None
+
+
+def gaze_l1_loss(y: Tensor, y_hat: Tensor) -> Tensor:
+    return _LpLossFn.apply(y, y_hat, 1)
+
+
+def gaze_l2_loss(y: Tensor, y_hat: Tensor) -> Tensor:
+    return _LpLossFn.apply(y, y_hat, 2)
+
+
 class GazeLoss(nn.Module):
     def __init__(self, gaze_weight, loss_type: str, head_weight=1.0):
         super().__init__()
         self.gaze_weight = gaze_weight
         self.head_weight = head_weight
         assert loss_type in ['l1', 'l2', 'angular']
-        if loss_type != 'angular':
-            raise NotImplementedError("only loss_type='angular' is on the hot path (stereo_loss.py:37-39)")
         self.loss_type = loss_type
 
     def forward(self, pred, label):
-        return gaze_angular_loss(pred, label)
+        if self.loss_type == 'angular':                     # the only type StereoL1Loss builds (stereo_loss.py:37-39)
+            return gaze_angular_loss(pred, label)
+        assert pred.shape[-1] == 2 and label.shape[-1] == 2, \
+            f"the prediction should be in pitchyaw [batch, 2], got pred: {pred.shape}, and label should be in pitchyaw, got label: {label.shape}"
+        return gaze_l1_loss(pred, label) if self.loss_type == 'l1' else gaze_l2_loss(pred, label)
 
 
 class AbstractLoss(nn.Module):

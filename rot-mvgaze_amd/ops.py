@@ -303,6 +303,10 @@ def gaze_angular_loss(pred, gt, n, row_weight, loss, accumulate=False, dpred=Non
                                       _s()), "gaze_angular_loss")
 
 
+def gaze_lp_loss(pred, label, n, p, loss, dpred=None):
+    check(lib().mvg_gaze_lp_loss(_p(pred), _p(label), n, p, _p(loss), _p(dpred), _s()), "gaze_lp_loss")
+
+
 # ---------------------------------------------------------------- profiling
 def prof_enable(on: bool):
     lib().mvg_prof_enable(int(on))

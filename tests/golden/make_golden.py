@@ -96,6 +96,22 @@ def gen_geometry():
     print("geometry_loss: loss", float(loss), "known-answer", float(l2))
 
 
+def gen_lp_loss():
+    """GazeLoss loss_type 'l1' / 'l2' (losses/gaze_loss.py:21-29,56-64): value and gradient wrt pred."""
+    pred = torch.tensor(synth.uniform01(64, 18, "lp_pred").reshape(32, 2) - 0.5, dtype=torch.float32)
+    label = torch.tensor(synth.uniform01(64, 18, "lp_label").reshape(32, 2) - 0.5, dtype=torch.float32)
+    pred[3] = label[3]                                  # |x| at 0: zero gradient
+    out = {"pred": t2n(pred), "label": t2n(label)}
+    for lt in ("l1", "l2"):
+        p = pred.clone().requires_grad_(True)
+        loss = ref_gaze_loss.GazeLoss(gaze_weight=1.0, loss_type=lt)(p, label)
+        loss.backward()
+        out[f"{lt}_loss"] = t2n(loss)
+        out[f"{lt}_dpred"] = t2n(p.grad)
+    np.savez_compressed(os.path.join(HERE, "lp_loss.npz"), **out)
+    print("lp_loss: l1", float(out["l1_loss"]), "l2", float(out["l2_loss"]))
+
+
 def gen_vec2py():
     """utils/math.py:62-94 (imported by trainer.py:26 and losses/gaze_loss.py:6, not called on the path):
     vector_to_pitchyaw on un-normalised vectors, torch and numpy branches."""
@@ -357,6 +373,9 @@ if __name__ == "__main__":
     if "--erase" in sys.argv:
         gen_multi_erase()
         sys.exit(0)
+    if "--lp" in sys.argv:
+        gen_lp_loss()
+        sys.exit(0)
     if "--vec2py" in sys.argv:
         gen_vec2py()
         sys.exit(0)
@@ -373,3 +392,4 @@ if __name__ == "__main__":
     gen_multi_erase()
     gen_resize()
     gen_vec2py()
+    gen_lp_loss()

@@ -387,6 +387,25 @@ def test_geometry_and_loss_golden(golden_dir):
     np.testing.assert_allclose(d2.cpu().numpy(), g["ka_dpred"], rtol=1e-4)
 
 
+def test_gaze_loss_l1_l2_match_reference(golden_dir):
+    """GazeLoss(loss_type='l1' | 'l2') (losses/gaze_loss.py:21-29,56-64) through the host class: value and
+    the gradient autograd hands back, against the reference's own (tests/golden/lp_loss.npz); 1e-6 relative."""
+    from rot_mvgaze_amd.losses import GazeLoss
+    g = np.load(os.path.join(golden_dir, "lp_loss.npz"))
+    label = torch.from_numpy(g["label"]).to(dev())
+    for lt in ("l1", "l2"):
+        pred = torch.from_numpy(g["pred"]).to(dev()).requires_grad_(True)
+        loss = GazeLoss(gaze_weight=1.0, loss_type=lt)(pred, label)
+        (3.0 * loss).backward()
+        np.testing.assert_allclose(loss.item(), g[f"{lt}_loss"], rtol=1e-6)
+        np.testing.assert_allclose(pred.grad.cpu().numpy(), 3.0 * g[f"{lt}_dpred"], rtol=1e-6, atol=1e-9)
+        assert pred.grad[3].abs().max().item() == 0.0           # pred == label: torch.abs has zero gradient there
+    with pytest.raises(AssertionError):
+        GazeLoss(1.0, "huber")
+    with pytest.raises(AssertionError):
+        GazeLoss(1.0, "l1")(torch.zeros(4, 3, device=dev()), torch.zeros(4, 3, device=dev()))
+
+
 def test_rotcat_and_relative_rotation():
     from rot_mvgaze_amd import ops
     B, V, cf, nvec = 5, 3, 512, 512
