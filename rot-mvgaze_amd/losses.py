@@ -205,7 +205,11 @@ class MultiViewIterationLoss(AbstractLoss):
         V = out["views"]
         vi, _ = directed_pairs(V)
         npairs = D // 2
-        gt_dir = gt.to(torch.float32).permute(1, 0, 2)[vi].contiguous()          # [D,B,2] (index plumbing)
+        # [D,B,2] (index plumbing).  Slices, not gt[...][vi]: indexing with a Python list builds the index
+        # tensor on the host and its pageable H2D copy waits for the stream - a host/GPU sync per step
+        # that stops the host from queueing the next step's launches under this step's backward
+        g32 = gt.to(torch.float32)
+        gt_dir = torch.stack([g32[:, v] for v in vi], 0)
         iw = [self._iter_decay ** (I - 1 - i) for i in range(I)]
         dw = [(self._rel_weight if d % 2 == 0 else self._rel_weight * self._reference_decay) / npairs
               for d in range(D)]
