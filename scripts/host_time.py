@@ -55,3 +55,33 @@ for it in range(4):
     opt.step(); t.append(time.perf_counter())
     print(f"step {it}: zero {1e3*(t[1]-t[0]):.2f} fwd {1e3*(t[2]-t[1]):.2f} loss {1e3*(t[3]-t[2]):.2f} bwd {1e3*(t[4]-t[3]):.2f} opt {1e3*(t[5]-t[4]):.2f}", flush=True)
 torch.cuda.synchronize()
+
+# the reference's own API (FeatRotationSymm(dict) + IterationLoss(StereoL1Loss), main.py:231-240)
+from rot_mvgaze_amd.model import FeatRotationSymm
+from rot_mvgaze_amd.losses import StereoL1Loss, IterationLoss
+m2 = FeatRotationSymm(18, 3)
+m2.load_state_dict(model.state_dict(), strict=True)
+m2.to(dev).train()
+crit2 = IterationLoss(StereoL1Loss(rel_weight=0.01, reference_decay=1.0), iter_decay=0.5)
+opt2 = Adam(m2.parameters(), lr=1e-4, weight_decay=1e-6)
+img_nchw = [i for i in img]
+def data():
+    return {"img_0": img_nchw[0], "img_1": img_nchw[1], "rot_0": rot[:, 0].contiguous(), "rot_1": rot[:, 1].contiguous(),
+            "gt_gaze": gt[:, 0].contiguous(), "gt_gaze_1": gt[:, 1].contiguous()}
+for _ in range(3):
+    opt2.zero_grad(); d = m2(data()); crit2(d).backward(); opt2.step()
+torch.cuda.synchronize()
+for it in range(4):
+    t = [time.perf_counter()]
+    opt2.zero_grad(); t.append(time.perf_counter())
+    d = m2(data()); t.append(time.perf_counter())
+    loss = crit2(d); t.append(time.perf_counter())
+    loss.backward(); t.append(time.perf_counter())
+    opt2.step(); t.append(time.perf_counter())
+    print(f"dict API step {it}: zero {1e3*(t[1]-t[0]):.2f} fwd {1e3*(t[2]-t[1]):.2f} loss {1e3*(t[3]-t[2]):.2f} bwd {1e3*(t[4]-t[3]):.2f} opt {1e3*(t[5]-t[4]):.2f}", flush=True)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(20):
+    opt2.zero_grad(); d = m2(data()); crit2(d).backward(); opt2.step()
+torch.cuda.synchronize()
+print(f"dict API: {1e3*(time.perf_counter()-t0)/20:.2f} ms/step")
