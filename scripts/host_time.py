@@ -85,3 +85,14 @@ for _ in range(20):
     opt2.zero_grad(); d = m2(data()); crit2(d).backward(); opt2.step()
 torch.cuda.synchronize()
 print(f"dict API: {1e3*(time.perf_counter()-t0)/20:.2f} ms/step")
+
+# is the host ahead of the GPU with slack?  add host-only delay per step and watch the step time
+for delay in (0.0, 0.002, 0.005, 0.008):
+    torch.cuda.synchronize()
+    for _ in range(3): step()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        time.sleep(delay) if delay else None
+        step()
+    torch.cuda.synchronize()
+    print(f"host delay {1e3*delay:.0f} ms/step -> {1e3*(time.perf_counter()-t0)/20:.2f} ms/step", flush=True)
