@@ -556,6 +556,43 @@ def test_raw_uint8_input_is_resized_like_the_reference_transform():
     assert rel < 1e-4, rel
 
 
+def test_training_step_does_not_synchronise_the_host():
+    """Neither API's training step may contain a host/GPU synchronisation (a device value read on the
+    host, a copy from pageable memory - e.g. indexing a device tensor with a Python list): one such copy
+    in the loss held the whole step back by 5-7 %.  torch's sync debug mode raises on the synchronising
+    calls torch itself would make; the library's own launches never synchronise."""
+    from rot_mvgaze_amd.losses import MultiViewIterationLoss
+    from rot_mvgaze_amd.optim import Adam
+    m = build(18)
+    crit, crit_mv = metrics(), MultiViewIterationLoss(rel_weight=0.01, reference_decay=1.0, iter_decay=0.5)
+    opt = Adam(m.parameters(), lr=1e-4, weight_decay=1e-6)
+    d = inputs(4, 64)
+    img = [d["img_0"], d["img_1"]]
+    rot = torch.stack([d["rot_0"], d["rot_1"]], 1).contiguous()
+    gt = torch.stack([d["gt_gaze"], d["gt_gaze_1"]], 1).contiguous()
+
+    def step_dict():
+        opt.zero_grad()
+        data = m(dict(d))
+        crit(data).backward()
+        opt.step()
+
+    def step_mv():
+        m.zero_grad(set_to_none=True)
+        crit_mv(m.forward_multiview(img, rot), gt).backward()
+        opt.step()
+    for fn in (step_dict, step_mv):
+        fn()                                     # first call: arenas, index tensors, scratch buffers
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            fn()
+            fn()
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        torch.cuda.synchronize()
+
+
 def test_view_swap_symmetry_eval():
     m = build(18, train=False)
     with torch.no_grad():
