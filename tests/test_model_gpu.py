@@ -341,6 +341,19 @@ def test_dp_reducer_one_rank_over_rccl(monkeypatch):
         for k, p in m2.named_parameters():
             if p.grad is not None:
                 assert torch.equal(p.grad, plain[k]), k
+        # a second step under torch's sync debug mode: issuing the bucket all-reduces must not block the host
+        d2 = inputs(4, 96, seed=11)
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            m2.zero_grad(set_to_none=True)
+            metrics()(m2(d2)).backward()
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        torch.cuda.synchronize()
+        for k, p in m2.named_parameters():
+            if p.grad is not None:
+                assert torch.equal(p.grad, plain[k]), k
     finally:
         dist.destroy_process_group()
         ops.set_reserved_cus(0)
