@@ -28,6 +28,8 @@ WORKLOADS = {
     "c3": (50, 4, 128, "C3: ResNet-50, V=4, B=128 per GPU, 3x224x224, fwd+loss+bwd"),
     "c4": (50, 4, 32, "C4: ResNet-50, V=4, B=32 per GPU (256 on 8 GPUs), 3x224x224, fwd+loss+bwd"),
     "r50v2": (50, 2, 64, "ResNet-50, V=2, B=64 per GPU, 3x224x224, fwd+loss+bwd"),
+    "c5fp32": (50, 8, 64, "C5 shapes: ResNet-50, V=8, B=64 per GPU (512 on 8 GPUs), 3x224x224, fwd+loss+bwd - in fp32: "
+                          "the bf16 MFMA path of config 5 is not built"),
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0

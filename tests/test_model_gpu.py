@@ -424,13 +424,15 @@ def test_gradient_accumulation_and_zero_grad():
     opt.step()
 
 
-def test_multiview_v3_against_oracle():
-    """A9: V=3 - shared backbone features, every pair equals the two-view oracle recurrence."""
+@pytest.mark.parametrize("V,B", [(3, 4), (4, 3), (8, 2)], ids=["V3", "V4_c3_c4", "V8_c5"])
+def test_multiview_against_oracle(V, B):
+    """A9: V > 2 views (configs C3/C4: V = 4, C5: V = 8, here at reduced batch and image size, fp32) -
+    shared backbone features, every pair equals the two-view oracle recurrence."""
     from oracle import restatement as R
     from rot_mvgaze_amd.geometry import rotation_matrix_2d
     from rot_mvgaze_amd.losses import MultiViewIterationLoss
     from rot_mvgaze_amd.model import MultiViewGaze
-    depth, B, V, hw = 18, 4, 3, 64
+    depth, hw = 18, 64
     m = MultiViewGaze(depth, 3)
     sdn = synth.make_state_dict(depth, 0, 3, perturb_bn=True)
     m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sdn.items()})
