@@ -1874,15 +1874,18 @@ static int launch_igemm6p(IgemmParams &p, TileChoice t, hipStream_t st) {
 
 // split-K plan for a GEMM whose tile grid cannot fill the device: returns splits (>= 1) and sets
 // ktiles_per_split; bounded by the caller's workspace.
-static int plan_splitk(IgemmParams &p, TileChoice t, size_t ws_floats) {
+static int plan_splitk(IgemmParams &p, TileChoice t, size_t ws_floats, bool dgrad) {
   p.splits = 1;
   if (ws_floats == 0 || p.ncols % 4 != 0) return 1;
   const int cus = compute_cus();
   const long long tiles = (long long)p.groups * ceil_div(p.rows_per_group, t.bm) * ceil_div(p.ncols, t.bn);
   if (tiles >= cus) return 1;
-  const int KT = ceil_div(p.ktotal, 16);
+  // K-steps in the units of the kernel that will run (the 128x128 fprop tile steps by 32: counting in
+  // 16s here made the trailing splits start past the end of K and left their slabs unwritten)
+  const int bk = tile_bk(t.bm, t.bn, dgrad);
+  const int KT = ceil_div(p.ktotal, bk);
   long long s = (2LL * cus + tiles - 1) / tiles;
-  if (s > KT / 8) s = KT / 8;
+  if (s > (long long)KT * bk / 128) s = (long long)KT * bk / 128;      // >= 128 k per split
   const long long slab = (long long)p.groups * p.rows_per_group * p.ncols;
   if (s > (long long)(ws_floats / (size_t)slab)) s = (long long)(ws_floats / (size_t)slab);
   if (s < 2) return 1;
@@ -1984,7 +1987,7 @@ static int fprop_impl(const mvg_conv_desc *d, const float *x, const float *wgt, 
   }
   p.ncls = 1;
   class_from_params(p.cls[0], p);
-  if (!stats && plan_splitk(p, t, ws ? ws_floats : 0) > 1) {
+  if (!stats && plan_splitk(p, t, ws ? ws_floats : 0, false) > 1) {
     p.slab = ws;
     if (launch_igemm<false>(p, t, (hipStream_t)stream)) return 1;
     return launch_splitk_reduce(p, (hipStream_t)stream);
@@ -2117,7 +2120,7 @@ static int dgrad_impl(const mvg_conv_desc *d, const float *dy, const float *wgt,
     }
   m.no_remap = m.ncls > 1;
   const TileChoice t = choose_tile_multi(cls_rows, cls_k, m.ncls, d->groups, d->cin, true);
-  if (m.ncls == 1 && step == 1 && plan_splitk(m, t, ws ? ws_floats : 0) > 1) {
+  if (m.ncls == 1 && step == 1 && plan_splitk(m, t, ws ? ws_floats : 0, true) > 1) {
     m.slab = ws;
     if (launch_igemm<true>(m, t, (hipStream_t)stream)) return 1;
     return launch_splitk_reduce(m, (hipStream_t)stream);

@@ -387,6 +387,35 @@ def test_geometry_and_loss_golden(golden_dir):
     np.testing.assert_allclose(d2.cpu().numpy(), g["ka_dpred"], rtol=1e-4)
 
 
+@pytest.mark.parametrize("rows,fin,fout", [(584, 1984, 1728), (1239, 2072, 1520), (1536, 2048, 2048), (128, 2048, 2048),
+                                            (3584, 2048, 1536)])
+def test_linear_split_k_covers_every_slab(rows, fin, fout):
+    """Linear GEMMs at the row counts of configs C3-C5 (M = pairs x batch = 1536, 3584) and at ragged sizes:
+    the split-K plan must count K-steps in the units of the kernel that runs (the 128x128 fprop tile steps
+    by 32; counting in 16s left the trailing slabs unwritten).  The workspace is poisoned with NaN so an
+    unwritten slab cannot hide behind stale memory."""
+    import ctypes as C
+    from rot_mvgaze_amd import ops
+    from rot_mvgaze_amd._lib import lib
+    rng = np.random.default_rng(rows)
+    x = torch.from_numpy(rng.standard_normal((rows, fin)).astype(np.float32))
+    w = torch.from_numpy((rng.standard_normal((fout, fin)) / np.sqrt(fin)).astype(np.float32))
+    b = torch.from_numpy(rng.standard_normal(fout).astype(np.float32))
+    gy = torch.from_numpy(rng.standard_normal((rows, fout)).astype(np.float32))
+    xd, wd, bd, gyd = x.to(dev()), w.to(dev()), b.to(dev()), gy.to(dev())
+    n = lib().mvg_linear_workspace_floats(rows, fin, fout)
+    ws = torch.full((n,), float("nan"), device=dev())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    y = torch.full((rows, fout), float("nan"), device=dev())
+    assert lib().mvg_linear_fprop(p(xd), p(wd), p(bd), 1, p(y), rows, fin, fout, p(ws), n, st) == 0
+    close(y, torch.relu(x.double() @ w.double().T + b.double()), what="linear fprop")
+    ws.fill_(float("nan"))
+    dx = torch.full((rows, fin), float("nan"), device=dev())
+    assert lib().mvg_linear_dgrad(p(gyd), p(wd), None, None, p(dx), rows, fin, fout, p(ws), n, st) == 0
+    close(dx, gy.double() @ w.double(), what="linear dgrad")
+
+
 def test_gaze_loss_l1_l2_match_reference(golden_dir):
     """GazeLoss(loss_type='l1' | 'l2') (losses/gaze_loss.py:21-29,56-64) through the host class: value and
     the gradient autograd hands back, against the reference's own (tests/golden/lp_loss.npz); 1e-6 relative."""

@@ -424,10 +424,11 @@ def test_gradient_accumulation_and_zero_grad():
     opt.step()
 
 
-@pytest.mark.parametrize("V,B", [(3, 4), (4, 3), (8, 2)], ids=["V3", "V4_c3_c4", "V8_c5"])
+@pytest.mark.parametrize("V,B", [(3, 4), (4, 3), (8, 2), (4, 64)], ids=["V3", "V4_c3_c4", "V8_c5", "V4_768_fusion_rows"])
 def test_multiview_against_oracle(V, B):
     """A9: V > 2 views (configs C3/C4: V = 4, C5: V = 8, here at reduced batch and image size, fp32) -
-    shared backbone features, every pair equals the two-view oracle recurrence."""
+    shared backbone features, every pair equals the two-view oracle recurrence.  The last case has
+    12 x 64 = 768 fusion-block rows: the large-tile, split-K Linear launches of the full-size configs."""
     from oracle import restatement as R
     from rot_mvgaze_amd.geometry import rotation_matrix_2d
     from rot_mvgaze_amd.losses import MultiViewIterationLoss
