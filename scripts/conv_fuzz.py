@@ -31,9 +31,9 @@ for it in range(cases):
     G, N = int(rng.integers(1, 4)), int(rng.integers(1, 10))
     H, W = int(rng.integers(k, 41)), int(rng.integers(k, 41))
     if len(sys.argv) > 3 and sys.argv[3] == "big":
-        cin = int(rng.choice([64, 128, 256]))
+        cin = int(rng.choice([16, 32, 64, 128, 256]))
         cout = int(rng.choice([64, 128, 256, 512]))
-        k = int(rng.choice([1, 3, 3]))
+        k = int(rng.choice([1, 3, 3, 5]))
         pad = k // 2
         G, N = int(rng.integers(1, 3)), int(rng.integers(8, 40))
         H, W = int(rng.integers(12, 58)), int(rng.integers(12, 58))
