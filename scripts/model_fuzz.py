@@ -69,9 +69,19 @@ for it in range(cases):
         e = ((a - b).norm() / (b.norm() + 1e-30)).item()
         if e > worst[0]:
             worst = (e, names[0])
-    ok = e_loss <= tol and e_pred <= tol and worst[0] <= (5e-2 if B >= 4 else 0.3)   # B < 4: 4..12-sample BatchNorm
+    # inference path (BN from running statistics folded into the conv epilogues) on fresh weights
+    me = FeatRotationSymm(backbone_depth=depth, num_iter=3, **kw)
+    me.load_state_dict({k: torch.from_numpy(np.array(x)) for k, x in sdn.items()}, strict=True)
+    me.to(dev).eval()
+    with torch.no_grad():
+        de = me({k: data[k] for k in ("img_0", "img_1", "rot_0", "rot_1")})
+        sde = {k: torch.from_numpy(np.array(x)) for k, x in sdn.items()}
+        oe = R.model_forward(sde, {k: od[k] for k in ("img_0", "img_1", "rot_0", "rot_1")}, depth, 3, False, variant=v)
+    q_dev, q_ref = de["pred_gaze"].cpu().double(), oe["pred_gaze"].double()
+    e_eval = ((q_dev - q_ref).abs().max() / q_ref.abs().max()).item()
+    ok = e_loss <= tol and e_pred <= tol and e_eval <= 1e-4 and worst[0] <= (5e-2 if B >= 4 else 0.3)   # B < 4: 4..12-sample BatchNorm
     bad += not ok
-    print(("ok  " if ok else "FAIL"), f"R{depth} B{B} hw{hw} {kw}: loss {e_loss:.1e} pred {e_pred:.1e} worst grad L2 {worst[0]:.1e} ({worst[1]})", flush=True)
-    del m, data, loss
+    print(("ok  " if ok else "FAIL"), f"R{depth} B{B} hw{hw} {kw}: loss {e_loss:.1e} pred {e_pred:.1e} eval pred {e_eval:.1e} worst grad L2 {worst[0]:.1e} ({worst[1]})", flush=True)
+    del m, me, data, loss
 print("failures:", bad)
 sys.exit(1 if bad else 0)
