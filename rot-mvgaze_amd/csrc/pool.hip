@@ -159,21 +159,27 @@ struct AaAxis {
   int in_size, max_k;
 };
 __device__ __forceinline__ void aa_window(const AaAxis &a, int i, float &center, int &x0, int &xs, float &total) {
+  // The product must be rounded before it is used: the window bounds are truncations of centre -+ support
+  // + 0.5 and ATen's host code rounds each step.  hipcc contracts a*b+c into an fma by default (its
+  // __fmul_rn / __fadd_rn are plain operators and `#pragma clang fp contract(off)` did not survive the
+  // inlining here): fma(scale, i + 0.5, -support) moved the first tap of every third column at scale 5/3.
+  // The empty asm makes the rounded product an opaque value.
   center = a.scale * ((float)i + 0.5f);
-  x0 = (int)(center - a.support + 0.5f);
+  asm volatile("" : "+v"(center));
+  x0 = (int)__fadd_rn(__fsub_rn(center, a.support), 0.5f);
   if (x0 < 0) x0 = 0;
-  int hi = (int)(center + a.support + 0.5f);
+  int hi = (int)__fadd_rn(__fadd_rn(center, a.support), 0.5f);
   if (hi > a.in_size) hi = a.in_size;
   xs = hi - x0;
   xs = xs < 0 ? 0 : (xs > a.max_k ? a.max_k : xs);
   total = 0.f;
   for (int j = 0; j < xs; ++j) {
-    const float t = ((float)(j + x0) - center + 0.5f) * a.invscale;
+    const float t = __fmul_rn(__fadd_rn(__fsub_rn((float)(j + x0), center), 0.5f), a.invscale);
     total = __fadd_rn(total, fmaxf(0.f, 1.f - fabsf(t)));
   }
 }
 __device__ __forceinline__ float aa_weight(const AaAxis &a, int j, int x0, float center, float total) {
-  const float t = ((float)(j + x0) - center + 0.5f) * a.invscale;
+  const float t = __fmul_rn(__fadd_rn(__fsub_rn((float)(j + x0), center), 0.5f), a.invscale);
   const float w = fmaxf(0.f, 1.f - fabsf(t));
   return total != 0.f ? w / total : w;
 }
