@@ -20,7 +20,7 @@ def rel(got, ref):
 
 bad = 0
 for it in range(cases):
-    rows = int(rng.choice([1, 2, 3, 7, 64, 127, 128, 129, 384, 640, int(rng.integers(1, 1500))]))
+    rows = int(rng.choice([1, 2, 3, 7, 64, 127, 128, 129, 384, 640, 1536, 3584, int(rng.integers(1, 1500)), int(rng.integers(1500, 6000))]))
     fin = 4 * int(rng.integers(1, 520))
     fout = 4 * int(rng.integers(1, 520))
     x = torch.from_numpy(rng.standard_normal((rows, fin)).astype(np.float32))
