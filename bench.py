@@ -44,48 +44,69 @@ def sample_flops(depth, views):
     return views * bb + 3 * (views * lifter + npairs * pair)
 
 
-def cpu_baseline(depth, views, seconds_budget=20.0):
-    """The CPU oracle (restatement of the reference path, validated against the reference's own
-    outputs in tests/) on a bounded sample of the workload: B=8 samples, fwd+loss+bwd."""
+def _oracle_time(depth, views, batch, threads, fwd_only, max_steps, seconds_budget):
+    """Median ms/step of the CPU oracle (checker / baseline only - never the product path)."""
     import numpy as np
     import torch
     from rot_mvgaze_amd import synth
-    from oracle import restatement as R            # checker / baseline only - never the product path
+    from oracle import restatement as R
+    torch.set_num_threads(threads)
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in synth.make_state_dict(depth, 0, 3).items()}
+    if not fwd_only:
+        for k, v in sd.items():
+            if v.dtype == torch.float32 and "running" not in k and ".fc." not in k:
+                v.requires_grad_(True)
+    inp = synth.make_inputs(batch, views, 1234, 224)
+    img, hp, gt = (torch.from_numpy(inp[k]) for k in ("img", "head_pose", "gt_gaze"))
+    rot = R.rotation_matrix_2d(hp.reshape(-1, 2)).reshape(batch, views, 3, 3)
+
+    def step():
+        if fwd_only:
+            with torch.no_grad():
+                R.multiview_forward(sd, img, rot, depth, 3, False)       # eval forward (BASELINE.md 2: "eval forward")
+            return
+        for v in sd.values():
+            if v.requires_grad:
+                v.grad = None
+        out = R.multiview_forward(sd, img, rot, depth, 3, True)
+        R.multiview_loss(out, gt).backward()
+
+    step()                                            # warm-up (allocator, oneDNN primitive cache)
+    times = []
+    t_end = time.time() + seconds_budget
+    while len(times) < max_steps and (time.time() < t_end or len(times) < 2):
+        t0 = time.time()
+        step()
+        times.append(time.time() - t0)
+    times.sort()
+    return times[len(times) // 2] * 1e3, len(times)
+
+
+def cpu_baseline(depth, views):
+    """The CPU oracle (restatement of the reference path, validated against the reference's own
+    outputs in tests/) on a bounded sample of the workload - B = 8 samples, fwd+loss+bwd, all of this
+    box's host threads (<= 16) - plus the shapes BASELINE.md 4 names: C1 (ResNet-18, V=2, B=8,
+    forward only) and fwd+bwd at B=8 for ResNet-18 / ResNet-50 (V=2), each also on 8 threads for
+    comparison with the survey container's figures."""
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
     cores = max(1, min(avail, 16))         # a one-GPU box's CPU share; oversubscribing oneDNN is far slower
-    torch.set_num_threads(cores)
     B = 8
-    sd = {k: torch.from_numpy(np.array(v)) for k, v in synth.make_state_dict(depth, 0, 3).items()}
-    for k, v in sd.items():
-        if v.dtype == torch.float32 and "running" not in k and ".fc." not in k:
-            v.requires_grad_(True)
-    inp = synth.make_inputs(B, views, 1234, 224)
-    img, hp, gt = (torch.from_numpy(inp[k]) for k in ("img", "head_pose", "gt_gaze"))
-    rot = R.rotation_matrix_2d(hp.reshape(-1, 2)).reshape(B, views, 3, 3)
-
-    def step():
-        for v in sd.values():
-            if v.requires_grad:
-                v.grad = None
-        out = R.multiview_forward(sd, img, rot, depth, 3, True)
-        loss = R.multiview_loss(out, gt)
-        loss.backward()
-
-    step()
-    times = []
-    t_end = time.time() + seconds_budget
-    while len(times) < 10 and (time.time() < t_end or len(times) < 2):
-        t0 = time.time()
-        step()
-        times.append(time.time() - t0)
-    times.sort()
-    med = times[len(times) // 2]
-    return {"value": B / med, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"B=8 of the workload's samples (V={views}, ResNet-{depth}, 224x224), fwd+loss+bwd, "
-                      f"{len(times)} steps, median {med * 1e3:.0f} ms/step, torch CPU {torch.get_num_threads()} threads"}
+    ms, n = _oracle_time(depth, views, B, cores, False, 5, 12.0)
+    out = {"value": B / (ms * 1e-3), "unit": "samples/s", "cores": cores, "kind": "port",
+           "sample": f"B=8 of the workload's samples (V={views}, ResNet-{depth}, 224x224), fwd+loss+bwd, "
+                     f"{n} steps, median {ms:.0f} ms/step, torch CPU {cores} threads",
+           "host_cpus": avail, "shapes": {}}
+    plan = [("c1_r18_v2_b8_eval_fwd", 18, 2, True, 5, 2.0), ("r18_v2_b8_fwd_bwd", 18, 2, False, 5, 3.0),
+            ("r50_v2_b8_fwd_bwd", 50, 2, False, 3, 5.0)]
+    for name, d, v, fwd_only, steps, budget in plan:
+        for thr in sorted({cores, min(8, cores)}, reverse=True):
+            m, k = _oracle_time(d, v, B, thr, fwd_only, steps, budget)
+            out["shapes"][f"{name}_{thr}thr"] = {"ms_per_step": round(m, 1), "samples_per_s": round(B / (m * 1e-3), 2),
+                                                 "threads": thr, "steps": k}
+    return out
 
 
 def main():
@@ -93,11 +114,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS),
+                    help="default: the largest single-GPU configuration of BASELINE.json (C3)")
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--bucket-mb", type=float, default=25.0)
+    ap.add_argument("--bucket-mb", type=float, default=25.0, help="data-parallel gradient bucket size")
+    ap.add_argument("--reserved-cus", type=int, default=int(os.environ.get("MVG_RESERVED_CUS", "12")),
+                    help="N > 1: CUs the persistent conv grids leave to the RCCL kernels")
+    ap.add_argument("--nccl-channels", type=int, default=int(os.environ.get("NCCL_MAX_NCHANNELS", "8")),
+                    help="N > 1: NCCL_MAX_NCHANNELS for the gradient all-reduce")
     ap.add_argument("--no-optimizer", action="store_true", help="time forward+loss+backward only (no Adam step)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the backward-weight kernels on the compute stream (per-kernel profiling: rocprofv3 --stats)")
@@ -138,7 +164,7 @@ def main():
         torch.cuda.set_device(local_rank)
         # the gradient stream is ~160-360 MB per step: 8 RCCL channels move it inside backward and leave
         # the CUs to the persistent conv kernels (see rot_mvgaze_amd/dp.py)
-        os.environ.setdefault("NCCL_MAX_NCHANNELS", "8")
+        os.environ["NCCL_MAX_NCHANNELS"] = str(args.nccl_channels)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -161,7 +187,8 @@ def main():
     criterion = MultiViewIterationLoss(rel_weight=0.01, reference_decay=1.0, iter_decay=0.5)
     from rot_mvgaze_amd.optim import Adam
     optimizer = None if args.no_optimizer else Adam(model.parameters(), lr=1e-4, weight_decay=1e-6)   # trainer.py:54
-    reducer = GradAllReducer(model, bucket_mb=args.bucket_mb, force=force_dist) if (world > 1 or force_dist) else None
+    reducer = GradAllReducer(model, bucket_mb=args.bucket_mb, force=force_dist, reserved_cus=args.reserved_cus) \
+        if (world > 1 or force_dist) else None
 
     if args.mode == "eval":
         model.eval()
@@ -191,11 +218,18 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    # hipEvents on the compute stream at every step boundary (recording an event costs no synchronisation):
+    # the per-step durations give the median SURVEY 8(d) asks for next to the wall-clock mean
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        marks[i].record()
         loss = step()
+    marks[args.steps].record()
     fence()
     elapsed = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2] if step_ms else None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -249,6 +283,32 @@ def main():
                         "gbs": round(e["bytes"] / (e["ms"] * 1e-3) / 1e9, 1) if e["ms"] > 0 and e["bytes"] > 0 else None}
                     for k, e in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
 
+    # ---- the fusion block's GEMM family (lifter + fusers + heads: fprop / dgrad / wgrad launches), priced against
+    # BOTH roofs (SURVEY 8(d) "Bounding roofline"): fp32 MFMA and the HBM stream of weights + activations
+    roofline_fusion = None
+    if families is not None:
+        lin = [prof[k] for k in ("linear_fprop", "linear_dgrad", "linear_wgrad") if k in prof]
+        lms = sum(e["ms"] for e in lin)
+        if lms > 0:
+            lfl, lby = sum(e["flops"] for e in lin), sum(e["bytes"] for e in lin)
+            tf, gbs = lfl / (lms * 1e-3) / 1e12, lby / (lms * 1e-3) / 1e9
+            D = V * (V - 1)
+            roofline_fusion = {
+                "kernel": "fusion-block GEMMs (lifter, fusers, gaze heads: linear_fprop + linear_dgrad + linear_wgrad)",
+                "rows_per_gemm": D * B, "achieved_tflops": round(tf, 2), "frac_mfma_fp32": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                "achieved_gbs": round(gbs, 1), "frac_hbm": round(gbs / PEAK_HBM_GBS, 4),
+                "bound": "mfma" if tf / PEAK_FP32_MFMA_TFLOPS >= gbs / PEAK_HBM_GBS else "hbm",
+                "intensity_flop_per_byte": round(lfl / lby, 1), "machine_balance_flop_per_byte": round(PEAK_FP32_MFMA_TFLOPS * 1e3 / PEAK_HBM_GBS, 1),
+                "ms_per_step": round(lms / nprof, 4),
+                "launches_per_step": sum(e["launches"] for e in lin) / nprof,
+                "block_ms_per_step": round(sum(prof[k]["ms"] for k in ("linear_fprop", "linear_dgrad", "linear_wgrad", "colsum",
+                                                                        "rotcat", "loss", "geometry") if k in prof) / nprof, 4),
+                "block_launches_per_step": sum(prof[k]["launches"] for k in ("linear_fprop", "linear_dgrad", "linear_wgrad",
+                                                                             "colsum", "rotcat", "loss", "geometry") if k in prof) / nprof,
+                "note": "algorithmic bytes = operands + result of every GEMM once (weights dominate); in fp32 the "
+                        "intensity (rows/2 flop per weight byte) is above the machine balance at every BASELINE config, "
+                        "so the matrix pipe, not the weight stream, bounds this family"}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(depth, V)
@@ -258,7 +318,8 @@ def main():
             "metric": "multi-view samples/sec (fwd+bwd), BxVx3x224x224" if args.mode == "train" else
                       "multi-view samples/sec (inference forward), BxVx3x224x224",
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 3), "ms_per_step_median_events": round(median_ms, 3) if median_ms else None,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "backbone": f"ResNet-{depth}", "views": V, "batch_per_gpu": B,
                        "global_batch": B * world, "image": "3x224x224", "parallelism": f"dp{world}" + ("" if os.environ.get("MVG_DIST_BACKEND", "nccl") == "nccl" else " (REHEARSAL: gloo, ranks share devices - not a measurement)"),
@@ -266,9 +327,14 @@ def main():
                                         "forward + loss + backward" + (" + RCCL gradient all-reduce" if world > 1 else "") +
                                         ("" if args.no_optimizer else " + fused Adam step")),
                        "weights": "random init, seed 0 (kaiming-normal convs, default Linear)",
+                       "rccl_ranks": (dist.get_world_size() if (world > 1 or force_dist) else 1),
+                       "dp": ({"bucket_mb": args.bucket_mb, "buckets": len(reducer.buckets) if hasattr(reducer, "buckets") else None,
+                               "reserved_cus": reducer.reserved_cus, "nccl_max_nchannels": int(os.environ.get("NCCL_MAX_NCHANNELS", "0")),
+                               "backend": os.environ.get("MVG_DIST_BACKEND", "nccl"), "params_broadcast_from_rank0": True}
+                              if reducer is not None else None),
                        "images_per_s": round(value * V, 1), "loss": loss_val,
                        "model_tflops": round(value * sample_flops(depth, V) / 1e12, 2)},
-            "roofline": roofline, "cpu_baseline": cpu, "kernel_families": families,
+            "roofline": roofline, "roofline_fusion": roofline_fusion, "cpu_baseline": cpu, "kernel_families": families,
         }
         print(json.dumps(line))
     if world > 1 or force_dist:

@@ -225,6 +225,7 @@ class Backbone:
 
     def _side(self, dev) -> "torch.cuda.Stream":
         if self._wg_stream is None or self._wg_stream.device != dev or self._wg_low != self.wgrad_low_priority:
+            old = self._wg_stream if (self._wg_stream is not None and self._wg_stream.device == dev) else None
             self._wg_low = self.wgrad_low_priority
             try:
                 if not self._wg_low:
@@ -232,6 +233,8 @@ class Backbone:
                 self._wg_stream = ops.low_priority_stream(dev)   # fills what the critical path leaves idle
             except RuntimeError:                                 # ordinary side stream (also: no priority support)
                 self._wg_stream = torch.cuda.Stream(device=dev)
+            if old is not None:
+                self._wg_stream.wait_stream(old)                 # whoever joins the new stream also joins the old one's work
             self.grad_streams[:] = [self._wg_stream]
         return self._wg_stream
 

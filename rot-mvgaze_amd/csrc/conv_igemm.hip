@@ -1575,6 +1575,10 @@ __global__ __launch_bounds__(256) void dgrad_empty_class_kernel(float4 *__restri
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+// Algorithmic input channels of a conv for the profiler's FLOP / byte accounting: the 7x7 stem is the
+// only conv with cin == 4 and its fourth channel is zero padding (SURVEY 8(d) counts Cin = 3).
+static double alg_cin(const mvg_conv_desc *d) { return d->cin == 4 ? 3.0 : (double)d->cin; }
+
 static int ilog2_exact(int v) {
   int s = 0;
   while ((1 << s) < v) ++s;
@@ -1967,8 +1971,8 @@ static int fprop_impl(const mvg_conv_desc *d, const float *x, const float *wgt, 
   p.ohw_div = make_fastdiv((unsigned)(p.out_h * p.out_w));
   p.ow_div = make_fastdiv((unsigned)p.out_w);
   const TileChoice t = choose_tile(p.rows_per_group, d->groups, d->cout, p.ktotal, false);
-  const double flops = 2.0 * d->groups * (double)p.rows_per_group * d->cout * p.ktotal;
-  const double bytes = 4.0 * (d->groups * (double)d->n * d->h * d->w * d->cin + (double)d->cout * p.ktotal +
+  const double flops = 2.0 * d->groups * (double)p.rows_per_group * d->cout * d->r * d->s * alg_cin(d);
+  const double bytes = 4.0 * (d->groups * (double)d->n * d->h * d->w * alg_cin(d) + (double)d->cout * d->r * d->s * alg_cin(d) +
                               d->groups * (double)p.rows_per_group * d->cout);
   const bool lin = d->r == 1 && d->s == 1 && d->h == 1 && d->w == 1;
   ProfScope ps(lin ? MVG_K_LINEAR_FPROP : MVG_K_CONV_FPROP, (hipStream_t)stream, flops, bytes);
@@ -2031,9 +2035,9 @@ static int dgrad_impl(const mvg_conv_desc *d, const float *dy, const float *wgt,
   p.b_bytes = 4ll * d->cout * d->r * d->s * d->cin;
   MVG_REQUIRE(p.a_group_bytes < 0x7FFFFFF0ll && p.b_bytes < 0x7FFFFFF0ll, "conv: a group / the weights exceed 2 GiB");
   // algorithmic flops: the transposed conv touches each (output pixel, tap) pair of the fprop once
-  const double flops = 2.0 * d->groups * (double)d->n * d->ho * d->wo * d->cout * d->r * d->s * d->cin;
-  const double bytes = 4.0 * (d->groups * (double)d->n * d->ho * d->wo * d->cout + (double)d->cout * d->r * d->s * d->cin +
-                              d->groups * (double)d->n * d->h * d->w * d->cin);
+  const double flops = 2.0 * d->groups * (double)d->n * d->ho * d->wo * d->cout * d->r * d->s * alg_cin(d);
+  const double bytes = 4.0 * (d->groups * (double)d->n * d->ho * d->wo * d->cout + (double)d->cout * d->r * d->s * alg_cin(d) +
+                              d->groups * (double)d->n * d->h * d->w * alg_cin(d));
   const bool lin = d->r == 1 && d->s == 1 && d->h == 1 && d->w == 1;
   ProfScope ps(lin ? MVG_K_LINEAR_DGRAD : MVG_K_CONV_DGRAD, (hipStream_t)stream, flops, bytes);
   const int step = d->stride;
@@ -2323,9 +2327,9 @@ int mvg_conv_wgrad(const mvg_conv_desc *d, const float *x, const float *dy, floa
   hipStream_t st = (hipStream_t)stream;
   const bool lin = d->r == 1 && d->s == 1 && d->h == 1 && d->w == 1;
   {
-    const double flops = 2.0 * (double)p.pixels * d->cout * p.ncols;
-    const double bytes = 4.0 * ((double)d->groups * d->n * d->h * d->w * d->cin + (double)p.pixels * d->cout +
-                                (double)d->cout * p.ncols);
+    const double flops = 2.0 * (double)p.pixels * d->cout * d->r * d->s * alg_cin(d);
+    const double bytes = 4.0 * ((double)d->groups * d->n * d->h * d->w * alg_cin(d) + (double)p.pixels * d->cout +
+                                (double)d->cout * d->r * d->s * alg_cin(d));
     ProfScope ps(lin ? MVG_K_LINEAR_WGRAD : MVG_K_CONV_WGRAD, st, flops, bytes);
     MVG_REQUIRE((long long)p.mtiles * p.ntiles * splits < (1LL << 31), "wgrad: grid too large");
     dim3 grid(p.mtiles * p.ntiles * splits), block(256);

@@ -9,6 +9,12 @@ The model's gradient arena is already laid out in grad-ready order (heads/fusers
 before backbone backward even starts - then layer4 ... stem), so buckets are contiguous arena
 slices: no flatten/unflatten copies, one ``all_reduce`` per bucket issued the moment its last
 parameter is published, on a side stream that waits on an event recorded on the compute stream.
+
+Replicas are made identical at construction: rank 0's parameter arena, the parameters outside it
+(the unused ``resnet.fc``) and every buffer (BatchNorm / IntensityBatchNorm running statistics) are
+broadcast to the other ranks (``sync()``), as torch's DistributedDataParallel does - each process
+otherwise draws its own random initial weights (model.py:_init_tensor) and averaged gradients of
+different replicas mean nothing.
 """
 from __future__ import annotations
 
@@ -20,17 +26,71 @@ import torch.distributed as dist
 
 
 class GradAllReducer:
-    def __init__(self, model, bucket_mb: float = 64.0, process_group=None, average: bool = True, force: bool = False):
+    def __init__(self, model, bucket_mb: float = 64.0, process_group=None, average: bool = True, force: bool = False,
+                 broadcast: bool = True, reserved_cus: Optional[int] = None):
         self.model = model
         self.pg = process_group
         self.average = average
         self.bucket_bytes = int(bucket_mb * (1 << 20))
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.force = force            # run the collectives even with one rank (rehearsal of the RCCL path)
+        self.reserved_cus = int(os.environ.get("MVG_RESERVED_CUS", "12")) if reserved_cus is None else int(reserved_cus)
         self._built_for = None
         self._side: Optional[torch.cuda.Stream] = None
         model._on_grads_ready = self._on_ready
         model._on_backward_done = self._on_done
+        # Everything that changes how a backward runs (the stream the backward-weight kernels use, the
+        # CUs the persistent conv grids plan for) is applied HERE, before any backward work exists:
+        # flipping them from the first publish callback - in the middle of the first backward - left the
+        # head's weight gradients on a stream nobody joined.
+        self._configure()
+        first = next(iter(model.parameters()), None) if hasattr(model, "parameters") else None
+        if first is not None and hasattr(model, "ensure_layout") and first.is_cuda:
+            model.ensure_layout()
+            self._build()
+        if broadcast and hasattr(model, "param_arena"):
+            self.sync()
+
+    @property
+    def active(self) -> bool:
+        return self.world > 1 or self.force
+
+    def _configure(self):
+        if not self.active or not hasattr(self.model, "_wgrad_low_priority"):
+            return
+        # The conv kernels run as persistent stream-K grids sized to fill every CU; an RCCL kernel that
+        # is resident when one starts would push part of that grid into a second round (2x the kernel
+        # time).  Plan the grids for a few CUs less and keep RCCL to a few channels (the gradient
+        # stream needs ~15 GB/s of bus bandwidth at C2 / C4, a fraction of what 8 channels move).
+        from . import ops
+        ops.set_reserved_cus(self.reserved_cus)
+        # backward-weight kernels on a LOWEST-priority stream finish last, which would hold every
+        # backbone bucket back until the end of backward; with ranks to feed they run on an ordinary
+        # side stream (still off the critical path, +3 % instead of +4 %).  The model applies the
+        # setting to every Backbone it (re)builds.
+        if os.environ.get("MVG_DP_LOW_PRIORITY_WGRAD", "0") == "0":
+            self.model._wgrad_low_priority = False
+            bb = getattr(self.model, "_backbone", None)
+            if bb is not None:
+                bb.wgrad_low_priority = False
+
+    def sync(self, src: int = 0):
+        """Make this replica identical to rank ``src``: parameter arena, parameters outside the arena
+        (``resnet.fc``: in the state_dict, never trained) and all buffers."""
+        if self.world <= 1:
+            return
+        m = self.model
+        if hasattr(m, "ensure_layout"):
+            first = next(iter(m.parameters()))
+            if first.is_cuda:
+                m.ensure_layout()
+        arena = m.param_arena() if getattr(m, "_layout_sig", True) is not None else None
+        in_arena = getattr(m, "_grad_offsets", {})
+        tensors = ([arena] if arena is not None else []) + \
+                  [p.data for p in m.parameters() if arena is None or id(p) not in in_arena] + list(m.buffers())
+        with torch.no_grad():
+            for t in tensors:
+                dist.broadcast(t, src, group=self.pg)
 
     # bucket = [start, end) element range of the arena + the id of its last parameter
     def _build(self):
@@ -53,19 +113,6 @@ class GradAllReducer:
         self._param_end = {id(p): off + n for (p, off, n) in entries}
         self._next = 0
         self._done_upto = 0
-        if arena.is_cuda and (self.world > 1 or self.force):
-            # The conv kernels run as persistent stream-K grids sized to fill every CU; an RCCL kernel that
-            # is resident when one starts would push part of that grid into a second round (2x the kernel
-            # time).  Plan the grids for a few CUs less and keep RCCL to a few channels (the gradient
-            # stream needs ~15 GB/s of bus bandwidth at C2 / C4, a fraction of what 8 channels move).
-            from . import ops
-            ops.set_reserved_cus(int(os.environ.get("MVG_RESERVED_CUS", "12")))
-            # backward-weight kernels on a LOWEST-priority stream finish last, which would hold every
-            # backbone bucket back until the end of backward; with ranks to feed they run on an ordinary
-            # side stream (still off the critical path, +3 % instead of +4 %)
-            bb = getattr(self.model, "_backbone", None)
-            if bb is not None and os.environ.get("MVG_DP_LOW_PRIORITY_WGRAD", "0") == "0":
-                bb.wgrad_low_priority = False
         if arena.is_cuda and self._side is None:
             self._side = torch.cuda.Stream(device=arena.device)
         self._built_for = arena.data_ptr()
@@ -73,7 +120,7 @@ class GradAllReducer:
     def _launch(self, b: int):
         s, e = self.buckets[b]
         buf = self.arena[s:e]
-        if self.world == 1 and not self.force:
+        if not self.active:
             return
         if self.arena.is_cuda:
             # gradients of this bucket are complete once the compute stream AND the model's other gradient
@@ -104,7 +151,7 @@ class GradAllReducer:
         while self._next < len(self.buckets):         # anything left (should be nothing)
             self._launch(self._next)
             self._next += 1
-        if self.arena.is_cuda and (self.world > 1 or self.force):
+        if self.arena.is_cuda and self.active:
             torch.cuda.current_stream().wait_stream(self._side)
         self._next = 0
         self._done_upto = 0

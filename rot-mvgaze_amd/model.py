@@ -113,9 +113,14 @@ class _BackboneFn(torch.autograd.Function):
     def backward(ctx, dfeat):
         model, tape = ctx.model, ctx.tape
         n_in = ctx.n_views + len(model._backbone_params)
-        if dfeat is None or tape is None:
-            return (None, None, None) + (None,) * n_in
+        if tape is None:
+            raise RuntimeError("FeatRotationSymm: backward through the backbone a second time - the saved activations "
+                               "were released by the first backward (retain_graph is not supported; run forward again)")
         ctx.tape = None
+        if dfeat is None:                         # nothing upstream depends on the image features
+            model._sink.active = False
+            model._finish_backward()
+            return (None, None, None) + (None,) * n_in
         model._sink.begin()
         dimgs = model._backbone.backward(tape, dfeat.contiguous(), model._sink, ctx.need_dimg)
         model._sink.active = False
@@ -140,14 +145,19 @@ class _HeadFn(torch.autograd.Function):
         model, tape = ctx.model, ctx.tape
         nparam = len(model._head_params)
         if tape is None:
-            return (None, None, None) + (None,) * nparam
+            raise RuntimeError("FeatRotationSymm: backward through the fusion head a second time - the saved "
+                               "activations were released by the first backward (retain_graph is not supported; "
+                               "run forward again)")
         ctx.tape = None
         model._sink.begin()                       # the head's backward is the first node to run
         bb = model._backbone
         side = bb._side(tape["img_feat"].device) if (bb.overlap_wgrad and bb.overlap_head and tape["img_feat"].is_cuda) else None
         dimg = model._head.backward(tape, d_lifted, d_feats, d_preds, model._sink, side)
-        if side is not None and not ctx.needs_input_grad[1]:
-            torch.cuda.current_stream().wait_stream(side)     # no backbone backward will follow to join it
+        if not ctx.needs_input_grad[1]:                        # no backbone backward will follow
+            if side is not None:
+                torch.cuda.current_stream().wait_stream(side)
+            model._sink.active = False
+            model._finish_backward()
         return (None, dimg, None) + (None,) * nparam
 
 
@@ -199,6 +209,7 @@ class MultiViewGaze(nn.Module):
         self.input_bgr = False                    # raw uint8 inputs: swap B and R first (dataset color_type 'bgr')
         self.input_size: Optional[int] = 224      # raw uint8 inputs: Resize((S, S), antialias=True), main.py:40,53; None = keep
         self._sink = _ArenaSink(self)
+        self._wgrad_low_priority = True           # data-parallel runs set False (dp.GradAllReducer._configure)
 
     # ---------------------------------------------------------------- plumbing
     def _named_tensors(self) -> Dict[str, Tensor]:
@@ -224,6 +235,7 @@ class MultiViewGaze(nn.Module):
             if p.dtype != torch.float32:
                 raise RuntimeError("fp32 parameters only")
         self._backbone = Backbone(self._depth, named)
+        self._backbone.wgrad_low_priority = self._wgrad_low_priority
         self._grad_streams = self._backbone.grad_streams   # streams besides the caller's that write gradients
         self._head = FusionHead(named, self._fc_dim, self._num_iter, self._variant)
         # grad-ready order: heads+fusers I-1..0 (shared weights: once), lifter, backbone blocks last..first, stem
@@ -242,7 +254,10 @@ class MultiViewGaze(nn.Module):
         self._backbone_params = bb
         order += bb
         self._grad_order = order
-        total = (sum(p.numel() for p in order) + 3) // 4 * 4          # float4-friendly (zero tail)
+        # every entry starts on a 16-byte boundary (the kernels move float4 / 16-byte buffer loads; the
+        # 2-element head biases would otherwise leave every later slice 8-byte aligned); gaps stay zero in
+        # both arenas, so the one-launch optimizer leaves them at zero
+        total = sum((p.numel() + 3) // 4 * 4 for p in order)
         self._grad_arena = torch.zeros(total, dtype=torch.float32, device=first.device)
         # parameters live in a second arena with the SAME offsets (one-launch optimizer, flat
         # broadcast / checkpoint staging); each Parameter becomes a view of its slice
@@ -264,7 +279,8 @@ class MultiViewGaze(nn.Module):
             pv.copy_(p.data)
             p.data = pv
             p.grad = None
-            off += p.numel()
+            assert off % 4 == 0 and pv.data_ptr() % 16 == 0
+            off += (p.numel() + 3) // 4 * 4
         first = next(self.parameters())
         self._layout_sig = (first.data_ptr(), str(first.device), sum(1 for _ in self.parameters()))
 

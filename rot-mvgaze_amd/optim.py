@@ -24,6 +24,7 @@ class Adam(torch.optim.Optimizer):
         if len(self.param_groups) != 1:
             raise NotImplementedError("one parameter group (the reference uses one)")
         self._flat: Dict[int, dict] = {}
+        self._pending = None          # moments restored by load_state_dict, adopted by the next step()
 
     def _owners(self):
         owners = {}
@@ -55,6 +56,15 @@ class Adam(torch.optim.Optimizer):
                                        "module's backward (a view of its gradient arena)")
             st = self._flat.get(id(model))
             arena_p = model.param_arena()
+            if st is None and self._pending:
+                saved = self._pending.pop(0)
+                if saved["exp_avg"].numel() != arena_p.numel():
+                    raise RuntimeError("optimizer state does not match this model's parameter arena "
+                                       f"({saved['exp_avg'].numel()} vs {arena_p.numel()} elements)")
+                st = {"step": int(saved["step"]), "n": arena_p.numel(),
+                      "exp_avg": saved["exp_avg"].to(arena_p.device, torch.float32).contiguous(),
+                      "exp_avg_sq": saved["exp_avg_sq"].to(arena_p.device, torch.float32).contiguous()}
+                self._flat[id(model)] = st
             if st is None or st["exp_avg"].data_ptr() == 0 or st["n"] != arena_p.numel() or \
                     st["exp_avg"].device != arena_p.device:
                 st = {"step": 0, "n": arena_p.numel(), "exp_avg": torch.zeros_like(arena_p),
@@ -64,3 +74,24 @@ class Adam(torch.optim.Optimizer):
             ops.adam_step(arena_p, arena_g, st["exp_avg"], st["exp_avg_sq"], float(g["lr"]), float(g["betas"][0]),
                           float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), st["step"])
         return loss
+
+    # The moments live in flat buffers that mirror the model's parameter arena (one launch updates all of
+    # them), not in ``self.state``; checkpoints carry them under one extra key so that a resumed run keeps
+    # its bias correction and moments (the reference itself checkpoints the model only, trainer.py:91-96).
+    def state_dict(self):
+        sd = super().state_dict()
+        flat = []
+        for model in self._owners():
+            st = self._flat.get(id(model))
+            if st is not None:
+                flat.append({"step": st["step"], "exp_avg": st["exp_avg"].detach().clone(),
+                             "exp_avg_sq": st["exp_avg_sq"].detach().clone()})
+        sd["mvg_arena_state"] = flat
+        return sd
+
+    def load_state_dict(self, state_dict):
+        sd = dict(state_dict)
+        flat = sd.pop("mvg_arena_state", None)
+        super().load_state_dict(sd)
+        self._flat.clear()
+        self._pending = [dict(e) for e in flat] if flat else None

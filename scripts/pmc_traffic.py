@@ -42,7 +42,7 @@ out = {"workload": sys.argv[3],
        "ops": n, "kernel_launches": fetch["conv"][0], "read_bytes_per_op": rd / n, "write_bytes_per_op": wr / n,
        "traffic_bytes_per_launch": (rd + wr) / n,
        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over scripts/conv_pass.py (every conv "
-                 "op of one C2 step once); read = 2*FETCH_SIZE*1024 (gfx950 correction), write = WRITE_SIZE*1024; "
+                 f"op of one {sys.argv[3]} step once); read = 2*FETCH_SIZE*1024 (gfx950 correction), write = WRITE_SIZE*1024; "
                  "summed over the op's kernels, divided by the number of ops",
        "other_kernels_total_MB": {k: round((2.0 * fetch[k][1] + write.get(k, [0, 0])[1]) * 1024 / 1e6, 1)
                                   for k in fetch if k != "conv"}}

@@ -40,6 +40,57 @@ class _FakeModel:
         return self.arena, self.entries
 
 
+class _FakeReplica(_FakeModel):
+    """... with a parameter arena, a parameter outside it and a buffer, each seeded per rank: what
+    GradAllReducer.sync() must make identical to rank 0's."""
+
+    def __init__(self, sizes, rank):
+        super().__init__(sizes, rank)
+        g = torch.Generator().manual_seed(500 + rank)
+        self.parena = torch.randn(sum(sizes), generator=g)
+        for (p, off, n) in self.entries:
+            p.data = self.parena[off:off + n]
+        self.outside = torch.nn.Parameter(torch.randn(7, generator=g))          # like resnet.fc: no gradient, not in the arena
+        self.buf = torch.randn(5, generator=g)
+        self.count = torch.tensor(3 + rank, dtype=torch.long)
+        self._grad_offsets = {id(p): off for (p, off, n) in self.entries}
+
+    def param_arena(self):
+        return self.parena
+
+    def parameters(self):
+        return self.params + [self.outside]
+
+    def buffers(self):
+        return [self.buf, self.count]
+
+
+def _sync_worker(rank, world, port, sizes, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rot_mvgaze_amd.dp import GradAllReducer
+    m = _FakeReplica(sizes, rank)
+    GradAllReducer(m, bucket_mb=0.01)                 # broadcast=True is the default
+    torch.save({"arena": m.parena.clone(), "p0": m.params[0].data.clone(), "outside": m.outside.data.clone(),
+                "buf": m.buf.clone(), "count": m.count.clone()}, os.path.join(out_dir, f"s{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_replicas_are_broadcast_from_rank0(tmp_path):
+    """Ranks that start from different weights (each process draws its own random init) end up with rank
+    0's parameter arena, out-of-arena parameters and buffers after GradAllReducer(model)."""
+    sizes = [1000, 37, 4096, 5]
+    port = _free_port()
+    mp.spawn(_sync_worker, args=(2, port, sizes, str(tmp_path)), nprocs=2, join=True)
+    a, b = (torch.load(tmp_path / f"s{r}.pt", weights_only=True) for r in range(2))
+    ref = _FakeReplica(sizes, 0)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert torch.equal(a["arena"], ref.parena) and torch.equal(a["outside"], ref.outside.data)
+    assert int(a["count"]) == 3 and torch.equal(a["p0"], ref.parena[:1000])
+
+
 def _worker(rank, world, port, sizes, bucket_mb, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

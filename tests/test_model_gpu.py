@@ -23,7 +23,11 @@ GTOL = 2e-4      # gradients, same ReLU activation pattern on both sides (strict
 # relative, but a flipped ReLU decision moves downstream gradients discontinuously, and at the tiny
 # fixture batches - 2..3 samples - one element is up to 1/sqrt(rows) of a weight gradient).  Those
 # checks therefore bound the relative L2 error instead of the max error.
-GTOL_L2_FLIPS = 5e-2
+# Bound: 1e-2 (round 1 held 5e-2).  What sets it: the full-size runs measure 1e-6 (fusion block) .. 3e-3
+# (layer4) .. 6e-3 (stem) at C2; the 2-3-sample reference fixtures (model_r50_b3_hw64, variant_*) are the
+# worst cases because one flipped element is a larger share of a weight gradient there.
+GTOL_L2_FLIPS = 1e-2
+_L2_LOG = os.environ.get("MVG_TEST_L2_LOG")      # optional: append every relative-L2 figure to this file
 
 
 def dev():
@@ -66,6 +70,9 @@ def l2_close(got, ref, tol, what):
     got = got.detach().cpu().double().numpy() if isinstance(got, torch.Tensor) else np.asarray(got, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
     err = np.linalg.norm((got - ref).ravel()) / (np.linalg.norm(ref.ravel()) + 1e-30)
+    if _L2_LOG:
+        with open(_L2_LOG, "a") as f:
+            f.write(f"{err:.3e} {tol:.1e} {os.environ.get('PYTEST_CURRENT_TEST', '?').split('::')[-1]} {what}\n")
     assert err <= tol, f"{what}: relative L2 error {err:.3e} > {tol}"
 
 
@@ -353,10 +360,14 @@ def test_dp_reducer_one_rank_over_rccl(monkeypatch):
     try:
         m2 = build(18)
         red = GradAllReducer(m2, bucket_mb=8.0, force=True)
+        # stream / CU settings are applied at construction, not from the first publish callback in the
+        # middle of the first backward: the backward-weight stream is the same object before and after
+        assert m2._backbone.wgrad_low_priority is False and len(red.buckets) > 3
+        wg0 = m2._backbone._side(dev())
         data = m2(inputs(4, 96, seed=11))
         metrics()(data).backward()
+        assert m2._backbone._wg_stream is wg0 and m2._grad_streams == [wg0]
         torch.cuda.synchronize()
-        assert len(red.buckets) > 3
         for k, p in m2.named_parameters():
             if p.grad is not None:
                 assert torch.equal(p.grad, plain[k]), k
@@ -386,8 +397,11 @@ def _dp_rank(rank, port, out_dir):
     os.environ["MVG_RESERVED_CUS"] = "0"
     dist.init_process_group("gloo", rank=rank, world_size=2)
     try:
-        m = build(18)
+        m = build(18, seed=rank)          # replicas start DIFFERENT; the reducer broadcasts rank 0's weights
         GradAllReducer(m, bucket_mb=16.0)
+        sd0 = synth.make_state_dict(18, 0, 3, perturb_bn=True)
+        for k, v in m.state_dict().items():
+            assert torch.equal(v.cpu(), torch.from_numpy(np.array(sd0[k]))), f"rank {rank}: {k} not rank 0's"
         data = m(inputs(3, 64, seed=300 + rank))
         metrics()(data).backward()
         torch.cuda.synchronize()
@@ -423,6 +437,48 @@ def test_data_parallel_two_ranks_equals_average_of_independent_steps(tmp_path):
             assert torch.equal(got[k], want[k]), (r, k)
 
 
+def test_second_backward_through_released_tape_raises():
+    m = build(18)
+    d = m(inputs(2, 64))
+    loss = metrics()(d)
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second time"):
+        loss.backward()
+
+
+def test_fused_adam_state_dict_round_trip():
+    """optimizer.state_dict() carries the flat moments and the step count; a restored optimizer continues
+    exactly like the original one."""
+    from rot_mvgaze_amd.optim import Adam
+
+    def run(resume_after):
+        m = build(18)
+        opt = Adam(m.parameters(), lr=1e-3, weight_decay=1e-6)
+        for it in range(3):
+            if it == resume_after:
+                blob = opt.state_dict()
+                opt = Adam(m.parameters(), lr=1e-3, weight_decay=1e-6)
+                opt.load_state_dict(blob)
+            opt.zero_grad()
+            metrics()(m(inputs(2, 64, seed=40 + it))).backward()
+            opt.step()
+        return {k: p.detach().clone() for k, p in m.named_parameters()}, opt.state_dict()
+    a, sa = run(None)
+    b, sb = run(2)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert sa["mvg_arena_state"][0]["step"] == sb["mvg_arena_state"][0]["step"] == 3
+    assert torch.equal(sa["mvg_arena_state"][0]["exp_avg_sq"], sb["mvg_arena_state"][0]["exp_avg_sq"])
+
+
+def test_gradient_arena_slices_are_16_byte_aligned():
+    m = build(18)
+    m.ensure_layout()
+    arena, entries = m.grad_arena()
+    for p, off, n in entries:
+        assert off % 4 == 0 and p.data_ptr() % 16 == 0 and m._grad_views[id(p)].data_ptr() % 16 == 0
+
+
 def test_gradient_accumulation_and_zero_grad():
     m = build(18)
     d = m(inputs(3, 64))
@@ -443,31 +499,38 @@ def test_gradient_accumulation_and_zero_grad():
     opt.step()
 
 
-@pytest.mark.parametrize("V,B", [(3, 4), (4, 3), (8, 2), (4, 64)], ids=["V3", "V4_c3_c4", "V8_c5", "V4_768_fusion_rows"])
-def test_multiview_against_oracle(V, B):
-    """A9: V > 2 views (configs C3/C4: V = 4, C5: V = 8, here at reduced batch and image size, fp32) -
-    shared backbone features, every pair equals the two-view oracle recurrence.  The last case has
-    12 x 64 = 768 fusion-block rows: the large-tile, split-K Linear launches of the full-size configs."""
+MV_CASES = [
+    # depth, V, B, hw
+    (18, 3, 4, 64), (18, 4, 3, 64), (18, 8, 2, 64),
+    (18, 4, 64, 64),            # 12 x 64 = 768 fusion-block rows: the large-tile, split-K Linear launches
+    (50, 4, 3, 64), (50, 8, 2, 64),                    # ResNet-50 x V > 2 (C3 / C4 / C5 recurrences), small maps
+    (50, 4, 4, 224), (50, 8, 2, 224),                  # ... at the benchmark's image size (K_in = 3584 rows of 3584)
+]
+
+
+def _multiview_case(depth, V, B, hw, seed=5, perturb_bn=True, grad_keys=None, gtol=GTOL_L2_FLIPS):
+    """One training step of MultiViewGaze against the CPU oracle on the same inputs: loss, every pair's
+    features and predictions (rot_mv.py:187-269 per pair) at 1e-4, sampled weight gradients in relative L2."""
     from oracle import restatement as R
     from rot_mvgaze_amd.geometry import rotation_matrix_2d
     from rot_mvgaze_amd.losses import MultiViewIterationLoss
     from rot_mvgaze_amd.model import MultiViewGaze
-    depth, hw = 18, 64
     m = MultiViewGaze(depth, 3)
-    sdn = synth.make_state_dict(depth, 0, 3, perturb_bn=True)
+    sdn = synth.make_state_dict(depth, 0, 3, perturb_bn=perturb_bn)
     m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sdn.items()})
     m.to(dev()).train()
-    inp = synth.make_inputs(B, V, 5, hw)
+    inp = synth.make_inputs(B, V, seed, hw)
     img, hp, gt = (torch.from_numpy(inp[k]) for k in ("img", "head_pose", "gt_gaze"))
     rot_d = rotation_matrix_2d(hp.reshape(-1, 2).to(dev())).reshape(B, V, 3, 3)
-    out = m.forward_multiview(img.to(dev()), rot_d)
-    loss = MultiViewIterationLoss()(out, gt.to(dev()))
+    out = m.forward_multiview([img[:, v].contiguous().to(dev()) for v in range(V)], rot_d)
+    loss = MultiViewIterationLoss(rel_weight=0.01, reference_decay=1.0, iter_decay=0.5)(out, gt.to(dev()))
     loss.backward()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     sd = {k: torch.from_numpy(np.array(v)) for k, v in sdn.items()}
     leaves = {k: v.requires_grad_(True) for k, v in sd.items() if v.dtype == torch.float32 and "running" not in k}
     rot = R.rotation_matrix_2d(hp.reshape(-1, 2)).reshape(B, V, 3, 3)
     oo = R.multiview_forward(sd, img, rot, depth, 3, True)
-    ol = R.multiview_loss(oo, gt)
+    ol = R.multiview_loss(oo, gt, iter_decay=0.5, rel_weight=0.01, reference_decay=1.0)
     ol.backward()
     rel_close(loss, ol.item(), TOL, "mv loss")
     for pr in R.view_pairs(V):
@@ -476,11 +539,30 @@ def test_multiview_against_oracle(V, B):
                 rel_close(out["pairs"][pr][f"iter_{it}"][k], oo["pairs"][pr][f"iter_{it}"][k].detach().numpy(), TOL,
                           f"pair {pr} iter {it} {k}")
     params = dict(m.named_parameters())
-    for k in ("_lifter._lifter.blocks.0.0.weight", "_img_fusers.0._fuser.blocks.0.0.weight",
-              "_gaze_estimators.1.blocks.1.0.weight", "_feat_extractor.0.layer3.0.conv1.weight",
-              "_feat_extractor.0.bn1.bias"):
-        l2_close(params[k].grad, leaves[k].grad.numpy(), GTOL_L2_FLIPS, "mv grad " + k)
+    for k in grad_keys or ("_lifter._lifter.blocks.0.0.weight", "_img_fusers.0._fuser.blocks.0.0.weight",
+                           "_gaze_estimators.1.blocks.1.0.weight", "_feat_extractor.0.layer3.0.conv1.weight",
+                           "_feat_extractor.0.bn1.bias"):
+        l2_close(params[k].grad, leaves[k].grad.numpy(), gtol, "mv grad " + k)
     assert int(m.state_dict()["_feat_extractor.0.bn1.num_batches_tracked"]) == V
+    return m
+
+
+@pytest.mark.parametrize("depth,V,B,hw", MV_CASES, ids=[f"r{d}_V{v}_B{b}_hw{h}" for d, v, b, h in MV_CASES])
+def test_multiview_against_oracle(depth, V, B, hw):
+    """A9: V > 2 views (configs C3/C4: V = 4, C5: V = 8) for BOTH backbones, at reduced batch, fp32 - shared
+    backbone features, every pair equals the two-view oracle recurrence."""
+    _multiview_case(depth, V, B, hw)
+
+
+def test_benchmark_configuration_c4_share_full_size_against_oracle():
+    """C4's per-GPU share at full size (ResNet-50, V = 4, B = 32, 224 x 224: 128 images, 384 fusion-block
+    rows, bench.py's weights and inputs) against the CPU oracle; C3 is the same launch geometry with 4x the
+    images per view.  Loss and every pair's features / predictions within 1e-4; one weight gradient per stage."""
+    _multiview_case(50, 4, 32, 224, seed=1234, perturb_bn=False,
+                    grad_keys=("_feat_extractor.0.conv1.weight", "_feat_extractor.0.layer1.0.conv3.weight",
+                               "_feat_extractor.0.layer2.0.downsample.0.weight", "_feat_extractor.0.layer3.2.conv2.weight",
+                               "_feat_extractor.0.layer4.2.conv1.weight", "_lifter._lifter.blocks.1.0.weight",
+                               "_img_fusers.2._fuser.blocks.0.0.weight", "_gaze_estimators.0.blocks.0.0.weight"))
 
 
 def test_bf16x6_conv_math_end_to_end():
