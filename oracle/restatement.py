@@ -291,18 +291,25 @@ def view_pairs(views: int) -> List[Tuple[int, int]]:
 
 
 def multiview_forward(sd: SD, img: Tensor, rot: Tensor, depth: int, num_iter: int = 3,
-                      training: bool = False) -> Dict[str, Any]:
+                      training: bool = False, masks: Optional[Dict[Any, Any]] = None) -> Dict[str, Any]:
     """img [B,V,3,H,W], rot [B,V,3,3].  Backbone + lifter once per view in view order (BN
-    statistics per view call); fusion over every unordered pair i<j in lexicographic order."""
+    statistics per view call); fusion over every unordered pair i<j in lexicographic order.
+    ``masks`` (test aid, see _relu): {"backbone": [iterator per view], "lift": [mask per view],
+    ("fuse", it) / ("head", it): [mask per DIRECTED pair d = 2p (i<-j), 2p+1 (j<-i)]}."""
     spec = backbone_spec(depth)
     V = img.shape[1]
-    feats = [backbone_forward(sd, img[:, v], spec, training) for v in range(V)]
-    lifted = [lift(sd, f) for f in feats]
+    bm = masks["backbone"] if masks is not None else [None] * V
+    lm = masks["lift"] if masks is not None else [None] * V
+    feats = [backbone_forward(sd, img[:, v], spec, training, None, bm[v]) for v in range(V)]
+    lifted = [lift(sd, f, lm[v]) for v, f in enumerate(feats)]
     out: Dict[str, Any] = {"num_iter": num_iter, "views": V, "img_feat": feats, "initial_rot_feat": lifted,
                            "pairs": {}}
-    for (i, j) in view_pairs(V):
+    for p, (i, j) in enumerate(view_pairs(V)):
+        pm = None
+        if masks is not None:
+            pm = {k: v[2 * p:2 * p + 2] for k, v in masks.items() if isinstance(k, tuple)}
         out["pairs"][(i, j)] = fuse_pair(sd, num_iter, feats[i], feats[j], lifted[i], lifted[j],
-                                         rot[:, i], rot[:, j])
+                                         rot[:, i], rot[:, j], pm)
     out["pred_gaze"] = out["pairs"][(0, 1)][f"iter_{num_iter - 1}"]["pred_gaze_0"]
     return out
 
