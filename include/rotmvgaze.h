@@ -106,26 +106,6 @@ int mvg_conv_stats_partials(const mvg_conv_desc *d, int32_t *out_rows_per_partia
 int mvg_conv_dgrad(const mvg_conv_desc *d, const float *dy, const float *wgt, float *dx,
                    const float *mask, const float *addend, void *stream);
 
-/* Conv math mode: 0 = fp32 matrix cores (v_mfma_f32_32x32x2_f32), 1 = "bf16x6": each fp32 operand
- * is split EXACTLY into three bf16 pieces (hi + mid + lo == value) and every product is six bf16
- * MFMAs accumulated in fp32 - fp32-level accuracy at a 2.67x higher matrix roof (2.5 PF / 6).
- * Default 0 (env MVG_CONV_MATH=bf16x6 or mvg_set_conv_math(1) selects 1).  In mode 1
- * mvg_conv_fprop / mvg_conv_dgrad split their fp32 operands inside the kernel; the _pp entry
- * points take operands already split by their producers in the plane-interleaved format: a row of
- * C values is C/8 groups of [hi x8 | mid x8 | lo x8] bf16 (48 bytes), so a K-slice of a row is one
- * contiguous run.  mvg_split_planes converts any [rows][c] fp32 buffer (c % 8 == 0, 6 bytes per
- * element out); mvg_weight_split converts the weights once per step (transpose = 0: rows = cout,
- * k = (tap, cin) for fprop; 1: rows = cin, k = (tap, cout) for dgrad; k zero-padded to 8). */
-int mvg_conv_math(void);
-int mvg_set_conv_math(int mode);
-int mvg_split_planes(const float *x, void *planes, int64_t rows, int c, void *stream);
-size_t mvg_weight_planes_bytes(const mvg_conv_desc *d, int transpose);
-int mvg_weight_split(const mvg_conv_desc *d, const float *wgt, int transpose, void *planes, void *stream);
-int mvg_conv_fprop_pp(const mvg_conv_desc *d, const void *xplanes, const void *wplanes, float *y,
-                      float *stats, void *stream);
-int mvg_conv_dgrad_pp(const mvg_conv_desc *d, const void *dyplanes, const void *wplanes_t, float *dx,
-                      const float *mask, const float *addend, void *stream);
-
 /* dw[cout][r][s][cin] (+)= sum over all groups/images/pixels of dy (x) x.  Split over the pixel
  * axis into `splits` slabs in `workspace` (splits * cout*r*s*cin floats, ignored when
  * splits == 1) that a second kernel sums in a fixed order (bitwise reproducible).

@@ -55,13 +55,6 @@ SIGNATURES = {
     "mvg_conv_fprop_affine": (_I, [_D, _P, _P, _P, _P, _P, _P, _I, _P]),
     "mvg_conv_stats_partials": (_I, [_D, C.POINTER(C.c_int32)]),
     "mvg_conv_dgrad": (_I, [_D, _P, _P, _P, _P, _P, _P]),
-    "mvg_conv_math": (_I, []),
-    "mvg_set_conv_math": (_I, [_I]),
-    "mvg_weight_planes_bytes": (C.c_size_t, [_D, _I]),
-    "mvg_weight_split": (_I, [_D, _P, _I, _P, _P]),
-    "mvg_split_planes": (_I, [_P, _P, _I64, _I, _P]),
-    "mvg_conv_fprop_pp": (_I, [_D, _P, _P, _P, _P, _P]),
-    "mvg_conv_dgrad_pp": (_I, [_D, _P, _P, _P, _P, _P, _P]),
     "mvg_conv_wgrad": (_I, [_D, _P, _P, _P, _P, _I, _I, _P]),
     "mvg_conv_wgrad_splits": (_I, [_D]),
     "mvg_linear_workspace_floats": (C.c_size_t, [_I, _I, _I]),

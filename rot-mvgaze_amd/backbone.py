@@ -43,7 +43,7 @@ class GradSink:
 
 class _Unit:
     """Saved state of one conv + BN (+ReLU) (+residual) for the backward pass."""
-    __slots__ = ("spec", "desc", "x_in", "y", "out", "mean", "invstd", "relu", "rows", "w", "wp_t", "trained", "pool",
+    __slots__ = ("spec", "desc", "x_in", "y", "out", "mean", "invstd", "relu", "rows", "w", "trained", "pool",
                  "relu_affine")
 
 
@@ -93,10 +93,6 @@ class Backbone:
         rm, rv = self.p[c.bn + ".running_mean"], self.p[c.bn + ".running_var"]
         aff = torch.empty(4, G, c.cout, dtype=torch.float32, device=dev)
         mean, invstd, scale, shift = aff[0], aff[1], aff[2], aff[3]
-        # bf16x6 conv math: the weights are split into three bf16 planes once per step (fprop reads
-        # [cout][tap][cin]; backward-data reads the transposed [cin][tap][cout] planes)
-        x6 = ops.conv_math() == 1
-        wp = None
 
         def fprop(stats_buf):
             ops.conv_fprop(d, x, w, y, None, False, stats_buf)
@@ -130,7 +126,6 @@ class Backbone:
             u = _Unit()
             u.spec, u.desc, u.x_in, u.y, u.out, u.mean, u.invstd, u.relu, u.rows, u.w = \
                 c, d, x, y, (None if pool else out), mean, invstd, relu, rows, w
-            u.wp_t = x6 and cin >= 64
             u.trained = training
             # ReLU without residual: the backward rebuilds the mask from y (saves reading `out` twice)
             u.relu_affine = (scale, shift) if (relu and residual is None and not pool) else None

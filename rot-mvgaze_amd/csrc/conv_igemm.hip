@@ -132,8 +132,7 @@ struct IgemmParams {
   int sk_tiles;
   int no_remap;              // several classes, one tile per workgroup: keep the dispatch order (longest class first)
   int ncls;
-  IgemmClass cls[4];         // the fp32 kernels read the class view from here (top-level copies: bf16x6 kernels)
-  int b_row_pad;             // bf16x6 with pre-split weights: padded row length of the planes
+  IgemmClass cls[4];         // per-class view (one class unless this is a stride-2 dgrad)
 };
 
 // bijective XCD-aware remap of a 1-D grid (cdna_hip_programming.md §5 "XCD swizzle must be
@@ -733,509 +732,6 @@ __global__ __launch_bounds__(256) void igemm_fixup_kernel(IgemmParams p, int P) 
                                           DGRAD ? row_lds : nullptr);
 }
 
-// ------------------------------------------------------------------------------------------
-// fp32-accurate convolution on the bf16 matrix cores ("bf16x6")
-// ------------------------------------------------------------------------------------------
-// Every fp32 operand is split EXACTLY into three bf16 pieces by truncation,
-//   a = hi + mid + lo,   hi = a & 0xFFFF0000,  mid = (a - hi) & 0xFFFF0000,  lo = a - hi - mid
-// (3 x 8 significant bits = the 24-bit fp32 mantissa), and the product a*b is accumulated in fp32 as
-//   lo*hi' + hi*lo' + mid*mid' + mid*hi' + hi*mid' + hi*hi'
-// with six v_mfma_f32_32x32x16_bf16 (bf16 x bf16 products are exact in fp32; the three dropped
-// cross terms are <= 2^-24 relative).  Six bf16 MFMAs per 16-deep k-step cost 6 x 32 cycles vs
-// 8 x 64 cycles for the fp32 MFMA: a 2.67x higher matrix roof (2.5 PF / 6 = 417 TFLOP/s) at
-// fp32-level accuracy (tests hold the same tolerances for both paths).
-// The split happens once per element when a tile goes registers -> LDS; LDS holds 3 bf16 planes
-// per operand, [row][k] with rows padded to 80 bytes (conflict-free ds_read_b128 fragments).
-// Both operands are k-contiguous: dgrad reads weights pre-transposed to [cin][r][s][cout].
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ void split3(float v, unsigned &h, unsigned &m, unsigned &l) {
-  h = __float_as_uint(v) & 0xFFFF0000u;
-  const float r1 = v - __uint_as_float(h);
-  m = __float_as_uint(r1) & 0xFFFF0000u;
-  l = __float_as_uint(r1 - __uint_as_float(m));      // <= 8 significant bits left: exact in bf16
-}
-__device__ __forceinline__ unsigned pack_hi16(unsigned e0, unsigned e1) { return (e0 >> 16) | (e1 & 0xFFFF0000u); }
-
-template <int BM, int BN, int BK, int WGM, int WGN, bool DGRAD>
-__global__ __launch_bounds__(256) void igemm6_kernel(IgemmParams p) {
-  constexpr bool BPL = false;
-  constexpr int WTM = BM / WGM, WTN = BN / WGN;
-  constexpr int TM = WTM / 32, TN = WTN / 32;
-  constexpr int KV = BK / 4;                 // float4 per row
-  constexpr int RPP = 256 / KV;              // 32 rows per loader pass
-  constexpr int A_PASSES = BM / RPP, B_PASSES = BN / RPP;
-  constexpr int LDK = BK + 8;                // bf16 elements per LDS row (80 bytes)
-  constexpr int A_PLANE = BM * LDK, B_PLANE = BN * LDK;       // elements
-  constexpr int BUF = 3 * (A_PLANE + B_PLANE);
-  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile");
-  __shared__ __attribute__((aligned(16))) unsigned short smem[2 * BUF];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WGN, wn = wave % WGN;
-  const int li = lane & 31, lh = lane >> 5;
-
-  const int nwg = gridDim.x;
-  const int wg_all = xcd_remap(blockIdx.x, nwg);
-  const int tiles_total = nwg / p.splits;
-  const int split = wg_all / tiles_total;
-  const int wg = wg_all - split * tiles_total;
-  const int ntile = wg % p.ntiles;
-  const int mt_all = wg / p.ntiles;
-  const int g = mt_all / p.mtiles_per_group;
-  const int mtile = mt_all - g * p.mtiles_per_group;
-
-  const int a_kv = tid % KV;
-  const int a_r0 = tid / KV;
-  unsigned a_img[A_PASSES];
-  int a_y0[A_PASSES], a_x0[A_PASSES];
-  bool a_ok[A_PASSES];
-  const int ohw = p.out_h * p.out_w;
-#pragma unroll
-  for (int i = 0; i < A_PASSES; ++i) {
-    const long long m = (long long)mtile * BM + a_r0 + i * RPP;
-    a_ok[i] = m < p.rows_per_group;
-    const int mm = a_ok[i] ? (int)m : 0;
-    const int img = (int)fdiv((unsigned)mm, p.ohw_div);
-    const int rem = mm - img * ohw;
-    const int oy = (int)fdiv((unsigned)rem, p.ow_div), ox = rem - oy * p.out_w;
-    if (DGRAD) {
-      a_y0[i] = oy + p.cls_cy;
-      a_x0[i] = ox + p.cls_cx;
-    } else {
-      a_y0[i] = oy * p.stride - p.pad;
-      a_x0[i] = ox * p.stride - p.pad;
-    }
-    a_img[i] = (unsigned)(img * p.src_img_stride * 4);
-  }
-  const __amdgpu_buffer_rsrc_t rs_a =
-      make_rsrc(p.a + (long long)g * p.imgs_per_group * p.src_img_stride, p.a_group_bytes);
-  const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(p.b, p.b_bytes);
-
-  float4 a_reg[A_PASSES], b_reg[BPL ? 1 : B_PASSES];
-  constexpr int BCH = BK / 8;                          // 16-byte chunks (8 bf16) per row per plane
-  constexpr int B_LOADS = (3 * BN * BCH + 255) / 256;  // pre-split B: 16-byte copies per thread
-  u32x4 bp_reg[BPL ? B_LOADS : 1];
-  int klimit = p.ktotal;
-
-  auto load_tiles = [&](int kt) {
-    const int k0 = kt * BK + a_kv * 4;
-    int tap = 0, c = k0;
-    if (p.ntaps > 1) {
-      tap = k0 >> p.src_c_shift;
-      c = k0 - (tap << p.src_c_shift);
-    }
-    const int fr = (int)fdiv((unsigned)tap, p.tap_ns_div), fs = tap - fr * p.tap_ns;
-    const bool kok = k0 < klimit;
-#pragma unroll
-    for (int i = 0; i < A_PASSES; ++i) {
-      const int iy = DGRAD ? a_y0[i] - fr : a_y0[i] + fr;
-      const int ix = DGRAD ? a_x0[i] - fs : a_x0[i] + fs;
-      const bool ok = a_ok[i] & kok & ((unsigned)iy < (unsigned)p.src_h) & ((unsigned)ix < (unsigned)p.src_w);
-      a_reg[i] = buf_ld16(rs_a, pred_off(a_img[i] + (unsigned)((iy * p.src_w + ix) * p.src_c + c) * 4u, ok));
-    }
-    // B rows are output columns n; fprop: w[n][k] (KRSC); dgrad: w_t[n = cin][filter tap][cout]
-    unsigned bk_off;
-    if (DGRAD) {
-      const int btap = (p.tap_r0 + p.tap_step * fr) * p.s + p.tap_s0 + p.tap_step * fs;
-      bk_off = (unsigned)(btap * p.src_c + c);
-    } else {
-      bk_off = (unsigned)k0;
-    }
-    const unsigned b_row_elems = DGRAD ? (unsigned)(p.rs * p.src_c) : (unsigned)p.ktotal;
-    if (!BPL) {
-#pragma unroll
-      for (int i = 0; i < B_PASSES; ++i) {
-        const int n = ntile * BN + a_r0 + i * RPP;
-        b_reg[i] = buf_ld16(rs_b, pred_off(((unsigned)n * b_row_elems + bk_off) * 4u, (n < p.ncols) & kok));
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < B_LOADS; ++i) {
-        const int idx = tid + i * 256;                 // (plane, row, chunk)
-        const int pl = idx / (BN * BCH);
-        const int rem = idx - pl * (BN * BCH);
-        const int row = rem / BCH, ch = rem - row * BCH;
-        const int n = ntile * BN + row;
-        const int kk = kt * BK + ch * 8;
-        unsigned koff;
-        if (DGRAD) {
-          int t2 = 0, c2 = kk;
-          if (p.ntaps > 1) {
-            t2 = kk >> p.src_c_shift;
-            c2 = kk - (t2 << p.src_c_shift);
-          }
-          const int r2 = (int)fdiv((unsigned)t2, p.tap_ns_div), s2 = t2 - r2 * p.tap_ns;
-          koff = (unsigned)(((p.tap_r0 + p.tap_step * r2) * p.s + p.tap_s0 + p.tap_step * s2) * p.src_c + c2);
-        } else {
-          koff = (unsigned)kk;
-        }
-        const bool ok = (pl < 3) & (n < p.ncols) & (kk < klimit);
-        const unsigned off = (((unsigned)pl * (unsigned)p.ncols + (unsigned)n) * (unsigned)p.b_row_pad + koff) * 2u;
-        bp_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, pred_off(off, ok), 0, 0);
-      }
-    }
-  };
-
-  auto store_tiles = [&](int buf) {
-    unsigned short *A0 = smem + buf * BUF;
-    unsigned short *B0 = A0 + 3 * A_PLANE;
-#pragma unroll
-    for (int i = 0; i < A_PASSES; ++i) {
-      unsigned h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
-      split3(a_reg[i].x, h0, m0, l0);
-      split3(a_reg[i].y, h1, m1, l1);
-      split3(a_reg[i].z, h2, m2, l2);
-      split3(a_reg[i].w, h3, m3, l3);
-      unsigned short *d = A0 + (a_r0 + i * RPP) * LDK + a_kv * 4;
-      *reinterpret_cast<uint2 *>(d) = make_uint2(pack_hi16(h0, h1), pack_hi16(h2, h3));
-      *reinterpret_cast<uint2 *>(d + A_PLANE) = make_uint2(pack_hi16(m0, m1), pack_hi16(m2, m3));
-      *reinterpret_cast<uint2 *>(d + 2 * A_PLANE) = make_uint2(pack_hi16(l0, l1), pack_hi16(l2, l3));
-    }
-    if (!BPL) {
-#pragma unroll
-      for (int i = 0; i < B_PASSES; ++i) {
-        unsigned h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
-        split3(b_reg[i].x, h0, m0, l0);
-        split3(b_reg[i].y, h1, m1, l1);
-        split3(b_reg[i].z, h2, m2, l2);
-        split3(b_reg[i].w, h3, m3, l3);
-        unsigned short *d = B0 + (a_r0 + i * RPP) * LDK + a_kv * 4;
-        *reinterpret_cast<uint2 *>(d) = make_uint2(pack_hi16(h0, h1), pack_hi16(h2, h3));
-        *reinterpret_cast<uint2 *>(d + B_PLANE) = make_uint2(pack_hi16(m0, m1), pack_hi16(m2, m3));
-        *reinterpret_cast<uint2 *>(d + 2 * B_PLANE) = make_uint2(pack_hi16(l0, l1), pack_hi16(l2, l3));
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < B_LOADS; ++i) {
-        const int idx = tid + i * 256;
-        const int pl = idx / (BN * BCH);
-        const int rem = idx - pl * (BN * BCH);
-        const int row = rem / BCH, ch = rem - row * BCH;
-        if (3 * BN * BCH % 256 == 0 || pl < 3)
-          *reinterpret_cast<u32x4 *>(B0 + pl * B_PLANE + row * LDK + ch * 8) = bp_reg[i];
-      }
-    }
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  const int KT_all = (p.ktotal + BK - 1) / BK;
-  const int kt_begin = split * p.ktiles_per_split;
-  const int KT = (kt_begin + p.ktiles_per_split < KT_all) ? kt_begin + p.ktiles_per_split : KT_all;
-  klimit = KT * BK < p.ktotal ? KT * BK : p.ktotal;
-  load_tiles(kt_begin);
-  store_tiles(kt_begin & 1);
-  __syncthreads();
-
-  auto mfma_kstep = [&](const unsigned short *A0, const unsigned short *B0, int ks) {
-    bf16x8 af[3][TM], bf[3][TN];
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-        af[pl][i] = *reinterpret_cast<const bf16x8 *>(A0 + pl * A_PLANE + (wm * WTM + i * 32 + li) * LDK + ks * 16 + lh * 8);
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        bf[pl][j] = *reinterpret_cast<const bf16x8 *>(B0 + pl * B_PLANE + (wn * WTN + j * 32 + li) * LDK + ks * 16 + lh * 8);
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        f32x16 c = acc[i][j];
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], c, 0, 0, 0);   // lo * hi
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], c, 0, 0, 0);   // hi * lo
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], c, 0, 0, 0);   // mid * mid
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], c, 0, 0, 0);   // mid * hi
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], c, 0, 0, 0);   // hi * mid
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], c, 0, 0, 0);   // hi * hi
-        acc[i][j] = c;
-      }
-  };
-
-  for (int kt = kt_begin; kt < KT; ++kt) {
-    const int cur = kt & 1;
-    const unsigned short *A0 = smem + cur * BUF;
-    const unsigned short *B0 = A0 + 3 * A_PLANE;
-    // Two-stage pipeline with no loop-carried registers: the global loads of tile kt+1 are issued
-    // first and land while the first k-step multiplies; the second k-step's MFMAs are interleaved
-    // with the split (VALU) of the freshly loaded tile, whose ds_writes go to the other LDS buffer
-    // after this step's fragment reads in program order.
-    load_tiles(kt + 1);
-    if (BK == 32) {
-      mfma_kstep(A0, B0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_kstep(A0, B0, BK / 16 - 1);
-    } else {
-      mfma_kstep(A0, B0, 0);
-    }
-    store_tiles(cur ^ 1);
-    {
-      constexpr int NMFMA = TM * TN * 6;
-      constexpr int NVALU = 6 * (A_PASSES + B_PASSES) * 4 + 16;
-      constexpr int PER = (NVALU + NMFMA - 1) / NMFMA;
-#pragma unroll
-      for (int q = 0; q < NMFMA; ++q) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // 1 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, PER, 0);   // PER VALU
-      }
-    }
-    __syncthreads();
-  }
-  igemm_epilogue<BM, BN, WGM, WGN, DGRAD>(p, p.cls[0], acc, g, mtile, ntile, split, wm, wn, li, lh, ohw);
-}
-
-// bf16x6 with BOTH operands pre-split into bf16 planes by their producers (activations: bn_apply /
-// bn_bwd_apply / maxpool write three planes next to the fp32 tensor; weights: weight_split_kernel):
-// the loader is pure 16-byte copies global -> registers -> LDS, three-stage pipelined like the fp32
-// kernel, and the wave's VALU stays free for addressing.  BM = 128, BK = 16 (one MFMA k-step per
-// tile), LDS 3 planes x (BM + BN) rows x 48 B x 2 buffers = 36-72 KB -> two workgroups per CU.
-template <int BN, int BK, bool DGRAD>
-__global__ __launch_bounds__(256, 2) void igemm6p_kernel(IgemmParams p) {
-  constexpr int BM = 128, WGM = 2, WGN = 2;
-  constexpr int WTM = BM / WGM, WTN = BN / WGN;
-  constexpr int TM = WTM / 32, TN = WTN / 32;
-  constexpr int BCH = BK / 8;                 // channel groups (8 bf16 = 16 bytes per plane) per row
-  constexpr int RCH = 3 * BCH;                // 16-byte chunks per row: [grp][plane], contiguous in HBM
-  constexpr int LDK = BK + 8;                 // 48-byte LDS rows: conflict-free ds_read_b128
-  constexpr int A_PLANE = BM * LDK, B_PLANE = BN * LDK;
-  constexpr int BUF = 3 * (A_PLANE + B_PLANE);
-  constexpr int A_LOADS = BM * RCH / 256, B_LOADS = (BN * RCH + 255) / 256;
-  static_assert(BM * RCH % 256 == 0, "tile");
-  __shared__ __attribute__((aligned(16))) unsigned short smem[2 * BUF];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WGN, wn = wave % WGN;
-  const int li = lane & 31, lh = lane >> 5;
-  const int nwg = gridDim.x;
-  const int wg = xcd_remap(blockIdx.x, nwg);
-  const int ntile = wg % p.ntiles;
-  const int mt_all = wg / p.ntiles;
-  const int g = mt_all / p.mtiles_per_group;
-  const int mtile = mt_all - g * p.mtiles_per_group;
-  const int split = 0;
-
-  // A chunk idx = tid + i*256 -> (row = idx / RCH, j = idx % RCH -> group j / 3, plane j % 3):
-  // RCH consecutive lanes copy one row's contiguous 16*RCH bytes.
-  const int ohw = p.out_h * p.out_w;
-  int a_y0[A_LOADS], a_x0[A_LOADS], a_row[A_LOADS], a_j[A_LOADS];
-  unsigned a_img[A_LOADS];
-  bool a_ok[A_LOADS];
-#pragma unroll
-  for (int i = 0; i < A_LOADS; ++i) {
-    const int idx = tid + i * 256;
-    a_row[i] = idx / RCH;
-    a_j[i] = idx - a_row[i] * RCH;
-    const long long am = (long long)mtile * BM + a_row[i];
-    a_ok[i] = am < p.rows_per_group;
-    const int mm = a_ok[i] ? (int)am : 0;
-    const int img = (int)fdiv((unsigned)mm, p.ohw_div);
-    const int rem = mm - img * ohw;
-    const int oy = (int)fdiv((unsigned)rem, p.ow_div), ox = rem - oy * p.out_w;
-    a_y0[i] = DGRAD ? oy + p.cls_cy : oy * p.stride - p.pad;
-    a_x0[i] = DGRAD ? ox + p.cls_cx : ox * p.stride - p.pad;
-    a_img[i] = (unsigned)(img * p.src_img_stride * 6);          // 3 planes x 2 bytes per element
-  }
-  const unsigned short *a0 = reinterpret_cast<const unsigned short *>(p.a) + (long long)g * p.imgs_per_group * p.src_img_stride * 3;
-  const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(a0, p.a_group_bytes);
-  const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(p.b, p.b_bytes);
-
-  // Two register sets: a tile is fetched TWO K-steps before it is written to LDS (a bf16x6 K-step
-  // is only 24 MFMAs = 768 cycles, less than an L2 miss), the K loop is unrolled by two so that
-  // each set is written and read at fixed program points (no dynamic register indexing).
-  u32x4 aR0[A_LOADS], bR0[B_LOADS], aR1[A_LOADS], bR1[B_LOADS];
-  auto load_tiles = [&](int kt, u32x4 (&a_reg)[A_LOADS], u32x4 (&b_reg)[B_LOADS]) {
-#pragma unroll
-    for (int i = 0; i < A_LOADS; ++i) {
-      const int grp = a_j[i] / 3, pl = a_j[i] - grp * 3;
-      const int kk = kt * BK + grp * 8;
-      int tap = 0, c = kk;
-      if (p.ntaps > 1) {
-        tap = kk >> p.src_c_shift;
-        c = kk - (tap << p.src_c_shift);
-      }
-      const int fr = (int)fdiv((unsigned)tap, p.tap_ns_div), fs = tap - fr * p.tap_ns;
-      const int iy = DGRAD ? a_y0[i] - fr : a_y0[i] + fr;
-      const int ix = DGRAD ? a_x0[i] - fs : a_x0[i] + fs;
-      const bool ok = a_ok[i] & (kk < p.ktotal) & ((unsigned)iy < (unsigned)p.src_h) & ((unsigned)ix < (unsigned)p.src_w);
-      const unsigned off = a_img[i] + ((unsigned)((iy * p.src_w + ix) * p.src_c + c) * 3u + (unsigned)pl * 8u) * 2u;
-      a_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, pred_off(off, ok), 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < B_LOADS; ++i) {
-      const int idx = tid + i * 256;
-      const int row = idx / RCH, j = idx - row * RCH;
-      const int grp = j / 3, pl = j - grp * 3;
-      const int n = ntile * BN + row;
-      const int kb = kt * BK + grp * 8;
-      unsigned koff;
-      if (DGRAD) {
-        int t2 = 0, c2 = kb;
-        if (p.ntaps > 1) {
-          t2 = kb >> p.src_c_shift;
-          c2 = kb - (t2 << p.src_c_shift);
-        }
-        const int r2 = (int)fdiv((unsigned)t2, p.tap_ns_div), s2 = t2 - r2 * p.tap_ns;
-        koff = (unsigned)(((p.tap_r0 + p.tap_step * r2) * p.s + p.tap_s0 + p.tap_step * s2) * p.src_c + c2);
-      } else {
-        koff = (unsigned)kb;
-      }
-      const bool bok = (row < BN) & (n < p.ncols) & (kb < p.ktotal);
-      const unsigned boff = (((unsigned)n * (unsigned)p.b_row_pad + koff) * 3u + (unsigned)pl * 8u) * 2u;
-      b_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, pred_off(boff, bok), 0, 0);
-    }
-  };
-  auto store_tiles = [&](int buf, const u32x4 (&a_reg)[A_LOADS], const u32x4 (&b_reg)[B_LOADS]) {
-    unsigned short *A0 = smem + buf * BUF;
-    unsigned short *B0 = A0 + 3 * A_PLANE;
-#pragma unroll
-    for (int i = 0; i < A_LOADS; ++i) {
-      const int grp = a_j[i] / 3, pl = a_j[i] - grp * 3;
-      *reinterpret_cast<u32x4 *>(A0 + pl * A_PLANE + a_row[i] * LDK + grp * 8) = a_reg[i];
-    }
-#pragma unroll
-    for (int i = 0; i < B_LOADS; ++i) {
-      const int idx = tid + i * 256;
-      const int row = idx / RCH, j = idx - row * RCH;
-      const int grp = j / 3, pl = j - grp * 3;
-      if (BN * RCH % 256 == 0 || row < BN)
-        *reinterpret_cast<u32x4 *>(B0 + pl * B_PLANE + row * LDK + grp * 8) = b_reg[i];
-    }
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  auto mfma_tile = [&](int buf) {
-    const unsigned short *A0 = smem + buf * BUF;
-    const unsigned short *B0 = A0 + 3 * A_PLANE;
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      bf16x8 af[3][TM], bf[3][TN];
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-          af[pl][i] = *reinterpret_cast<const bf16x8 *>(A0 + pl * A_PLANE + (wm * WTM + i * 32 + li) * LDK + ks * 16 + lh * 8);
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          bf[pl][j] = *reinterpret_cast<const bf16x8 *>(B0 + pl * B_PLANE + (wn * WTN + j * 32 + li) * LDK + ks * 16 + lh * 8);
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          f32x16 c = acc[i][j];
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], c, 0, 0, 0);   // lo * hi
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], c, 0, 0, 0);   // hi * lo
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], c, 0, 0, 0);   // mid * mid
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], c, 0, 0, 0);   // mid * hi
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], c, 0, 0, 0);   // hi * mid
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], c, 0, 0, 0);   // hi * hi
-          acc[i][j] = c;
-        }
-    }
-    // schedule: ALL fragment reads of the K-step first (one LDS latency per step instead of one per
-    // MFMA - a 32-cycle bf16 MFMA cannot cover a ~130-cycle ds_read), then the MFMAs with the next
-    // tile's global loads spread between them.
-    constexpr int NLOADS = A_LOADS + B_LOADS;
-    constexpr int NREADS = 3 * (TM + TN) * (BK / 16);
-    constexpr int NMFMA = 6 * TM * TN * (BK / 16);
-    __builtin_amdgcn_sched_group_barrier(0x100, NREADS, 0);
-#pragma unroll
-    for (int l = 0; l < NLOADS; ++l) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - 2 * NLOADS, 0);
-  };
-
-  const int KT = (p.ktotal + BK - 1) / BK;
-  load_tiles(0, aR0, bR0);
-  store_tiles(0, aR0, bR0);
-  load_tiles(1, aR0, bR0);
-  load_tiles(2, aR1, bR1);
-  __syncthreads();
-  for (int kt = 0; kt < KT; kt += 2) {
-    // even step: LDS[0] = tile kt;  R0 = tile kt+1, R1 = tile kt+2
-    store_tiles(1, aR0, bR0);
-    load_tiles(kt + 3, aR0, bR0);
-    mfma_tile(0);
-    __syncthreads();
-    if (kt + 1 < KT) {
-      // odd step: LDS[1] = tile kt+1;  R1 = tile kt+2, R0 = tile kt+3
-      store_tiles(0, aR1, bR1);
-      load_tiles(kt + 4, aR1, bR1);
-      mfma_tile(1);
-      __syncthreads();
-    }
-  }
-  igemm_epilogue<BM, BN, WGM, WGN, DGRAD>(p, p.cls[0], acc, g, mtile, ntile, split, wm, wn, li, lh, ohw);
-}
-
-// Plane-interleaved bf16x6 operand format: a row of C fp32 values becomes C/8 groups of
-// [hi x8 | mid x8 | lo x8] (48 bytes), so a K-slice of one row is ONE contiguous run for all three
-// planes (96 B for 16 channels) - separate planes would cost three 32-B L2 requests instead.
-__global__ __launch_bounds__(256) void split_planes_kernel(const float4 *__restrict__ x, unsigned short *__restrict__ planes,
-                                                           long long n4, int c4n) {
-  const long long stride = (long long)gridDim.x * 256;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-    const float4 v = x[i];
-    unsigned h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
-    split3(v.x, h0, m0, l0);
-    split3(v.y, h1, m1, l1);
-    split3(v.z, h2, m2, l2);
-    split3(v.w, h3, m3, l3);
-    const long long row = i / c4n;
-    const int cq = (int)(i - row * c4n);               // float4 index inside the row
-    unsigned short *d = planes + (row * c4n * 4) * 3 + (cq >> 1) * 24 + (cq & 1) * 4;
-    *reinterpret_cast<uint2 *>(d) = make_uint2(pack_hi16(h0, h1), pack_hi16(h2, h3));
-    *reinterpret_cast<uint2 *>(d + 8) = make_uint2(pack_hi16(m0, m1), pack_hi16(m2, m3));
-    *reinterpret_cast<uint2 *>(d + 16) = make_uint2(pack_hi16(l0, l1), pack_hi16(l2, l3));
-  }
-}
-
-// Weights in the plane-interleaved format, rows zero-padded to kpad (multiple of 8).
-// transpose == 0: rows n = cout, k = (tap, cin)  [fprop];  1: n = cin, k = (tap, cout)  [dgrad].
-__global__ __launch_bounds__(256) void weight_split_kernel(const float *__restrict__ w, unsigned short *__restrict__ planes,
-                                                           int cout, int rs, int cin, int kpad, int transpose) {
-  const int nrows = transpose ? cin : cout;
-  const int klen = transpose ? rs * cout : rs * cin;
-  const long long total = (long long)nrows * kpad;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int n = (int)(i / kpad), k = (int)(i - (long long)n * kpad);
-    float v = 0.f;
-    if (k < klen) {
-      if (transpose) {
-        const int tap = k / cout, o = k - tap * cout;
-        v = w[((long long)o * rs + tap) * cin + n];
-      } else {
-        v = w[(long long)n * klen + k];
-      }
-    }
-    unsigned h, m, l;
-    split3(v, h, m, l);
-    unsigned short *d = planes + ((long long)n * kpad) * 3 + (k >> 3) * 24 + (k & 7);
-    d[0] = (unsigned short)(h >> 16);
-    d[8] = (unsigned short)(m >> 16);
-    d[16] = (unsigned short)(l >> 16);
-  }
-}
-
 // out = epilogue(sum_s slab[s]) : fprop (bias, relu) / dgrad (mask, addend); fixed summation order.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float4 *__restrict__ slab, float4 *out, long long n4,
                                                             int splits, int c4n, const float4 *__restrict__ bias, int relu,
@@ -1615,7 +1111,7 @@ static int tile_bk(int bm, int bn, bool dgrad) {
   return (bm == 128 && bn == 128 && (dgrad ? bk32 >= 2 : bk32 >= 1)) ? 32 : 16;
 }
 
-// the class view of the top-level fields (single-class launches; bf16x6 kernels' epilogue)
+// the class view of the top-level fields (single-class launches)
 static void class_from_params(IgemmClass &c, const IgemmParams &p) {
   memset(&c, 0, sizeof(c));
   c.out_h = p.out_h;
@@ -1813,69 +1309,6 @@ static int launch_igemm(IgemmParams &p, TileChoice t, hipStream_t st) {
   return launch_igemm_tile<128, 32, 16, 4, 1, DGRAD>(p, tiles, units, st);
 }
 
-// conv math: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = bf16x6 split on the bf16 MFMA
-static int g_conv_math = -1;
-static int conv_math() {
-  if (g_conv_math < 0) {
-    const char *e = getenv("MVG_CONV_MATH");
-    g_conv_math = (e && (!strcmp(e, "bf16x6") || !strcmp(e, "1"))) ? 1 : 0;
-  }
-  return g_conv_math;
-}
-
-template <bool DGRAD>
-static int launch_igemm6(IgemmParams &p, TileChoice t, hipStream_t st) {
-  p.mtiles_per_group = ceil_div(p.rows_per_group, t.bm);
-  p.ntiles = ceil_div(p.ncols, t.bn);
-  p.splits = 1;
-  p.ktiles_per_split = 1 << 30;
-  const long long nblk = (long long)p.groups * p.mtiles_per_group * p.ntiles;
-  MVG_REQUIRE(nblk < (1LL << 31), "conv: grid too large");
-  if (p.rows_per_group <= 0) return 0;
-  p.ncls = 1;
-  class_from_params(p.cls[0], p);
-  dim3 grid((unsigned)nblk), block(256);
-  if (t.bm == 128 && t.bn == 128)
-    hipLaunchKernelGGL((igemm6_kernel<128, 128, 16, 2, 2, DGRAD>), grid, block, 0, st, p);
-  else if (t.bm == 128 && t.bn == 64)
-    hipLaunchKernelGGL((igemm6_kernel<128, 64, 16, 2, 2, DGRAD>), grid, block, 0, st, p);
-  else
-    hipLaunchKernelGGL((igemm6_kernel<64, 64, 16, 2, 2, DGRAD>), grid, block, 0, st, p);
-  return check_launch(DGRAD ? "conv_dgrad(bf16x6)" : "conv_fprop(bf16x6)");
-}
-
-// tile for the bf16x6 kernels: one workgroup per CU is resident (LDS), so prefer the biggest tile
-// that still gives every CU >= ~2 tiles.
-static TileChoice choose_tile6(long long rows_per_group, int groups, int ncols) {
-  const int cus = compute_cus();
-  // BM is always 128 in this mode, so that BN partial statistics have one geometry (64-row partials)
-  if (ncols >= 128) {
-    const long long blocks = (long long)groups * ceil_div(rows_per_group, 128) * ceil_div(ncols, 128);
-    if (blocks >= 2LL * cus) return {128, 128};
-  }
-  return {128, 64};
-}
-
-template <bool DGRAD>
-static int launch_igemm6p(IgemmParams &p, TileChoice t, hipStream_t st) {
-  p.mtiles_per_group = ceil_div(p.rows_per_group, 128);
-  p.ntiles = ceil_div(p.ncols, t.bn);
-  p.splits = 1;
-  p.ktiles_per_split = 1 << 30;
-  const long long nblk = (long long)p.groups * p.mtiles_per_group * p.ntiles;
-  MVG_REQUIRE(nblk < (1LL << 31), "conv: grid too large");
-  if (p.rows_per_group <= 0) return 0;
-  p.ncls = 1;
-  class_from_params(p.cls[0], p);
-  dim3 grid((unsigned)nblk), block(256);
-  // BK = 16: two workgroups per CU; BK = 32 (one per CU) measured 20 % slower
-  if (t.bn == 128)
-    hipLaunchKernelGGL((igemm6p_kernel<128, 16, DGRAD>), grid, block, 0, st, p);
-  else
-    hipLaunchKernelGGL((igemm6p_kernel<64, 16, DGRAD>), grid, block, 0, st, p);
-  return check_launch(DGRAD ? "conv_dgrad(bf16x6p)" : "conv_fprop(bf16x6p)");
-}
-
 // split-K plan for a GEMM whose tile grid cannot fill the device: returns splits (>= 1) and sets
 // ktiles_per_split; bounded by the caller's workspace.
 static int plan_splitk(IgemmParams &p, TileChoice t, size_t ws_floats, bool dgrad) {
@@ -1919,17 +1352,15 @@ extern "C" {
 int mvg_conv_stats_partials(const mvg_conv_desc *d, int32_t *rows_per_partial) {
   if (validate(d)) return -1;
   const long long rows = (long long)d->n * d->ho * d->wo;
-  const bool lin = d->r == 1 && d->s == 1 && d->h == 1 && d->w == 1;
-  const TileChoice t = (!lin && conv_math() == 1 && d->cout >= 64) ? choose_tile6(rows, d->groups, d->cout)
-                                                                  : choose_tile(rows, d->groups, d->cout, d->r * d->s * d->cin, false);
+  const TileChoice t = choose_tile(rows, d->groups, d->cout, d->r * d->s * d->cin, false);
   const int wr = wave_rows(t);
   if (rows_per_partial) *rows_per_partial = wr;
   return ceil_div(rows, t.bm) * (t.bm / wr);
 }
 
 static int fprop_impl(const mvg_conv_desc *d, const float *x, const float *wgt, float *y, const float *bias, int relu,
-                      float *stats, float *ws, size_t ws_floats, void *stream, const void *wplanes = nullptr,
-                      const void *aplanes = nullptr, const float *scale = nullptr, const float *residual = nullptr) {
+                      float *stats, float *ws, size_t ws_floats, void *stream, const float *scale = nullptr,
+                      const float *residual = nullptr) {
   if (validate(d)) return 2;
   IgemmParams p;
   memset(&p, 0, sizeof(p));
@@ -1976,19 +1407,6 @@ static int fprop_impl(const mvg_conv_desc *d, const float *x, const float *wgt, 
                               d->groups * (double)p.rows_per_group * d->cout);
   const bool lin = d->r == 1 && d->s == 1 && d->h == 1 && d->w == 1;
   ProfScope ps(lin ? MVG_K_LINEAR_FPROP : MVG_K_CONV_FPROP, (hipStream_t)stream, flops, bytes);
-  if (!lin && conv_math() == 1 && d->cout >= 64) {
-    const TileChoice t6 = choose_tile6(p.rows_per_group, d->groups, d->cout);
-    if (wplanes && aplanes) {
-      p.b = (const float *)wplanes;
-      p.b_row_pad = (p.ktotal + 7) / 8 * 8;
-      p.b_bytes = 6ll * d->cout * p.b_row_pad;
-      p.a = (const float *)aplanes;
-      p.a_group_bytes = 6ll * d->n * p.src_img_stride;
-      MVG_REQUIRE(p.a_group_bytes < 0x7FFFFFF0ll, "conv: a group of planes exceeds 2 GiB");
-      return launch_igemm6p<false>(p, t6, (hipStream_t)stream);
-    }
-    return launch_igemm6<false>(p, t6, (hipStream_t)stream);
-  }
   p.ncls = 1;
   class_from_params(p.cls[0], p);
   if (!stats && plan_splitk(p, t, ws ? ws_floats : 0, false) > 1) {
@@ -2000,8 +1418,7 @@ static int fprop_impl(const mvg_conv_desc *d, const float *x, const float *wgt, 
 }
 
 static int dgrad_impl(const mvg_conv_desc *d, const float *dy, const float *wgt, float *dx, const float *mask,
-                      const float *addend, float *ws, size_t ws_floats, void *stream, const void *wplanes = nullptr,
-                      const void *aplanes = nullptr) {
+                      const float *addend, float *ws, size_t ws_floats, void *stream) {
   if (validate(d)) return 2;
   MVG_REQUIRE(d->cout % 4 == 0, "dgrad: cout %% 4 != 0 (%d)", d->cout);
   IgemmParams p;
@@ -2041,7 +1458,6 @@ static int dgrad_impl(const mvg_conv_desc *d, const float *dy, const float *wgt,
   const bool lin = d->r == 1 && d->s == 1 && d->h == 1 && d->w == 1;
   ProfScope ps(lin ? MVG_K_LINEAR_DGRAD : MVG_K_CONV_DGRAD, (hipStream_t)stream, flops, bytes);
   const int step = d->stride;
-  const bool x6 = wplanes && aplanes;
   IgemmParams m = p;                   // the merged fp32 launch: every parity class in one grid
   m.ncls = 0;
   long long cls_rows[4];
@@ -2071,18 +1487,6 @@ static int dgrad_impl(const mvg_conv_desc *d, const float *dy, const float *wgt,
       q.cls_px = px;
       q.cls_cy = (py + d->pad - r0) / step;
       q.cls_cx = (px + d->pad - s0) / step;
-      if (x6) {
-        q.b = (const float *)wplanes;
-        q.b_row_pad = d->r * d->s * d->cout;          // multiple of 8 (cout >= 64)
-        q.b_bytes = 6ll * d->cin * q.b_row_pad;
-        q.a = (const float *)aplanes;
-        q.a_group_bytes = 6ll * d->n * q.src_img_stride;
-        MVG_REQUIRE(q.a_group_bytes < 0x7FFFFFF0ll, "conv: a group of planes exceeds 2 GiB");
-        // a parity class without taps has ktotal == 0: every load is predicated off -> zeros
-        const TileChoice t6 = choose_tile6(q.rows_per_group, d->groups, d->cin);
-        if (launch_igemm6p<true>(q, t6, (hipStream_t)stream)) return 1;
-        continue;
-      }
       if (q.ntaps == 0) {
         // no tap reaches this class: dx = addend (nothing to do when the caller accumulates in place)
         if (addend != dx || !addend) {
@@ -2108,7 +1512,7 @@ static int dgrad_impl(const mvg_conv_desc *d, const float *dy, const float *wgt,
       cls_k[m.ncls] = q.ktotal;
       class_from_params(m.cls[m.ncls++], q);
     }
-  if (x6 || m.ncls == 0) return 0;
+  if (m.ncls == 0) return 0;
   // longest class first: with one tile per workgroup the short tiles then fill the tail
   for (int i = 1; i < m.ncls; ++i)
     for (int j = i; j > 0 && cls_k[j] > cls_k[j - 1]; --j) {
@@ -2154,60 +1558,7 @@ int mvg_conv_dgrad(const mvg_conv_desc *d, const float *dy, const float *wgt, fl
 int mvg_conv_fprop_affine(const mvg_conv_desc *d, const float *x, const float *wgt, float *out, const float *scale,
                           const float *shift, const float *residual, int relu, void *stream) {
   MVG_REQUIRE(scale && shift, "fprop_affine: scale and shift are required");
-  return fprop_impl(d, x, wgt, out, shift, relu, nullptr, nullptr, 0, stream, nullptr, nullptr, scale, residual);
-}
-
-int mvg_conv_math(void) { return conv_math(); }
-int mvg_set_conv_math(int mode) {
-  MVG_REQUIRE(mode == 0 || mode == 1, "conv math mode must be 0 (fp32 MFMA) or 1 (bf16x6)");
-  g_conv_math = mode;
-  return 0;
-}
-
-size_t mvg_weight_planes_bytes(const mvg_conv_desc *d, int transpose) {
-  const long long nrows = transpose ? d->cin : d->cout;
-  const long long klen = (long long)d->r * d->s * (transpose ? d->cout : d->cin);
-  return (size_t)(3 * nrows * ((klen + 7) / 8 * 8) * 2);
-}
-
-int mvg_weight_split(const mvg_conv_desc *d, const float *wgt, int transpose, void *planes, void *stream) {
-  if (validate(d)) return 2;
-  hipStream_t st = (hipStream_t)stream;
-  const int rs = d->r * d->s;
-  const int klen = rs * (transpose ? d->cout : d->cin);
-  const int kpad = (klen + 7) / 8 * 8;
-  const long long total = (long long)(transpose ? d->cin : d->cout) * kpad;
-  ProfScope ps(MVG_K_LAYOUT, st, 0.0, 10.0 * total);
-  long long blocks = (total + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(weight_split_kernel, dim3((unsigned)blocks), dim3(256), 0, st, wgt, (unsigned short *)planes, d->cout, rs,
-                     d->cin, kpad, transpose);
-  return check_launch("weight_split");
-}
-
-int mvg_split_planes(const float *x, void *planes, int64_t rows, int c, void *stream) {
-  MVG_REQUIRE(c % 8 == 0, "split_planes: c %% 8 != 0");
-  hipStream_t st = (hipStream_t)stream;
-  const long long n = (long long)rows * c;
-  ProfScope ps(MVG_K_ELEMENTWISE, st, 0.0, 10.0 * (double)n);
-  long long blocks = (n / 4 + 255) / 256;
-  if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float4 *)x, (unsigned short *)planes,
-                     n / 4, c / 4);
-  return check_launch("split_planes");
-}
-
-int mvg_conv_fprop_pp(const mvg_conv_desc *d, const void *xplanes, const void *wplanes, float *y, float *stats,
-                      void *stream) {
-  MVG_REQUIRE(d && d->cout >= 64 && d->cin >= 64 && d->cin % 8 == 0, "fprop_pp: cin, cout must be >= 64");
-  MVG_REQUIRE(conv_math() == 1, "fprop_pp needs conv math mode 1 (bf16x6)");
-  return fprop_impl(d, nullptr, nullptr, y, nullptr, 0, stats, nullptr, 0, stream, wplanes, xplanes);
-}
-
-int mvg_conv_dgrad_pp(const mvg_conv_desc *d, const void *dyplanes, const void *wplanes_t, float *dx, const float *mask,
-                      const float *addend, void *stream) {
-  MVG_REQUIRE(d && d->cin >= 64 && d->cout >= 64 && d->cout % 8 == 0, "dgrad_pp: cin, cout must be >= 64");
-  return dgrad_impl(d, nullptr, nullptr, dx, mask, addend, nullptr, 0, stream, wplanes_t, dyplanes);
+  return fprop_impl(d, x, wgt, out, shift, relu, nullptr, nullptr, 0, stream, scale, residual);
 }
 
 size_t mvg_linear_workspace_floats(int rows, int fin, int fout) {

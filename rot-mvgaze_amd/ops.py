@@ -56,41 +56,6 @@ def conv_dgrad(d: ConvDesc, dy: Tensor, w: Tensor, dx: Tensor, mask: Optional[Te
     check(lib().mvg_conv_dgrad(C.byref(d), _p(dy), _p(w), _p(dx), _p(mask), _p(addend), _s()), "conv_dgrad")
 
 
-def conv_math() -> int:
-    return lib().mvg_conv_math()
-
-
-def set_conv_math(mode: int):
-    check(lib().mvg_set_conv_math(mode), "set_conv_math")
-
-
-def weight_split(d: ConvDesc, w: Tensor, transpose: bool) -> Tensor:
-    """three bf16 planes (opaque int16 buffer) of the weights, for conv_fprop_wp / conv_dgrad_wp."""
-    nbytes = lib().mvg_weight_planes_bytes(C.byref(d), int(transpose))
-    planes = torch.empty(nbytes // 2, dtype=torch.int16, device=w.device)
-    check(lib().mvg_weight_split(C.byref(d), _p(w), int(transpose), _p(planes), _s()), "weight_split")
-    return planes
-
-
-def split_planes(x: Tensor, planes: Optional[Tensor] = None) -> Tensor:
-    """x [..., C] fp32 -> plane-interleaved bf16 [..., C/8, 3, 8] (int16 storage), hi+mid+lo == x."""
-    c = x.shape[-1]
-    if planes is None:
-        planes = torch.empty(tuple(x.shape[:-1]) + (c // 8, 3, 8), dtype=torch.int16, device=x.device)
-    check(lib().mvg_split_planes(_p(x), _p(planes), x.numel() // c, c, _s()), "split_planes")
-    return planes
-
-
-def conv_fprop_pp(d: ConvDesc, xplanes: Tensor, wplanes: Tensor, y: Tensor, stats: Optional[Tensor] = None):
-    check(lib().mvg_conv_fprop_pp(C.byref(d), _p(xplanes), _p(wplanes), _p(y), _p(stats), _s()), "conv_fprop_pp")
-
-
-def conv_dgrad_pp(d: ConvDesc, dyplanes: Tensor, wplanes_t: Tensor, dx: Tensor, mask: Optional[Tensor] = None,
-                  addend: Optional[Tensor] = None):
-    check(lib().mvg_conv_dgrad_pp(C.byref(d), _p(dyplanes), _p(wplanes_t), _p(dx), _p(mask), _p(addend), _s()),
-          "conv_dgrad_pp")
-
-
 def conv_wgrad(d: ConvDesc, x: Tensor, dy: Tensor, dw: Tensor, accumulate: bool = False):
     splits = lib().mvg_conv_wgrad_splits(C.byref(d))
     if splits < 1:

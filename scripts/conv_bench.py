@@ -56,18 +56,8 @@ for (cin, cout, k, st, pad, h), cnt in shapes.items():
     dx = torch.empty_like(x)
     dw = torch.empty_like(w)
     flops = 2.0 * G * N * d.ho * d.wo * cout * k * k * cin
-    if cout >= 64 and cin >= 64 and ops.conv_math() == 1:
-        wp = ops.weight_split(d, w, False)
-        xp = ops.split_planes(x)
-        tf = timeit(lambda: ops.conv_fprop_pp(d, xp, wp, y, stats))
-    else:
-        tf = timeit(lambda: ops.conv_fprop(d, x, w, y, None, False, stats))
-    if cin >= 64 and ops.conv_math() == 1:
-        wpt = ops.weight_split(d, w, True)
-        gyp = ops.split_planes(gy)
-        td = timeit(lambda: ops.conv_dgrad_pp(d, gyp, wpt, dx))
-    else:
-        td = timeit(lambda: ops.conv_dgrad(d, gy, w, dx)) if cin > 4 else float("nan")
+    tf = timeit(lambda: ops.conv_fprop(d, x, w, y, None, False, stats))
+    td = timeit(lambda: ops.conv_dgrad(d, gy, w, dx)) if cin > 4 else float("nan")
     tw = timeit(lambda: ops.conv_wgrad(d, x, gy, dw))
     print(f"{cin:5d} {cout:5d} {k} {st} {h:4d} {cnt:3d} | {tf*1e3:9.3f} {flops/tf/1e12:6.1f} | {td*1e3:9.3f} {flops/td/1e12:6.1f} | {tw*1e3:9.3f} {flops/tw/1e12:6.1f}")
     for name, t in (("fprop", tf), ("dgrad", td), ("wgrad", tw)):

@@ -61,18 +61,8 @@ CONV_CASES = [
 ]
 
 
-@pytest.fixture(params=[0, 1], ids=["fp32mfma", "bf16x6"])
-def conv_math(request):
-    """Both conv math modes: exact-fp32 MFMA (default) and the bf16x6 split on the bf16 MFMA."""
-    from rot_mvgaze_amd import ops
-    old = ops.conv_math()
-    ops.set_conv_math(request.param)
-    yield request.param
-    ops.set_conv_math(old)
-
-
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_fprop_dgrad_wgrad(case, conv_math):
+def test_conv_fprop_dgrad_wgrad(case):
     from rot_mvgaze_amd import ops
     from rot_mvgaze_amd._lib import ConvDesc
     G, N, H, W, Cin, Cout, k, st, pad = case
@@ -125,20 +115,6 @@ def test_conv_fprop_dgrad_wgrad(case, conv_math):
     dx2 = add.clone()
     ops.conv_dgrad(d, gyd, wd, dx2, mask, dx2)
     close(dx2, dx_ref * (mask.cpu() > 0) + add.cpu(), what="dgrad epilogue")
-
-    if Cout >= 64 and Cin >= 64 and ops.conv_math() == 1:
-        # both operands pre-split by their producers (what the backbone uses in bf16x6 mode)
-        xp = ops.split_planes(xd)
-        rec = xp.view(torch.bfloat16).float().sum(-2).reshape(xd.shape)
-        assert torch.equal(rec, xd), "hi + mid + lo must reproduce the fp32 value exactly"
-        y3 = torch.empty_like(y)
-        st3 = torch.full((G, P, 2, Cout), float("nan"), device=dev())
-        ops.conv_fprop_pp(d, xp, ops.weight_split(d, wd, False), y3, st3)
-        close(y3, y_ref, what="fprop_pp")
-        close(st3[:, :, 0].sum(1), y_ref.reshape(G, rows, Cout).sum(1), 1e-4, "fprop_pp stats")
-        dx5 = add.clone()
-        ops.conv_dgrad_pp(d, ops.split_planes(gyd), ops.weight_split(d, wd, True), dx5, mask, dx5)
-        close(dx5, dx_ref * (mask.cpu() > 0) + add.cpu(), what="dgrad_pp epilogue")
 
     dw = torch.empty(Cout, k, k, Cin, device=dev())
     ops.conv_wgrad(d, xd, gyd, dw, False)

@@ -629,31 +629,6 @@ def test_benchmark_configuration_c4_share_full_size_against_oracle():
                                "_img_fusers.2._fuser.blocks.0.0.weight", "_gaze_estimators.0.blocks.0.0.weight"))
 
 
-def test_bf16x6_conv_math_end_to_end():
-    """Opt-in bf16x6 conv math (fp32 operands split into three bf16 pieces, six bf16 MFMAs per
-    product): same step as the fp32-MFMA path within the north star's 1e-4 on predictions/loss."""
-    from rot_mvgaze_amd import ops
-    m = build(18)
-    d0 = m(inputs(4, 128, seed=5))
-    l0 = metrics()(d0)
-    l0.backward()
-    g0 = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
-    ops.set_conv_math(1)
-    try:
-        m2 = build(18)
-        d1 = m2(inputs(4, 128, seed=5))
-        l1 = metrics()(d1)
-        l1.backward()
-    finally:
-        ops.set_conv_math(0)
-    rel_close(l1, l0.item(), TOL, "loss bf16x6 vs fp32")
-    for i in range(3):
-        rel_close(d1[f"iter_{i}"]["pred_gaze_0"], d0[f"iter_{i}"]["pred_gaze_0"].detach().cpu().numpy(), TOL, "pred")
-    for k, p in m2.named_parameters():
-        if p.grad is not None:
-            l2_close(p.grad, g0[k].cpu().numpy(), GTOL_L2_FLIPS, "grad bf16x6 vs fp32 " + k)
-
-
 def test_fused_adam_matches_torch_adam():
     """mvg_adam_step over the arenas == torch.optim.Adam (trainer.py:54: lr, weight_decay 1e-6),
     three steps on the same gradients; CyclicLR drives it like the reference scheduler does."""
