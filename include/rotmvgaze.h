@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MVG_ABI_VERSION 4
+#define MVG_ABI_VERSION 5
 
 /* ---------------------------------------------------------------- library */
 int mvg_abi_version(void);
@@ -310,6 +310,63 @@ int mvg_gaze_lp_loss(const float *pred, const float *label, int n, int p, float 
 int mvg_mt19937_seed(uint32_t *host_state /*[625]*/, uint64_t seed);
 int64_t mvg_pair_index_build(uint32_t *host_state, const int64_t *host_file_rows, int n_files,
                              int camera_tag, int64_t *host_out /*[capacity][3]*/, int64_t capacity);
+
+
+/* ---------------------------------------------------------------------------------------------
+ * bf16 storage path (BASELINE.json configs[4]: "bf16 MFMA path").  Nothing in the reference
+ * corresponds to it (the reference is fp32 everywhere: models/resnet.py:31-47, models/backbones/
+ * blocks.py:41-47); these entry points are the same operators as above with activations, their
+ * gradients and the conv weights held as bf16 (uint16_t storage) in HBM.  Matrix products run on
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation; BatchNorm statistics, scale/shift, biases, weight
+ * gradients and the loss stay fp32.  Channels (cin, cout) must be multiples of 8 (16-byte vectors);
+ * the 3-channel stem input is padded to 8 by mvg_nchw_to_nhwc8_bf16.  The parity bar of this path is
+ * declared in tests/test_bf16_gpu.py (it cannot meet the fp32 path's 1e-4).
+ * --------------------------------------------------------------------------------------------- */
+/* fp32 KRSC weights (cin_src <= d->cin channels per tap, the rest zero) -> bf16 KRSC `w_krsc`
+ * [cout][r][s][d->cin] and, when w_crsk != NULL, the transposed copy [d->cin][r][s][cout] that
+ * mvg_conv_dgrad_bf16 reads (one cast per weight per step: the master weights stay fp32). */
+int mvg_cast_weights_bf16(const mvg_conv_desc *d, const float *w, int cin_src, void *w_krsc, void *w_crsk,
+                          void *stream);
+/* like mvg_conv_fprop / mvg_conv_stats_partials; x, wgt (KRSC), y are bf16, bias/stats fp32 */
+int mvg_conv_fprop_bf16(const mvg_conv_desc *d, const void *x, const void *wgt, void *y, const float *bias,
+                        int relu, float *stats, void *stream);
+int mvg_conv_stats_partials_bf16(const mvg_conv_desc *d, int32_t *out_rows_per_partial);
+/* like mvg_conv_dgrad; wgt_crsk = the transposed bf16 weights; mask/addend (bf16) like dx */
+int mvg_conv_dgrad_bf16(const mvg_conv_desc *d, const void *dy, const void *wgt_crsk, void *dx,
+                        const void *mask, const void *addend, void *stream);
+/* like mvg_conv_wgrad / mvg_conv_wgrad_splits; x, dy bf16, dw (and the slabs in workspace) fp32 */
+int mvg_conv_wgrad_bf16(const mvg_conv_desc *d, const void *x, const void *dy, float *dw, float *workspace,
+                        int splits, int accumulate, void *stream);
+int mvg_conv_wgrad_splits_bf16(const mvg_conv_desc *d);
+/* the BatchNorm / pooling passes with bf16 activations (same arguments as the fp32 entry points) */
+int mvg_bn_apply_bf16(const uint16_t *y, const float *scale, const float *shift, const uint16_t *residual,
+                      int relu, uint16_t *out, int groups, int64_t rows_per_group, int c, void *stream);
+int mvg_bn_bwd_reduce_bf16(const uint16_t *g, const uint16_t *act, const uint16_t *y, const float *mean,
+                           const float *invstd, const float *relu_scale, const float *relu_shift, int groups,
+                           int64_t rows_per_group, int c, float *s1, float *s2, float *dgamma, float *dbeta,
+                           int accumulate, float *workspace, void *stream);
+int mvg_bn_bwd_apply_bf16(const uint16_t *g, const uint16_t *act, const uint16_t *y, const float *mean,
+                          const float *invstd, const float *gamma, const float *s1, const float *s2,
+                          const float *relu_scale, const float *relu_shift, int groups, int64_t rows_per_group,
+                          int c, uint16_t *dy, uint16_t *dz_out, void *stream);
+int mvg_bn_relu_maxpool_fwd_bf16(const uint16_t *y, const float *scale, const float *shift, uint16_t *pooled,
+                                 uint8_t *argmax, int groups, int n_per_group, int h, int w, int c, int ho,
+                                 int wo, void *stream);
+int mvg_bn_relu_maxpool_bwd_reduce_bf16(const uint16_t *g_pooled, const uint8_t *argmax, const uint16_t *y,
+                                        const float *mean, const float *invstd, const float *scale,
+                                        const float *shift, int groups, int n_per_group, int h, int w, int c,
+                                        int ho, int wo, float *s1, float *s2, float *dgamma, float *dbeta,
+                                        int accumulate, float *workspace, void *stream);
+int mvg_bn_relu_maxpool_bwd_apply_bf16(const uint16_t *g_pooled, const uint8_t *argmax, const uint16_t *y,
+                                       const float *mean, const float *invstd, const float *gamma,
+                                       const float *scale, const float *shift, const float *s1,
+                                       const float *s2, int groups, int n_per_group, int h, int w, int c,
+                                       int ho, int wo, uint16_t *dy, void *stream);
+/* bf16 feature map -> fp32 pooled features and back (the fusion block stays fp32) */
+int mvg_avgpool_fwd_bf16(const uint16_t *x, float *y, int n, int hw, int c, void *stream);
+int mvg_avgpool_bwd_bf16(const float *dy, uint16_t *dx, int n, int hw, int c, void *stream);
+/* fp32 NCHW images (rot_mv.py:188-189) -> bf16 NHWC with the channels zero-padded to 8 */
+int mvg_nchw_to_nhwc8_bf16(const float *src, uint16_t *dst, int n, int c, int h, int w, void *stream);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "librotmvgaze_hip.so")
 
 K_FAMILIES = 18
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class ConvDesc(C.Structure):
@@ -97,6 +97,23 @@ SIGNATURES = {
     "mvg_linear_skinny_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "mvg_adam_step": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _I, _P]),
     "mvg_gaze_angular_loss": (_I, [_P, _P, _I, _F, _P, _I, _P, _P, _P]),
+    # bf16 storage path (same argument lists as the fp32 entry points)
+    "mvg_cast_weights_bf16": (_I, [_D, _P, _I, _P, _P, _P]),
+    "mvg_conv_fprop_bf16": (_I, [_D, _P, _P, _P, _P, _I, _P, _P]),
+    "mvg_conv_stats_partials_bf16": (_I, [_D, C.POINTER(C.c_int32)]),
+    "mvg_conv_dgrad_bf16": (_I, [_D, _P, _P, _P, _P, _P, _P]),
+    "mvg_conv_wgrad_bf16": (_I, [_D, _P, _P, _P, _P, _I, _I, _P]),
+    "mvg_conv_wgrad_splits_bf16": (_I, [_D]),
+    "mvg_bn_apply_bf16": (_I, [_P, _P, _P, _P, _I, _P, _I, _I64, _I, _P]),
+    "mvg_bn_bwd_reduce_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _P, _P, _P, _P, _I, _P, _P]),
+    "mvg_bn_bwd_apply_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _P, _P, _P]),
+    "mvg_bn_relu_maxpool_fwd_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "mvg_bn_relu_maxpool_bwd_reduce_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I,
+                                                 _P, _P]),
+    "mvg_bn_relu_maxpool_bwd_apply_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "mvg_avgpool_fwd_bf16": (_I, [_P, _P, _I, _I, _I, _P]),
+    "mvg_avgpool_bwd_bf16": (_I, [_P, _P, _I, _I, _I, _P]),
+    "mvg_nchw_to_nhwc8_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "mvg_mt19937_seed": (_I, [_P, C.c_uint64]),
     "mvg_pair_index_build": (_I64, [_P, _P, _I, _I, _P, _I64]),
 }

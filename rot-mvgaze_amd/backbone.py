@@ -62,6 +62,13 @@ class Backbone:
         self.grad_streams: List[torch.cuda.Stream] = []
         self._wg_stream: Optional[torch.cuda.Stream] = None
         self._wg_low = True
+        # storage type of activations / activation gradients / conv operands: fp32 = the parity path (1e-4 vs
+        # the reference); bf16 = BASELINE config C5's "bf16 MFMA path" (fp32 master weights, statistics, gradients)
+        self.act_dtype = torch.float32
+
+    @property
+    def bf16(self) -> bool:
+        return self.act_dtype == torch.bfloat16
 
     # ---------------------------------------------------------------- helpers
     def _weight(self, c: ConvSpec) -> Tensor:
@@ -83,11 +90,18 @@ class Backbone:
                   residual: Optional[Tensor], tape: Optional[list], pool: bool = False):
         """conv -> BatchNorm (-> + residual) (-> ReLU).  pool=True (the stem): the 3x3/2 max pool is
         fused behind the ReLU and (pooled, argmax) is returned; the normalised map is not stored."""
-        cin = 4 if c.cin == 3 else c.cin
+        bf = self.bf16
+        cin = (8 if bf else 4) if c.cin == 3 else c.cin
         d = ConvDesc.make(G, N, H, W, cin, c.cout, c.k, c.stride, c.pad)
         dev = x.device
-        w = self._weight(c)
-        y = torch.empty(G, N, d.ho, d.wo, c.cout, dtype=torch.float32, device=dev)
+        if bf:
+            # one cast of the fp32 master weights per step: KRSC for fprop, CRSK (transposed) for backward-data
+            wsrc = self.p[c.name + ".weight"].detach()
+            assert wsrc.is_contiguous(memory_format=torch.channels_last) or (c.k == 1 and wsrc.is_contiguous())
+            w, w_t = ops.cast_weights_bf16(d, wsrc, c.cin, need_transposed=(tape is not None and c.cin != 3))
+        else:
+            w, w_t = self._weight(c), None
+        y = torch.empty(G, N, d.ho, d.wo, c.cout, dtype=self.act_dtype, device=dev)
         rows = N * d.ho * d.wo
         gamma, beta = self.p[c.bn + ".weight"].detach(), self.p[c.bn + ".bias"].detach()
         rm, rv = self.p[c.bn + ".running_mean"], self.p[c.bn + ".running_var"]
@@ -97,12 +111,12 @@ class Backbone:
         def fprop(stats_buf):
             ops.conv_fprop(d, x, w, y, None, False, stats_buf)
         if training:
-            P, rpp = ops.conv_stats_partials(d)
+            P, rpp = ops.conv_stats_partials(d, bf)
             stats = torch.empty(G, P, 2, c.cout, dtype=torch.float32, device=dev)
             fprop(stats)
             ops.bn_finalize(stats, G, P, rpp, rows, c.cout, gamma, beta, rm, rv, BN_MOMENTUM, BN_EPS, mean, invstd,
                             scale, shift)
-        elif tape is None:
+        elif tape is None and not bf:
             # inference: BN (running statistics) + residual + ReLU folded into the conv epilogue
             ops.bn_eval_affine(1, c.cout, gamma, beta, rm, rv, BN_EPS, scale[:1], shift[:1])
             ops.conv_fprop_affine(d, x, w, y, scale[0], shift[0], residual, relu)
@@ -116,7 +130,7 @@ class Backbone:
         if pool:
             assert relu and residual is None
             hp, wp_ = (d.ho + 2 - 3) // 2 + 1, (d.wo + 2 - 3) // 2 + 1
-            out = torch.empty(G, N, hp, wp_, c.cout, dtype=torch.float32, device=dev)
+            out = torch.empty(G, N, hp, wp_, c.cout, dtype=self.act_dtype, device=dev)
             argmax = torch.empty(G, N, hp, wp_, c.cout, dtype=torch.uint8, device=dev)
             ops.bn_relu_maxpool_fwd(y, scale, shift, out, argmax, G, N, d.ho, d.wo, c.cout, hp, wp_)
         else:
@@ -125,7 +139,7 @@ class Backbone:
         if keep:
             u = _Unit()
             u.spec, u.desc, u.x_in, u.y, u.out, u.mean, u.invstd, u.relu, u.rows, u.w = \
-                c, d, x, y, (None if pool else out), mean, invstd, relu, rows, w
+                c, d, x, y, (None if pool else out), mean, invstd, relu, rows, (w_t if bf else w)
             u.trained = training
             # ReLU without residual: the backward rebuilds the mask from y (saves reading `out` twice)
             u.relu_affine = (scale, shift) if (relu and residual is None and not pool) else None
@@ -157,10 +171,15 @@ class Backbone:
             B, C, H, W = imgs[0].shape
         assert C == 3
         dev = imgs[0].device
-        x0 = torch.empty(V, B, H, W, 4, dtype=torch.float32, device=dev)
+        if self.bf16 and raw:
+            raise NotImplementedError("raw uint8 input with the bf16 path: normalise to fp32 NCHW first")
+        x0 = torch.empty(V, B, H, W, 8 if self.bf16 else 4, dtype=self.act_dtype, device=dev)
         for v, im in enumerate(imgs):
             assert im.shape == imgs[0].shape and im.is_cuda and im.dtype == imgs[0].dtype
-            if raw:
+            if self.bf16:
+                assert im.dtype == torch.float32
+                ops.nchw_to_nhwc8_bf16(im.detach().contiguous(), x0[v], B, 3, H, W)
+            elif raw:
                 ops.preprocess_u8hwc_resize(im.contiguous(), x0[v], B, Hin, Win, H, W, IMAGE_MEAN, IMAGE_STD, input_bgr)
             else:
                 assert im.dtype == torch.float32
@@ -253,7 +272,7 @@ class Backbone:
         c = u.spec
         wp = self.p[c.name + ".weight"]
         if c.cin == 3:
-            dw4 = torch.empty(c.cout, c.k, c.k, 4, dtype=torch.float32, device=dy.device)
+            dw4 = torch.empty(c.cout, c.k, c.k, u.desc.cin, dtype=torch.float32, device=dy.device)
             ops.conv_wgrad(u.desc, u.x_in, dy, dw4, False)
             gv = sink.view(wp).permute(0, 2, 3, 1)
             if sink.accumulate(wp):
@@ -276,7 +295,9 @@ class Backbone:
             raise NotImplementedError("backward through eval-mode BatchNorm (running statistics) is not implemented: "
                                       "call model.train() for gradient steps")
         Hc, Wc = tape["final_hw"]
-        g = torch.empty(V, B, Hc, Wc, self.fc_dim, dtype=torch.float32, device=dfeat.device)
+        if need_dimg and self.bf16:
+            raise NotImplementedError("d(loss)/d(img) is not produced by the bf16 path")
+        g = torch.empty(V, B, Hc, Wc, self.fc_dim, dtype=self.act_dtype, device=dfeat.device)
         ops.avgpool_bwd(dfeat.contiguous(), g, V * B, Hc * Wc, self.fc_dim)
         P = self.p
         for (idx, ds_idx) in reversed(tape["blocks"]):

@@ -3,6 +3,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "elem.h"
 
 namespace mvg {
 
@@ -166,10 +167,12 @@ __global__ void bn_eval_affine_kernel(int groups, int c, const float *gamma, con
 }
 
 // ---- apply: out = [relu](y*scale + shift [+ residual]) -------------------------------------
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float4 *__restrict__ y, const float *__restrict__ scale,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T *__restrict__ y, const float *__restrict__ scale,
                                                        const float *__restrict__ shift,
-                                                       const float4 *__restrict__ residual, int relu,
-                                                       float4 *__restrict__ out, long long n4_per_group, int c4n, int c) {
+                                                       const T *__restrict__ residual, int relu,
+                                                       T *__restrict__ out, long long n4_per_group, int c4n, int c) {
+  typedef Elem<T> E;
   const int g = blockIdx.y;
   const float4 *sc4 = reinterpret_cast<const float4 *>(scale + (long long)g * c);
   const float4 *sh4 = reinterpret_cast<const float4 *>(shift + (long long)g * c);
@@ -179,13 +182,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float4 *__restrict_
   int cq = (int)(i % c4n);
   const int step = (int)(stride % c4n);
   for (; i < n4_per_group; i += stride) {
-    const float4 v = y[base + i];
+    const float4 v = E::ld4(y, base + i);
     const float4 a = sc4[cq], b = sh4[cq];
     // explicit fma: the backward kernels rebuild the ReLU mask from y with the same expression
     float4 o = make_float4(__builtin_fmaf(v.x, a.x, b.x), __builtin_fmaf(v.y, a.y, b.y), __builtin_fmaf(v.z, a.z, b.z),
                            __builtin_fmaf(v.w, a.w, b.w));
     if (residual) {
-      const float4 r = residual[base + i];
+      const float4 r = E::ld4(residual, base + i);
       o.x += r.x;
       o.y += r.y;
       o.z += r.z;
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float4 *__restrict_
       o.z = fmaxf(o.z, 0.f);
       o.w = fmaxf(o.w, 0.f);
     }
-    out[base + i] = o;
+    E::st4(out, base + i, o);
     cq += step;
     if (cq >= c4n) cq -= c4n;
   }
@@ -205,8 +208,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float4 *__restrict_
 
 // ---- backward reduce ------------------------------------------------------------------------
 // grid = (chunks, column blocks, groups); thread = one float4 column group x one row lane.
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float4 *__restrict__ g, const float4 *__restrict__ act,
-                                                            const float4 *__restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *__restrict__ g, const T *__restrict__ act,
+                                                            const T *__restrict__ y,
                                                             const float *__restrict__ mean,
                                                             const float *__restrict__ invstd,
                                                             const float *__restrict__ mscale,
@@ -236,10 +240,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float4 *__rest
     // compiler keeps a single row in flight otherwise: latency-bound at 2.9 TB/s)
     auto row = [&](long long r, float4 &a1, float4 &a2) {
       const long long off = gbase + r * c4n + cq;
-      float4 d = g[off];
-      const float4 v = y[off];
+      float4 d = Elem<T>::ld4(g, off);
+      const float4 v = Elem<T>::ld4(y, off);
       if (act) {
-        const float4 a = act[off];
+        const float4 a = Elem<T>::ld4(act, off);
         d.x = a.x > 0.f ? d.x : 0.f;
         d.y = a.y > 0.f ? d.y : 0.f;
         d.z = a.z > 0.f ? d.z : 0.f;
@@ -328,8 +332,9 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float *__re
   }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float4 *__restrict__ g, const float4 *__restrict__ act,
-                                                           const float4 *__restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__ g, const T *__restrict__ act,
+                                                           const T *__restrict__ y,
                                                            const float *__restrict__ mean,
                                                            const float *__restrict__ invstd,
                                                            const float *__restrict__ gamma,
@@ -337,7 +342,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float4 *__restr
                                                            const float *__restrict__ mscale,
                                                            const float *__restrict__ mshift,
                                                            long long n4_per_group, float inv_rows, int c4n, int c,
-                                                           float4 *__restrict__ dy, float4 *__restrict__ dz_out) {
+                                                           T *__restrict__ dy, T *__restrict__ dz_out) {
+  typedef Elem<T> E;
   const int grp = blockIdx.y;
   const float4 *mu4 = reinterpret_cast<const float4 *>(mean + (long long)grp * c);
   const float4 *is4 = reinterpret_cast<const float4 *>(invstd + (long long)grp * c);
@@ -350,10 +356,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float4 *__restr
   int cq = (int)(i % c4n);
   const int step = (int)(stride % c4n);
   for (; i < n4_per_group; i += stride) {
-    float4 d = g[base + i];
-    const float4 v = y[base + i];
+    float4 d = E::ld4(g, base + i);
+    const float4 v = E::ld4(y, base + i);
     if (act) {
-      const float4 a = act[base + i];
+      const float4 a = E::ld4(act, base + i);
       d.x = a.x > 0.f ? d.x : 0.f;
       d.y = a.y > 0.f ? d.y : 0.f;
       d.z = a.z > 0.f ? d.z : 0.f;
@@ -372,8 +378,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float4 *__restr
     o.y = ga.y * is.y * (d.y - sa.y * inv_rows - (v.y - mu.y) * is.y * (sb.y * inv_rows));
     o.z = ga.z * is.z * (d.z - sa.z * inv_rows - (v.z - mu.z) * is.z * (sb.z * inv_rows));
     o.w = ga.w * is.w * (d.w - sa.w * inv_rows - (v.w - mu.w) * is.w * (sb.w * inv_rows));
-    if (dz_out) dz_out[base + i] = d;
-    dy[base + i] = o;
+    if (dz_out) E::st4(dz_out, base + i, d);
+    E::st4(dy, base + i, o);
     cq += step;
     if (cq >= c4n) cq -= c4n;
   }
@@ -391,8 +397,9 @@ __device__ __forceinline__ float4 bn_relu4(float4 v, float4 a, float4 b) {
 
 // grid = (ceil(wo*c4n / 256), images*ho): one thread = one (image, oy, ox, 4 channels), no per-thread
 // divisions by runtime values except ox/cq.  First maximum in (kh, kw) scan order (ATen's rule).
-__global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const float4 *__restrict__ y, const float *__restrict__ scale,
-                                                                  const float *__restrict__ shift, float4 *__restrict__ pooled,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const T *__restrict__ y, const float *__restrict__ scale,
+                                                                  const float *__restrict__ shift, T *__restrict__ pooled,
                                                                   uchar4 *__restrict__ argmax, int n_per_group, int h, int w,
                                                                   int c4n, int ho, int wo) {
   const int t = blockIdx.x * 256 + threadIdx.x;
@@ -413,7 +420,7 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const float4 *
     for (int kw = 0; kw < 3; ++kw) {
       const int ix = ox * 2 - 1 + kw;
       if ((unsigned)ix >= (unsigned)w) continue;
-      const float4 v = bn_relu4(y[(((long long)n * h + iy) * w + ix) * c4n + cq], a, b);
+      const float4 v = bn_relu4(Elem<T>::ld4(y, (((long long)n * h + iy) * w + ix) * c4n + cq), a, b);
       const unsigned char k = (unsigned char)(kh * 3 + kw);
       if (first) {
         best = v;
@@ -428,12 +435,13 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const float4 *
     }
   }
   const long long o = (((long long)n * ho + oy) * wo + ox) * c4n + cq;
-  pooled[o] = best;
+  Elem<T>::st4(pooled, o, best);
   argmax[o] = idx;
 }
 
 // gradient wrt the (never stored) ReLU output at pixel (n, iy, ix): the pooled gradients of the windows it won
-__device__ __forceinline__ float4 pool_gather(const float4 *__restrict__ gp, const uchar4 *__restrict__ am, long long n, int iy,
+template <typename T>
+__device__ __forceinline__ float4 pool_gather(const T *__restrict__ gp, const uchar4 *__restrict__ am, long long n, int iy,
                                               int ix, int cq, int c4n, int ho, int wo) {
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   const int oy0 = iy >> 1, ox0 = ix >> 1;
@@ -449,7 +457,7 @@ __device__ __forceinline__ float4 pool_gather(const float4 *__restrict__ gp, con
       if (kw < 0 || kw > 2 || ox >= wo) continue;
       const long long o = ((n * ho + oy) * wo + ox) * c4n + cq;
       const uchar4 k = am[o];
-      const float4 g = gp[o];
+      const float4 g = Elem<T>::ld4(gp, o);
       const unsigned char me = (unsigned char)(kh * 3 + kw);
       if (k.x == me) acc.x += g.x;
       if (k.y == me) acc.y += g.y;
@@ -465,8 +473,9 @@ __device__ __forceinline__ float4 pool_gather(const float4 *__restrict__ gp, con
 // fetches y only at its argmax pixel (one scalar per channel) - a quarter of the elements and a tenth
 // of the instructions of the per-pixel gather.  A chunk is a range of pooled lines (image, oy); the
 // 256/cw row lanes stride along ox.
-__global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const float4 *__restrict__ gp, const uchar4 *__restrict__ am,
-                                                                 const float *__restrict__ y, const float *__restrict__ mean,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const T *__restrict__ gp, const uchar4 *__restrict__ am,
+                                                                 const T *__restrict__ y, const float *__restrict__ mean,
                                                                  const float *__restrict__ invstd,
                                                                  const float *__restrict__ scale,
                                                                  const float *__restrict__ shift, int lines_per_chunk,
@@ -493,9 +502,9 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const float4 *_
       const int img = l / ho, oy = l - img * ho;
       const long long n = (long long)grp * n_per_group + img;
       const long long prow = ((n * ho + oy) * wo) * c4n + cq;
-      const float *yimg = y + n * h * w * c + cq * 4;
+      const T *yimg = y + n * h * w * c + cq * 4;
       for (int ox = rl; ox < wo; ox += nrl) {
-        const float4 g4 = gp[prow + (long long)ox * c4n];
+        const float4 g4 = Elem<T>::ld4(gp, prow + (long long)ox * c4n);
         const uchar4 k4 = am[prow + (long long)ox * c4n];
         const float g[4] = {g4.x, g4.y, g4.z, g4.w};
         const int k[4] = {k4.x, k4.y, k4.z, k4.w};
@@ -503,7 +512,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const float4 *_
         for (int j = 0; j < 4; ++j) {
           const int kh = (k[j] * 11) >> 5, kw = k[j] - 3 * kh;          // k / 3, k % 3 for k < 9
           const int iy = 2 * oy - 1 + kh, ix = 2 * ox - 1 + kw;          // the winner is an in-bounds pixel
-          const float v = yimg[((long long)iy * w + ix) * c + j];
+          const float v = Elem<T>::ld1(yimg, ((long long)iy * w + ix) * c + j);
           const float d = __builtin_fmaf(v, sa[j], sb[j]) > 0.f ? g[j] : 0.f;
           s1[j] += d;
           s2[j] += d * ((v - mu[j]) * is[j]);
@@ -528,15 +537,16 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const float4 *_
 }
 
 // grid = (ceil(w*c4n / 256), images*h): one thread = one (image, iy, ix, 4 channels) of the conv output
-__global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float4 *__restrict__ gp, const uchar4 *__restrict__ am,
-                                                                const float4 *__restrict__ y, const float *__restrict__ mean,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const T *__restrict__ gp, const uchar4 *__restrict__ am,
+                                                                const T *__restrict__ y, const float *__restrict__ mean,
                                                                 const float *__restrict__ invstd,
                                                                 const float *__restrict__ gamma,
                                                                 const float *__restrict__ scale,
                                                                 const float *__restrict__ shift, const float *__restrict__ s1,
                                                                 const float *__restrict__ s2, int n_per_group, int h, int w,
                                                                 int ho, int wo, int c4n, float inv_rows,
-                                                                float4 *__restrict__ dy) {
+                                                                T *__restrict__ dy) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= w * c4n) return;
   const int ix = t / c4n, cq = t - ix * c4n;
@@ -547,8 +557,8 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float4 *__
   const float4 sa = reinterpret_cast<const float4 *>(scale)[gq], sb = reinterpret_cast<const float4 *>(shift)[gq];
   const float4 a1 = reinterpret_cast<const float4 *>(s1)[gq], a2 = reinterpret_cast<const float4 *>(s2)[gq];
   const float4 ga = reinterpret_cast<const float4 *>(gamma)[cq];
-  const float4 v = y[i];
-  float4 d = pool_gather(gp, am, n, iy, ix, cq, c4n, ho, wo);
+  const float4 v = Elem<T>::ld4(y, i);
+  float4 d = pool_gather<T>(gp, am, n, iy, ix, cq, c4n, ho, wo);
   d.x = __builtin_fmaf(v.x, sa.x, sb.x) > 0.f ? d.x : 0.f;
   d.y = __builtin_fmaf(v.y, sa.y, sb.y) > 0.f ? d.y : 0.f;
   d.z = __builtin_fmaf(v.z, sa.z, sb.z) > 0.f ? d.z : 0.f;
@@ -558,7 +568,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float4 *__
   o.y = ga.y * is.y * (d.y - a1.y * inv_rows - (v.y - mu.y) * is.y * (a2.y * inv_rows));
   o.z = ga.z * is.z * (d.z - a1.z * inv_rows - (v.z - mu.z) * is.z * (a2.z * inv_rows));
   o.w = ga.w * is.w * (d.w - a1.w * inv_rows - (v.w - mu.w) * is.w * (a2.w * inv_rows));
-  dy[i] = o;
+  Elem<T>::st4(dy, i, o);
 }
 
 static int bwd_chunks(int groups, long long rows, int c) {
@@ -621,24 +631,24 @@ int mvg_bn_eval_affine(int groups, int c, const float *gamma, const float *beta,
   return check_launch("bn_eval_affine");
 }
 
-int mvg_bn_apply(const float *y, const float *scale, const float *shift, const float *residual, int relu, float *out,
-                 int groups, int64_t rows_per_group, int c, void *stream) {
+}  // extern "C" (templated implementations below)
+
+template <typename T>
+static int bn_apply_impl(const T *y, const float *scale, const float *shift, const T *residual, int relu, T *out, int groups,
+                         int64_t rows_per_group, int c, void *stream) {
   MVG_REQUIRE(c % 4 == 0, "bn_apply: c %% 4 != 0");
   hipStream_t st = (hipStream_t)stream;
   const long long n4 = rows_per_group * (c / 4);
-  ProfScope ps(MVG_K_BN_APPLY, st, 0.0, 16.0 * groups * (double)n4 * (residual ? 3 : 2));
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(n4), groups), dim3(256), 0, st, (const float4 *)y, scale, shift,
-                     (const float4 *)residual, relu, (float4 *)out, n4, c / 4, c);
+  ProfScope ps(MVG_K_BN_APPLY, st, 0.0, 4.0 * Elem<T>::kBytes * groups * (double)n4 * (residual ? 3 : 2));
+  hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(grid_for(n4), groups), dim3(256), 0, st, y, scale, shift, residual, relu, out, n4,
+                     c / 4, c);
   return check_launch("bn_apply");
 }
 
-size_t mvg_bn_bwd_workspace_floats(int groups, int64_t rows_per_group, int c) {
-  return (size_t)groups * bwd_chunks(groups, rows_per_group, c) * 2 * c;
-}
-
-int mvg_bn_bwd_reduce(const float *g, const float *act, const float *y, const float *mean, const float *invstd,
-                      const float *relu_scale, const float *relu_shift, int groups, int64_t rows_per_group, int c, float *s1,
-                      float *s2, float *dgamma, float *dbeta, int accumulate, float *workspace, void *stream) {
+template <typename T>
+static int bn_bwd_reduce_impl(const T *g, const T *act, const T *y, const float *mean, const float *invstd,
+                              const float *relu_scale, const float *relu_shift, int groups, int64_t rows_per_group, int c,
+                              float *s1, float *s2, float *dgamma, float *dbeta, int accumulate, float *workspace, void *stream) {
   MVG_REQUIRE(!(act && relu_scale), "bn_bwd_reduce: give the ReLU mask either as act or as (relu_scale, relu_shift)");
   MVG_REQUIRE((relu_scale == nullptr) == (relu_shift == nullptr), "bn_bwd_reduce: relu_scale and relu_shift go together");
   MVG_REQUIRE(c % 4 == 0, "bn_bwd_reduce: c %% 4 != 0");
@@ -649,49 +659,49 @@ int mvg_bn_bwd_reduce(const float *g, const float *act, const float *y, const fl
   MVG_REQUIRE(256 % cw == 0, "bn_bwd_reduce: c/4 must divide 256 or be a multiple of it (c=%d)", c);
   const int chunks = bwd_chunks(groups, rows_per_group, c);
   const long long rpc = (rows_per_group + chunks - 1) / chunks;
-  ProfScope ps(MVG_K_BN_BWD_REDUCE, st, 0.0, 4.0 * groups * (double)rows_per_group * c * (act ? 3 : 2));
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(chunks, ceil_div(c4n, cw), groups), dim3(256), 0, st, (const float4 *)g,
-                     (const float4 *)act, (const float4 *)y, mean, invstd, relu_scale, relu_shift, (long long)rows_per_group,
-                     rpc, c, c4n, cw, workspace, chunks);
+  ProfScope ps(MVG_K_BN_BWD_REDUCE, st, 0.0, Elem<T>::kBytes * groups * (double)rows_per_group * c * (act ? 3 : 2));
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(chunks, ceil_div(c4n, cw), groups), dim3(256), 0, st, g, act, y, mean, invstd,
+                     relu_scale, relu_shift, (long long)rows_per_group, rpc, c, c4n, cw, workspace, chunks);
   if (check_launch("bn_bwd_reduce")) return 1;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(c, 16)), dim3(1024), 0, st, workspace, groups, chunks, c, s1, s2,
                      dgamma, dbeta, accumulate);
   return check_launch("bn_bwd_finalize");
 }
 
-int mvg_bn_bwd_apply(const float *g, const float *act, const float *y, const float *mean, const float *invstd,
-                     const float *gamma, const float *s1, const float *s2, const float *relu_scale, const float *relu_shift,
-                     int groups, int64_t rows_per_group, int c, float *dy, float *dz_out, void *stream) {
+template <typename T>
+static int bn_bwd_apply_impl(const T *g, const T *act, const T *y, const float *mean, const float *invstd, const float *gamma,
+                             const float *s1, const float *s2, const float *relu_scale, const float *relu_shift, int groups,
+                             int64_t rows_per_group, int c, T *dy, T *dz_out, void *stream) {
   MVG_REQUIRE(!(act && relu_scale), "bn_bwd_apply: give the ReLU mask either as act or as (relu_scale, relu_shift)");
   MVG_REQUIRE((relu_scale == nullptr) == (relu_shift == nullptr), "bn_bwd_apply: relu_scale and relu_shift go together");
   MVG_REQUIRE(c % 4 == 0, "bn_bwd_apply: c %% 4 != 0");
   hipStream_t st = (hipStream_t)stream;
   const long long n4 = rows_per_group * (c / 4);
-  ProfScope ps(MVG_K_BN_BWD_APPLY, st, 0.0, 16.0 * groups * (double)n4 * ((act ? 4 : 3) + (dz_out ? 1 : 0)));
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n4), groups), dim3(256), 0, st, (const float4 *)g,
-                     (const float4 *)act, (const float4 *)y, mean, invstd, gamma, s1, s2, relu_scale, relu_shift, n4,
-                     1.0f / (float)rows_per_group, c / 4, c, (float4 *)dy, (float4 *)dz_out);
+  ProfScope ps(MVG_K_BN_BWD_APPLY, st, 0.0, 4.0 * Elem<T>::kBytes * groups * (double)n4 * ((act ? 4 : 3) + (dz_out ? 1 : 0)));
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid_for(n4), groups), dim3(256), 0, st, g, act, y, mean, invstd, gamma, s1, s2,
+                     relu_scale, relu_shift, n4, 1.0f / (float)rows_per_group, c / 4, c, dy, dz_out);
   return check_launch("bn_bwd_apply");
 }
 
-int mvg_bn_relu_maxpool_fwd(const float *y, const float *scale, const float *shift, float *pooled, uint8_t *argmax, int groups,
-                            int n_per_group, int h, int w, int c, int ho, int wo, void *stream) {
+template <typename T>
+static int bn_relu_maxpool_fwd_impl(const T *y, const float *scale, const float *shift, T *pooled, uint8_t *argmax, int groups,
+                                    int n_per_group, int h, int w, int c, int ho, int wo, void *stream) {
   MVG_REQUIRE(c % 4 == 0, "bn_relu_maxpool: c %% 4 != 0");
   MVG_REQUIRE(ho == (h + 2 - 3) / 2 + 1 && wo == (w + 2 - 3) / 2 + 1, "bn_relu_maxpool: bad output size");
   const long long total = (long long)groups * n_per_group * ho * wo * (c / 4);
   hipStream_t st = (hipStream_t)stream;
-  ProfScope ps(MVG_K_POOL, st, 0.0, 4.0 * ((double)groups * n_per_group * h * w * c + (double)total * 5));
+  ProfScope ps(MVG_K_POOL, st, 0.0, Elem<T>::kBytes * ((double)groups * n_per_group * h * w * c + (double)total * 4) + (double)total * 4);
   MVG_REQUIRE((long long)groups * n_per_group * ho < 65536, "bn_relu_maxpool: images*ho must fit grid.y");
-  hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel, dim3(ceil_div((long long)wo * (c / 4), 256), groups * n_per_group * ho),
-                     dim3(256), 0, st, (const float4 *)y, scale, shift, (float4 *)pooled, (uchar4 *)argmax, n_per_group, h, w,
-                     c / 4, ho, wo);
+  hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel<T>, dim3(ceil_div((long long)wo * (c / 4), 256), groups * n_per_group * ho),
+                     dim3(256), 0, st, y, scale, shift, pooled, (uchar4 *)argmax, n_per_group, h, w, c / 4, ho, wo);
   return check_launch("bn_relu_maxpool_fwd");
 }
 
-int mvg_bn_relu_maxpool_bwd_reduce(const float *g_pooled, const uint8_t *argmax, const float *y, const float *mean,
-                                   const float *invstd, const float *scale, const float *shift, int groups, int n_per_group,
-                                   int h, int w, int c, int ho, int wo, float *s1, float *s2, float *dgamma, float *dbeta,
-                                   int accumulate, float *workspace, void *stream) {
+template <typename T>
+static int bn_relu_maxpool_bwd_reduce_impl(const T *g_pooled, const uint8_t *argmax, const T *y, const float *mean,
+                                           const float *invstd, const float *scale, const float *shift, int groups,
+                                           int n_per_group, int h, int w, int c, int ho, int wo, float *s1, float *s2,
+                                           float *dgamma, float *dbeta, int accumulate, float *workspace, void *stream) {
   MVG_REQUIRE(c % 4 == 0, "bn_relu_maxpool_bwd_reduce: c %% 4 != 0");
   MVG_REQUIRE(workspace != nullptr, "bn_relu_maxpool_bwd_reduce: workspace required");
   hipStream_t st = (hipStream_t)stream;
@@ -706,29 +716,79 @@ int mvg_bn_relu_maxpool_bwd_reduce(const float *g_pooled, const uint8_t *argmax,
   const int lpc = (lines + chunks - 1) / chunks;
   chunks = (lines + lpc - 1) / lpc;
   ProfScope ps(MVG_K_BN_BWD_REDUCE, st, 0.0,
-               4.0 * groups * ((double)rows * c + (double)n_per_group * ho * wo * c * 1.25));
-  hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3(chunks, ceil_div(c4n, cw), groups), dim3(256), 0, st,
-                     (const float4 *)g_pooled, (const uchar4 *)argmax, y, mean, invstd, scale, shift, lpc,
-                     n_per_group, h, w, ho, wo, c, c4n, cw, workspace, chunks);
+               Elem<T>::kBytes * groups * ((double)rows * c + (double)n_per_group * ho * wo * c * 1.25));
+  hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel<T>, dim3(chunks, ceil_div(c4n, cw), groups), dim3(256), 0, st, g_pooled,
+                     (const uchar4 *)argmax, y, mean, invstd, scale, shift, lpc, n_per_group, h, w, ho, wo, c, c4n, cw, workspace,
+                     chunks);
   if (check_launch("bn_relu_maxpool_bwd_reduce")) return 1;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(c, 16)), dim3(1024), 0, st, workspace, groups, chunks, c, s1, s2,
                      dgamma, dbeta, accumulate);
   return check_launch("bn_bwd_finalize");
 }
 
-int mvg_bn_relu_maxpool_bwd_apply(const float *g_pooled, const uint8_t *argmax, const float *y, const float *mean,
-                                  const float *invstd, const float *gamma, const float *scale, const float *shift,
-                                  const float *s1, const float *s2, int groups, int n_per_group, int h, int w, int c, int ho,
-                                  int wo, float *dy, void *stream) {
+template <typename T>
+static int bn_relu_maxpool_bwd_apply_impl(const T *g_pooled, const uint8_t *argmax, const T *y, const float *mean,
+                                          const float *invstd, const float *gamma, const float *scale, const float *shift,
+                                          const float *s1, const float *s2, int groups, int n_per_group, int h, int w, int c,
+                                          int ho, int wo, T *dy, void *stream) {
   MVG_REQUIRE(c % 4 == 0, "bn_relu_maxpool_bwd_apply: c %% 4 != 0");
   hipStream_t st = (hipStream_t)stream;
-  ProfScope ps(MVG_K_BN_BWD_APPLY, st, 0.0, 4.0 * groups * ((double)n_per_group * h * w * c * 2 + (double)n_per_group * ho * wo * c * 1.25));
+  ProfScope ps(MVG_K_BN_BWD_APPLY, st, 0.0,
+               Elem<T>::kBytes * groups * ((double)n_per_group * h * w * c * 2 + (double)n_per_group * ho * wo * c * 1.25));
   MVG_REQUIRE((long long)groups * n_per_group * h < 65536, "bn_relu_maxpool: images*h must fit grid.y");
-  hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(ceil_div((long long)w * (c / 4), 256), groups * n_per_group * h), dim3(256),
-                     0, st, (const float4 *)g_pooled, (const uchar4 *)argmax, (const float4 *)y, mean, invstd, gamma, scale,
-                     shift, s1, s2, n_per_group, h, w, ho, wo, c / 4, 1.0f / (float)((long long)n_per_group * h * w),
-                     (float4 *)dy);
+  hipLaunchKernelGGL(bn_pool_bwd_apply_kernel<T>, dim3(ceil_div((long long)w * (c / 4), 256), groups * n_per_group * h), dim3(256),
+                     0, st, g_pooled, (const uchar4 *)argmax, y, mean, invstd, gamma, scale, shift, s1, s2, n_per_group, h, w, ho,
+                     wo, c / 4, 1.0f / (float)((long long)n_per_group * h * w), dy);
   return check_launch("bn_relu_maxpool_bwd_apply");
 }
+
+extern "C" {
+
+size_t mvg_bn_bwd_workspace_floats(int groups, int64_t rows_per_group, int c) {
+  return (size_t)groups * bwd_chunks(groups, rows_per_group, c) * 2 * c;
+}
+
+#define MVG_BN_FACES(SUFFIX, T)                                                                                              \
+  int mvg_bn_apply##SUFFIX(const T *y, const float *scale, const float *shift, const T *residual, int relu, T *out,        \
+                           int groups, int64_t rows_per_group, int c, void *stream) {                                       \
+    return bn_apply_impl<T>(y, scale, shift, residual, relu, out, groups, rows_per_group, c, stream);                       \
+  }                                                                                                                          \
+  int mvg_bn_bwd_reduce##SUFFIX(const T *g, const T *act, const T *y, const float *mean, const float *invstd,               \
+                                const float *relu_scale, const float *relu_shift, int groups, int64_t rows_per_group,       \
+                                int c, float *s1, float *s2, float *dgamma, float *dbeta, int accumulate,                   \
+                                float *workspace, void *stream) {                                                           \
+    return bn_bwd_reduce_impl<T>(g, act, y, mean, invstd, relu_scale, relu_shift, groups, rows_per_group, c, s1, s2,        \
+                                 dgamma, dbeta, accumulate, workspace, stream);                                             \
+  }                                                                                                                          \
+  int mvg_bn_bwd_apply##SUFFIX(const T *g, const T *act, const T *y, const float *mean, const float *invstd,                \
+                               const float *gamma, const float *s1, const float *s2, const float *relu_scale,               \
+                               const float *relu_shift, int groups, int64_t rows_per_group, int c, T *dy, T *dz_out,        \
+                               void *stream) {                                                                              \
+    return bn_bwd_apply_impl<T>(g, act, y, mean, invstd, gamma, s1, s2, relu_scale, relu_shift, groups, rows_per_group,     \
+                                c, dy, dz_out, stream);                                                                     \
+  }                                                                                                                          \
+  int mvg_bn_relu_maxpool_fwd##SUFFIX(const T *y, const float *scale, const float *shift, T *pooled, uint8_t *argmax,       \
+                                      int groups, int n_per_group, int h, int w, int c, int ho, int wo, void *stream) {     \
+    return bn_relu_maxpool_fwd_impl<T>(y, scale, shift, pooled, argmax, groups, n_per_group, h, w, c, ho, wo, stream);      \
+  }                                                                                                                          \
+  int mvg_bn_relu_maxpool_bwd_reduce##SUFFIX(const T *g_pooled, const uint8_t *argmax, const T *y, const float *mean,       \
+                                             const float *invstd, const float *scale, const float *shift, int groups,       \
+                                             int n_per_group, int h, int w, int c, int ho, int wo, float *s1, float *s2,    \
+                                             float *dgamma, float *dbeta, int accumulate, float *workspace,                 \
+                                             void *stream) {                                                                \
+    return bn_relu_maxpool_bwd_reduce_impl<T>(g_pooled, argmax, y, mean, invstd, scale, shift, groups, n_per_group, h, w,   \
+                                              c, ho, wo, s1, s2, dgamma, dbeta, accumulate, workspace, stream);             \
+  }                                                                                                                          \
+  int mvg_bn_relu_maxpool_bwd_apply##SUFFIX(const T *g_pooled, const uint8_t *argmax, const T *y, const float *mean,        \
+                                            const float *invstd, const float *gamma, const float *scale,                    \
+                                            const float *shift, const float *s1, const float *s2, int groups,               \
+                                            int n_per_group, int h, int w, int c, int ho, int wo, T *dy, void *stream) {    \
+    return bn_relu_maxpool_bwd_apply_impl<T>(g_pooled, argmax, y, mean, invstd, gamma, scale, shift, s1, s2, groups,        \
+                                             n_per_group, h, w, c, ho, wo, dy, stream);                                     \
+  }
+
+MVG_BN_FACES(, float)
+MVG_BN_FACES(_bf16, uint16_t)
+#undef MVG_BN_FACES
 
 }  // extern "C"

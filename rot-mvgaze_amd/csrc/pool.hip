@@ -1,5 +1,6 @@
 // MaxPool2d(3,2,1), global average pool, and the NCHW <-> NHWC4 boundary repack.  HBM-bound.
 #include "common.h"
+#include "elem.h"
 
 namespace mvg {
 
@@ -83,7 +84,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float4 *__restri
   dx[i] = acc;
 }
 
-__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float4 *__restrict__ x, float4 *__restrict__ y, int n,
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T *__restrict__ x, float4 *__restrict__ y, int n,
                                                           int hw, int c4n) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long long)n * c4n) return;
@@ -91,14 +93,15 @@ __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float4 *__restri
   const long long img = i / c4n;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int p = 0; p < hw; ++p) {
-    const float4 v = x[(img * hw + p) * c4n + cq];
+    const float4 v = Elem<T>::ld4(x, (img * hw + p) * c4n + cq);
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
   }
   const float inv = 1.f / (float)hw;
   y[i] = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
 }
 
-__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float4 *__restrict__ dy, float4 *__restrict__ dx,
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float4 *__restrict__ dy, T *__restrict__ dx,
                                                           long long total, int hw, int c4n) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
@@ -106,7 +109,20 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float4 *__restri
   const long long img = i / ((long long)hw * c4n);
   const float inv = 1.f / (float)hw;
   const float4 g = dy[img * c4n + cq];
-  dx[i] = make_float4(g.x * inv, g.y * inv, g.z * inv, g.w * inv);
+  Elem<T>::st4(dx, i, make_float4(g.x * inv, g.y * inv, g.z * inv, g.w * inv));
+}
+
+// fp32 NCHW images -> bf16 NHWC with the channels zero-padded to 8 (one 16-byte vector per pixel): the
+// bf16 stem reads 8-channel pixels (K = 7*7*8)
+__global__ __launch_bounds__(256) void nchw_to_nhwc8_bf16_kernel(const float *__restrict__ src, uint4 *__restrict__ dst,
+                                                                 long long pixels, int c, long long hw) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= pixels) return;
+  const long long n = i / hw, p = i - n * hw;
+  const float *s = src + n * c * hw + p;
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < c; ++k) v[k] = s[k * hw];
+  dst[i] = make_uint4(bf16_pack2(v[0], v[1]), bf16_pack2(v[2], v[3]), bf16_pack2(v[4], v[5]), bf16_pack2(v[6], v[7]));
 }
 
 __global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float *__restrict__ src, float4 *__restrict__ dst,
@@ -270,23 +286,36 @@ int mvg_maxpool3x3s2_bwd(const float *dy, const uint8_t *argmax, float *dx, int 
   return check_launch("maxpool_bwd");
 }
 
-int mvg_avgpool_fwd(const float *x, float *y, int n, int hw, int c, void *stream) {
-  MVG_REQUIRE(c % 4 == 0, "avgpool: c %% 4 != 0");
-  hipStream_t st = (hipStream_t)stream;
-  ProfScope ps(MVG_K_POOL, st, 0.0, 4.0 * (double)n * (hw + 1) * c);
-  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(ceil_div((long long)n * (c / 4), 256)), dim3(256), 0, st,
-                     (const float4 *)x, (float4 *)y, n, hw, c / 4);
-  return check_launch("avgpool_fwd");
-}
+#define MVG_AVGPOOL_FACES(SUFFIX, T)                                                                                  \
+  int mvg_avgpool_fwd##SUFFIX(const T *x, float *y, int n, int hw, int c, void *stream) {                             \
+    MVG_REQUIRE(c % 4 == 0, "avgpool: c %% 4 != 0");                                                                   \
+    hipStream_t st = (hipStream_t)stream;                                                                             \
+    ProfScope ps(MVG_K_POOL, st, 0.0, (double)n * (Elem<T>::kBytes * hw + 4.0) * c);                                  \
+    hipLaunchKernelGGL(avgpool_fwd_kernel<T>, dim3(ceil_div((long long)n * (c / 4), 256)), dim3(256), 0, st, x,       \
+                       (float4 *)y, n, hw, c / 4);                                                                    \
+    return check_launch("avgpool_fwd");                                                                               \
+  }                                                                                                                    \
+  int mvg_avgpool_bwd##SUFFIX(const float *dy, T *dx, int n, int hw, int c, void *stream) {                           \
+    MVG_REQUIRE(c % 4 == 0, "avgpool: c %% 4 != 0");                                                                   \
+    hipStream_t st = (hipStream_t)stream;                                                                             \
+    const long long total = (long long)n * hw * (c / 4);                                                              \
+    ProfScope ps(MVG_K_POOL, st, 0.0, (double)n * (Elem<T>::kBytes * hw + 4.0) * c);                                  \
+    hipLaunchKernelGGL(avgpool_bwd_kernel<T>, dim3(ceil_div(total, 256)), dim3(256), 0, st, (const float4 *)dy, dx,    \
+                       total, hw, c / 4);                                                                             \
+    return check_launch("avgpool_bwd");                                                                               \
+  }
+MVG_AVGPOOL_FACES(, float)
+MVG_AVGPOOL_FACES(_bf16, uint16_t)
+#undef MVG_AVGPOOL_FACES
 
-int mvg_avgpool_bwd(const float *dy, float *dx, int n, int hw, int c, void *stream) {
-  MVG_REQUIRE(c % 4 == 0, "avgpool: c %% 4 != 0");
+int mvg_nchw_to_nhwc8_bf16(const float *src, uint16_t *dst, int n, int c, int h, int w, void *stream) {
+  MVG_REQUIRE(c >= 1 && c <= 8, "nchw_to_nhwc8_bf16: c must be 1..8");
   hipStream_t st = (hipStream_t)stream;
-  const long long total = (long long)n * hw * (c / 4);
-  ProfScope ps(MVG_K_POOL, st, 0.0, 4.0 * (double)n * (hw + 1) * c);
-  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, (const float4 *)dy, (float4 *)dx,
-                     total, hw, c / 4);
-  return check_launch("avgpool_bwd");
+  const long long pixels = (long long)n * h * w;
+  ProfScope ps(MVG_K_LAYOUT, st, 0.0, (double)pixels * (4.0 * c + 16.0));
+  hipLaunchKernelGGL(nchw_to_nhwc8_bf16_kernel, dim3(ceil_div(pixels, 256)), dim3(256), 0, st, src, (uint4 *)dst, pixels, c,
+                     (long long)h * w);
+  return check_launch("nchw_to_nhwc8_bf16");
 }
 
 int mvg_nchw_to_nhwc4(const float *src, float *dst, int n, int c, int h, int w, void *stream) {

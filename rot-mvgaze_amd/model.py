@@ -210,6 +210,9 @@ class MultiViewGaze(nn.Module):
         self.input_size: Optional[int] = 224      # raw uint8 inputs: Resize((S, S), antialias=True), main.py:40,53; None = keep
         self._sink = _ArenaSink(self)
         self._wgrad_low_priority = True           # data-parallel runs set False (dp.GradAllReducer._configure)
+        # storage / matrix-core type of the backbone: torch.float32 (default: the path held to 1e-4 against the
+        # reference) or torch.bfloat16 (BASELINE config C5: bf16 activations + weights copies, fp32 everything else)
+        self.compute_dtype = torch.float32
 
     # ---------------------------------------------------------------- plumbing
     def _named_tensors(self) -> Dict[str, Tensor]:
@@ -236,6 +239,7 @@ class MultiViewGaze(nn.Module):
                 raise RuntimeError("fp32 parameters only")
         self._backbone = Backbone(self._depth, named)
         self._backbone.wgrad_low_priority = self._wgrad_low_priority
+        self._backbone.act_dtype = self.compute_dtype
         self._grad_streams = self._backbone.grad_streams   # streams besides the caller's that write gradients
         self._head = FusionHead(named, self._fc_dim, self._num_iter, self._variant)
         # grad-ready order: heads+fusers I-1..0 (shared weights: once), lifter, backbone blocks last..first, stem
@@ -307,6 +311,9 @@ class MultiViewGaze(nn.Module):
         if not imgs[0].is_cuda:
             raise RuntimeError("inputs must be device tensors (no CPU fallback)")
         self._ensure_layout(dev)
+        if self.compute_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("compute_dtype must be torch.float32 or torch.bfloat16")
+        self._backbone.act_dtype = self.compute_dtype
         self._sink.active = False
         img_feat = _BackboneFn.apply(self, self.training, len(imgs), *imgs, *self._backbone_params)
         lifted, feats, preds = _HeadFn.apply(self, img_feat, rot, *self._head_params)

@@ -18,7 +18,7 @@ Tensor = torch.Tensor
 def _p(t: Optional[Tensor]):
     if t is None:
         return None
-    assert t.is_cuda and t.dtype in (torch.float32, torch.int32, torch.uint8, torch.int16), (t.device, t.dtype)
+    assert t.is_cuda and t.dtype in (torch.float32, torch.int32, torch.uint8, torch.int16, torch.bfloat16), (t.device, t.dtype)
     return C.c_void_p(t.data_ptr())
 
 
@@ -31,10 +31,15 @@ def _f32c(t: Tensor) -> Tensor:
     return t
 
 
+def _fn(name: str, t: Tensor):
+    """The entry point for t's storage type: activations are fp32 (parity path) or bf16 (config C5's path)."""
+    return getattr(lib(), name + "_bf16" if t.dtype == torch.bfloat16 else name)
+
+
 # ---------------------------------------------------------------- conv / linear
-def conv_stats_partials(d: ConvDesc):
+def conv_stats_partials(d: ConvDesc, bf16: bool = False):
     rpp = C.c_int32(0)
-    n = lib().mvg_conv_stats_partials(C.byref(d), C.byref(rpp))
+    n = (lib().mvg_conv_stats_partials_bf16 if bf16 else lib().mvg_conv_stats_partials)(C.byref(d), C.byref(rpp))
     if n < 0:
         check(1, "conv_stats_partials")
     return n, rpp.value
@@ -42,7 +47,7 @@ def conv_stats_partials(d: ConvDesc):
 
 def conv_fprop(d: ConvDesc, x: Tensor, w: Tensor, y: Tensor, bias: Optional[Tensor] = None, relu: bool = False,
                stats: Optional[Tensor] = None):
-    check(lib().mvg_conv_fprop(C.byref(d), _p(x), _p(w), _p(y), _p(bias), int(relu), _p(stats), _s()), "conv_fprop")
+    check(_fn("mvg_conv_fprop", x)(C.byref(d), _p(x), _p(w), _p(y), _p(bias), int(relu), _p(stats), _s()), "conv_fprop")
 
 
 def conv_fprop_affine(d: ConvDesc, x: Tensor, w: Tensor, out: Tensor, scale: Tensor, shift: Tensor,
@@ -53,17 +58,25 @@ def conv_fprop_affine(d: ConvDesc, x: Tensor, w: Tensor, out: Tensor, scale: Ten
 
 def conv_dgrad(d: ConvDesc, dy: Tensor, w: Tensor, dx: Tensor, mask: Optional[Tensor] = None,
                addend: Optional[Tensor] = None):
-    check(lib().mvg_conv_dgrad(C.byref(d), _p(dy), _p(w), _p(dx), _p(mask), _p(addend), _s()), "conv_dgrad")
+    check(_fn("mvg_conv_dgrad", dy)(C.byref(d), _p(dy), _p(w), _p(dx), _p(mask), _p(addend), _s()), "conv_dgrad")
+
+
+def cast_weights_bf16(d: ConvDesc, w: Tensor, cin_src: int, need_transposed: bool = True):
+    """fp32 KRSC weights -> (bf16 KRSC [cout][r][s][d.cin], bf16 CRSK [d.cin][r][s][cout] or None)."""
+    wk = torch.empty(d.cout, d.r, d.s, d.cin, dtype=torch.bfloat16, device=w.device)
+    wt = torch.empty(d.cin, d.r, d.s, d.cout, dtype=torch.bfloat16, device=w.device) if need_transposed else None
+    check(lib().mvg_cast_weights_bf16(C.byref(d), _p(w), cin_src, _p(wk), _p(wt), _s()), "cast_weights_bf16")
+    return wk, wt
 
 
 def conv_wgrad(d: ConvDesc, x: Tensor, dy: Tensor, dw: Tensor, accumulate: bool = False):
-    splits = lib().mvg_conv_wgrad_splits(C.byref(d))
+    splits = _fn("mvg_conv_wgrad_splits", x)(C.byref(d))
     if splits < 1:
         check(1, "conv_wgrad_splits")
     ws = None
     if splits > 1:
         ws = torch.empty(splits * d.cout * d.r * d.s * d.cin, dtype=torch.float32, device=x.device)
-    check(lib().mvg_conv_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _p(ws), splits, int(accumulate), _s()), "conv_wgrad")
+    check(_fn("mvg_conv_wgrad", x)(C.byref(d), _p(x), _p(dy), _p(dw), _p(ws), splits, int(accumulate), _s()), "conv_wgrad")
 
 
 def _linear_ws(x: Tensor, rows: int, fin: int, fout: int):
@@ -98,7 +111,7 @@ def bn_eval_affine(groups, c, gamma, beta, running_mean, running_var, eps, scale
 
 
 def bn_apply(y, scale, shift, residual, relu, out, groups, rows_per_group, c):
-    check(lib().mvg_bn_apply(_p(y), _p(scale), _p(shift), _p(residual), int(relu), _p(out), groups, rows_per_group, c,
+    check(_fn("mvg_bn_apply", y)(_p(y), _p(scale), _p(shift), _p(residual), int(relu), _p(out), groups, rows_per_group, c,
                              _s()), "bn_apply")
 
 
@@ -107,13 +120,13 @@ def bn_bwd_reduce(g, act, y, mean, invstd, groups, rows_per_group, c, s1, s2, dg
     n = lib().mvg_bn_bwd_workspace_floats(groups, rows_per_group, c)
     ws = torch.empty(n, dtype=torch.float32, device=g.device)
     rs, rh = relu_affine if relu_affine is not None else (None, None)
-    check(lib().mvg_bn_bwd_reduce(_p(g), _p(act), _p(y), _p(mean), _p(invstd), _p(rs), _p(rh), groups, rows_per_group, c,
+    check(_fn("mvg_bn_bwd_reduce", g)(_p(g), _p(act), _p(y), _p(mean), _p(invstd), _p(rs), _p(rh), groups, rows_per_group, c,
                                   _p(s1), _p(s2), _p(dgamma), _p(dbeta), int(accumulate), _p(ws), _s()), "bn_bwd_reduce")
 
 
 def bn_bwd_apply(g, act, y, mean, invstd, gamma, s1, s2, groups, rows_per_group, c, dy, dz_out=None, relu_affine=None):
     rs, rh = relu_affine if relu_affine is not None else (None, None)
-    check(lib().mvg_bn_bwd_apply(_p(g), _p(act), _p(y), _p(mean), _p(invstd), _p(gamma), _p(s1), _p(s2), _p(rs), _p(rh),
+    check(_fn("mvg_bn_bwd_apply", g)(_p(g), _p(act), _p(y), _p(mean), _p(invstd), _p(gamma), _p(s1), _p(s2), _p(rs), _p(rh),
                                  groups, rows_per_group, c, _p(dy), _p(dz_out), _s()), "bn_bwd_apply")
 
 
@@ -127,7 +140,7 @@ def maxpool_bwd(dy, argmax, dx, n, h, w, c, ho, wo):
 
 
 def bn_relu_maxpool_fwd(y, scale, shift, pooled, argmax, groups, n_per_group, h, w, c, ho, wo):
-    check(lib().mvg_bn_relu_maxpool_fwd(_p(y), _p(scale), _p(shift), _p(pooled), _p(argmax), groups, n_per_group, h, w, c, ho,
+    check(_fn("mvg_bn_relu_maxpool_fwd", y)(_p(y), _p(scale), _p(shift), _p(pooled), _p(argmax), groups, n_per_group, h, w, c, ho,
                                         wo, _s()), "bn_relu_maxpool_fwd")
 
 
@@ -135,28 +148,32 @@ def bn_relu_maxpool_bwd_reduce(g_pooled, argmax, y, mean, invstd, scale, shift, 
                                dgamma, dbeta, accumulate):
     n = lib().mvg_bn_bwd_workspace_floats(groups, n_per_group * h * w, c)
     ws = torch.empty(n, dtype=torch.float32, device=y.device)
-    check(lib().mvg_bn_relu_maxpool_bwd_reduce(_p(g_pooled), _p(argmax), _p(y), _p(mean), _p(invstd), _p(scale), _p(shift),
+    check(_fn("mvg_bn_relu_maxpool_bwd_reduce", y)(_p(g_pooled), _p(argmax), _p(y), _p(mean), _p(invstd), _p(scale), _p(shift),
                                                groups, n_per_group, h, w, c, ho, wo, _p(s1), _p(s2), _p(dgamma), _p(dbeta),
                                                int(accumulate), _p(ws), _s()), "bn_relu_maxpool_bwd_reduce")
 
 
 def bn_relu_maxpool_bwd_apply(g_pooled, argmax, y, mean, invstd, gamma, scale, shift, s1, s2, groups, n_per_group, h, w, c,
                               ho, wo, dy):
-    check(lib().mvg_bn_relu_maxpool_bwd_apply(_p(g_pooled), _p(argmax), _p(y), _p(mean), _p(invstd), _p(gamma), _p(scale),
+    check(_fn("mvg_bn_relu_maxpool_bwd_apply", y)(_p(g_pooled), _p(argmax), _p(y), _p(mean), _p(invstd), _p(gamma), _p(scale),
                                               _p(shift), _p(s1), _p(s2), groups, n_per_group, h, w, c, ho, wo, _p(dy), _s()),
           "bn_relu_maxpool_bwd_apply")
 
 
 def avgpool_fwd(x, y, n, hw, c):
-    check(lib().mvg_avgpool_fwd(_p(x), _p(y), n, hw, c, _s()), "avgpool_fwd")
+    check(_fn("mvg_avgpool_fwd", x)(_p(x), _p(y), n, hw, c, _s()), "avgpool_fwd")
 
 
 def avgpool_bwd(dy, dx, n, hw, c):
-    check(lib().mvg_avgpool_bwd(_p(dy), _p(dx), n, hw, c, _s()), "avgpool_bwd")
+    check(_fn("mvg_avgpool_bwd", dx)(_p(dy), _p(dx), n, hw, c, _s()), "avgpool_bwd")
 
 
 def nchw_to_nhwc4(src, dst, n, c, h, w):
     check(lib().mvg_nchw_to_nhwc4(_p(src), _p(dst), n, c, h, w, _s()), "nchw_to_nhwc4")
+
+
+def nchw_to_nhwc8_bf16(src, dst, n, c, h, w):
+    check(lib().mvg_nchw_to_nhwc8_bf16(_p(src), _p(dst), n, c, h, w, _s()), "nchw_to_nhwc8_bf16")
 
 
 def nhwc4_to_nchw(src, dst, n, c, h, w):
