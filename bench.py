@@ -28,9 +28,12 @@ WORKLOADS = {
     "c3": (50, 4, 128, "C3: ResNet-50, V=4, B=128 per GPU, 3x224x224, fwd+loss+bwd"),
     "c4": (50, 4, 32, "C4: ResNet-50, V=4, B=32 per GPU (256 on 8 GPUs), 3x224x224, fwd+loss+bwd"),
     "r50v2": (50, 2, 64, "ResNet-50, V=2, B=64 per GPU, 3x224x224, fwd+loss+bwd"),
-    "c5fp32": (50, 8, 64, "C5 shapes: ResNet-50, V=8, B=64 per GPU (512 on 8 GPUs), 3x224x224, fwd+loss+bwd - in fp32: "
-                          "the bf16 MFMA path of config 5 is not built"),
+    "c5": (50, 8, 64, "C5: ResNet-50, V=8, B=64 per GPU (512 on 8 GPUs), 3x224x224, fwd+loss+bwd, bf16 MFMA path "
+                      "(bf16 activations + weight copies in the backbone; fp32 statistics, fusion block, loss, master weights)"),
+    "c5fp32": (50, 8, 64, "C5 shapes in fp32: ResNet-50, V=8, B=64 per GPU (512 on 8 GPUs), 3x224x224, fwd+loss+bwd"),
 }
+BF16_WORKLOADS = {"c5"}
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (the 5 PF headline includes 2:1 sparsity)
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0
 
@@ -127,6 +130,8 @@ def main():
     ap.add_argument("--no-optimizer", action="store_true", help="time forward+loss+backward only (no Adam step)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the backward-weight kernels on the compute stream (per-kernel profiling: rocprofv3 --stats)")
+    ap.add_argument("--dtype", default=None, choices=["f32", "bf16"],
+                    help="backbone storage / matrix-core type (default: f32, bf16 for --workload c5)")
     ap.add_argument("--mode", default="train", choices=["train", "eval"],
                     help="eval = inference forward only (model.eval(), BN folded into the convs; SURVEY §8(f) rank 2)")
     args = ap.parse_args()
@@ -178,6 +183,9 @@ def main():
     model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
     del sd
     model.to(dev).train()
+    bf16 = (args.dtype == "bf16") if args.dtype else (args.workload in BF16_WORKLOADS)
+    if bf16:
+        model.compute_dtype = torch.bfloat16
     inp = synth.make_inputs(B, V, 1234 + rank, 224)
     img = [torch.from_numpy(np.ascontiguousarray(inp["img"][:, v])).to(dev) for v in range(V)]   # one tensor per view
     gt = torch.from_numpy(inp["gt_gaze"]).to(dev)
@@ -266,13 +274,16 @@ def main():
         traffic, traffic_src = None, None
         import glob
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*pmc_traffic_{args.workload}.json")))
-        if cands and not args.batch:
+        if cands and not args.batch and not args.dtype:
             with open(cands[-1]) as f:
                 tj = json.load(f)
             traffic, traffic_src = tj["traffic_bytes_per_launch"], os.path.relpath(cands[-1], ROOT)
-        roofline = {"bound": "mfma", "kernel": "igemm_kernel/wgrad_kernel (fp32 MFMA implicit-GEMM conv: fprop+dgrad+wgrad)",
-                    "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+        peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
+        roofline = {"bound": "mfma",
+                    "kernel": ("igemm_bf16_kernel/wgrad_bf16_kernel (bf16 MFMA implicit-GEMM conv: fprop+dgrad+wgrad)" if bf16 else
+                               "igemm_kernel/wgrad_kernel (fp32 MFMA implicit-GEMM conv: fprop+dgrad+wgrad)"),
+                    "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(achieved / peak, 4), "traffic": traffic,
                     "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE*2 + WRITE_SIZE, separate passes)",
                     "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": sum(e["bytes"] for e in conv) / max(launches, 1),
@@ -320,7 +331,7 @@ def main():
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "ms_per_step_median_events": round(median_ms, 3) if median_ms else None,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
             "config": {"workload": desc, "backbone": f"ResNet-{depth}", "views": V, "batch_per_gpu": B,
                        "global_batch": B * world, "image": "3x224x224", "parallelism": f"dp{world}" + ("" if os.environ.get("MVG_DIST_BACKEND", "nccl") == "nccl" else " (REHEARSAL: gloo, ranks share devices - not a measurement)"),
                        "timed_region": ("inference forward (BN folded into conv epilogues)" if args.mode == "eval" else

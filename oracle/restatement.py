@@ -85,26 +85,55 @@ def _relu(x: Tensor, masks) -> Tensor:
     return x * next(masks).to(x.dtype)
 
 
-def _conv_bn(sd: SD, x: Tensor, c: ConvSpec, training: bool) -> Tensor:
+def bf16_round(x: Tensor) -> Tensor:
+    """Round to bfloat16 and back (round-to-nearest-even); differentiable like any dtype cast."""
+    return x.to(torch.bfloat16).to(x.dtype)
+
+
+def _conv_bn(sd: SD, x: Tensor, c: ConvSpec, training: bool, q=None) -> Tensor:
     """conv (bias=False) -> BatchNorm2d(eps 1e-5, momentum 0.1).
     Train mode: batch statistics over this call's (B,H,W); running stats updated in place in
     ``sd`` (unbiased var, num_batches_tracked += 1) exactly like nn.BatchNorm2d.
-    /root/reference/models/resnet.py:31-47 (convs), :187,73 (BN use)."""
-    y = F.conv2d(x, sd[c.name + ".weight"], None, c.stride, c.pad)
+    /root/reference/models/resnet.py:31-47 (convs), :187,73 (BN use).
+
+    ``q`` (None for the reference arithmetic) emulates the repo's bf16 STORAGE path, which the reference
+    does not have: the conv reads bf16 weights, its fp32 result gives the batch statistics, the result is
+    then stored rounded (``q``) and the normalisation y*scale + shift is applied to the stored values -
+    the rounding points of rot-mvgaze_amd/csrc/conv_bf16.hip + bn.hip, so that the bf16 kernels can be
+    compared with the same arithmetic instead of with fp32 (tests/test_bf16_gpu.py)."""
+    w = sd[c.name + ".weight"]
+    if q is None:
+        y = F.conv2d(x, w, None, c.stride, c.pad)
+        if training:
+            sd[c.bn + ".num_batches_tracked"] += 1
+        return F.batch_norm(y, sd[c.bn + ".running_mean"], sd[c.bn + ".running_var"],
+                            sd[c.bn + ".weight"], sd[c.bn + ".bias"], training, 0.1, 1e-5)
+    y = F.conv2d(x, q(w), None, c.stride, c.pad)
+    rm, rv = sd[c.bn + ".running_mean"], sd[c.bn + ".running_var"]
     if training:
         sd[c.bn + ".num_batches_tracked"] += 1
-    return F.batch_norm(y, sd[c.bn + ".running_mean"], sd[c.bn + ".running_var"],
-                        sd[c.bn + ".weight"], sd[c.bn + ".bias"], training, 0.1, 1e-5)
+        mean, var = y.mean((0, 2, 3)), y.var((0, 2, 3), unbiased=False)
+        n = y.numel() // y.shape[1]
+        with torch.no_grad():
+            rm.mul_(0.9).add_(0.1 * mean.detach())
+            rv.mul_(0.9).add_(0.1 * var.detach() * (n / max(n - 1, 1)))
+    else:
+        mean, var = rm, rv
+    scale = sd[c.bn + ".weight"] * torch.rsqrt(var + 1e-5)
+    shift = sd[c.bn + ".bias"] - mean * scale
+    return q(y) * scale[None, :, None, None] + shift[None, :, None, None]
 
 
 def backbone_forward(sd: SD, x: Tensor, spec: BackboneSpec, training: bool, trace: Optional[list] = None,
-                     relu_masks=None) -> Tensor:
+                     relu_masks=None, q=None) -> Tensor:
     """One ResNet pass over ONE view's images [B,3,H,W] -> pooled feature [B, fc_dim].
 
     /root/reference/models/resnet.py:261-275 (stem, maxpool, layer1..4, avgpool) wrapped by
     /root/reference/models/rot_mv.py:124-128 (avgpool again - identity on 1x1 - and flatten);
-    residual blocks :80-96 (basic) and :128-148 (bottleneck)."""
-    x = _relu(_conv_bn(sd, x, spec.stem, training), relu_masks)
+    residual blocks :80-96 (basic) and :128-148 (bottleneck).  ``q``: see _conv_bn (every stored
+    activation - input image, unit outputs, block outputs - is rounded; None = reference arithmetic)."""
+    s = (lambda t: t) if q is None else q
+    x = s(_relu(_conv_bn(sd, s(x), spec.stem, training, q), relu_masks))
     x = F.max_pool2d(x, 3, 2, 1)
     if trace is not None:
         trace.append(x)
@@ -112,12 +141,12 @@ def backbone_forward(sd: SD, x: Tensor, spec: BackboneSpec, training: bool, trac
         identity = x
         out = x
         for i, c in enumerate(blk.convs):
-            out = _conv_bn(sd, out, c, training)
+            out = _conv_bn(sd, out, c, training, q)
             if i + 1 < len(blk.convs):
-                out = _relu(out, relu_masks)
+                out = s(_relu(out, relu_masks))
         if blk.downsample is not None:
-            identity = _conv_bn(sd, x, blk.downsample, training)
-        x = _relu(out + identity, relu_masks)
+            identity = s(_conv_bn(sd, x, blk.downsample, training, q))
+        x = s(_relu(out + identity, relu_masks))
         if trace is not None:       # debugging aid: per-block activations (tests may retain_grad them)
             trace.append(x)
     return F.adaptive_avg_pool2d(x, 1).flatten(1)
@@ -291,16 +320,17 @@ def view_pairs(views: int) -> List[Tuple[int, int]]:
 
 
 def multiview_forward(sd: SD, img: Tensor, rot: Tensor, depth: int, num_iter: int = 3,
-                      training: bool = False, masks: Optional[Dict[Any, Any]] = None) -> Dict[str, Any]:
+                      training: bool = False, masks: Optional[Dict[Any, Any]] = None, storage=None) -> Dict[str, Any]:
     """img [B,V,3,H,W], rot [B,V,3,3].  Backbone + lifter once per view in view order (BN
     statistics per view call); fusion over every unordered pair i<j in lexicographic order.
     ``masks`` (test aid, see _relu): {"backbone": [iterator per view], "lift": [mask per view],
-    ("fuse", it) / ("head", it): [mask per DIRECTED pair d = 2p (i<-j), 2p+1 (j<-i)]}."""
+    ("fuse", it) / ("head", it): [mask per DIRECTED pair d = 2p (i<-j), 2p+1 (j<-i)]}.
+    ``storage`` = bf16_round emulates the repo's bf16 backbone storage (see _conv_bn); the fusion block is fp32."""
     spec = backbone_spec(depth)
     V = img.shape[1]
     bm = masks["backbone"] if masks is not None else [None] * V
     lm = masks["lift"] if masks is not None else [None] * V
-    feats = [backbone_forward(sd, img[:, v], spec, training, None, bm[v]) for v in range(V)]
+    feats = [backbone_forward(sd, img[:, v], spec, training, None, bm[v], storage) for v in range(V)]
     lifted = [lift(sd, f, lm[v]) for v, f in enumerate(feats)]
     out: Dict[str, Any] = {"num_iter": num_iter, "views": V, "img_feat": feats, "initial_rot_feat": lifted,
                            "pairs": {}}
