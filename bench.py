@@ -312,10 +312,10 @@ def main():
                 "intensity_flop_per_byte": round(lfl / lby, 1), "machine_balance_flop_per_byte": round(PEAK_FP32_MFMA_TFLOPS * 1e3 / PEAK_HBM_GBS, 1),
                 "ms_per_step": round(lms / nprof, 4),
                 "launches_per_step": sum(e["launches"] for e in lin) / nprof,
-                "block_ms_per_step": round(sum(prof[k]["ms"] for k in ("linear_fprop", "linear_dgrad", "linear_wgrad", "colsum",
+                "block_ms_per_step": round(sum(prof[k]["ms"] for k in ("linear_fprop", "linear_dgrad", "linear_wgrad",
                                                                         "rotcat", "loss", "geometry") if k in prof) / nprof, 4),
                 "block_launches_per_step": sum(prof[k]["launches"] for k in ("linear_fprop", "linear_dgrad", "linear_wgrad",
-                                                                             "colsum", "rotcat", "loss", "geometry") if k in prof) / nprof,
+                                                                             "rotcat", "loss", "geometry") if k in prof) / nprof,
                 "note": "algorithmic bytes = operands + result of every GEMM once (weights dominate); in fp32 the "
                         "intensity (rows/2 flop per weight byte) is above the machine balance at every BASELINE config, "
                         "so the matrix pipe, not the weight stream, bounds this family"}

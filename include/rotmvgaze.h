@@ -114,6 +114,12 @@ int mvg_conv_wgrad(const mvg_conv_desc *d, const float *x, const float *dy, floa
                    float *workspace, int splits, int accumulate, void *stream);
 /* a split count that fills the device for this shape (host helper, no launch). */
 int mvg_conv_wgrad_splits(const mvg_conv_desc *d);
+/* nn.Linear backward-weight (blocks.py:41-47 under autograd): dw[fout][fin] (+)= dy^T x and, in the SAME
+ * launch, the bias gradient db[fout] (+)= column sums of dy (the kernel streams dy anyway; db may be NULL).
+ * splits = mvg_conv_wgrad_splits(linear descriptor); workspace: splits * (fout*fin + fout) floats when
+ * splits > 1. */
+int mvg_linear_wgrad(const float *x, const float *dy, float *dw, float *db, int rows, int fin, int fout,
+                     float *workspace, int splits, int accumulate, void *stream);
 
 /* nn.Linear forward / backward-data (backbones/blocks.py:41-47 inside Mlp): the conv kernels with
  * h = w = r = s = 1 plus split-K - with a few hundred rows the tile grid cannot fill 256 CUs, so
@@ -144,19 +150,25 @@ int mvg_bn_finalize(const float *stats, int groups, int partials, int rows_per_p
 int mvg_bn_eval_affine(int groups, int c, const float *gamma, const float *beta,
                        const float *running_mean, const float *running_var, float eps,
                        float *scale, float *shift, void *stream);
-/* out = [relu]( y*scale[g] + shift[g] [+ residual] );  y,out,residual: [groups][rows][c]. */
+/* out = [relu]( y*scale[g] + shift[g] [+ residual] );  y,out,residual: [groups][rows][c].
+ * res_scale/res_shift ([groups][c], both or neither): the residual is the RAW output of the block's
+ * downsample conv and its BatchNorm (residual*res_scale + res_shift) is applied here, so the normalised
+ * downsample map is never written (resnet.py:88-93,137-145). */
 int mvg_bn_apply(const float *y, const float *scale, const float *shift, const float *residual,
-                 int relu, float *out, int groups, int64_t rows_per_group, int c, void *stream);
+                 const float *res_scale, const float *res_shift, int relu, float *out, int groups,
+                 int64_t rows_per_group, int c, void *stream);
 /* Backward, step 1: per (group, channel) s1 = sum(dz), s2 = sum(dz * xhat), xhat = (y - mean) * invstd,
  * dz = g masked by the unit's ReLU.  The mask comes from `act` (the unit's output: act > 0) or, for
  * a ReLU without residual, from (relu_scale, relu_shift) = the scale/shift mvg_bn_apply used:
  * fma(y, scale, shift) > 0 is the same bit pattern and saves reading act.  Both NULL: no ReLU.
  * Also dgamma[c] (+)= sum_g s2, dbeta[c] (+)= sum_g s1 (accumulate flag).
+ * dz_out (may be NULL, may alias g): the masked gradient dz is written out, so that mvg_bn_bwd_apply can
+ * run on it without reading the mask again and the residual branch gets its gradient from the same buffer.
  * workspace: mvg_bn_bwd_workspace_floats() floats. */
 int mvg_bn_bwd_reduce(const float *g, const float *act, const float *y, const float *mean,
                       const float *invstd, const float *relu_scale, const float *relu_shift,
                       int groups, int64_t rows_per_group, int c, float *s1, float *s2, float *dgamma,
-                      float *dbeta, int accumulate, float *workspace, void *stream);
+                      float *dbeta, int accumulate, float *workspace, float *dz_out, void *stream);
 size_t mvg_bn_bwd_workspace_floats(int groups, int64_t rows_per_group, int c);
 /* Backward, step 2: dy = gamma*invstd*(dz - s1/n - xhat*s2/n); dz_out (optional, may alias g)
  * receives the masked gradient for the residual branch. */
@@ -266,8 +278,6 @@ int mvg_paircat_bwd(const float *dx, const float *rel, const float *scales, cons
 int mvg_segment_sum(const float *x, int64_t row_stride, int width, const int32_t *seg_of, float *out,
                     int batch, int dirs, int segments, int accumulate, void *stream);
 
-/* out[c] (+)= sum_rows x[rows][c]   (bias gradient of nn.Linear). */
-int mvg_colsum(const float *x, float *out, int64_t rows, int c, int accumulate, void *stream);
 /* y = a*x + b*y (n floats) - gradient fan-in accumulation. */
 int mvg_axpby(const float *x, float *y, float a, float b, int64_t n, void *stream);
 /* out = x * scale[0] with the scale read on the device (upstream gradient of a scalar loss). */
@@ -340,11 +350,12 @@ int mvg_conv_wgrad_bf16(const mvg_conv_desc *d, const void *x, const void *dy, f
 int mvg_conv_wgrad_splits_bf16(const mvg_conv_desc *d);
 /* the BatchNorm / pooling passes with bf16 activations (same arguments as the fp32 entry points) */
 int mvg_bn_apply_bf16(const uint16_t *y, const float *scale, const float *shift, const uint16_t *residual,
-                      int relu, uint16_t *out, int groups, int64_t rows_per_group, int c, void *stream);
+                      const float *res_scale, const float *res_shift, int relu, uint16_t *out, int groups,
+                      int64_t rows_per_group, int c, void *stream);
 int mvg_bn_bwd_reduce_bf16(const uint16_t *g, const uint16_t *act, const uint16_t *y, const float *mean,
                            const float *invstd, const float *relu_scale, const float *relu_shift, int groups,
                            int64_t rows_per_group, int c, float *s1, float *s2, float *dgamma, float *dbeta,
-                           int accumulate, float *workspace, void *stream);
+                           int accumulate, float *workspace, uint16_t *dz_out, void *stream);
 int mvg_bn_bwd_apply_bf16(const uint16_t *g, const uint16_t *act, const uint16_t *y, const float *mean,
                           const float *invstd, const float *gamma, const float *s1, const float *s2,
                           const float *relu_scale, const float *relu_shift, int groups, int64_t rows_per_group,

@@ -145,7 +145,7 @@ def backbone_forward(sd: SD, x: Tensor, spec: BackboneSpec, training: bool, trac
             if i + 1 < len(blk.convs):
                 out = s(_relu(out, relu_masks))
         if blk.downsample is not None:
-            identity = s(_conv_bn(sd, x, blk.downsample, training, q))
+            identity = _conv_bn(sd, x, blk.downsample, training, q)      # normalised on the fly by the consumer: never stored
         x = s(_relu(out + identity, relu_masks))
         if trace is not None:       # debugging aid: per-block activations (tests may retain_grad them)
             trace.append(x)

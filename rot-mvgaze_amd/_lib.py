@@ -57,13 +57,14 @@ SIGNATURES = {
     "mvg_conv_dgrad": (_I, [_D, _P, _P, _P, _P, _P, _P]),
     "mvg_conv_wgrad": (_I, [_D, _P, _P, _P, _P, _I, _I, _P]),
     "mvg_conv_wgrad_splits": (_I, [_D]),
+    "mvg_linear_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _I, _I, _P]),
     "mvg_linear_workspace_floats": (C.c_size_t, [_I, _I, _I]),
     "mvg_linear_fprop": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _P, C.c_size_t, _P]),
     "mvg_linear_dgrad": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, C.c_size_t, _P]),
     "mvg_bn_finalize": (_I, [_P, _I, _I, _I, _I64, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
     "mvg_bn_eval_affine": (_I, [_I, _I, _P, _P, _P, _P, _F, _P, _P, _P]),
-    "mvg_bn_apply": (_I, [_P, _P, _P, _P, _I, _P, _I, _I64, _I, _P]),
-    "mvg_bn_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _P, _P, _P, _P, _I, _P, _P]),
+    "mvg_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _I, _I64, _I, _P]),
+    "mvg_bn_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
     "mvg_bn_bwd_workspace_floats": (C.c_size_t, [_I, _I64, _I]),
     "mvg_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _P, _P, _P]),
     "mvg_maxpool3x3s2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
@@ -90,7 +91,6 @@ SIGNATURES = {
     "mvg_paircat_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "mvg_paircat_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "mvg_segment_sum": (_I, [_P, _I64, _I, _P, _P, _I, _I, _I, _I, _P]),
-    "mvg_colsum": (_I, [_P, _P, _I64, _I, _I, _P]),
     "mvg_axpby": (_I, [_P, _P, _F, _F, _I64, _P]),
     "mvg_scale_by": (_I, [_P, _P, _P, _I64, _P]),
     "mvg_linear_skinny_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
@@ -104,8 +104,8 @@ SIGNATURES = {
     "mvg_conv_dgrad_bf16": (_I, [_D, _P, _P, _P, _P, _P, _P]),
     "mvg_conv_wgrad_bf16": (_I, [_D, _P, _P, _P, _P, _I, _I, _P]),
     "mvg_conv_wgrad_splits_bf16": (_I, [_D]),
-    "mvg_bn_apply_bf16": (_I, [_P, _P, _P, _P, _I, _P, _I, _I64, _I, _P]),
-    "mvg_bn_bwd_reduce_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _P, _P, _P, _P, _I, _P, _P]),
+    "mvg_bn_apply_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _I, _I64, _I, _P]),
+    "mvg_bn_bwd_reduce_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
     "mvg_bn_bwd_apply_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _P, _P, _P]),
     "mvg_bn_relu_maxpool_fwd_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mvg_bn_relu_maxpool_bwd_reduce_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I,

@@ -87,9 +87,13 @@ class Backbone:
 
     # ---------------------------------------------------------------- forward
     def _unit_fwd(self, c: ConvSpec, x: Tensor, G: int, N: int, H: int, W: int, training: bool, relu: bool,
-                  residual: Optional[Tensor], tape: Optional[list], pool: bool = False):
+                  residual: Optional[Tensor], tape: Optional[list], pool: bool = False, residual_affine=None,
+                  defer_apply: bool = False):
         """conv -> BatchNorm (-> + residual) (-> ReLU).  pool=True (the stem): the 3x3/2 max pool is
-        fused behind the ReLU and (pooled, argmax) is returned; the normalised map is not stored."""
+        fused behind the ReLU and (pooled, argmax) is returned; the normalised map is not stored.
+        defer_apply (the downsample branch): stop after the statistics and return (y, (scale, shift)) - the
+        normalisation is applied by the consumer, the block's last unit, which takes them as
+        residual / residual_affine; the normalised downsample map is never written."""
         bf = self.bf16
         cin = (8 if bf else 4) if c.cin == 3 else c.cin
         d = ConvDesc.make(G, N, H, W, cin, c.cout, c.k, c.stride, c.pad)
@@ -127,6 +131,16 @@ class Backbone:
             fprop(None)
             ops.bn_eval_affine(G, c.cout, gamma, beta, rm, rv, BN_EPS, scale, shift)
         keep = tape is not None
+        if defer_apply:
+            assert not relu and residual is None and not pool
+            if keep:
+                u = _Unit()
+                u.spec, u.desc, u.x_in, u.y, u.out, u.mean, u.invstd, u.relu, u.rows, u.w = \
+                    c, d, x, y, None, mean, invstd, False, rows, (w_t if bf else w)
+                u.trained = training
+                u.relu_affine = None
+                tape.append(u)
+            return y, (scale, shift)
         if pool:
             assert relu and residual is None
             hp, wp_ = (d.ho + 2 - 3) // 2 + 1, (d.wo + 2 - 3) // 2 + 1
@@ -135,7 +149,7 @@ class Backbone:
             ops.bn_relu_maxpool_fwd(y, scale, shift, out, argmax, G, N, d.ho, d.wo, c.cout, hp, wp_)
         else:
             out = torch.empty_like(y) if keep else y            # inference: normalise in place
-            ops.bn_apply(y, scale, shift, residual, relu, out, G, rows, c.cout)
+            ops.bn_apply(y, scale, shift, residual, relu, out, G, rows, c.cout, residual_affine)
         if keep:
             u = _Unit()
             u.spec, u.desc, u.x_in, u.y, u.out, u.mean, u.invstd, u.relu, u.rows, u.w = \
@@ -200,10 +214,17 @@ class Backbone:
                 out = self._unit_fwd(c, out, V, B, h, w, training, True, None, ulist)
                 h, w = out.shape[2], out.shape[3]
             ds_idx = None
+            ident_affine = None
             if blk.downsample is not None:
-                identity = self._unit_fwd(blk.downsample, x, V, B, Hc, Wc, training, False, None, ulist)
+                if training or keep_tape or self.bf16:
+                    # raw downsample conv output + its (scale, shift): normalised inside the last unit's bn_apply
+                    identity, ident_affine = self._unit_fwd(blk.downsample, x, V, B, Hc, Wc, training, False, None, ulist,
+                                                            defer_apply=True)
+                else:
+                    identity = self._unit_fwd(blk.downsample, x, V, B, Hc, Wc, training, False, None, ulist)
                 ds_idx = len(ulist) - 1 if keep_tape else None
-            out = self._unit_fwd(blk.convs[-1], out, V, B, h, w, training, True, identity, ulist)
+            out = self._unit_fwd(blk.convs[-1], out, V, B, h, w, training, True, identity, ulist,
+                                 residual_affine=ident_affine)
             if keep_tape:
                 n_main = len(blk.convs)
                 idx = list(range(first, first + n_main - 1)) + [len(ulist) - 1]
@@ -228,12 +249,16 @@ class Backbone:
         act = u.out if (u.relu and ra is None) else None
         acc = sink.accumulate(gp)
         assert acc == sink.accumulate(bp)
+        if need_dz:
+            # the reduce pass writes the masked gradient dz over g: the apply pass then reads (dz, y) only - no
+            # second look at the ReLU mask, no second dz store - and the residual branch takes dz from g
+            ops.bn_bwd_reduce(g, act, u.y, u.mean, u.invstd, G, u.rows, c.cout, s12[0], s12[1], sink.view(gp), sink.view(bp),
+                              acc, ra, dz_out=g)
+            dy = torch.empty_like(g)
+            ops.bn_bwd_apply(g, None, u.y, u.mean, u.invstd, gp.detach(), s12[0], s12[1], G, u.rows, c.cout, dy, None, None)
+            return dy, g
         ops.bn_bwd_reduce(g, act, u.y, u.mean, u.invstd, G, u.rows, c.cout, s12[0], s12[1], sink.view(gp), sink.view(bp),
                           acc, ra)
-        if need_dz:
-            dy = torch.empty_like(g)
-            ops.bn_bwd_apply(g, act, u.y, u.mean, u.invstd, gp.detach(), s12[0], s12[1], G, u.rows, c.cout, dy, g, ra)
-            return dy, g
         ops.bn_bwd_apply(g, act, u.y, u.mean, u.invstd, gp.detach(), s12[0], s12[1], G, u.rows, c.cout, g, None, ra)
         return g, None
 

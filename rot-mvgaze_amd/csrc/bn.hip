@@ -170,9 +170,15 @@ __global__ void bn_eval_affine_kernel(int groups, int c, const float *gamma, con
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T *__restrict__ y, const float *__restrict__ scale,
                                                        const float *__restrict__ shift,
-                                                       const T *__restrict__ residual, int relu,
+                                                       const T *__restrict__ residual,
+                                                       const float *__restrict__ res_scale,
+                                                       const float *__restrict__ res_shift, int relu,
                                                        T *__restrict__ out, long long n4_per_group, int c4n, int c) {
   typedef Elem<T> E;
+  // res_scale / res_shift: the residual is the RAW output of the block's downsample conv and its BatchNorm
+  // is applied here (the normalised downsample map is never written: resnet.py:88-93,137-145)
+  const float4 *rs4 = res_scale ? reinterpret_cast<const float4 *>(res_scale + (long long)blockIdx.y * c) : nullptr;
+  const float4 *rh4 = res_shift ? reinterpret_cast<const float4 *>(res_shift + (long long)blockIdx.y * c) : nullptr;
   const int g = blockIdx.y;
   const float4 *sc4 = reinterpret_cast<const float4 *>(scale + (long long)g * c);
   const float4 *sh4 = reinterpret_cast<const float4 *>(shift + (long long)g * c);
@@ -188,7 +194,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T *__restrict__ y, 
     float4 o = make_float4(__builtin_fmaf(v.x, a.x, b.x), __builtin_fmaf(v.y, a.y, b.y), __builtin_fmaf(v.z, a.z, b.z),
                            __builtin_fmaf(v.w, a.w, b.w));
     if (residual) {
-      const float4 r = E::ld4(residual, base + i);
+      float4 r = E::ld4(residual, base + i);
+      if (rs4) {
+        const float4 ra = rs4[cq], rb = rh4[cq];
+        r = make_float4(__builtin_fmaf(r.x, ra.x, rb.x), __builtin_fmaf(r.y, ra.y, rb.y), __builtin_fmaf(r.z, ra.z, rb.z),
+                        __builtin_fmaf(r.w, ra.w, rb.w));
+      }
       o.x += r.x;
       o.y += r.y;
       o.z += r.z;
@@ -209,14 +220,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T *__restrict__ y, 
 // ---- backward reduce ------------------------------------------------------------------------
 // grid = (chunks, column blocks, groups); thread = one float4 column group x one row lane.
 template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *__restrict__ g, const T *__restrict__ act,
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *g, const T *__restrict__ act,
                                                             const T *__restrict__ y,
                                                             const float *__restrict__ mean,
                                                             const float *__restrict__ invstd,
                                                             const float *__restrict__ mscale,
                                                             const float *__restrict__ mshift, long long rows,
                                                             long long rows_per_chunk, int c, int c4n, int cw,
-                                                            float *__restrict__ partial, int chunks) {
+                                                            float *__restrict__ partial, int chunks, T *dz_out) {
   __shared__ float4 sh[2][256];
   const int grp = blockIdx.z;
   const int rl = threadIdx.x / cw, cl = threadIdx.x % cw;
@@ -254,6 +265,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *__restrict_
         d.z = __builtin_fmaf(v.z, ma.z, mb.z) > 0.f ? d.z : 0.f;
         d.w = __builtin_fmaf(v.w, ma.w, mb.w) > 0.f ? d.w : 0.f;
       }
+      if (dz_out) Elem<T>::st4(dz_out, off, d);      // the masked gradient (may alias g): the apply pass then needs no mask
       a1.x += d.x;
       a1.y += d.y;
       a1.z += d.z;
@@ -634,21 +646,24 @@ int mvg_bn_eval_affine(int groups, int c, const float *gamma, const float *beta,
 }  // extern "C" (templated implementations below)
 
 template <typename T>
-static int bn_apply_impl(const T *y, const float *scale, const float *shift, const T *residual, int relu, T *out, int groups,
-                         int64_t rows_per_group, int c, void *stream) {
+static int bn_apply_impl(const T *y, const float *scale, const float *shift, const T *residual, const float *res_scale,
+                         const float *res_shift, int relu, T *out, int groups, int64_t rows_per_group, int c, void *stream) {
   MVG_REQUIRE(c % 4 == 0, "bn_apply: c %% 4 != 0");
+  MVG_REQUIRE((res_scale == nullptr) == (res_shift == nullptr) && (residual || !res_scale),
+              "bn_apply: res_scale / res_shift go together and need a residual");
   hipStream_t st = (hipStream_t)stream;
   const long long n4 = rows_per_group * (c / 4);
   ProfScope ps(MVG_K_BN_APPLY, st, 0.0, 4.0 * Elem<T>::kBytes * groups * (double)n4 * (residual ? 3 : 2));
-  hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(grid_for(n4), groups), dim3(256), 0, st, y, scale, shift, residual, relu, out, n4,
-                     c / 4, c);
+  hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(grid_for(n4), groups), dim3(256), 0, st, y, scale, shift, residual, res_scale,
+                     res_shift, relu, out, n4, c / 4, c);
   return check_launch("bn_apply");
 }
 
 template <typename T>
 static int bn_bwd_reduce_impl(const T *g, const T *act, const T *y, const float *mean, const float *invstd,
                               const float *relu_scale, const float *relu_shift, int groups, int64_t rows_per_group, int c,
-                              float *s1, float *s2, float *dgamma, float *dbeta, int accumulate, float *workspace, void *stream) {
+                              float *s1, float *s2, float *dgamma, float *dbeta, int accumulate, float *workspace, T *dz_out,
+                              void *stream) {
   MVG_REQUIRE(!(act && relu_scale), "bn_bwd_reduce: give the ReLU mask either as act or as (relu_scale, relu_shift)");
   MVG_REQUIRE((relu_scale == nullptr) == (relu_shift == nullptr), "bn_bwd_reduce: relu_scale and relu_shift go together");
   MVG_REQUIRE(c % 4 == 0, "bn_bwd_reduce: c %% 4 != 0");
@@ -659,9 +674,9 @@ static int bn_bwd_reduce_impl(const T *g, const T *act, const T *y, const float 
   MVG_REQUIRE(256 % cw == 0, "bn_bwd_reduce: c/4 must divide 256 or be a multiple of it (c=%d)", c);
   const int chunks = bwd_chunks(groups, rows_per_group, c);
   const long long rpc = (rows_per_group + chunks - 1) / chunks;
-  ProfScope ps(MVG_K_BN_BWD_REDUCE, st, 0.0, Elem<T>::kBytes * groups * (double)rows_per_group * c * (act ? 3 : 2));
+  ProfScope ps(MVG_K_BN_BWD_REDUCE, st, 0.0, Elem<T>::kBytes * groups * (double)rows_per_group * c * ((act ? 3 : 2) + (dz_out ? 1 : 0)));
   hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(chunks, ceil_div(c4n, cw), groups), dim3(256), 0, st, g, act, y, mean, invstd,
-                     relu_scale, relu_shift, (long long)rows_per_group, rpc, c, c4n, cw, workspace, chunks);
+                     relu_scale, relu_shift, (long long)rows_per_group, rpc, c, c4n, cw, workspace, chunks, dz_out);
   if (check_launch("bn_bwd_reduce")) return 1;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(c, 16)), dim3(1024), 0, st, workspace, groups, chunks, c, s1, s2,
                      dgamma, dbeta, accumulate);
@@ -749,16 +764,17 @@ size_t mvg_bn_bwd_workspace_floats(int groups, int64_t rows_per_group, int c) {
 }
 
 #define MVG_BN_FACES(SUFFIX, T)                                                                                              \
-  int mvg_bn_apply##SUFFIX(const T *y, const float *scale, const float *shift, const T *residual, int relu, T *out,        \
-                           int groups, int64_t rows_per_group, int c, void *stream) {                                       \
-    return bn_apply_impl<T>(y, scale, shift, residual, relu, out, groups, rows_per_group, c, stream);                       \
+  int mvg_bn_apply##SUFFIX(const T *y, const float *scale, const float *shift, const T *residual,                           \
+                           const float *res_scale, const float *res_shift, int relu, T *out, int groups,                    \
+                           int64_t rows_per_group, int c, void *stream) {                                                   \
+    return bn_apply_impl<T>(y, scale, shift, residual, res_scale, res_shift, relu, out, groups, rows_per_group, c, stream);  \
   }                                                                                                                          \
   int mvg_bn_bwd_reduce##SUFFIX(const T *g, const T *act, const T *y, const float *mean, const float *invstd,               \
                                 const float *relu_scale, const float *relu_shift, int groups, int64_t rows_per_group,       \
                                 int c, float *s1, float *s2, float *dgamma, float *dbeta, int accumulate,                   \
-                                float *workspace, void *stream) {                                                           \
+                                float *workspace, T *dz_out, void *stream) {                                                \
     return bn_bwd_reduce_impl<T>(g, act, y, mean, invstd, relu_scale, relu_shift, groups, rows_per_group, c, s1, s2,        \
-                                 dgamma, dbeta, accumulate, workspace, stream);                                             \
+                                 dgamma, dbeta, accumulate, workspace, dz_out, stream);                                     \
   }                                                                                                                          \
   int mvg_bn_bwd_apply##SUFFIX(const T *g, const T *act, const T *y, const float *mean, const float *invstd,                \
                                const float *gamma, const float *s1, const float *s2, const float *relu_scale,               \

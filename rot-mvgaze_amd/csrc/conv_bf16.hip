@@ -373,8 +373,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradParams p) {
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int LDA = BM + 32, LDB = BN + 32;
   constexpr int MV = BM / 8, NVB = BN / 8;
-  constexpr int A_KRPP = 256 / MV, B_KRPP = 256 / NVB;
-  constexpr int A_PASSES = BK / A_KRPP, B_PASSES = BK / B_KRPP;
+  constexpr int A_KRPP = 256 / MV;
+  constexpr int A_PASSES = BK / A_KRPP;
   constexpr int A_ELEMS = BK * LDA, B_ELEMS = BK * LDB;
   __shared__ __attribute__((aligned(16))) unsigned short smem[2 * (A_ELEMS + B_ELEMS)];
 

@@ -781,12 +781,27 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
       b_reg[i] = buf_ld16(rs_b, pred_off((unsigned)(((img * p.h + iy) * p.w + ix) * p.cin + b_c) * 4u, ok));
     }
   };
+  // Linear layers: the bias gradient is the column sum of dy, and this kernel streams dy anyway: the
+  // workgroups of the first column tile add up what they load (each K-step's rows exactly once, in order)
+  const bool do_bias = (p.db != nullptr) & (ntile == 0);
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
   auto store_tiles = [&](int buf) {
     float *As = smem + buf * (A_ELEMS + B_ELEMS);
     float *Bs = As + A_ELEMS;
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i)
       *reinterpret_cast<float4 *>(As + (a_k0 + i * A_KRPP) * LDA + a_mv * 4) = a_reg[i];
+    if (do_bias) {
+#pragma unroll
+      for (int i = 0; i < A_PASSES; ++i) {
+        if (a_k0 + i * A_KRPP < BK) {
+          bsum.x += a_reg[i].x;
+          bsum.y += a_reg[i].y;
+          bsum.z += a_reg[i].z;
+          bsum.w += a_reg[i].w;
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < B_PASSES; ++i) {
       if (INCR)
@@ -839,6 +854,31 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     __syncthreads();
   }
 
+  if (do_bias) {
+    // rows of the loader (a_k0) summed through LDS in a fixed order; the K loop ended with a barrier
+    float4 *sh = reinterpret_cast<float4 *>(smem);
+    sh[tid] = bsum;
+    __syncthreads();
+    if (a_k0 == 0 && a_cok) {
+      float4 t = sh[a_mv];
+      for (int k = 1; k < A_KRPP; ++k) {
+        const float4 v = sh[k * MV + a_mv];
+        t.x += v.x;
+        t.y += v.y;
+        t.z += v.z;
+        t.w += v.w;
+      }
+      float4 *dst = reinterpret_cast<float4 *>(p.db + (long long)split * p.cout + a_col);
+      if (p.accumulate) {
+        const float4 o = *dst;
+        t.x += o.x;
+        t.y += o.y;
+        t.z += o.z;
+        t.w += o.w;
+      }
+      *dst = t;
+    }
+  }
   float *out = p.out + (long long)split * p.cout * p.ncols;
   // fast path (wave-uniform): the wave's block lies inside dw - no predicates, 32-bit offsets
   if (mtile * BM + wm * WTM + WTM <= p.cout && ntile * BN + wn * WTN + WTN <= p.ncols &&
@@ -1412,8 +1452,8 @@ int mvg_conv_wgrad_splits(const mvg_conv_desc *d) {
   return (int)want;
 }
 
-int mvg_conv_wgrad(const mvg_conv_desc *d, const float *x, const float *dy, float *dw, float *workspace, int splits,
-                   int accumulate, void *stream) {
+static int wgrad_impl(const mvg_conv_desc *d, const float *x, const float *dy, float *dw, float *db, float *workspace,
+                      int splits, int accumulate, void *stream) {
   if (validate(d)) return 2;
   MVG_REQUIRE(d->cout % 4 == 0, "wgrad: cout %% 4 != 0 (%d)", d->cout);
   MVG_REQUIRE(splits >= 1, "wgrad: splits < 1");
@@ -1448,6 +1488,8 @@ int mvg_conv_wgrad(const mvg_conv_desc *d, const float *x, const float *dy, floa
   p.ntiles = ceil_div(p.ncols, t.bn);
   p.out = splits == 1 ? dw : workspace;
   p.accumulate = (splits == 1) ? accumulate : 0;
+  float *db_slab = workspace ? workspace + (size_t)splits * d->cout * p.ncols : nullptr;     // after the dw slabs
+  p.db = db ? (splits == 1 ? db : db_slab) : nullptr;
   hipStream_t st = (hipStream_t)stream;
   const bool lin = d->r == 1 && d->s == 1 && d->h == 1 && d->w == 1;
   {
@@ -1488,8 +1530,27 @@ int mvg_conv_wgrad(const mvg_conv_desc *d, const float *x, const float *dy, floa
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, workspace, dw, n / 4, splits, accumulate,
                        lanes);
     if (check_launch("wgrad_reduce")) return 1;
+    if (db) {
+      const long long nb = d->cout;
+      const long long bblocks = (nb / 4 + 256 / lanes - 1) / (256 / lanes);
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)bblocks), dim3(256), 0, st, db_slab, db, nb / 4, splits, accumulate,
+                         lanes);
+      if (check_launch("wgrad_reduce(bias)")) return 1;
+    }
   }
   return 0;
+}
+
+int mvg_conv_wgrad(const mvg_conv_desc *d, const float *x, const float *dy, float *dw, float *workspace, int splits,
+                   int accumulate, void *stream) {
+  return wgrad_impl(d, x, dy, dw, nullptr, workspace, splits, accumulate, stream);
+}
+
+int mvg_linear_wgrad(const float *x, const float *dy, float *dw, float *db, int rows, int fin, int fout, float *workspace,
+                     int splits, int accumulate, void *stream) {
+  const mvg_conv_desc d = linear_desc(rows, fin, fout);
+  MVG_REQUIRE(dw != nullptr, "linear_wgrad: dw is required");
+  return wgrad_impl(&d, x, dy, dw, db, workspace, splits, accumulate, stream);
 }
 
 }  // extern "C"

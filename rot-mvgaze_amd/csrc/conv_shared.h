@@ -145,6 +145,8 @@ struct WgradParams {
   long long x_bytes;
   int mtiles, ntiles;
   int accumulate;   // only meaningful when splits == 1
+  float *db;        // Linear layers: column sums of dy (the bias gradient) ride along, [splits][cout] slabs like `out`
+                    // (or the gradient itself when splits == 1); null = not wanted
   FastDiv ohw_div, wo_div, cin_div, s_div;
 };
 

@@ -262,22 +262,6 @@ __global__ __launch_bounds__(256) void scale_by_kernel(const float *__restrict__
 }
 
 // out[c] (+)= sum_rows x[rows][c] : block = 64 channels x 4 row lanes
-__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x, float *__restrict__ out, long long rows,
-                                                     int c, int accumulate) {
-  __shared__ float sh[4][64];
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int ch = blockIdx.x * 64 + cl;
-  float s = 0.f;
-  if (ch < c)
-    for (long long r = rl; r < rows; r += 4) s += x[r * c + ch];
-  sh[rl][cl] = s;
-  __syncthreads();
-  if (rl == 0 && ch < c) {
-    s = sh[0][cl] + sh[1][cl] + sh[2][cl] + sh[3][cl];
-    out[ch] = (accumulate ? out[ch] : 0.f) + s;
-  }
-}
-
 __global__ __launch_bounds__(256) void axpby_kernel(const float *__restrict__ x, float *__restrict__ y, float a, float b,
                                                     long long n) {
   const long long stride = (long long)gridDim.x * 256;
@@ -548,13 +532,6 @@ int mvg_scale_by(const float *x, const float *scale, float *out, int64_t n, void
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(scale_by_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, scale, out, (long long)n);
   return check_launch("scale_by");
-}
-
-int mvg_colsum(const float *x, float *out, int64_t rows, int c, int accumulate, void *stream) {
-  hipStream_t st = (hipStream_t)stream;
-  ProfScope ps(MVG_K_COLSUM, st, 0.0, 4.0 * (double)rows * c);
-  hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(c, 64)), dim3(256), 0, st, x, out, (long long)rows, c, accumulate);
-  return check_launch("colsum");
 }
 
 int mvg_axpby(const float *x, float *y, float a, float b, int64_t n, void *stream) {

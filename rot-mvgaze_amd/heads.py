@@ -144,8 +144,7 @@ class _Mlp:
                 def padded_grads(inp=inp, g=g, l=l, fin=fin, fout=fout, accs=accs):
                     dwp = torch.empty(fout, fin, dtype=torch.float32, device=dev)
                     dbp = torch.empty(fout, dtype=torch.float32, device=dev)
-                    ops.conv_wgrad(ConvDesc.linear(rows, fin, fout), inp, g, dwp, False)
-                    ops.colsum(g, dbp, rows, fout, False)
+                    ops.linear_wgrad(inp, g, dwp, dbp, rows, fin, fout, False)
                     for p, src, a in ((self.w[l], dwp[: self.fout[l], : self.fin[l]], accs[0]),
                                       (self.b[l], dbp[: self.fout[l]], accs[1])):
                         if a:
@@ -163,9 +162,12 @@ class _Mlp:
             else:
                 aw, ab = wr.acc(self.w[l]), wr.acc(self.b[l])
 
-                def grads(inp=inp, g=g, l=l, fin=fin, fout=fout, aw=aw, ab=ab):
-                    ops.conv_wgrad(ConvDesc.linear(rows, fin, fout), inp, g, sink.view(self.w[l]), aw)
-                    ops.colsum(g, sink.view(self.b[l]), rows, fout, ab)
+                assert aw == ab
+
+                def grads(inp=inp, g=g, l=l, fin=fin, fout=fout, aw=aw):
+                    # weight AND bias gradient in one launch: the bias gradient (column sums of g) rides on the
+                    # kernel that streams g for the weight gradient
+                    ops.linear_wgrad(inp, g, sink.view(self.w[l]), sink.view(self.b[l]), rows, fin, fout, aw)
                 wr.off_path(grads, inp, g)
             # ---- input gradient
             if l == 0:

@@ -79,6 +79,17 @@ def conv_wgrad(d: ConvDesc, x: Tensor, dy: Tensor, dw: Tensor, accumulate: bool 
     check(_fn("mvg_conv_wgrad", x)(C.byref(d), _p(x), _p(dy), _p(dw), _p(ws), splits, int(accumulate), _s()), "conv_wgrad")
 
 
+def linear_wgrad(x: Tensor, dy: Tensor, dw: Tensor, db: Optional[Tensor], rows: int, fin: int, fout: int, accumulate: bool = False):
+    """dw (+)= dy^T x and db (+)= column sums of dy in one launch (+ the fixed-order slab reduce)."""
+    d = ConvDesc.linear(rows, fin, fout)
+    splits = lib().mvg_conv_wgrad_splits(C.byref(d))
+    if splits < 1:
+        check(1, "conv_wgrad_splits")
+    ws = torch.empty(splits * (fout * fin + fout), dtype=torch.float32, device=x.device) if splits > 1 else None
+    check(lib().mvg_linear_wgrad(_p(x), _p(dy), _p(dw), _p(db), rows, fin, fout, _p(ws), splits, int(accumulate), _s()),
+          "linear_wgrad")
+
+
 def _linear_ws(x: Tensor, rows: int, fin: int, fout: int):
     n = lib().mvg_linear_workspace_floats(rows, fin, fout)
     return torch.empty(n, dtype=torch.float32, device=x.device), n
@@ -110,18 +121,22 @@ def bn_eval_affine(groups, c, gamma, beta, running_mean, running_var, eps, scale
                                    _p(shift), _s()), "bn_eval_affine")
 
 
-def bn_apply(y, scale, shift, residual, relu, out, groups, rows_per_group, c):
-    check(_fn("mvg_bn_apply", y)(_p(y), _p(scale), _p(shift), _p(residual), int(relu), _p(out), groups, rows_per_group, c,
-                             _s()), "bn_apply")
+def bn_apply(y, scale, shift, residual, relu, out, groups, rows_per_group, c, residual_affine=None):
+    """residual_affine = (scale, shift) of the downsample branch's BatchNorm when `residual` is its RAW conv output."""
+    rs, rh = residual_affine if residual_affine is not None else (None, None)
+    check(_fn("mvg_bn_apply", y)(_p(y), _p(scale), _p(shift), _p(residual), _p(rs), _p(rh), int(relu), _p(out), groups,
+                                 rows_per_group, c, _s()), "bn_apply")
 
 
-def bn_bwd_reduce(g, act, y, mean, invstd, groups, rows_per_group, c, s1, s2, dgamma, dbeta, accumulate, relu_affine=None):
-    """relu_affine = (scale, shift) of the forward bn_apply: ReLU mask rebuilt from y (units without residual)."""
+def bn_bwd_reduce(g, act, y, mean, invstd, groups, rows_per_group, c, s1, s2, dgamma, dbeta, accumulate, relu_affine=None,
+                  dz_out=None):
+    """relu_affine = (scale, shift) of the forward bn_apply: ReLU mask rebuilt from y (units without residual).
+    dz_out (may be g itself): the masked gradient is written out for the apply pass and the residual branch."""
     n = lib().mvg_bn_bwd_workspace_floats(groups, rows_per_group, c)
     ws = torch.empty(n, dtype=torch.float32, device=g.device)
     rs, rh = relu_affine if relu_affine is not None else (None, None)
     check(_fn("mvg_bn_bwd_reduce", g)(_p(g), _p(act), _p(y), _p(mean), _p(invstd), _p(rs), _p(rh), groups, rows_per_group, c,
-                                  _p(s1), _p(s2), _p(dgamma), _p(dbeta), int(accumulate), _p(ws), _s()), "bn_bwd_reduce")
+                                  _p(s1), _p(s2), _p(dgamma), _p(dbeta), int(accumulate), _p(ws), _p(dz_out), _s()), "bn_bwd_reduce")
 
 
 def bn_bwd_apply(g, act, y, mean, invstd, gamma, s1, s2, groups, rows_per_group, c, dy, dz_out=None, relu_affine=None):
@@ -252,10 +267,6 @@ def paircat_bwd(dx, rel, scales, src_of, da_dir, dfeat, batch, dirs, nvec):
 def segment_sum(x, row_stride, width, seg_of, out, batch, dirs, segments, accumulate):
     check(lib().mvg_segment_sum(_p(x), row_stride, width, _p(seg_of), _p(out), batch, dirs, segments, int(accumulate),
                                 _s()), "segment_sum")
-
-
-def colsum(x, out, rows, c, accumulate=False):
-    check(lib().mvg_colsum(_p(x), _p(out), rows, c, int(accumulate), _s()), "colsum")
 
 
 def axpby(x, y, a=1.0, b=1.0):

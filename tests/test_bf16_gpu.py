@@ -247,7 +247,7 @@ def _check_units_teacher_forced(m, img_feat):
     units = tape["units"]
     P = dict(m.named_parameters())
     q = lambda t: t.to(torch.bfloat16).float()
-    identity_of, final_of = {}, set()
+    identity_of, affine_of = {}, {}
     for idx, ds_idx in tape["blocks"]:
         identity_of[idx[-1]] = ("ds", ds_idx) if ds_idx is not None else ("x", idx[0])
     n_checked = 0
@@ -269,16 +269,20 @@ def _check_units_teacher_forced(m, img_feat):
         sc = scale.reshape(G, 1, c.cout, 1, 1).expand(G, N, c.cout, 1, 1).reshape(G * N, c.cout, 1, 1)
         sh = shift.reshape(G, 1, c.cout, 1, 1).expand(G, N, c.cout, 1, 1).reshape(G * N, c.cout, 1, 1)
         act = y_got * sc + sh
+        affine_of[ui] = (y_got, sc, sh)
         if ui in identity_of:
             kind, j = identity_of[ui]
-            src = units[j].out if kind == "ds" else units[j].x_in
-            act = act + src.float().cpu().reshape(G * N, d.ho, d.wo, c.cout).permute(0, 3, 1, 2)
+            if kind == "ds":        # the downsample branch's raw conv output, normalised on the fly (never stored)
+                yd, scd, shd = affine_of[j]
+                act = act + (yd * scd + shd)
+            else:
+                act = act + units[j].x_in.float().cpu().reshape(G * N, d.ho, d.wo, c.cout).permute(0, 3, 1, 2)
         if u.relu:
             act = F.relu(act)
         if u.out is not None:
             got = u.out.float().cpu().reshape(G * N, d.ho, d.wo, c.cout).permute(0, 3, 1, 2)
             close(got, q(act), OUT_RTOL, f"{c.name}: activation")
-        else:                                                                      # stem: BN + ReLU + max pool fused
+        elif ui == 0:                                                              # stem: BN + ReLU + max pool fused
             nxt = units[1].x_in.float().cpu()
             got = nxt.reshape(G * N, nxt.shape[2], nxt.shape[3], c.cout).permute(0, 3, 1, 2)
             close(got, q(F.max_pool2d(act, 3, 2, 1)), OUT_RTOL, "stem: pooled activation")
@@ -307,7 +311,7 @@ def _check_blocks_backward_teacher_forced(m, tape, dfeat):
     def nchw(t):            # [N,H,W,C] -> [N,C,H,W] fp64
         return t.double().permute(0, 3, 1, 2)
 
-    def unit(x, c, wts, relu, identity=None):
+    def unit(x, c, wts, relu, identity=None, stored=True):
         w = wts.setdefault(c.name + ".weight", q(P[c.name + ".weight"].detach().cpu().double().contiguous()).requires_grad_(True))
         ga = wts.setdefault(c.bn + ".weight", P[c.bn + ".weight"].detach().cpu().double().requires_grad_(True))
         be = wts.setdefault(c.bn + ".bias", P[c.bn + ".bias"].detach().cpu().double().requires_grad_(True))
@@ -317,6 +321,8 @@ def _check_blocks_backward_teacher_forced(m, tape, dfeat):
         o = q(y) * scale[None, :, None, None] + (be - mean * scale)[None, :, None, None]
         if identity is not None:
             o = o + identity
+        if not stored:
+            return o                                   # the downsample branch: normalised inside its consumer, never rounded
         return q(F.relu(o)) if relu else q(o)
 
     report = []
@@ -338,7 +344,7 @@ def _check_blocks_backward_teacher_forced(m, tape, dfeat):
             o = x
             for c in blk.convs[:-1]:
                 o = unit(o, c, wts, True)
-            identity = unit(x, blk.downsample, wts, False) if blk.downsample is not None else x
+            identity = unit(x, blk.downsample, wts, False, None, False) if blk.downsample is not None else x
             o = unit(o, blk.convs[-1], wts, True, identity)
             o.backward(nchw(g_out[g]))
             dxs.append(x.grad.permute(0, 2, 3, 1))

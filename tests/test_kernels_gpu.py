@@ -125,7 +125,7 @@ def test_conv_fprop_dgrad_wgrad(case):
 
 
 @pytest.mark.parametrize("rows,fin,fout,relu", [(128, 2048, 2048, True), (6, 512, 1536, False), (70, 3584, 512, True),
-                                                (33, 1536, 1536, False)])
+                                                (33, 1536, 1536, False), (1536, 3584, 3584, True), (3000, 2048, 1536, False)])
 def test_linear_via_conv(rows, fin, fout, relu):
     from rot_mvgaze_amd import ops
     from rot_mvgaze_amd._lib import ConvDesc
@@ -150,9 +150,14 @@ def test_linear_via_conv(rows, fin, fout, relu):
     dw = torch.empty(fout, fin, device=dev())
     ops.conv_wgrad(d, xd, g, dw)
     close(dw, wr.grad, what="linear wgrad")
-    db = torch.empty(fout, device=dev())
-    ops.colsum(g, db, rows, fout)
-    close(db, br.grad, what="bias grad")
+    # weight and bias gradient in one launch (the bias gradient rides on the kernel that streams g)
+    dw2, db = torch.full((fout, fin), float("nan"), device=dev()), torch.full((fout,), float("nan"), device=dev())
+    ops.linear_wgrad(xd, g, dw2, db, rows, fin, fout, False)
+    close(dw2, wr.grad, what="linear_wgrad dw")
+    close(db, br.grad, what="linear_wgrad db")
+    ops.linear_wgrad(xd, g, dw2, db, rows, fin, fout, True)
+    close(dw2, 2 * wr.grad, what="linear_wgrad dw accumulate")
+    close(db, 2 * br.grad, what="linear_wgrad db accumulate")
     # split-K entry points (what the fusion block calls), incl. the fused mask / addend epilogue
     y2 = torch.empty(rows, fout, device=dev())
     ops.linear_fprop(xd, wd, bd, relu, y2, rows, fin, fout)
@@ -250,6 +255,28 @@ def test_bn_apply_and_backward(G, N, H, W, C, relu, res):
         ops.bn_bwd_apply(g3, act, yd, mean, invstd, gd, s1, s2, G, rows, C, dy3, g3)
         close(dy3, yr.grad, 1e-4, "bn dy (dz in place)")
         close(g3, rr.grad, what="residual grad (in place)")
+    if res and relu:
+        # what the backbone runs for a block's last unit: the reduce pass writes the masked gradient over g,
+        # the apply pass reads (dz, y) only; same sums and gradients bit for bit
+        g4 = god.clone()
+        s1c, s2c, dgc, dbc = (torch.empty_like(t) for t in (s1, s2, dgamma, dbeta))
+        ops.bn_bwd_reduce(g4, act, yd, mean, invstd, G, rows, C, s1c, s2c, dgc, dbc, False, None, dz_out=g4)
+        assert torch.equal(s1c, s1) and torch.equal(s2c, s2) and torch.equal(dgc, dgamma) and torch.equal(dbc, dbeta)
+        assert torch.equal(g4, dz)
+        dy4 = torch.empty_like(dy)
+        ops.bn_bwd_apply(g4, None, yd, mean, invstd, gd, s1c, s2c, G, rows, C, dy4, None, None)
+        assert torch.equal(dy4, dy)
+    if res:
+        # residual given as the RAW output of the downsample conv + its BatchNorm's (scale, shift)
+        rs = (rnd((G, C), 11, "rs") * 0.2 + 1).to(dev())
+        rh = (rnd((G, C), 12, "rh") * 0.2).to(dev())
+        raw = r.to(dev())
+        normalised = torch.empty_like(raw)
+        ops.bn_apply(raw, rs, rh, None, False, normalised, G, rows, C)
+        want, got = torch.empty_like(out), torch.empty_like(out)
+        ops.bn_apply(yd, scale, shift, normalised, relu, want, G, rows, C)
+        ops.bn_apply(yd, scale, shift, raw, relu, got, G, rows, C, (rs, rh))
+        assert torch.equal(got, want), "downsample BatchNorm folded into the consumer's bn_apply"
 
 
 @pytest.mark.parametrize("G,N,H,W", [(2, 3, 14, 18), (1, 2, 15, 13)])
