@@ -106,6 +106,20 @@ int mvg_conv_stats_partials(const mvg_conv_desc *d, int32_t *out_rows_per_partia
 int mvg_conv_dgrad(const mvg_conv_desc *d, const float *dy, const float *wgt, float *dx,
                    const float *mask, const float *addend, void *stream);
 
+/* mvg_conv_dgrad fused with mvg_bn_bwd_reduce of the conv+BatchNorm unit whose OUTPUT gradient this launch
+ * produces (the unit feeding the conv: resnet.py:80-96,128-148 under autograd): the epilogue masks dx by that
+ * unit's ReLU (bn_act > 0, or fma(bn_y, relu_scale, relu_shift) > 0, or none), stores the masked gradient and
+ * adds up s1 = sum(dx), s2 = sum(dx * xhat) per wave; a second, tiny launch merges the partials in a fixed
+ * order (fp64) into s1, s2 [groups][cin] and dgamma / dbeta [cin].  The separate reduce pass over (g, act, y)
+ * disappears; mvg_bn_bwd_apply then runs on (dx, bn_y) without a mask.  Stride-1 convs only:
+ * mvg_conv_dgrad_bn_partials() returns P (partials: [groups][P][2][cin] floats) or 0 when not fusable. */
+int mvg_conv_dgrad_bn_partials(const mvg_conv_desc *d);
+int mvg_conv_dgrad_bnreduce(const mvg_conv_desc *d, const float *dy, const float *wgt, float *dx,
+                            const float *addend, const float *bn_y, const float *bn_act, const float *bn_mean,
+                            const float *bn_invstd, const float *relu_scale, const float *relu_shift,
+                            float *partials, float *s1, float *s2, float *dgamma, float *dbeta, int accumulate,
+                            void *stream);
+
 /* dw[cout][r][s][cin] (+)= sum over all groups/images/pixels of dy (x) x.  Split over the pixel
  * axis into `splits` slabs in `workspace` (splits * cout*r*s*cin floats, ignored when
  * splits == 1) that a second kernel sums in a fixed order (bitwise reproducible).

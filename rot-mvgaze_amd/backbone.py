@@ -44,7 +44,10 @@ class GradSink:
 class _Unit:
     """Saved state of one conv + BN (+ReLU) (+residual) for the backward pass."""
     __slots__ = ("spec", "desc", "x_in", "y", "out", "mean", "invstd", "relu", "rows", "w", "trained", "pool",
-                 "relu_affine")
+                 "relu_affine", "fused_s12")
+
+    def __init__(self):
+        self.fused_s12 = None     # BatchNorm-backward sums delivered by the backward-data launch that produced this unit's gradient
 
 
 class Backbone:
@@ -65,6 +68,9 @@ class Backbone:
         # storage type of activations / activation gradients / conv operands: fp32 = the parity path (1e-4 vs
         # the reference); bf16 = BASELINE config C5's "bf16 MFMA path" (fp32 master weights, statistics, gradients)
         self.act_dtype = torch.float32
+        # BatchNorm-backward reduce pass fused into the epilogue of the backward-data launch that produces the
+        # unit's output gradient (fp32 path, stride-1 producers): MVG_BN_FUSE=0 runs the separate pass instead
+        self.fuse_bn_reduce = os.environ.get("MVG_BN_FUSE", "1") != "0"
 
     @property
     def bf16(self) -> bool:
@@ -244,6 +250,12 @@ class Backbone:
         c = u.spec
         G = u.y.shape[0]
         gp, bp = self.p[c.bn + ".weight"], self.p[c.bn + ".bias"]
+        if u.fused_s12 is not None:
+            # g arrived masked by this unit's ReLU and its sums (incl. dgamma / dbeta) came with it
+            s12, u.fused_s12 = u.fused_s12, None
+            dy = torch.empty_like(g) if need_dz else g
+            ops.bn_bwd_apply(g, None, u.y, u.mean, u.invstd, gp.detach(), s12[0], s12[1], G, u.rows, c.cout, dy, None, None)
+            return dy, (g if need_dz else None)
         s12 = torch.empty(2, G, c.cout, dtype=torch.float32, device=g.device)
         ra = u.relu_affine
         act = u.out if (u.relu and ra is None) else None
@@ -277,7 +289,8 @@ class Backbone:
             self.grad_streams[:] = [self._wg_stream]
         return self._wg_stream
 
-    def _conv_bwd(self, u: _Unit, dy: Tensor, need_dx: bool, addend: Optional[Tensor], sink: GradSink):
+    def _conv_bwd(self, u: _Unit, dy: Tensor, need_dx: bool, addend: Optional[Tensor], sink: GradSink,
+                  fuse_for: Optional[_Unit] = None):
         if self.overlap_wgrad and dy.is_cuda:
             side = self._side(dy.device)
             side.wait_stream(torch.cuda.current_stream())         # dy (and everything before it) is ready
@@ -290,7 +303,7 @@ class Backbone:
         dx = None
         if need_dx:
             dx = torch.empty_like(u.x_in)
-            self._dgrad(u, dy, dx, addend)
+            self._dgrad(u, dy, dx, addend, fuse_for, sink)
         return dx
 
     def _wgrad(self, u: _Unit, dy: Tensor, sink: GradSink):
@@ -307,8 +320,22 @@ class Backbone:
         else:
             ops.conv_wgrad(u.desc, u.x_in, dy, sink.view(wp), sink.accumulate(wp))
 
-    @staticmethod
-    def _dgrad(u: _Unit, dy: Tensor, dx: Tensor, addend: Optional[Tensor]):
+    def _dgrad(self, u: _Unit, dy: Tensor, dx: Tensor, addend: Optional[Tensor], fuse_for: Optional[_Unit] = None,
+               sink: Optional[GradSink] = None):
+        """dx = backward-data of unit u (+ addend).  fuse_for = the unit whose OUTPUT gradient dx is, when dx
+        is final with this launch: its ReLU mask is applied and its BatchNorm-backward sums (s1, s2, dgamma,
+        dbeta) are produced by the same launch (mvg_conv_dgrad_bnreduce) instead of a pass over (g, act, y)."""
+        if fuse_for is not None and self.fuse_bn_reduce and not self.bf16 and u.desc.stride == 1:
+            U, c = fuse_for, fuse_for.spec
+            gp, bp = self.p[c.bn + ".weight"], self.p[c.bn + ".bias"]
+            acc = sink.accumulate(gp)
+            assert acc == sink.accumulate(bp)
+            s12 = torch.empty(2, dx.shape[0], c.cout, dtype=torch.float32, device=dx.device)
+            act = U.out if (U.relu and U.relu_affine is None) else None
+            ops.conv_dgrad_bnreduce(u.desc, dy, u.w, dx, addend, U.y, act, U.mean, U.invstd, U.relu_affine, s12[0], s12[1],
+                                    sink.view(gp), sink.view(bp), acc)
+            U.fused_s12 = s12
+            return
         ops.conv_dgrad(u.desc, dy, u.w, dx, None, addend)
 
     def backward(self, tape: dict, dfeat: Tensor, sink: GradSink, need_dimg: bool = False):
@@ -325,11 +352,16 @@ class Backbone:
         g = torch.empty(V, B, Hc, Wc, self.fc_dim, dtype=self.act_dtype, device=dfeat.device)
         ops.avgpool_bwd(dfeat.contiguous(), g, V * B, Hc * Wc, self.fc_dim)
         P = self.p
-        for (idx, ds_idx) in reversed(tape["blocks"]):
+        blocks = tape["blocks"]
+        for bi in range(len(blocks) - 1, -1, -1):
+            idx, ds_idx = blocks[bi]
             last = units[idx[-1]]
+            # the unit that receives this block's input gradient: the previous block's last unit (the stem's
+            # fused pool backward takes it for the first block)
+            prev_last = units[blocks[bi - 1][0][-1]] if bi > 0 else None
             done: List[torch.nn.Parameter] = []
             dy, dz = self._bn_bwd(last, g, True, sink)
-            d = self._conv_bwd(last, dy, True, None, sink)
+            d = self._conv_bwd(last, dy, True, None, sink, fuse_for=units[idx[-2]])
             done += [P[last.spec.name + ".weight"], P[last.spec.bn + ".weight"], P[last.spec.bn + ".bias"]]
             last.y = last.out = None
             del dy
@@ -337,16 +369,18 @@ class Backbone:
                 u = units[idx[k]]
                 dy, _ = self._bn_bwd(u, d, False, sink)
                 if k == 0:
-                    d = self._conv_bwd(u, dy, True, dz if ds_idx is None else None, sink)
+                    # with a downsample branch the block-input gradient is final only after that branch's launch
+                    d = self._conv_bwd(u, dy, True, dz if ds_idx is None else None, sink,
+                                       fuse_for=prev_last if ds_idx is None else None)
                 else:
-                    d = self._conv_bwd(u, dy, True, None, sink)
+                    d = self._conv_bwd(u, dy, True, None, sink, fuse_for=units[idx[k - 1]])
                 done += [P[u.spec.name + ".weight"], P[u.spec.bn + ".weight"], P[u.spec.bn + ".bias"]]
                 u.y = u.out = None
             if ds_idx is not None:
                 ud = units[ds_idx]
                 dyd, _ = self._bn_bwd(ud, dz, False, sink)
                 self._conv_bwd(ud, dyd, False, None, sink)                # wgrad only
-                self._dgrad(ud, dyd, d, d)                                # d += dgrad (aliasing addend)
+                self._dgrad(ud, dyd, d, d, prev_last, sink)               # d += dgrad (aliasing addend): now final
                 done += [P[ud.spec.name + ".weight"], P[ud.spec.bn + ".weight"], P[ud.spec.bn + ".bias"]]
                 ud.y = ud.out = None
             sink.publish(done)

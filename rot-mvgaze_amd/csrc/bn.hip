@@ -602,6 +602,13 @@ static int grid_for(long long n4) {
   return (int)b;
 }
 
+int bn_bwd_finalize_launch(const float *partial, int groups, int chunks, int c, float *s1, float *s2, float *dgamma,
+                           float *dbeta, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(c, 16)), dim3(1024), 0, st, partial, groups, chunks, c, s1, s2,
+                     dgamma, dbeta, accumulate);
+  return check_launch("bn_bwd_finalize");
+}
+
 }  // namespace mvg
 
 using namespace mvg;

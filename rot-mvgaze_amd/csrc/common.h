@@ -22,6 +22,11 @@ float *stream_scratch(hipStream_t st, size_t floats);
 // device CUs minus mvg_set_reserved_cus(): what stream-K grids, wgrad splits and split-K plan for
 int compute_cus();
 
+// bn.hip: merge [groups][chunks][2][c] partial sums (s1, s2) of a BatchNorm backward in fp64, in a fixed order;
+// dgamma / dbeta (+)= the sums over the groups.  Host launcher shared with the fused backward-data path.
+int bn_bwd_finalize_launch(const float *partial, int groups, int chunks, int c, float *s1, float *s2, float *dgamma,
+                           float *dbeta, int accumulate, hipStream_t st);
+
 struct ProfScope {
   int fam;
   hipStream_t s;

@@ -123,6 +123,13 @@ struct IgemmParams {
   int ncls;
   IgemmClass cls[4];         // per-class view (one class unless this is a stride-2 dgrad)
   int b_row_len;             // bf16 kernels: elements per row of the (k-contiguous) weight operand
+  // Backward-data fused with the BatchNorm-backward REDUCE pass of the unit whose output gradient this
+  // launch produces (fp32 kernels, stride-1 launches): the epilogue masks the gradient by that unit's ReLU
+  // (bn_act > 0, or fma(bn_y, bn_rscale, bn_rshift) > 0, or no mask), stores the masked gradient and adds up,
+  // per wave and column, s1 = sum(dz) and s2 = sum(dz * xhat), xhat = (bn_y - bn_mean) * bn_invstd, into
+  // bn_part [groups][P][2][ncols] (P = row partials per group, like the forward statistics).
+  const float *bn_y, *bn_act, *bn_mean, *bn_invstd, *bn_rscale, *bn_rshift;
+  float *bn_part;
 };
 
 // bijective XCD-aware remap of a 1-D grid (cdna_hip_programming.md §5 "XCD swizzle must be

@@ -61,6 +61,26 @@ def conv_dgrad(d: ConvDesc, dy: Tensor, w: Tensor, dx: Tensor, mask: Optional[Te
     check(_fn("mvg_conv_dgrad", dy)(C.byref(d), _p(dy), _p(w), _p(dx), _p(mask), _p(addend), _s()), "conv_dgrad")
 
 
+def conv_dgrad_bn_partials(d: ConvDesc) -> int:
+    """Row partials per group of conv_dgrad_bnreduce for this shape; 0 = not fusable (stride 2)."""
+    n = lib().mvg_conv_dgrad_bn_partials(C.byref(d))
+    if n < 0:
+        check(1, "conv_dgrad_bn_partials")
+    return n
+
+
+def conv_dgrad_bnreduce(d: ConvDesc, dy, w, dx, addend, bn_y, bn_act, bn_mean, bn_invstd, relu_affine, s1, s2, dgamma, dbeta,
+                        accumulate: bool):
+    """dx = dgrad(dy) (+ addend), masked by the ReLU of the unit whose output gradient dx is, and that unit's
+    BatchNorm-backward sums (s1, s2, dgamma, dbeta) from the same launch."""
+    P = conv_dgrad_bn_partials(d)
+    part = torch.empty(d.groups * P * 2 * d.cin, dtype=torch.float32, device=dy.device)
+    rs, rh = relu_affine if relu_affine is not None else (None, None)
+    check(lib().mvg_conv_dgrad_bnreduce(C.byref(d), _p(dy), _p(w), _p(dx), _p(addend), _p(bn_y), _p(bn_act), _p(bn_mean),
+                                        _p(bn_invstd), _p(rs), _p(rh), _p(part), _p(s1), _p(s2), _p(dgamma), _p(dbeta),
+                                        int(accumulate), _s()), "conv_dgrad_bnreduce")
+
+
 def cast_weights_bf16(d: ConvDesc, w: Tensor, cin_src: int, need_transposed: bool = True):
     """fp32 KRSC weights -> (bf16 KRSC [cout][r][s][d.cin], bf16 CRSK [d.cin][r][s][cout] or None)."""
     wk = torch.empty(d.cout, d.r, d.s, d.cin, dtype=torch.bfloat16, device=w.device)
