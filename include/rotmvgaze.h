@@ -106,15 +106,6 @@ int mvg_conv_stats_partials(const mvg_conv_desc *d, int32_t *out_rows_per_partia
 int mvg_conv_dgrad(const mvg_conv_desc *d, const float *dy, const float *wgt, float *dx,
                    const float *mask, const float *addend, void *stream);
 
-/* Backward-data with the weights also given pre-transposed, wgt_crsk = [cin][r][s][cout]
- * (mvg_transpose_weights, once per weight per step): the weight operand is then contiguous along the GEMM's
- * K like the forward's and takes the same path through LDS (one 16-byte read per four MFMA steps instead
- * of four scalar reads).  Same result as mvg_conv_dgrad bit for bit (same products, same order); shapes the
- * uniform-tap loader does not cover fall back to wgt. */
-int mvg_transpose_weights(const mvg_conv_desc *d, const float *w_krsc, float *w_crsk, void *stream);
-int mvg_conv_dgrad_t(const mvg_conv_desc *d, const float *dy, const float *wgt, const float *wgt_crsk, float *dx,
-                     const float *addend, void *stream);
-
 /* mvg_conv_dgrad fused with mvg_bn_bwd_reduce of the conv+BatchNorm unit whose OUTPUT gradient this launch
  * produces (the unit feeding the conv: resnet.py:80-96,128-148 under autograd): the epilogue masks dx by that
  * unit's ReLU (bn_act > 0, or fma(bn_y, relu_scale, relu_shift) > 0, or none), stores the masked gradient and

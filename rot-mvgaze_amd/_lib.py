@@ -55,8 +55,6 @@ SIGNATURES = {
     "mvg_conv_fprop_affine": (_I, [_D, _P, _P, _P, _P, _P, _P, _I, _P]),
     "mvg_conv_stats_partials": (_I, [_D, C.POINTER(C.c_int32)]),
     "mvg_conv_dgrad": (_I, [_D, _P, _P, _P, _P, _P, _P]),
-    "mvg_transpose_weights": (_I, [_D, _P, _P, _P]),
-    "mvg_conv_dgrad_t": (_I, [_D, _P, _P, _P, _P, _P, _P]),
     "mvg_conv_dgrad_bn_partials": (_I, [_D]),
     "mvg_conv_dgrad_bnreduce": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "mvg_conv_wgrad": (_I, [_D, _P, _P, _P, _P, _I, _I, _P]),

@@ -44,11 +44,10 @@ class GradSink:
 class _Unit:
     """Saved state of one conv + BN (+ReLU) (+residual) for the backward pass."""
     __slots__ = ("spec", "desc", "x_in", "y", "out", "mean", "invstd", "relu", "rows", "w", "trained", "pool",
-                 "relu_affine", "fused_s12", "w_t")
+                 "relu_affine", "fused_s12")
 
     def __init__(self):
         self.fused_s12 = None     # BatchNorm-backward sums delivered by the backward-data launch that produced this unit's gradient
-        self.w_t = None           # fp32 path: the weights transposed to CRSK for backward-data (k-contiguous B operand)
 
 
 class Backbone:
@@ -70,13 +69,8 @@ class Backbone:
         # the reference); bf16 = BASELINE config C5's "bf16 MFMA path" (fp32 master weights, statistics, gradients)
         self.act_dtype = torch.float32
         # BatchNorm-backward reduce pass fused into the epilogue of the backward-data launch that produces the
-        # unit's output gradient (fp32 path, stride-1 producers): MVG_BN_FUSE=1 switches it on.
-        # Default OFF: measured at C3 the fused launches cost more than the pass they replace (backward-data
-        # 41.7 -> 50.6 ms, reduce pass 13.4 -> 7.2 ms: the stream-K workgroups reach their epilogues together,
-        # so the extra dword loads of y / act are not hidden under other workgroups' MFMAs)
-        self.fuse_bn_reduce = os.environ.get("MVG_BN_FUSE", "0") == "1"
-        # backward-data reads pre-transposed weights (one small transpose per conv per step): MVG_DGRAD_T=0 = off
-        self.dgrad_transposed = os.environ.get("MVG_DGRAD_T", "1") != "0"
+        # unit's output gradient (fp32 path, stride-1 producers): MVG_BN_FUSE=0 runs the separate pass instead
+        self.fuse_bn_reduce = os.environ.get("MVG_BN_FUSE", "1") != "0"
 
     @property
     def bf16(self) -> bool:
@@ -151,8 +145,6 @@ class Backbone:
                     c, d, x, y, None, mean, invstd, False, rows, (w_t if bf else w)
                 u.trained = training
                 u.relu_affine = None
-                if self.dgrad_transposed and not bf and training:
-                    u.w_t = ops.transpose_weights(d, w)
                 tape.append(u)
             return y, (scale, shift)
         if pool:
@@ -173,8 +165,6 @@ class Backbone:
             u.relu_affine = (scale, shift) if (relu and residual is None and not pool) else None
             if pool:
                 u.pool = (argmax, scale, shift, d.ho, d.wo, hp, wp_)
-            if self.dgrad_transposed and not bf and training and c.cin != 3:
-                u.w_t = ops.transpose_weights(d, w)
             tape.append(u)
         return (out, argmax) if pool else out
 
@@ -345,9 +335,6 @@ class Backbone:
             ops.conv_dgrad_bnreduce(u.desc, dy, u.w, dx, addend, U.y, act, U.mean, U.invstd, U.relu_affine, s12[0], s12[1],
                                     sink.view(gp), sink.view(bp), acc)
             U.fused_s12 = s12
-            return
-        if u.w_t is not None:
-            ops.conv_dgrad_t(u.desc, dy, u.w, u.w_t, dx, addend)
             return
         ops.conv_dgrad(u.desc, dy, u.w, dx, None, addend)
 

@@ -293,13 +293,8 @@ constexpr int igemm_min_blocks(int bm, int bn, int bk, bool dgrad) { return (bm 
 // (scalar unit) and each row's bounds checks collapse to one bit of a per-segment tap mask.  PMC on the
 // 64-column kernel: VALU active 22 % + MFMA busy 71 % of the cycles - the vector ALU work of the loader
 // does not hide under the MFMAs, it displaces them.
-// BT (backward-data only, with FASTA): the weights come pre-transposed, [cin][r][s][cout], so the B operand is
-// k-contiguous like the forward's and takes the forward's path through LDS (16-byte rows, one ds_read_b128
-// per four MFMA steps) instead of the n-contiguous image whose fragments cost four scalar LDS reads each.
-template <int BM, int BN, int BK, int WGM, int WGN, bool DGRAD, bool FASTA = false, bool BT = false>
+template <int BM, int BN, int BK, int WGM, int WGN, bool DGRAD, bool FASTA = false>
 __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN, BK, DGRAD)) void igemm_kernel(IgemmParams p) {
-  static_assert(!BT || (DGRAD && FASTA), "BT: backward-data with the uniform-tap loader only");
-  constexpr bool BKC = !DGRAD || BT;         // B operand k-contiguous
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int KV = BK / 4;                 // float4 per k-contiguous row
@@ -313,7 +308,7 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN, BK, DGRAD)) void igem
   constexpr int KRPP = 256 / NV;             // k-rows per pass (dgrad B)
   constexpr int B_PASSES_D = (BK + KRPP - 1) / KRPP;
   constexpr int A_ELEMS = BM * LDA;
-  constexpr int B_ELEMS = BKC ? (B_PASSES_F * RPP) * LDA : (B_PASSES_D * KRPP) * LDB;
+  constexpr int B_ELEMS = DGRAD ? (B_PASSES_D * KRPP) * LDB : (B_PASSES_F * RPP) * LDA;
   static_assert(BM % RPP == 0, "tile");
   __shared__ __attribute__((aligned(16))) float smem[2 * (A_ELEMS + B_ELEMS)];
 
@@ -390,8 +385,8 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN, BK, DGRAD)) void igem
   }
   // FASTA: per row, byte offset of (image, y0, x0, channel 0) and the mask of in-bounds taps
   unsigned a_base[A_PASSES], a_vmask[A_PASSES];
-  unsigned b_base[BKC ? B_PASSES_F : B_PASSES_D];
-  bool b_ok[BKC ? B_PASSES_F : B_PASSES_D];
+  unsigned b_base[DGRAD ? B_PASSES_D : B_PASSES_F];
+  bool b_ok[DGRAD ? B_PASSES_D : B_PASSES_F];
   if (FASTA) {
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
@@ -405,13 +400,12 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN, BK, DGRAD)) void igem
       }
       a_vmask[i] = a_ok[i] ? m : 0u;
     }
-    if (BKC) {
-      const unsigned brow = BT ? (unsigned)p.b_row_len : (unsigned)c.ktotal;     // elements per weight row
+    if (!DGRAD) {
 #pragma unroll
       for (int i = 0; i < B_PASSES_F; ++i) {
         const int n = ntile * BN + a_r0 + i * RPP;
         b_ok[i] = n < p.ncols;
-        b_base[i] = ((unsigned)n * brow + (unsigned)a_kv * 4u) * 4u;
+        b_base[i] = ((unsigned)n * (unsigned)c.ktotal + (unsigned)a_kv * 4u) * 4u;
       }
     } else {
       const int ncol = ntile * BN + (tid % NV) * 4;
@@ -427,7 +421,7 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN, BK, DGRAD)) void igem
       make_rsrc(p.a + (long long)g * p.imgs_per_group * p.src_img_stride, p.a_group_bytes);
 
   float4 a_reg[A_PASSES];
-  float4 b_reg[BKC ? B_PASSES_F : B_PASSES_D];
+  float4 b_reg[DGRAD ? B_PASSES_D : B_PASSES_F];
 
   // Predicated loads are branch-free (buffer loads: an out-of-range offset reads zeros) so that the
   // whole K-step stays ONE basic block and the scheduler can interleave loader VALU / VMEM / LDS
@@ -456,12 +450,8 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN, BK, DGRAD)) void igem
         const bool ok = kok_u & (((a_vmask[i] >> tap_u) & 1u) != 0u);
         a_reg[i] = buf_ld16(rs_a, pred_off(a_base[i] + sdelta, ok));
       }
-      if (BKC) {
-        unsigned kb = (unsigned)ks * 4u;
-        if (BT) {       // k = (filter tap of this class's lattice point, output channel)
-          const int btap = (c.tap_r0 + p.tap_step * fru) * p.s + c.tap_s0 + p.tap_step * fsu;
-          kb = (unsigned)(btap * p.src_c + chb) * 4u;
-        }
+      if (!DGRAD) {
+        const unsigned kb = (unsigned)ks * 4u;
 #pragma unroll
         for (int i = 0; i < B_PASSES_F; ++i) b_reg[i] = buf_ld16(rs_b, pred_off(b_base[i] + kb, b_ok[i] & kok_u));
       } else {
@@ -489,13 +479,13 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN, BK, DGRAD)) void igem
       a_reg[i] = buf_ld16(rs_a, pred_off(a_img[i] + (unsigned)((iy * p.src_w + ix) * p.src_c + ch) * 4u, ok));
     }
     // ---- B
-    if constexpr (!DGRAD) {
+    if (!DGRAD) {
 #pragma unroll
       for (int i = 0; i < B_PASSES_F; ++i) {
         const int n = ntile * BN + a_r0 + i * RPP;
         b_reg[i] = buf_ld16(rs_b, pred_off((unsigned)(n * c.ktotal + k0) * 4u, (n < p.ncols) & kok));
       }
-    } else if constexpr (!BT) {
+    } else {
       const int nv = tid % NV;
       const int ncol = ntile * BN + nv * 4;
 #pragma unroll
@@ -521,7 +511,7 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN, BK, DGRAD)) void igem
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i)
       *reinterpret_cast<float4 *>(As + (a_r0 + i * RPP) * LDA + a_kv * 4) = a_reg[i];
-    if (BKC) {
+    if (!DGRAD) {
 #pragma unroll
       for (int i = 0; i < B_PASSES_F; ++i)
         *reinterpret_cast<float4 *>(Bs + (a_r0 + i * RPP) * LDA + a_kv * 4) = b_reg[i];
@@ -562,7 +552,7 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN, BK, DGRAD)) void igem
 #pragma unroll
       for (int i = 0; i < TM; ++i)
         av[slot][i] = *reinterpret_cast<const float4 *>(As + (wm * WTM + i * 32 + li) * LDA + kg * 8 + lh * 4);
-      if (BKC) {
+      if (!DGRAD) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           bv[slot][j] = *reinterpret_cast<const float4 *>(Bs + (wn * WTN + j * 32 + li) * LDA + kg * 8 + lh * 4);
@@ -590,7 +580,7 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN, BK, DGRAD)) void igem
     // schedule hint: issue the next tile's global loads early in the MFMA stream (one load every
     // two MFMAs) so their latency is covered by the remaining MFMAs of this step.
     {
-      constexpr int NLOADS = A_PASSES + (BKC ? B_PASSES_F : B_PASSES_D);
+      constexpr int NLOADS = A_PASSES + (DGRAD ? B_PASSES_D : B_PASSES_F);
 #pragma unroll
       for (int l = 0; l < NLOADS; ++l) {
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
@@ -1031,12 +1021,12 @@ static bool streamk_enabled() {
 }
 
 // ---- stream-K planning ---------------------------------------------------------------------
-template <int BM, int BN, int BK, int WGM, int WGN, bool DGRAD, bool FASTA = false, bool BT = false>
+template <int BM, int BN, int BK, int WGM, int WGN, bool DGRAD, bool FASTA = false>
 static int igemm_occupancy() {
   static int occ = 0;
   if (occ <= 0) {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<BM, BN, BK, WGM, WGN, DGRAD, FASTA, BT>, 256, 0) != hipSuccess) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<BM, BN, BK, WGM, WGN, DGRAD, FASTA>, 256, 0) != hipSuccess) {
       (void)hipGetLastError();
       n = 1;
     }
@@ -1116,11 +1106,11 @@ static TileChoice choose_tile(long long rows_per_group, int groups, int ncols, i
   return choose_tile_multi(&rows_per_group, &ktotal, 1, groups, ncols, dgrad);
 }
 
-template <int BM, int BN, int BK, int WGM, int WGN, bool DGRAD, bool FASTA = false, bool BT = false>
+template <int BM, int BN, int BK, int WGM, int WGN, bool DGRAD, bool FASTA = false>
 static int launch_igemm_tile(IgemmParams &p, long long tiles, long long units, hipStream_t st) {
   int P = 0;
   if (p.splits == 1 && units > tiles)
-    P = plan_streamk(tiles, (int)(units / tiles), BM, BN, igemm_occupancy<BM, BN, BK, WGM, WGN, DGRAD, FASTA, BT>(), BK);
+    P = plan_streamk(tiles, (int)(units / tiles), BM, BN, igemm_occupancy<BM, BN, BK, WGM, WGN, DGRAD, FASTA>(), BK);
   if (P > 0) {
     float *scratch = stream_scratch(st, (size_t)P * 2 * BM * BN);
     if (!scratch) P = 0;                                   // no scratch: plain launch
@@ -1128,13 +1118,13 @@ static int launch_igemm_tile(IgemmParams &p, long long tiles, long long units, h
   }
   if (P > 0) {
     p.sk_tiles = (int)tiles;
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, BK, WGM, WGN, DGRAD, FASTA, BT>), dim3((unsigned)P), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, BK, WGM, WGN, DGRAD, FASTA>), dim3((unsigned)P), dim3(256), 0, st, p);
     if (check_launch(DGRAD ? "conv_dgrad(stream-K)" : "conv_fprop(stream-K)")) return 1;
     hipLaunchKernelGGL((igemm_fixup_kernel<BM, BN, BK, WGM, WGN, DGRAD>), dim3((unsigned)(P - 1)), dim3(256), 0, st, p, P);
     return check_launch("conv stream-K fix-up");
   }
   p.sk_tiles = 0;
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, BK, WGM, WGN, DGRAD, FASTA, BT>), dim3((unsigned)(tiles * p.splits)), dim3(256), 0, st, p);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, BK, WGM, WGN, DGRAD, FASTA>), dim3((unsigned)(tiles * p.splits)), dim3(256), 0, st, p);
   return check_launch(DGRAD ? "conv_dgrad" : "conv_fprop");
 }
 
@@ -1170,15 +1160,6 @@ static int launch_igemm(IgemmParams &p, TileChoice t, hipStream_t st) {
   for (int i = 0; i < p.ncls; ++i) {
     const IgemmClass &c = p.cls[i];
     fasta = fasta && c.ntaps >= 1 && c.ntaps <= 32 && c.ktotal % bk == 0 && p.src_c % bk == 0;
-  }
-  if constexpr (DGRAD) {
-    // pre-transposed weights: the B operand takes the forward's k-contiguous path (igemm_kernel BT)
-    if (fasta && p.b_t != nullptr && bk == 16 && t.bn >= 64) {
-      p.b = p.b_t;
-      if (t.bm == 128 && t.bn == 128) return launch_igemm_tile<128, 128, 16, 2, 2, true, true, true>(p, tiles, units, st);
-      if (t.bm == 128 && t.bn == 64) return launch_igemm_tile<128, 64, 16, 2, 2, true, true, true>(p, tiles, units, st);
-      return launch_igemm_tile<64, 64, 16, 2, 2, true, true, true>(p, tiles, units, st);
-    }
   }
   if (t.bm == 128 && t.bn == 128) {
     if (bk == 32) {
@@ -1313,8 +1294,7 @@ struct BnFuse {            // see IgemmParams::bn_part
 };
 
 static int dgrad_impl(const mvg_conv_desc *d, const float *dy, const float *wgt, float *dx, const float *mask,
-                      const float *addend, float *ws, size_t ws_floats, void *stream, const BnFuse *bnf = nullptr,
-                      const float *wgt_t = nullptr) {
+                      const float *addend, float *ws, size_t ws_floats, void *stream, const BnFuse *bnf = nullptr) {
   if (validate(d)) return 2;
   MVG_REQUIRE(d->cout % 4 == 0, "dgrad: cout %% 4 != 0 (%d)", d->cout);
   MVG_REQUIRE(!bnf || (d->stride == 1 && ws == nullptr), "dgrad: the BatchNorm-backward fusion needs a stride-1, unsplit launch");
@@ -1331,8 +1311,6 @@ static int dgrad_impl(const mvg_conv_desc *d, const float *dy, const float *wgt,
   }
   p.a = dy;
   p.b = wgt;
-  p.b_t = wgt_t;
-  p.b_row_len = d->r * d->s * d->cout;
   p.out = dx;
   p.mask = mask;
   p.addend = addend;
@@ -1461,37 +1439,6 @@ int mvg_conv_fprop(const mvg_conv_desc *d, const float *x, const float *wgt, flo
 int mvg_conv_dgrad(const mvg_conv_desc *d, const float *dy, const float *wgt, float *dx, const float *mask,
                    const float *addend, void *stream) {
   return dgrad_impl(d, dy, wgt, dx, mask, addend, nullptr, 0, stream);
-}
-
-// KRSC -> CRSK: one thread per element of the transposed tensor (coalesced writes; the reads hit L2)
-__global__ __launch_bounds__(256) void transpose_weights_kernel(const float *__restrict__ w, float *__restrict__ wt, int cout,
-                                                                int rs, int cin) {
-  const long long total = (long long)cout * rs * cin;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int o = (int)(i % cout);
-    const long long t = i / cout;
-    const int tap = (int)(t % rs), c = (int)(t / rs);
-    wt[i] = w[((long long)o * rs + tap) * cin + c];
-  }
-}
-
-int mvg_transpose_weights(const mvg_conv_desc *d, const float *w_krsc, float *w_crsk, void *stream) {
-  if (validate(d)) return 2;
-  MVG_REQUIRE(w_krsc && w_crsk, "transpose_weights: null argument");
-  hipStream_t st = (hipStream_t)stream;
-  const long long total = (long long)d->cout * d->r * d->s * d->cin;
-  ProfScope ps(MVG_K_LAYOUT, st, 0.0, 8.0 * (double)total);
-  long long blocks = (total + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(transpose_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, st, w_krsc, w_crsk, d->cout, d->r * d->s,
-                     d->cin);
-  return check_launch("transpose_weights");
-}
-
-int mvg_conv_dgrad_t(const mvg_conv_desc *d, const float *dy, const float *wgt, const float *wgt_crsk, float *dx,
-                     const float *addend, void *stream) {
-  MVG_REQUIRE(wgt && wgt_crsk, "conv_dgrad_t: both weight layouts are required");
-  return dgrad_impl(d, dy, wgt, dx, nullptr, addend, nullptr, 0, stream, nullptr, wgt_crsk);
 }
 
 int mvg_conv_dgrad_bn_partials(const mvg_conv_desc *d) {

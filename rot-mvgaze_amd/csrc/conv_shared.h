@@ -122,8 +122,7 @@ struct IgemmParams {
   int no_remap;              // several classes, one tile per workgroup: keep the dispatch order (longest class first)
   int ncls;
   IgemmClass cls[4];         // per-class view (one class unless this is a stride-2 dgrad)
-  int b_row_len;             // k-contiguous weight operand (bf16 kernels; fp32 backward-data with b_t): elements per row
-  const float *b_t;          // fp32 backward-data: the weights transposed to [cin][r][s][cout], or null (igemm_kernel BT)
+  int b_row_len;             // bf16 kernels: elements per row of the (k-contiguous) weight operand
   // Backward-data fused with the BatchNorm-backward REDUCE pass of the unit whose output gradient this
   // launch produces (fp32 kernels, stride-1 launches): the epilogue masks the gradient by that unit's ReLU
   // (bn_act > 0, or fma(bn_y, bn_rscale, bn_rshift) > 0, or no mask), stores the masked gradient and adds up,

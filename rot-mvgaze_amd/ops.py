@@ -61,17 +61,6 @@ def conv_dgrad(d: ConvDesc, dy: Tensor, w: Tensor, dx: Tensor, mask: Optional[Te
     check(_fn("mvg_conv_dgrad", dy)(C.byref(d), _p(dy), _p(w), _p(dx), _p(mask), _p(addend), _s()), "conv_dgrad")
 
 
-def transpose_weights(d: ConvDesc, w: Tensor) -> Tensor:
-    """fp32 KRSC weights -> CRSK ([cin][r][s][cout]) for conv_dgrad_t."""
-    wt = torch.empty(d.cin, d.r, d.s, d.cout, dtype=torch.float32, device=w.device)
-    check(lib().mvg_transpose_weights(C.byref(d), _p(w), _p(wt), _s()), "transpose_weights")
-    return wt
-
-
-def conv_dgrad_t(d: ConvDesc, dy: Tensor, w: Tensor, w_t: Tensor, dx: Tensor, addend: Optional[Tensor] = None):
-    check(lib().mvg_conv_dgrad_t(C.byref(d), _p(dy), _p(w), _p(w_t), _p(dx), _p(addend), _s()), "conv_dgrad_t")
-
-
 def conv_dgrad_bn_partials(d: ConvDesc) -> int:
     """Row partials per group of conv_dgrad_bnreduce for this shape; 0 = not fusable (stride 2)."""
     n = lib().mvg_conv_dgrad_bn_partials(C.byref(d))

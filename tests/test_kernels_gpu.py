@@ -116,15 +116,6 @@ def test_conv_fprop_dgrad_wgrad(case):
     ops.conv_dgrad(d, gyd, wd, dx2, mask, dx2)
     close(dx2, dx_ref * (mask.cpu() > 0) + add.cpu(), what="dgrad epilogue")
 
-    # backward-data from pre-transposed (CRSK) weights: the same products in the same order
-    if Cin > 4:
-        wt = ops.transpose_weights(d, wd)
-        assert torch.equal(wt, wd.permute(3, 1, 2, 0).contiguous())
-        dx3, dx4 = add.clone(), add.clone()
-        ops.conv_dgrad(d, gyd, wd, dx3, None, dx3)
-        ops.conv_dgrad_t(d, gyd, wd, wt, dx4, dx4)
-        assert torch.equal(dx4, dx3), "dgrad from transposed weights"
-
     dw = torch.empty(Cout, k, k, Cin, device=dev())
     ops.conv_wgrad(d, xd, gyd, dw, False)
     dw_ref = wr.grad.float().permute(0, 2, 3, 1)
