@@ -128,6 +128,22 @@ int mvg_conv_wgrad(const mvg_conv_desc *d, const float *x, const float *dy, floa
                    float *workspace, int splits, int accumulate, void *stream);
 /* a split count that fills the device for this shape (host helper, no launch). */
 int mvg_conv_wgrad_splits(const mvg_conv_desc *d);
+/* The cross-view fusion GEMM with its input generated inside the kernel (rot_mv.py:44-50 ImageFeatFuser
+ * first layer on cat([img_feat_i, (R_ij @ F_j).flatten]), :234-239; and the gaze head's first layer on
+ * cat([img_feat_i, F_i.flatten]), :249-254, with rel = NULL):
+ *   y[m] = [relu]( W @ [ img_feat[row_img[m]] (cf) | rel[m] (3x3) @ feat[row_src[m]] (3 x nvec, axis-major) ] + bias )
+ * for m < rows.  The concatenated / rotated row is built by the GEMM's operand loader (three loads and
+ * three fmas per 16 bytes of the rotated part) - it is never written to memory; mvg_fuser_wgrad is the
+ * backward-weight twin (dw += dy^T X, db += column sums of dy) with X generated the same way.
+ * img_feat [img_rows][cf], feat [feat_rows][3*nvec], rel [rows][9] or NULL (identity), W [fout][cf + 3*nvec].
+ * Workspaces like mvg_linear_fprop / mvg_linear_wgrad (fin = cf + 3*nvec). */
+int mvg_fuser_fprop(const float *img_feat, const float *feat, const float *rel, const int32_t *row_img,
+                    const int32_t *row_src, const float *w, const float *bias, int relu, float *y, int rows, int cf,
+                    int nvec, int fout, int img_rows, int feat_rows, float *workspace, size_t ws_floats, void *stream);
+int mvg_fuser_wgrad(const float *img_feat, const float *feat, const float *rel, const int32_t *row_img,
+                    const int32_t *row_src, const float *dy, float *dw, float *db, int rows, int cf, int nvec, int fout,
+                    int img_rows, int feat_rows, float *workspace, int splits, int accumulate, void *stream);
+
 /* nn.Linear backward-weight (blocks.py:41-47 under autograd): dw[fout][fin] (+)= dy^T x and, in the SAME
  * launch, the bias gradient db[fout] (+)= column sums of dy (the kernel streams dy anyway; db may be NULL).
  * splits = mvg_conv_wgrad_splits(linear descriptor); workspace: splits * (fout*fin + fout) floats when

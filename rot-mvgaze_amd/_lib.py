@@ -60,6 +60,8 @@ SIGNATURES = {
     "mvg_conv_wgrad": (_I, [_D, _P, _P, _P, _P, _I, _I, _P]),
     "mvg_conv_wgrad_splits": (_I, [_D]),
     "mvg_linear_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _I, _I, _P]),
+    "mvg_fuser_fprop": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, C.c_size_t, _P]),
+    "mvg_fuser_wgrad": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P]),
     "mvg_linear_workspace_floats": (C.c_size_t, [_I, _I, _I]),
     "mvg_linear_fprop": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _P, C.c_size_t, _P]),
     "mvg_linear_dgrad": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, C.c_size_t, _P]),

@@ -293,8 +293,11 @@ constexpr int igemm_min_blocks(int bm, int bn, int bk, bool dgrad) { return (bm 
 // (scalar unit) and each row's bounds checks collapse to one bit of a per-segment tap mask.  PMC on the
 // 64-column kernel: VALU active 22 % + MFMA busy 71 % of the cycles - the vector ALU work of the loader
 // does not hide under the MFMAs, it displaces them.
-template <int BM, int BN, int BK, int WGM, int WGN, bool DGRAD, bool FASTA = false>
+// AMODE = 1 (Linear forward with FASTA): the cross-view fusion's rotate + concat runs inside the A loader
+// (IgemmParams::rc_*): X = [img_feat | R @ F] never exists in memory.
+template <int BM, int BN, int BK, int WGM, int WGN, bool DGRAD, bool FASTA = false, int AMODE = 0>
 __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN, BK, DGRAD)) void igemm_kernel(IgemmParams p) {
+  static_assert(AMODE == 0 || (!DGRAD && FASTA), "AMODE 1: forward GEMM with the uniform-tap loader");
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int KV = BK / 4;                 // float4 per k-contiguous row
@@ -417,8 +420,24 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN, BK, DGRAD)) void igem
       }
     }
   }
-  const __amdgpu_buffer_rsrc_t rs_a =
-      make_rsrc(p.a + (long long)g * p.imgs_per_group * p.src_img_stride, p.a_group_bytes);
+  const __amdgpu_buffer_rsrc_t rs_a = AMODE == 1 ? make_rsrc(p.a, p.rc_img_bytes)
+      : make_rsrc(p.a + (long long)g * p.imgs_per_group * p.src_img_stride, p.a_group_bytes);
+  // AMODE 1: per loader row, byte offsets of its image-feature row and its source-feature row, and its 3x3
+  __amdgpu_buffer_rsrc_t rs_f = rs_a;
+  unsigned rc_io[AMODE == 1 ? A_PASSES : 1], rc_fo[AMODE == 1 ? A_PASSES : 1];
+  float rc_r[AMODE == 1 ? A_PASSES : 1][9];
+  if constexpr (AMODE == 1) {
+    rs_f = make_rsrc(p.rc_feat, p.rc_feat_bytes);
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+      const long long m = (long long)mtile * BM + a_r0 + i * RPP;
+      const int mm = a_ok[i] ? (int)m : 0;
+      rc_io[i] = (unsigned)p.rc_row_img[mm] * (unsigned)p.rc_cf * 4u + (unsigned)a_kv * 16u;
+      rc_fo[i] = (unsigned)p.rc_row_src[mm] * (unsigned)(3 * p.rc_nvec) * 4u + (unsigned)a_kv * 16u;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) rc_r[i][k] = p.rc_rel ? p.rc_rel[(long long)mm * 9 + k] : ((k & 3) == 0 ? 1.f : 0.f);
+    }
+  }
 
   float4 a_reg[A_PASSES];
   float4 b_reg[DGRAD ? B_PASSES_D : B_PASSES_F];
@@ -445,10 +464,34 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN, BK, DGRAD)) void igem
       const int disp = (fru * p.src_w + fsu) * p.src_c;                              // the tap's pixel displacement
       const unsigned sdelta = (unsigned)(((DGRAD ? -disp : disp) + chb) * 4);
       const bool kok_u = (kt < KT) & (ks < c.ktotal);
+      if constexpr (AMODE == 1) {
+        if (ks < p.rc_cf) {                                   // image-feature part of the row
 #pragma unroll
-      for (int i = 0; i < A_PASSES; ++i) {
-        const bool ok = kok_u & (((a_vmask[i] >> tap_u) & 1u) != 0u);
-        a_reg[i] = buf_ld16(rs_a, pred_off(a_base[i] + sdelta, ok));
+          for (int i = 0; i < A_PASSES; ++i) a_reg[i] = buf_ld16(rs_a, pred_off(rc_io[i] + (unsigned)ks * 4u, kok_u & a_ok[i]));
+        } else {                                              // rotated part: axis and column are uniform over the wave
+          const int kk = ks - p.rc_cf;
+          const int axis = kk >> p.rc_nvec_shift;
+          const unsigned n0 = (unsigned)(kk - (axis << p.rc_nvec_shift)) * 4u;
+          const unsigned st1 = (unsigned)p.rc_nvec * 4u;
+#pragma unroll
+          for (int i = 0; i < A_PASSES; ++i) {
+            const bool ok = kok_u & a_ok[i];
+            const float4 f0 = buf_ld16(rs_f, pred_off(rc_fo[i] + n0, ok));
+            const float4 f1 = buf_ld16(rs_f, pred_off(rc_fo[i] + n0 + st1, ok));
+            const float4 f2 = buf_ld16(rs_f, pred_off(rc_fo[i] + n0 + 2u * st1, ok));
+            const float r0 = axis == 0 ? rc_r[i][0] : (axis == 1 ? rc_r[i][3] : rc_r[i][6]);
+            const float r1 = axis == 0 ? rc_r[i][1] : (axis == 1 ? rc_r[i][4] : rc_r[i][7]);
+            const float r2 = axis == 0 ? rc_r[i][2] : (axis == 1 ? rc_r[i][5] : rc_r[i][8]);
+            a_reg[i] = make_float4(r0 * f0.x + r1 * f1.x + r2 * f2.x, r0 * f0.y + r1 * f1.y + r2 * f2.y,
+                                   r0 * f0.z + r1 * f1.z + r2 * f2.z, r0 * f0.w + r1 * f1.w + r2 * f2.w);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i) {
+          const bool ok = kok_u & (((a_vmask[i] >> tap_u) & 1u) != 0u);
+          a_reg[i] = buf_ld16(rs_a, pred_off(a_base[i] + sdelta, ok));
+        }
       }
       if (!DGRAD) {
         const unsigned kb = (unsigned)ks * 4u;
@@ -703,8 +746,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float4 *__rest
 // stepped with one multiply-shift division instead of being decoded from the pixel index every time
 // (99 VALU instructions per K-step, 26 of them quarter-rate multiplies, against 32 MFMAs - and VALU
 // work displaces MFMAs on this machine; rows beyond the split fall outside the dy descriptor = zeros).
-template <int BM, int BN, int BK, int WGM, int WGN, bool INCR = false>
+// XMODE = 1 (Linear layers of the cross-view fusion, non-incremental loader): the x operand is the generated
+// row [img_feat | R @ F] of WgradParams::rc_* - the wgrad twin of igemm_kernel's AMODE 1.
+template <int BM, int BN, int BK, int WGM, int WGN, bool INCR = false, int XMODE = 0>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
+  static_assert(XMODE == 0 || !INCR, "XMODE 1 uses the per-row loader");
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int LDA = BM + 4, LDB = BN + 4;
@@ -740,6 +786,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(p.dy + m_begin * p.cout, 4ll * m_count * p.cout);
   const long long x_img_elems = (long long)p.h * p.w * p.cin;
   const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(p.x + img0 * x_img_elems, p.x_bytes - 4ll * img0 * x_img_elems);
+  const __amdgpu_buffer_rsrc_t rs_xi = XMODE == 1 ? make_rsrc(p.x, p.rc_img_bytes) : rs_b;
+  const __amdgpu_buffer_rsrc_t rs_xf = XMODE == 1 ? make_rsrc(p.rc_feat, p.rc_feat_bytes) : rs_b;
   const int a_mv = tid % MV, a_k0 = tid / MV;
   const int a_col = mtile * BM + a_mv * 4;
   const bool a_cok = a_col < p.cout;
@@ -825,6 +873,36 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     for (int i = 0; i < A_PASSES; ++i) {
       const int m = kt * BK + a_k0 + i * A_KRPP;
       a_reg[i] = buf_ld16(rs_a, pred_off((unsigned)(m * p.cout + a_col) * 4u, (m < m_count) & a_cok));
+    }
+    if constexpr (XMODE == 1) {
+      const bool is_img = b_col < p.rc_cf;                       // uniform over the workgroup: cf is a multiple of BN
+      const int kk = b_col - p.rc_cf;
+      const int axis = is_img ? 0 : kk / p.rc_nvec;
+      const int n0 = kk - axis * p.rc_nvec;
+#pragma unroll
+      for (int i = 0; i < B_PASSES; ++i) {
+        const int m = kt * BK + b_k0 + i * B_KRPP;
+        const bool ok = (m < m_count) & b_cok;
+        const long long row = ok ? m_begin + m : 0;
+        if (is_img) {
+          b_reg[i] = buf_ld16(rs_xi, pred_off(((unsigned)p.rc_row_img[row] * (unsigned)p.rc_cf + (unsigned)b_col) * 4u, ok));
+        } else {
+          const unsigned fo = ((unsigned)p.rc_row_src[row] * (unsigned)(3 * p.rc_nvec) + (unsigned)n0) * 4u;
+          const float4 f0 = buf_ld16(rs_xf, pred_off(fo, ok));
+          const float4 f1 = buf_ld16(rs_xf, pred_off(fo + (unsigned)p.rc_nvec * 4u, ok));
+          const float4 f2 = buf_ld16(rs_xf, pred_off(fo + (unsigned)p.rc_nvec * 8u, ok));
+          float r0 = axis == 0 ? 1.f : 0.f, r1 = axis == 1 ? 1.f : 0.f, r2 = axis == 2 ? 1.f : 0.f;
+          if (p.rc_rel) {
+            const float *rr = p.rc_rel + row * 9 + axis * 3;
+            r0 = rr[0];
+            r1 = rr[1];
+            r2 = rr[2];
+          }
+          b_reg[i] = make_float4(r0 * f0.x + r1 * f1.x + r2 * f2.x, r0 * f0.y + r1 * f1.y + r2 * f2.y,
+                                 r0 * f0.z + r1 * f1.z + r2 * f2.z, r0 * f0.w + r1 * f1.w + r2 * f2.w);
+        }
+      }
+      return;
     }
 #pragma unroll
     for (int i = 0; i < B_PASSES; ++i) {
@@ -1021,12 +1099,12 @@ static bool streamk_enabled() {
 }
 
 // ---- stream-K planning ---------------------------------------------------------------------
-template <int BM, int BN, int BK, int WGM, int WGN, bool DGRAD, bool FASTA = false>
+template <int BM, int BN, int BK, int WGM, int WGN, bool DGRAD, bool FASTA = false, int AMODE = 0>
 static int igemm_occupancy() {
   static int occ = 0;
   if (occ <= 0) {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<BM, BN, BK, WGM, WGN, DGRAD, FASTA>, 256, 0) != hipSuccess) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<BM, BN, BK, WGM, WGN, DGRAD, FASTA, AMODE>, 256, 0) != hipSuccess) {
       (void)hipGetLastError();
       n = 1;
     }
@@ -1106,11 +1184,11 @@ static TileChoice choose_tile(long long rows_per_group, int groups, int ncols, i
   return choose_tile_multi(&rows_per_group, &ktotal, 1, groups, ncols, dgrad);
 }
 
-template <int BM, int BN, int BK, int WGM, int WGN, bool DGRAD, bool FASTA = false>
+template <int BM, int BN, int BK, int WGM, int WGN, bool DGRAD, bool FASTA = false, int AMODE = 0>
 static int launch_igemm_tile(IgemmParams &p, long long tiles, long long units, hipStream_t st) {
   int P = 0;
   if (p.splits == 1 && units > tiles)
-    P = plan_streamk(tiles, (int)(units / tiles), BM, BN, igemm_occupancy<BM, BN, BK, WGM, WGN, DGRAD, FASTA>(), BK);
+    P = plan_streamk(tiles, (int)(units / tiles), BM, BN, igemm_occupancy<BM, BN, BK, WGM, WGN, DGRAD, FASTA, AMODE>(), BK);
   if (P > 0) {
     float *scratch = stream_scratch(st, (size_t)P * 2 * BM * BN);
     if (!scratch) P = 0;                                   // no scratch: plain launch
@@ -1118,13 +1196,13 @@ static int launch_igemm_tile(IgemmParams &p, long long tiles, long long units, h
   }
   if (P > 0) {
     p.sk_tiles = (int)tiles;
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, BK, WGM, WGN, DGRAD, FASTA>), dim3((unsigned)P), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, BK, WGM, WGN, DGRAD, FASTA, AMODE>), dim3((unsigned)P), dim3(256), 0, st, p);
     if (check_launch(DGRAD ? "conv_dgrad(stream-K)" : "conv_fprop(stream-K)")) return 1;
     hipLaunchKernelGGL((igemm_fixup_kernel<BM, BN, BK, WGM, WGN, DGRAD>), dim3((unsigned)(P - 1)), dim3(256), 0, st, p, P);
     return check_launch("conv stream-K fix-up");
   }
   p.sk_tiles = 0;
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, BK, WGM, WGN, DGRAD, FASTA>), dim3((unsigned)(tiles * p.splits)), dim3(256), 0, st, p);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, BK, WGM, WGN, DGRAD, FASTA, AMODE>), dim3((unsigned)(tiles * p.splits)), dim3(256), 0, st, p);
   return check_launch(DGRAD ? "conv_dgrad" : "conv_fprop");
 }
 
@@ -1134,7 +1212,7 @@ static int launch_igemm(IgemmParams &p, TileChoice t, hipStream_t st) {
   p.ntiles = ceil_div(p.ncols, t.bn);
   if (p.splits < 1) p.splits = 1;
   if (p.splits == 1) p.ktiles_per_split = 1 << 30;
-  const int bk = tile_bk(t.bm, t.bn, DGRAD);
+  const int bk = p.rc_feat ? 16 : tile_bk(t.bm, t.bn, DGRAD);     // the rotate + concat loader has a 16-deep instantiation only
   long long tiles = 0, units = 0;
   for (int i = 0; i < p.ncls; ++i) {
     IgemmClass &c = p.cls[i];
@@ -1160,6 +1238,14 @@ static int launch_igemm(IgemmParams &p, TileChoice t, hipStream_t st) {
   for (int i = 0; i < p.ncls; ++i) {
     const IgemmClass &c = p.cls[i];
     fasta = fasta && c.ntaps >= 1 && c.ntaps <= 32 && c.ktotal % bk == 0 && p.src_c % bk == 0;
+  }
+  if constexpr (!DGRAD) {
+    if (p.rc_feat != nullptr) {
+      MVG_REQUIRE(fasta && t.bn >= 64, "fuser GEMM: shape not covered by the rotate + concat loader");
+      if (t.bm == 128 && t.bn == 128) return launch_igemm_tile<128, 128, 16, 2, 2, false, true, 1>(p, tiles, units, st);
+      if (t.bm == 128 && t.bn == 64) return launch_igemm_tile<128, 64, 16, 2, 2, false, true, 1>(p, tiles, units, st);
+      return launch_igemm_tile<64, 64, 16, 2, 2, false, true, 1>(p, tiles, units, st);
+    }
   }
   if (t.bm == 128 && t.bn == 128) {
     if (bk == 32) {
@@ -1190,7 +1276,7 @@ static int plan_splitk(IgemmParams &p, TileChoice t, size_t ws_floats, bool dgra
   if (tiles >= cus) return 1;
   // K-steps in the units of the kernel that will run (the 128x128 fprop tile steps by 32: counting in
   // 16s here made the trailing splits start past the end of K and left their slabs unwritten)
-  const int bk = tile_bk(t.bm, t.bn, dgrad);
+  const int bk = p.rc_feat ? 16 : tile_bk(t.bm, t.bn, dgrad);
   const int KT = ceil_div(p.ktotal, bk);
   long long s = (2LL * cus + tiles - 1) / tiles;
   if (s > (long long)KT * bk / 128) s = (long long)KT * bk / 128;      // >= 128 k per split
@@ -1229,12 +1315,30 @@ int mvg_conv_stats_partials(const mvg_conv_desc *d, int32_t *rows_per_partial) {
   return ceil_div(rows, t.bm) * (t.bm / wr);
 }
 
+struct RotCat {            // generated cross-view input, see IgemmParams::rc_*
+  const float *feat, *rel;
+  const int *row_img, *row_src;
+  int cf, nvec;
+  long long img_rows, feat_rows;
+};
+
 static int fprop_impl(const mvg_conv_desc *d, const float *x, const float *wgt, float *y, const float *bias, int relu,
                       float *stats, float *ws, size_t ws_floats, void *stream, const float *scale = nullptr,
-                      const float *residual = nullptr) {
+                      const float *residual = nullptr, const RotCat *rc = nullptr) {
   if (validate(d)) return 2;
   IgemmParams p;
   memset(&p, 0, sizeof(p));
+  if (rc) {
+    p.rc_feat = rc->feat;
+    p.rc_rel = rc->rel;
+    p.rc_row_img = rc->row_img;
+    p.rc_row_src = rc->row_src;
+    p.rc_cf = rc->cf;
+    p.rc_nvec = rc->nvec;
+    p.rc_nvec_shift = ilog2_exact(rc->nvec);
+    p.rc_img_bytes = 4ll * rc->img_rows * rc->cf;
+    p.rc_feat_bytes = 4ll * rc->feat_rows * 3 * rc->nvec;
+  }
   p.a = x;
   p.b = wgt;
   p.out = y;
@@ -1550,7 +1654,7 @@ int mvg_conv_wgrad_splits(const mvg_conv_desc *d) {
 }
 
 static int wgrad_impl(const mvg_conv_desc *d, const float *x, const float *dy, float *dw, float *db, float *workspace,
-                      int splits, int accumulate, void *stream) {
+                      int splits, int accumulate, void *stream, const RotCat *rc = nullptr) {
   if (validate(d)) return 2;
   MVG_REQUIRE(d->cout % 4 == 0, "wgrad: cout %% 4 != 0 (%d)", d->cout);
   MVG_REQUIRE(splits >= 1, "wgrad: splits < 1");
@@ -1585,6 +1689,16 @@ static int wgrad_impl(const mvg_conv_desc *d, const float *x, const float *dy, f
   p.ntiles = ceil_div(p.ncols, t.bn);
   p.out = splits == 1 ? dw : workspace;
   p.accumulate = (splits == 1) ? accumulate : 0;
+  if (rc) {
+    p.rc_feat = rc->feat;
+    p.rc_rel = rc->rel;
+    p.rc_row_img = rc->row_img;
+    p.rc_row_src = rc->row_src;
+    p.rc_cf = rc->cf;
+    p.rc_nvec = rc->nvec;
+    p.rc_img_bytes = 4ll * rc->img_rows * rc->cf;
+    p.rc_feat_bytes = 4ll * rc->feat_rows * 3 * rc->nvec;
+  }
   float *db_slab = workspace ? workspace + (size_t)splits * d->cout * p.ncols : nullptr;     // after the dw slabs
   p.db = db ? (splits == 1 ? db : db_slab) : nullptr;
   hipStream_t st = (hipStream_t)stream;
@@ -1610,7 +1724,11 @@ static int wgrad_impl(const mvg_conv_desc *d, const float *x, const float *dy, f
     if (incr) hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, 16, WGM_, WGN_, true>), grid, block, 0, st, p);    \
     else hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, 16, WGM_, WGN_, false>), grid, block, 0, st, p);        \
   } while (0)
-    if (t.bm == 128 && t.bn == 128) MVG_WGRAD_LAUNCH(128, 128, 2, 2);
+    if (rc) {
+      MVG_REQUIRE(t.bn == 128 && (t.bm == 128 || t.bm == 64), "fuser wgrad: shape not covered by the generated-input loader");
+      if (t.bm == 128) hipLaunchKernelGGL((wgrad_kernel<128, 128, 16, 2, 2, false, 1>), grid, block, 0, st, p);
+      else hipLaunchKernelGGL((wgrad_kernel<64, 128, 16, 2, 2, false, 1>), grid, block, 0, st, p);
+    } else if (t.bm == 128 && t.bn == 128) MVG_WGRAD_LAUNCH(128, 128, 2, 2);
     else if (t.bm == 64 && t.bn == 128) MVG_WGRAD_LAUNCH(64, 128, 2, 2);
     else if (t.bm == 64 && t.bn == 64) MVG_WGRAD_LAUNCH(64, 64, 2, 2);
     else if (t.bm == 32 && t.bn == 128) MVG_WGRAD_LAUNCH(32, 128, 1, 4);
@@ -1641,6 +1759,34 @@ static int wgrad_impl(const mvg_conv_desc *d, const float *x, const float *dy, f
 int mvg_conv_wgrad(const mvg_conv_desc *d, const float *x, const float *dy, float *dw, float *workspace, int splits,
                    int accumulate, void *stream) {
   return wgrad_impl(d, x, dy, dw, nullptr, workspace, splits, accumulate, stream);
+}
+
+static int check_rotcat(int rows, int cf, int nvec, int fout, const float *img_feat, const float *feat, const int32_t *row_img,
+                        const int32_t *row_src, int img_rows, int feat_rows) {
+  MVG_REQUIRE(img_feat && feat && row_img && row_src, "fuser GEMM: null argument");
+  MVG_REQUIRE(rows > 0 && img_rows > 0 && feat_rows > 0, "fuser GEMM: bad sizes");
+  MVG_REQUIRE(cf % 128 == 0 && nvec % 128 == 0 && ilog2_exact(nvec) >= 0 && fout % 64 == 0 && fout >= 64,
+              "fuser GEMM: cf and nvec must be multiples of 128 (nvec a power of two), fout a multiple of 64");
+  MVG_REQUIRE(4ll * img_rows * cf < 0x7FFFFFF0ll && 12ll * feat_rows * nvec < 0x7FFFFFF0ll, "fuser GEMM: operands exceed 2 GiB");
+  return 0;
+}
+
+int mvg_fuser_fprop(const float *img_feat, const float *feat, const float *rel, const int32_t *row_img, const int32_t *row_src,
+                    const float *w, const float *bias, int relu, float *y, int rows, int cf, int nvec, int fout, int img_rows,
+                    int feat_rows, float *workspace, size_t ws_floats, void *stream) {
+  if (check_rotcat(rows, cf, nvec, fout, img_feat, feat, row_img, row_src, img_rows, feat_rows)) return 2;
+  const mvg_conv_desc d = linear_desc(rows, cf + 3 * nvec, fout);
+  const RotCat rc = {feat, rel, row_img, row_src, cf, nvec, img_rows, feat_rows};
+  return fprop_impl(&d, img_feat, w, y, bias, relu, nullptr, workspace, ws_floats, stream, nullptr, nullptr, &rc);
+}
+
+int mvg_fuser_wgrad(const float *img_feat, const float *feat, const float *rel, const int32_t *row_img, const int32_t *row_src,
+                    const float *dy, float *dw, float *db, int rows, int cf, int nvec, int fout, int img_rows, int feat_rows,
+                    float *workspace, int splits, int accumulate, void *stream) {
+  if (check_rotcat(rows, cf, nvec, fout, img_feat, feat, row_img, row_src, img_rows, feat_rows)) return 2;
+  const mvg_conv_desc d = linear_desc(rows, cf + 3 * nvec, fout);
+  const RotCat rc = {feat, rel, row_img, row_src, cf, nvec, img_rows, feat_rows};
+  return wgrad_impl(&d, img_feat, dy, dw, db, workspace, splits, accumulate, stream, &rc);
 }
 
 int mvg_linear_wgrad(const float *x, const float *dy, float *dw, float *db, int rows, int fin, int fout, float *workspace,

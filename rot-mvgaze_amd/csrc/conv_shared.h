@@ -130,6 +130,14 @@ struct IgemmParams {
   // bn_part [groups][P][2][ncols] (P = row partials per group, like the forward statistics).
   const float *bn_y, *bn_act, *bn_mean, *bn_invstd, *bn_rscale, *bn_rshift;
   float *bn_part;
+  // Cross-view fusion (igemm_kernel AMODE = 1, Linear forward): the A operand is never materialised - row m of
+  //   X = [ img_feat[rc_row_img[m]] (rc_cf floats) | rc_rel[m] (3x3) @ feat[rc_row_src[m]] (3 x rc_nvec, axis-major) ]
+  // (rot_mv.py:44-50,234-239) is generated by the loader: the image part is a plain row load (p.a = img_feat),
+  // the rotated part three loads and three fmas per float4.  rc_rel == null: no rotation (head input, ignore_rotmat).
+  const float *rc_feat, *rc_rel;
+  const int *rc_row_img, *rc_row_src;
+  int rc_cf, rc_nvec, rc_nvec_shift;
+  long long rc_img_bytes, rc_feat_bytes;
 };
 
 // bijective XCD-aware remap of a 1-D grid (cdna_hip_programming.md §5 "XCD swizzle must be
@@ -154,6 +162,11 @@ struct WgradParams {
   int accumulate;   // only meaningful when splits == 1
   float *db;        // Linear layers: column sums of dy (the bias gradient) ride along, [splits][cout] slabs like `out`
                     // (or the gradient itself when splits == 1); null = not wanted
+  // wgrad_kernel XMODE = 1: the x operand is the generated cross-view input X (see IgemmParams::rc_*); x = img_feat
+  const float *rc_feat, *rc_rel;
+  const int *rc_row_img, *rc_row_src;
+  int rc_cf, rc_nvec;
+  long long rc_img_bytes, rc_feat_bytes;
   FastDiv ohw_div, wo_div, cin_div, s_div;
 };
 

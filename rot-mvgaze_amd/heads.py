@@ -71,6 +71,16 @@ class _Written:
         return a
 
 
+class _GenInput:
+    """Rows [ img_feat[row_img[m]] | rel[m] @ feat[row_src[m]] ] of a fuser / head input, described instead of
+    stored: the first Linear's kernels build them in their operand loaders (ops.fuser_fprop / fuser_wgrad)."""
+    __slots__ = ("img", "feat", "rel", "row_img", "row_src", "cf", "nvec", "rows", "width")
+
+    def __init__(self, img, feat, rel, row_img, row_src, cf, nvec):
+        self.img, self.feat, self.rel, self.row_img, self.row_src, self.cf, self.nvec = img, feat, rel, row_img, row_src, cf, nvec
+        self.rows, self.width = row_img.shape[0], cf + 3 * nvec
+
+
 class _Mlp:
     """[Linear + ReLU] * (n - 1), Linear  (/root/reference/models/backbones/blocks.py:27-60; two layers
     for the lifter, ImageFeatFuser and the heads, three for ImageRotmatFeatFuser / RotFeatFuser).
@@ -108,17 +118,26 @@ class _Mlp:
         self._bp[l][: self.fout[l]].copy_(self.b[l].detach())
         return self._wp[l], self._bp[l]
 
-    def forward(self, x: Tensor, out: Optional[Tensor] = None):
-        """x [rows, in_width] -> (hidden activations [h_0 .. h_{n-2}], y [rows, fout_last])."""
-        rows, dev = x.shape[0], x.device
-        assert x.shape[1] == self.fin_p[0], (x.shape, self.fin_p[0])
+    def forward(self, x: Optional[Tensor], out: Optional[Tensor] = None, gen: Optional["_GenInput"] = None):
+        """x [rows, in_width] -> (hidden activations [h_0 .. h_{n-2}], y [rows, fout_last]).
+        gen (instead of x): the input rows [img_feat | R @ F] are generated inside the first layer's GEMM
+        (mvg_fuser_fprop) - the concatenated / rotated operand is never materialised."""
+        if gen is not None:
+            assert x is None and not self.padded[0] and gen.width == self.fin_p[0]
+            rows, dev = gen.rows, gen.img.device
+        else:
+            rows, dev = x.shape[0], x.device
+            assert x.shape[1] == self.fin_p[0], (x.shape, self.fin_p[0])
         hs: List[Tensor] = []
         cur = x
         for l in range(self.n):
             w, b = self._weights(l)
             last = l == self.n - 1
             y = out if (last and out is not None) else torch.empty(rows, self.fout_p[l], dtype=torch.float32, device=dev)
-            if last and self.fout[l] <= 4:
+            if l == 0 and gen is not None:
+                ops.fuser_fprop(gen.img, gen.feat, gen.rel, gen.row_img, gen.row_src, w, b, not last, y, rows, gen.cf, gen.nvec,
+                                self.fout_p[l])
+            elif last and self.fout[l] <= 4:
                 ops.linear_skinny_fwd(cur, w, b, y, rows, self.fin_p[l], self.fout[l])
             else:
                 ops.linear_fprop(cur, w, b, not last, y, rows, self.fin_p[l], self.fout_p[l])
@@ -127,10 +146,11 @@ class _Mlp:
             cur = y
         return hs, cur
 
-    def backward(self, x: Tensor, hs: List[Tensor], gy: Tensor, sink: GradSink, wr: _Written,
-                 dx_addend: Optional[Tensor] = None, dx_out: Optional[Tensor] = None) -> Tensor:
-        """gy = grad wrt the output; returns grad wrt x (optionally fused `+ dx_addend`)."""
-        rows, dev = x.shape[0], x.device
+    def backward(self, x: Optional[Tensor], hs: List[Tensor], gy: Tensor, sink: GradSink, wr: _Written,
+                 dx_addend: Optional[Tensor] = None, dx_out: Optional[Tensor] = None, gen: Optional["_GenInput"] = None) -> Tensor:
+        """gy = grad wrt the output; returns grad wrt x (optionally fused `+ dx_addend`).  gen: see forward
+        (the first layer's weight gradient regenerates the input rows inside mvg_fuser_wgrad)."""
+        rows, dev = gy.shape[0], gy.device
         g = gy
         for l in range(self.n - 1, -1, -1):
             inp = x if l == 0 else hs[l - 1]
@@ -167,8 +187,15 @@ class _Mlp:
                 def grads(inp=inp, g=g, l=l, fin=fin, fout=fout, aw=aw):
                     # weight AND bias gradient in one launch: the bias gradient (column sums of g) rides on the
                     # kernel that streams g for the weight gradient
-                    ops.linear_wgrad(inp, g, sink.view(self.w[l]), sink.view(self.b[l]), rows, fin, fout, aw)
-                wr.off_path(grads, inp, g)
+                    if l == 0 and gen is not None:
+                        ops.fuser_wgrad(gen.img, gen.feat, gen.rel, gen.row_img, gen.row_src, g, sink.view(self.w[l]),
+                                        sink.view(self.b[l]), rows, gen.cf, gen.nvec, fout, aw)
+                    else:
+                        ops.linear_wgrad(inp, g, sink.view(self.w[l]), sink.view(self.b[l]), rows, fin, fout, aw)
+                if l == 0 and gen is not None:
+                    wr.off_path(grads, gen.img, gen.feat, g)
+                else:
+                    wr.off_path(grads, inp, g)
             # ---- input gradient
             if l == 0:
                 dx = dx_out if dx_out is not None else torch.empty(rows, fin, dtype=torch.float32, device=dev)
@@ -192,6 +219,9 @@ class FusionHead:
             self.heads = [self.heads[0]] * num_iter
         self.ibn = [params[f"_img_fusers.{i}._batchnorm.running_mean"] for i in range(num_iter)] \
             if variant.share_feature else None
+        # MVG_FUSED_INPUT=0: materialise the fuser / head inputs with rotcat kernels instead (A/B switch)
+        import os as _os
+        self.fused_input = _os.environ.get("MVG_FUSED_INPUT", "1") != "0"
         self.kin = self.fusers[0].in_width            # row length of the fuser input (zero-padded)
         self.hin = self.heads[0].in_width
         self._idx_cache: Dict[Tuple[int, str], dict] = {}
@@ -214,6 +244,19 @@ class FusionHead:
             mk = lambda a: torch.tensor(a, dtype=torch.int32, device=dev)
             self._idx_cache[key] = {"vi": mk(vi), "vj": mk(vj), "partner": mk([d ^ 1 for d in range(D)]),
                                     "ident": mk(list(range(D))), "D": D}
+        return self._idx_cache[key]
+
+    def _row_tables(self, views: int, batch: int, dev) -> dict:
+        """Row-index tables (int32, device) of the generated fuser / head inputs: row (d, b) takes the image feature
+        of view vi[d] and the source feature row given by the table (partner view / partner direction / itself)."""
+        key = (views, batch, str(dev), "rows")
+        if key not in self._idx_cache:
+            vi, vj = directed_pairs(views)
+            D = len(vi)
+            b = torch.arange(batch, dtype=torch.int32)
+            tab = lambda idx: (torch.tensor(idx, dtype=torch.int32)[:, None] * batch + b[None, :]).reshape(-1).contiguous().to(dev)
+            self._idx_cache[key] = {"img": tab(vi), "view": tab(vj), "partner": tab([d ^ 1 for d in range(D)]),
+                                    "ident": tab(list(range(D)))}
         return self._idx_cache[key]
 
     # ---------------------------------------------------------------- operand builders
@@ -254,8 +297,24 @@ class FusionHead:
         a = lifted if self.v.share_feature else img_feat       # rot_mv.py:199-201
         saved = []
         src, src_idx = lifted, ix["vj"]                  # iteration 0 reads the partner VIEW's lifted feature
+        # default / ignore_rotmat variants: rotate + concat run inside the first Linear's operand loader - the
+        # fuser input X = [img_feat | R @ F] and the head input [img_feat | F] are never written (the other
+        # variants have 9 extra columns / interleaved rows and keep the materialised form)
+        fused_in = self.fused_input and not (self.v.share_feature or self.v.encode_rotmat)
+        rt = self._row_tables(V, B, dev) if fused_in else None
+        img2d = img_feat.reshape(V * B, cf)
         for it in range(I):
             scales = None
+            if fused_in:
+                gen_f = _GenInput(img2d, src.reshape(-1, ROT_DIM), None if self.v.ignore_rotmat else rel, rt["img"],
+                                  rt["view"] if it == 0 else rt["partner"], cf, NV)
+                Hf, Fn = self.fusers[it].forward(None, feats[it], gen=gen_f)
+                gen_h = _GenInput(img2d, Fn, None, rt["img"], rt["ident"], cf, NV)
+                Hh, _ = self.heads[it].forward(None, preds[it], gen=gen_h)
+                if keep_tape:
+                    saved.append((gen_f, Hf, gen_h, Hh, None))
+                src, src_idx = Fn, ix["partner"]
+                continue
             if self.v.share_feature:
                 scales = torch.empty(2 * D, NV, dtype=torch.float32, device=dev)
                 ops.ibn_scales(a, src, ix["vi"], src_idx, self.ibn[it], training, IBN_MOMENTUM, IBN_EPS, scales, B, D, NV)
@@ -315,9 +374,11 @@ class FusionHead:
                     dF = ext.clone()
                 else:
                     ops.axpby(ext, dF, 1.0, 1.0)
+            gen_f = X if isinstance(X, _GenInput) else None
+            gen_h = Xh if isinstance(Xh, _GenInput) else None
             if d_preds is not None:
                 gp = d_preds[it].reshape(D * B, 2).contiguous()
-                dXh = self.heads[it].backward(Xh, Hh, gp, sink, wr)
+                dXh = self.heads[it].backward(None if gen_h else Xh, Hh, gp, sink, wr, gen=gen_h)
                 dFh = torch.empty(D * B, ROT_DIM, dtype=torch.float32, device=dev)
                 split_input_grad(dXh, self.hin, None, None, ix["ident"], dFh)
                 if dF is None:
@@ -330,7 +391,7 @@ class FusionHead:
             if dF is None:
                 self._zero_grads(self.fusers[it], sink, wr)
             else:
-                dX = self.fusers[it].backward(X, Hf, dF, sink, wr)
+                dX = self.fusers[it].backward(None if gen_f else X, Hf, dF, sink, wr, gen=gen_f)
                 if it > 0:
                     dF_next = torch.empty(D * B, ROT_DIM, dtype=torch.float32, device=dev)
                     split_input_grad(dX, self.kin, rel_fuse, scales, ix["partner"], dF_next)

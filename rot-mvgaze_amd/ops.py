@@ -110,6 +110,26 @@ def linear_wgrad(x: Tensor, dy: Tensor, dw: Tensor, db: Optional[Tensor], rows: 
           "linear_wgrad")
 
 
+def fuser_fprop(img_feat, feat, rel, row_img, row_src, w, bias, relu, y, rows, cf, nvec, fout):
+    """y = [relu](W @ [img_feat[row_img] | rel @ feat[row_src]] + bias): the concatenated / rotated rows are built by
+    the GEMM's operand loader (mvg_fuser_fprop) - no X tensor."""
+    ws, n = _linear_ws(img_feat, rows, cf + 3 * nvec, fout)
+    check(lib().mvg_fuser_fprop(_p(img_feat), _p(feat), _p(rel), _p(row_img), _p(row_src), _p(w), _p(bias), int(relu), _p(y), rows,
+                                cf, nvec, fout, img_feat.numel() // cf, feat.numel() // (3 * nvec), _p(ws), n, _s()), "fuser_fprop")
+
+
+def fuser_wgrad(img_feat, feat, rel, row_img, row_src, dy, dw, db, rows, cf, nvec, fout, accumulate=False):
+    fin = cf + 3 * nvec
+    d = ConvDesc.linear(rows, fin, fout)
+    splits = lib().mvg_conv_wgrad_splits(C.byref(d))
+    if splits < 1:
+        check(1, "conv_wgrad_splits")
+    ws = torch.empty(splits * (fout * fin + fout), dtype=torch.float32, device=dy.device) if splits > 1 else None
+    check(lib().mvg_fuser_wgrad(_p(img_feat), _p(feat), _p(rel), _p(row_img), _p(row_src), _p(dy), _p(dw), _p(db), rows, cf, nvec,
+                                fout, img_feat.numel() // cf, feat.numel() // (3 * nvec), _p(ws), splits, int(accumulate), _s()),
+          "fuser_wgrad")
+
+
 def _linear_ws(x: Tensor, rows: int, fin: int, fout: int):
     n = lib().mvg_linear_workspace_floats(rows, fin, fout)
     return torch.empty(n, dtype=torch.float32, device=x.device), n

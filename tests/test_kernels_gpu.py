@@ -215,6 +215,44 @@ def test_linear_via_conv(rows, fin, fout, relu):
     close(dx2, xr.grad * (mask.cpu() > 0) + add.cpu(), what="linear_dgrad (split-K, mask+addend)")
 
 
+@pytest.mark.parametrize("V,B,cf,fout,use_rel", [(2, 64, 512, 2048, True), (4, 32, 2048, 3584, True), (4, 128, 2048, 512, False),
+                                                 (8, 5, 512, 2048, True), (2, 3, 2048, 3584, True)])
+def test_fuser_gemm_generates_rotate_concat_in_the_loader(V, B, cf, fout, use_rel):
+    """mvg_fuser_fprop / mvg_fuser_wgrad (X = [img_feat | R @ F] built inside the GEMM's operand loader, never
+    written) == rotcat_fwd + linear_fprop / linear_wgrad on the materialised X; rows up to C3's 1536."""
+    from rot_mvgaze_amd import ops
+    from rot_mvgaze_amd.heads import directed_pairs
+    nvec = 512
+    vi, vj = directed_pairs(V)
+    D = len(vi)
+    rows, kin = D * B, cf + 3 * nvec
+    img = rnd((V, B, cf), 1, "i").to(dev())
+    feat = rnd((V, B, 3, nvec), 2, "f").to(dev())
+    rel = rnd((D, B, 3, 3), 3, "r").to(dev()) if use_rel else None
+    w = rnd((fout, kin), 4, "w", kin ** -0.5).to(dev())
+    bias = rnd((fout,), 5, "b").to(dev())
+    vi_t, vj_t = torch.tensor(vi, dtype=torch.int32, device=dev()), torch.tensor(vj, dtype=torch.int32, device=dev())
+    X = torch.empty(rows, kin, device=dev())
+    ops.rotcat_fwd(img, feat, rel, vi_t, vj_t, X, B, D, cf, nvec)
+    y0 = torch.empty(rows, fout, device=dev())
+    ops.linear_fprop(X, w, bias, True, y0, rows, kin, fout)
+    b_idx = torch.arange(B, dtype=torch.int32)
+    row_img = (torch.tensor(vi, dtype=torch.int32)[:, None] * B + b_idx[None]).reshape(-1).to(dev())
+    row_src = (torch.tensor(vj, dtype=torch.int32)[:, None] * B + b_idx[None]).reshape(-1).to(dev())
+    y1 = torch.full((rows, fout), float("nan"), device=dev())
+    ops.fuser_fprop(img.reshape(V * B, cf), feat.reshape(V * B, 3 * nvec), rel, row_img, row_src, w, bias, True, y1, rows, cf, nvec,
+                    fout)
+    close(y1, y0, 1e-5, "fuser_fprop vs rotcat + linear_fprop")
+    g = rnd((rows, fout), 6, "g").to(dev())
+    dw0, db0 = torch.empty(fout, kin, device=dev()), torch.empty(fout, device=dev())
+    dw1, db1 = torch.full((fout, kin), float("nan"), device=dev()), torch.full((fout,), float("nan"), device=dev())
+    ops.linear_wgrad(X, g, dw0, db0, rows, kin, fout, False)
+    ops.fuser_wgrad(img.reshape(V * B, cf), feat.reshape(V * B, 3 * nvec), rel, row_img, row_src, g, dw1, db1, rows, cf, nvec, fout,
+                    False)
+    close(dw1, dw0, 1e-5, "fuser_wgrad dw")
+    close(db1, db0, 1e-6, "fuser_wgrad db")
+
+
 def test_linear_skinny():
     from rot_mvgaze_amd import ops
     rows, k, nout = 37, 512, 2
