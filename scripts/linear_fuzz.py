@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised sweep of mvg_linear_fprop / mvg_linear_dgrad / linear wgrad + colsum against float64:
+"""Randomised sweep of mvg_linear_fprop / mvg_linear_dgrad / mvg_linear_wgrad (weight + bias gradient) against float64:
 linear_fuzz.py [cases] [seed]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -37,10 +37,9 @@ for it in range(cases):
     ops.linear_dgrad(gyd, wd, mask.to(dev), dx, dx, rows, fin, fout)
     e.append(rel(dx, (gy.double() @ w.double()) * (mask > 0) + add.double()))
     dw = torch.full((fout, fin), float("nan"), device=dev)
-    ops.conv_wgrad(ConvDesc.linear(rows, fin, fout), xd, gyd, dw, False)
-    e.append(rel(dw, gy.double().T @ x.double()))
     db = torch.full((fout,), float("nan"), device=dev)
-    ops.colsum(gyd, db, rows, fout, False)
+    ops.linear_wgrad(xd, gyd, dw, db, rows, fin, fout, False)       # weight and bias gradient in one launch
+    e.append(rel(dw, gy.double().T @ x.double()))
     e.append(rel(db, gy.double().sum(0)))
     ok = all(v == v and v <= 3e-5 for v in e)
     bad += not ok
