@@ -378,6 +378,19 @@ int mvg_conv_dgrad_bf16(const mvg_conv_desc *d, const void *dy, const void *wgt_
 int mvg_conv_wgrad_bf16(const mvg_conv_desc *d, const void *x, const void *dy, float *dw, float *workspace,
                         int splits, int accumulate, void *stream);
 int mvg_conv_wgrad_splits_bf16(const mvg_conv_desc *d);
+/* nn.Linear of the fusion block in the bf16 path ("mixed"): activations, gradients, biases and outputs stay
+ * fp32 in memory, the operand loaders round to bf16 on the way into LDS and the product runs on the bf16
+ * matrix cores against the bf16 weight copies (w_bf16 [fout][fin]; wt_bf16 [fin][fout] for backward-data).
+ * No split-K: meant for the large row counts of the bf16 configuration (C5: 3584 rows per GPU).
+ *   fprop: y = [relu](x @ w^T + bias);  dgrad: dx = (dy @ w) * (mask > 0) + addend;
+ *   wgrad: dw (+)= dy^T x, db (+)= column sums of the fp32 dy; splits = mvg_conv_wgrad_splits_bf16(linear
+ *   descriptor), workspace splits * (fout*fin + fout) floats when splits > 1. */
+int mvg_linear_fprop_mixed(const float *x, const void *w_bf16, const float *bias, int relu, float *y, int rows, int fin,
+                           int fout, void *stream);
+int mvg_linear_dgrad_mixed(const float *dy, const void *wt_bf16, const float *mask, const float *addend, float *dx,
+                           int rows, int fin, int fout, void *stream);
+int mvg_linear_wgrad_mixed(const float *x, const float *dy, float *dw, float *db, int rows, int fin, int fout,
+                           float *workspace, int splits, int accumulate, void *stream);
 /* the BatchNorm / pooling passes with bf16 activations (same arguments as the fp32 entry points) */
 int mvg_bn_apply_bf16(const uint16_t *y, const float *scale, const float *shift, const uint16_t *residual,
                       const float *res_scale, const float *res_shift, int relu, uint16_t *out, int groups,

@@ -155,10 +155,21 @@ def backbone_forward(sd: SD, x: Tensor, spec: BackboneSpec, training: bool, trac
 # --------------------------------------------------------------------------------------------
 # MLP blocks, lifter, fuser, head
 # --------------------------------------------------------------------------------------------
+_LINEAR_Q = None      # set by multiview_forward(storage=...): operand rounding of the fusion block's Linear layers
+
+
 def mlp(sd: SD, prefix: str, x: Tensor, n_layers: int, relu_masks=None) -> Tensor:
-    """[Linear, ReLU]*(n-1), Linear.  /root/reference/models/backbones/blocks.py:27-82."""
+    """[Linear, ReLU]*(n-1), Linear.  /root/reference/models/backbones/blocks.py:27-82.
+    With the repo's bf16 path emulated (_LINEAR_Q), the operands of every Linear wider than 4 outputs are
+    rounded (activations and weights), the product accumulates in fp32 and the result stays fp32 - the
+    arithmetic of mvg_linear_*_mixed; the 512 -> 2 head layer stays fp32."""
+    q = _LINEAR_Q
     for i in range(n_layers):
-        x = F.linear(x, sd[f"{prefix}blocks.{i}.0.weight"], sd[f"{prefix}blocks.{i}.0.bias"])
+        w, b = sd[f"{prefix}blocks.{i}.0.weight"], sd[f"{prefix}blocks.{i}.0.bias"]
+        if q is not None and w.shape[0] > 4:
+            x = F.linear(q(x), q(w), b)
+        else:
+            x = F.linear(x, w, b)
         if i + 1 < n_layers:
             x = _relu(x, relu_masks)
     return x
@@ -326,8 +337,17 @@ def multiview_forward(sd: SD, img: Tensor, rot: Tensor, depth: int, num_iter: in
     ``masks`` (test aid, see _relu): {"backbone": [iterator per view], "lift": [mask per view],
     ("fuse", it) / ("head", it): [mask per DIRECTED pair d = 2p (i<-j), 2p+1 (j<-i)]}.
     ``storage`` = bf16_round emulates the repo's bf16 backbone storage (see _conv_bn); the fusion block is fp32."""
+    global _LINEAR_Q
     spec = backbone_spec(depth)
     V = img.shape[1]
+    _LINEAR_Q = storage
+    try:
+        return _multiview_forward(sd, img, rot, depth, num_iter, training, masks, storage, spec, V)
+    finally:
+        _LINEAR_Q = None
+
+
+def _multiview_forward(sd, img, rot, depth, num_iter, training, masks, storage, spec, V):
     bm = masks["backbone"] if masks is not None else [None] * V
     lm = masks["lift"] if masks is not None else [None] * V
     feats = [backbone_forward(sd, img[:, v], spec, training, None, bm[v], storage) for v in range(V)]

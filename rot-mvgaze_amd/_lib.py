@@ -108,6 +108,9 @@ SIGNATURES = {
     "mvg_conv_dgrad_bf16": (_I, [_D, _P, _P, _P, _P, _P, _P]),
     "mvg_conv_wgrad_bf16": (_I, [_D, _P, _P, _P, _P, _I, _I, _P]),
     "mvg_conv_wgrad_splits_bf16": (_I, [_D]),
+    "mvg_linear_fprop_mixed": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _P]),
+    "mvg_linear_dgrad_mixed": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "mvg_linear_wgrad_mixed": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _I, _I, _P]),
     "mvg_bn_apply_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _I, _I64, _I, _P]),
     "mvg_bn_bwd_reduce_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
     "mvg_bn_bwd_apply_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _P, _P, _P]),

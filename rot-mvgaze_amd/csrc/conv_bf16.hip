@@ -33,9 +33,14 @@ __device__ __forceinline__ unsigned pack_bf2(float a, float b) {          // rou
 
 constexpr int BF_BM = 128, BF_BK = 64, BF_LDK = BF_BK + 8;
 
-template <int BN, bool DGRAD, bool FASTA>
+// F32IO (the fusion block's Linear layers in the bf16 path): the gathered operand, the output and the epilogue
+// operands (mask, addend) are fp32 in memory - only the matrix product runs in bf16: the loader reads 32 bytes
+// per 8 k, rounds to bf16 on the way into LDS, the epilogue stores fp32.  The weights are the bf16 copies.
+template <int BN, bool DGRAD, bool FASTA, bool F32IO = false>
 __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(IgemmParams p) {
   constexpr int BM = BF_BM, BK = BF_BK, LDK = BF_LDK, WGM = 2, WGN = 2;
+  constexpr unsigned EA = F32IO ? 4u : 2u;   // bytes per element of the gathered operand
+  constexpr int AL = F32IO ? 2 : 1;          // 16-byte loads per 8 k
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int KV = BK / 8;                 // 16-byte vectors per row
@@ -83,7 +88,7 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(IgemmParams p) {
       a_y0[i] = oy * p.stride - p.pad;
       a_x0[i] = ox * p.stride - p.pad;
     }
-    a_img[i] = (unsigned)(img * p.src_img_stride * 2);
+    a_img[i] = (unsigned)(img * p.src_img_stride) * EA;
   }
   unsigned a_base[A_PASSES], a_vmask[A_PASSES], b_base[B_PASSES];
   bool b_ok[B_PASSES];
@@ -96,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(IgemmParams p) {
   if (FASTA) {
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
-      a_base[i] = a_img[i] + (unsigned)((a_y0[i] * p.src_w + a_x0[i]) * p.src_c) * 2u + (unsigned)a_kv * 16u;
+      a_base[i] = a_img[i] + (unsigned)((a_y0[i] * p.src_w + a_x0[i]) * p.src_c) * EA + (unsigned)a_kv * 8u * EA;
       unsigned m = 0;
       for (int t = 0; t < c.ntaps; ++t) {
         const int fr = (int)fdiv((unsigned)t, c.tap_ns_div), fs = t - fr * c.tap_ns;
@@ -108,10 +113,14 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(IgemmParams p) {
     }
   }
   const __amdgpu_buffer_rsrc_t rs_a =
-      make_rsrc(reinterpret_cast<const unsigned short *>(p.a) + (long long)g * p.imgs_per_group * p.src_img_stride, p.a_group_bytes);
+      make_rsrc(reinterpret_cast<const char *>(p.a) + (long long)g * p.imgs_per_group * p.src_img_stride * EA, p.a_group_bytes);
   const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(p.b, p.b_bytes);
 
-  u32x4 a_reg[A_PASSES], b_reg[B_PASSES];
+  u32x4 a_reg[A_PASSES][AL], b_reg[B_PASSES];
+  auto load_a = [&](int i, unsigned off, bool ok) {
+    a_reg[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, pred_off(off, ok), 0, 0);
+    if constexpr (F32IO) a_reg[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, pred_off(off + 16u, ok), 0, 0);
+  };
   auto load_tiles = [&](int kt) {
     // first k of this K-step; korder: (64-channel block, tap) instead of (tap, channel block) so that the
     // taps of a 3x3 filter revisit a pixel's 128-byte line within consecutive K-steps (L2 locality)
@@ -126,12 +135,12 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(IgemmParams p) {
       const int chb = ks - (tap_u << p.src_c_shift);
       const int fru = (int)fdiv((unsigned)tap_u, c.tap_ns_div), fsu = tap_u - fru * c.tap_ns;
       const int disp = (fru * p.src_w + fsu) * p.src_c;
-      const unsigned sdelta = (unsigned)(((DGRAD ? -disp : disp) + chb) * 2);
+      const unsigned sdelta = (unsigned)((DGRAD ? -disp : disp) + chb) * EA;
       const bool kok_u = (kt < KT) & (ks < c.ktotal);
 #pragma unroll
       for (int i = 0; i < A_PASSES; ++i) {
         const bool ok = kok_u & (((a_vmask[i] >> tap_u) & 1u) != 0u);
-        a_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, pred_off(a_base[i] + sdelta, ok), 0, 0);
+        load_a(i, a_base[i] + sdelta, ok);
       }
       unsigned kb = (unsigned)ks * 2u;
       if (DGRAD) {
@@ -156,8 +165,7 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(IgemmParams p) {
       const int iy = DGRAD ? a_y0[i] - fr : a_y0[i] + fr;
       const int ix = DGRAD ? a_x0[i] - fs : a_x0[i] + fs;
       const bool ok = a_ok[i] & kok & ((unsigned)iy < (unsigned)p.src_h) & ((unsigned)ix < (unsigned)p.src_w);
-      a_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(
-          rs_a, pred_off(a_img[i] + (unsigned)((iy * p.src_w + ix) * p.src_c + ch) * 2u, ok), 0, 0);
+      load_a(i, a_img[i] + (unsigned)((iy * p.src_w + ix) * p.src_c + ch) * EA, ok);
     }
     unsigned koff = (unsigned)k0;
     if (DGRAD) {
@@ -173,7 +181,17 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(IgemmParams p) {
     unsigned short *As = smem + buf * (A_ELEMS + B_ELEMS);
     unsigned short *Bs = As + A_ELEMS;
 #pragma unroll
-    for (int i = 0; i < A_PASSES; ++i) *reinterpret_cast<u32x4 *>(As + (a_r0 + i * RPP) * LDK + a_kv * 8) = a_reg[i];
+    for (int i = 0; i < A_PASSES; ++i) {
+      u32x4 v = a_reg[i][0];
+      if constexpr (F32IO) {          // 8 fp32 -> 8 bf16 (round to nearest even)
+        const u32x4 lo = a_reg[i][0], hi = a_reg[i][1];
+        v.x = pack_bf2(__uint_as_float(lo.x), __uint_as_float(lo.y));
+        v.y = pack_bf2(__uint_as_float(lo.z), __uint_as_float(lo.w));
+        v.z = pack_bf2(__uint_as_float(hi.x), __uint_as_float(hi.y));
+        v.w = pack_bf2(__uint_as_float(hi.z), __uint_as_float(hi.w));
+      }
+      *reinterpret_cast<u32x4 *>(As + (a_r0 + i * RPP) * LDK + a_kv * 8) = v;
+    }
 #pragma unroll
     for (int i = 0; i < B_PASSES; ++i) *reinterpret_cast<u32x4 *>(Bs + (a_r0 + i * RPP) * LDK + a_kv * 8) = b_reg[i];
   };
@@ -216,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(IgemmParams p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[kg & 1][i], bv[kg & 1][j], acc[i][j], 0, 0, 0);
     }
     {
-      constexpr int NLOADS = A_PASSES + B_PASSES;
+      constexpr int NLOADS = A_PASSES * AL + B_PASSES;
       constexpr int NMFMA = TM * TN * (BK / 16);
       constexpr int PER = NMFMA / NLOADS > 0 ? NMFMA / NLOADS : 1;
 #pragma unroll
@@ -298,6 +316,9 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(IgemmParams p) {
   unsigned short *out_g = reinterpret_cast<unsigned short *>(p.out) + (long long)g * gelems;
   const unsigned short *add_g = p.addend ? reinterpret_cast<const unsigned short *>(p.addend) + (long long)g * gelems : nullptr;
   const unsigned short *mask_g = p.mask ? reinterpret_cast<const unsigned short *>(p.mask) + (long long)g * gelems : nullptr;
+  float *out_f = p.out + (long long)g * gelems;
+  const float *add_f = p.addend ? p.addend + (long long)g * gelems : nullptr;
+  const float *mask_f = p.mask ? p.mask + (long long)g * gelems : nullptr;
   constexpr int CV = BN / 8;                 // 16-byte output vectors per tile row
 #pragma unroll
   for (int it = 0; it < BM * CV / 256; ++it) {
@@ -316,6 +337,21 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(IgemmParams p) {
     if (!DGRAD && p.relu) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) x[k] = fmaxf(x[k], 0.f);
+    }
+    if constexpr (F32IO) {
+      if (mask_f) {
+        const float4 m0 = *reinterpret_cast<const float4 *>(mask_f + off + col), m1 = *reinterpret_cast<const float4 *>(mask_f + off + col + 4);
+        const float mm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = mm[k] > 0.f ? x[k] : 0.f;
+      }
+      if (add_f) {
+        const float4 a0 = *reinterpret_cast<const float4 *>(add_f + off + col), a1 = *reinterpret_cast<const float4 *>(add_f + off + col + 4);
+        x[0] += a0.x; x[1] += a0.y; x[2] += a0.z; x[3] += a0.w; x[4] += a1.x; x[5] += a1.y; x[6] += a1.z; x[7] += a1.w;
+      }
+      *reinterpret_cast<float4 *>(out_f + off + col) = make_float4(x[0], x[1], x[2], x[3]);
+      *reinterpret_cast<float4 *>(out_f + off + col + 4) = make_float4(x[4], x[5], x[6], x[7]);
+      continue;
     }
     if (mask_g) {
       const u32x4 m = *reinterpret_cast<const u32x4 *>(mask_g + off + col);
@@ -366,9 +402,13 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned short *img, int ld, int
   return __builtin_bit_cast(bf16x8, z);
 }
 
-template <int BM, int BN, bool INCR>
+// F32IN (Linear layers of the fusion block in the bf16 path): x and dy are fp32 in memory and rounded to bf16 on
+// the way into LDS; the bias gradient (column sums of the fp32 dy) rides along like in the fp32 kernel.
+template <int BM, int BN, bool INCR, bool F32IN = false>
 __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradParams p) {
   constexpr int BK = 64, WGM = 2, WGN = 2;
+  constexpr unsigned EB = F32IN ? 4u : 2u;   // bytes per element of x and dy
+  constexpr int AL = F32IN ? 2 : 1;
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int LDA = BM + 32, LDB = BN + 32;
@@ -395,18 +435,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradParams p) {
   const long long img0 = m_begin / ohw;
   const unsigned rem0 = (unsigned)(m_begin - img0 * ohw);
 
-  const unsigned short *dy = reinterpret_cast<const unsigned short *>(p.dy);
-  const unsigned short *x = reinterpret_cast<const unsigned short *>(p.x);
-  const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(dy + m_begin * p.cout, 2ll * m_count * p.cout);
+  const char *dy = reinterpret_cast<const char *>(p.dy);
+  const char *x = reinterpret_cast<const char *>(p.x);
+  const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(dy + m_begin * p.cout * EB, (long long)EB * m_count * p.cout);
   const long long x_img_elems = (long long)p.h * p.w * p.cin;
-  const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(x + img0 * x_img_elems, p.x_bytes - 2ll * img0 * x_img_elems);
+  const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(x + img0 * x_img_elems * EB, p.x_bytes - (long long)EB * img0 * x_img_elems);
   const int a_mv = tid % MV, a_k0 = tid / MV;
   const int a_col = mtile * BM + a_mv * 8;
   const bool a_cok = a_col < p.cout;
   unsigned a_off[A_PASSES];
 #pragma unroll
   for (int i = 0; i < A_PASSES; ++i)
-    a_off[i] = a_cok ? (unsigned)((a_k0 + i * A_KRPP) * p.cout + a_col) * 2u : 0x80000000u;
+    a_off[i] = a_cok ? (unsigned)((a_k0 + i * A_KRPP) * p.cout + a_col) * EB : 0x80000000u;
 
   // B (x gather): a thread's loads of one K-step all come from ONE pixel row (row = tid / B_TPR) and differ
   // in the column group; INCR carries (oy, ox, image offset) of that pixel and steps it by BK pixels per K-step.
@@ -426,10 +466,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradParams p) {
     const int fr = (int)fdiv((unsigned)tap, p.s_div), fs = tap - fr * p.s;
     i_dy[j] = fr - p.pad;
     i_dx[j] = fs - p.pad;
-    i_tconst[j] = (unsigned)(((i_dy[j] * p.w + i_dx[j]) * p.cin + cc) * 2);
+    i_tconst[j] = (unsigned)((i_dy[j] * p.w + i_dx[j]) * p.cin + cc) * EB;
   }
-  const unsigned row_bytes = (unsigned)(p.stride * p.w * p.cin * 2), col_bytes = (unsigned)(p.stride * p.cin * 2);
-  const unsigned img_bytes = (unsigned)(x_img_elems * 2);
+  const unsigned row_bytes = (unsigned)(p.stride * p.w * p.cin) * EB, col_bytes = (unsigned)(p.stride * p.cin) * EB;
+  const unsigned img_bytes = (unsigned)x_img_elems * EB;
   int s_oy = 0, s_ox = 0;
   unsigned s_imgoff = 0;
   if (INCR) {
@@ -441,12 +481,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradParams p) {
     s_ox = (int)(rem - oy * (unsigned)p.wo);
     s_imgoff = img * img_bytes;
   }
-  u32x4 a_reg[A_PASSES], b_reg[B_CPT];
+  u32x4 a_reg[A_PASSES][AL], b_reg[B_CPT][AL];
+  const bool do_bias = F32IN && (p.db != nullptr) && (ntile == 0);
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   auto load_tiles = [&](int kt) {
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
-      a_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_off[i], 0, 0);     // rows >= m_count: beyond the descriptor = zeros
-      a_off[i] += (unsigned)(BK * p.cout * 2);
+      a_reg[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_off[i], 0, 0);  // rows >= m_count: beyond the descriptor = zeros
+      if constexpr (F32IN) a_reg[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_off[i] + 16u, 0, 0);
+      a_off[i] += (unsigned)(BK * p.cout) * EB;
     }
     const bool mok = kt * BK + i_row < m_count;
     int oy, ox;
@@ -469,7 +512,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradParams p) {
 #pragma unroll
     for (int j = 0; j < B_CPT; ++j) {
       const bool ok = mok & i_cok[j] & ((unsigned)(iy0 + i_dy[j]) < (unsigned)p.h) & ((unsigned)(ix0 + i_dx[j]) < (unsigned)p.w);
-      b_reg[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, pred_off(pixoff + i_tconst[j], ok), 0, 0);
+      b_reg[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, pred_off(pixoff + i_tconst[j], ok), 0, 0);
+      if constexpr (F32IN) b_reg[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, pred_off(pixoff + i_tconst[j] + 16u, ok), 0, 0);
     }
     if constexpr (INCR) {
       // advance BK pixels: columns wrap into rows, rows into the next image (at most once: ho*wo >= 2*BK)
@@ -483,13 +527,33 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradParams p) {
       s_imgoff += wrap ? img_bytes : 0u;
     }
   };
+  auto to_bf16 = [&](const u32x4 (&r)[AL]) -> u32x4 {
+    if constexpr (!F32IN) return r[0];
+    u32x4 v;
+    v.x = pack_bf2(__uint_as_float(r[0].x), __uint_as_float(r[0].y));
+    v.y = pack_bf2(__uint_as_float(r[0].z), __uint_as_float(r[0].w));
+    v.z = pack_bf2(__uint_as_float(r[AL - 1].x), __uint_as_float(r[AL - 1].y));
+    v.w = pack_bf2(__uint_as_float(r[AL - 1].z), __uint_as_float(r[AL - 1].w));
+    return v;
+  };
   auto store_tiles = [&](int buf) {
     unsigned short *As = smem + buf * (A_ELEMS + B_ELEMS);
     unsigned short *Bs = As + A_ELEMS;
 #pragma unroll
-    for (int i = 0; i < A_PASSES; ++i) *reinterpret_cast<u32x4 *>(As + (a_k0 + i * A_KRPP) * LDA + a_mv * 8) = a_reg[i];
+    for (int i = 0; i < A_PASSES; ++i) *reinterpret_cast<u32x4 *>(As + (a_k0 + i * A_KRPP) * LDA + a_mv * 8) = to_bf16(a_reg[i]);
+    if constexpr (F32IN) {
+      if (do_bias) {                   // every K-step's rows exactly once, in order, from the fp32 values
 #pragma unroll
-    for (int j = 0; j < B_CPT; ++j) *reinterpret_cast<u32x4 *>(Bs + i_row * LDB + (i_nv0 + j * B_TPR) * 8) = b_reg[j];
+        for (int i = 0; i < A_PASSES; ++i) {
+          bsum[0] += __uint_as_float(a_reg[i][0].x); bsum[1] += __uint_as_float(a_reg[i][0].y);
+          bsum[2] += __uint_as_float(a_reg[i][0].z); bsum[3] += __uint_as_float(a_reg[i][0].w);
+          bsum[4] += __uint_as_float(a_reg[i][AL - 1].x); bsum[5] += __uint_as_float(a_reg[i][AL - 1].y);
+          bsum[6] += __uint_as_float(a_reg[i][AL - 1].z); bsum[7] += __uint_as_float(a_reg[i][AL - 1].w);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < B_CPT; ++j) *reinterpret_cast<u32x4 *>(Bs + i_row * LDB + (i_nv0 + j * B_TPR) * 8) = to_bf16(b_reg[j]);
   };
 
   f32x16 acc[TM][TN];
@@ -526,6 +590,25 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradParams p) {
     __syncthreads();
   }
 
+  if constexpr (F32IN) {
+    if (do_bias) {                     // loader rows (a_k0) summed through LDS in a fixed order; the K loop ended with a barrier
+      float *sh = reinterpret_cast<float *>(smem);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sh[tid * 8 + k] = bsum[k];
+      __syncthreads();
+      if (a_k0 == 0 && a_cok) {
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = sh[a_mv * 8 + k];
+        for (int r = 1; r < A_KRPP; ++r)
+#pragma unroll
+          for (int k = 0; k < 8; ++k) t[k] += sh[(r * MV + a_mv) * 8 + k];
+        float *dst = p.db + (long long)split * p.cout + a_col;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dst[k] = (p.accumulate ? dst[k] : 0.f) + t[k];
+      }
+    }
+  }
   float *out = p.out + (long long)split * p.cout * p.ncols;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -591,7 +674,7 @@ static int validate_bf16(const mvg_conv_desc *d) {
 }
 
 template <bool DGRAD>
-static int launch_igemm_bf16(IgemmParams &p, hipStream_t st) {
+static int launch_igemm_bf16(IgemmParams &p, hipStream_t st, bool f32io = false) {
   const int bn = p.ncols >= 128 ? 128 : 64;
   p.ntiles = ceil_div(p.ncols, bn);
   p.splits = 1;
@@ -612,7 +695,15 @@ static int launch_igemm_bf16(IgemmParams &p, hipStream_t st) {
   MVG_REQUIRE(tiles < (1LL << 31), "bf16 conv: grid too large");
   if (tiles <= 0) return 0;
   dim3 grid((unsigned)tiles), block(256);
-  if (bn == 128) {
+  if (f32io) {
+    if (bn == 128) {
+      if (fasta) hipLaunchKernelGGL((igemm_bf16_kernel<128, DGRAD, true, true>), grid, block, 0, st, p);
+      else hipLaunchKernelGGL((igemm_bf16_kernel<128, DGRAD, false, true>), grid, block, 0, st, p);
+    } else {
+      if (fasta) hipLaunchKernelGGL((igemm_bf16_kernel<64, DGRAD, true, true>), grid, block, 0, st, p);
+      else hipLaunchKernelGGL((igemm_bf16_kernel<64, DGRAD, false, true>), grid, block, 0, st, p);
+    }
+  } else if (bn == 128) {
     if (fasta) hipLaunchKernelGGL((igemm_bf16_kernel<128, DGRAD, true>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((igemm_bf16_kernel<128, DGRAD, false>), grid, block, 0, st, p);
   } else {
@@ -648,9 +739,10 @@ int mvg_cast_weights_bf16(const mvg_conv_desc *d, const float *w, int cin_src, v
   return check_launch("cast_weights_bf16");
 }
 
-int mvg_conv_fprop_bf16(const mvg_conv_desc *d, const void *x, const void *wgt, void *y, const float *bias, int relu,
-                        float *stats, void *stream) {
+static int fprop_bf16_impl(const mvg_conv_desc *d, const void *x, const void *wgt, void *y, const float *bias, int relu,
+                           float *stats, void *stream, bool f32io) {
   if (validate_bf16(d)) return 2;
+  const long long EA = f32io ? 4 : 2;
   IgemmParams p;
   memset(&p, 0, sizeof(p));
   p.a = (const float *)x;
@@ -682,7 +774,7 @@ int mvg_conv_fprop_bf16(const mvg_conv_desc *d, const void *x, const void *wgt, 
   p.tap_ns = d->s;
   p.tap_step = 1;
   p.cls_step = 1;
-  p.a_group_bytes = 2ll * d->n * p.src_img_stride;
+  p.a_group_bytes = EA * d->n * p.src_img_stride;
   p.b_bytes = 2ll * d->cout * p.ktotal;
   MVG_REQUIRE(p.a_group_bytes < 0x7FFFFFF0ll && p.b_bytes < 0x7FFFFFF0ll, "bf16 conv: a group / the weights exceed 2 GiB");
   MVG_REQUIRE(p.rows_per_group * (long long)d->cout < (1ll << 31), "bf16 conv: a group of the output exceeds 2^31 elements");
@@ -697,12 +789,19 @@ int mvg_conv_fprop_bf16(const mvg_conv_desc *d, const void *x, const void *wgt, 
   ProfScope ps(lin ? MVG_K_LINEAR_FPROP : MVG_K_CONV_FPROP, (hipStream_t)stream, flops, bytes);
   p.ncls = 1;
   class_from_params(p.cls[0], p);
-  return launch_igemm_bf16<false>(p, (hipStream_t)stream);
+  return launch_igemm_bf16<false>(p, (hipStream_t)stream, f32io);
 }
 
-int mvg_conv_dgrad_bf16(const mvg_conv_desc *d, const void *dy, const void *wgt_crsk, void *dx, const void *mask,
-                        const void *addend, void *stream) {
+int mvg_conv_fprop_bf16(const mvg_conv_desc *d, const void *x, const void *wgt, void *y, const float *bias, int relu,
+                        float *stats, void *stream) {
+  return fprop_bf16_impl(d, x, wgt, y, bias, relu, stats, stream, false);
+}
+
+static int dgrad_bf16_impl(const mvg_conv_desc *d, const void *dy, const void *wgt_crsk, void *dx, const void *mask,
+                           const void *addend, void *stream, bool f32io) {
   if (validate_bf16(d)) return 2;
+  const long long EA = f32io ? 4 : 2;
+  MVG_REQUIRE(!f32io || d->stride == 1, "bf16 dgrad with fp32 operands: stride 1 only");
   IgemmParams p;
   memset(&p, 0, sizeof(p));
   p.a = (const float *)dy;
@@ -730,7 +829,7 @@ int mvg_conv_dgrad_bf16(const mvg_conv_desc *d, const void *dy, const void *wgt_
   p.imgs_per_group = d->n;
   p.full_h = d->h;
   p.full_w = d->w;
-  p.a_group_bytes = 2ll * d->n * p.src_img_stride;
+  p.a_group_bytes = EA * d->n * p.src_img_stride;
   p.b_bytes = 2ll * d->cin * p.b_row_len;
   MVG_REQUIRE(p.a_group_bytes < 0x7FFFFFF0ll && p.b_bytes < 0x7FFFFFF0ll, "bf16 conv: a group / the weights exceed 2 GiB");
   MVG_REQUIRE((long long)d->n * d->h * d->w * d->cin < (1ll << 31), "bf16 conv: a group of dx exceeds 2^31 elements");
@@ -801,7 +900,29 @@ int mvg_conv_dgrad_bf16(const mvg_conv_desc *d, const void *dy, const void *wgt_
       cls_k[j - 1] = tk;
     }
   m.no_remap = m.ncls > 1;
-  return launch_igemm_bf16<true>(m, (hipStream_t)stream);
+  return launch_igemm_bf16<true>(m, (hipStream_t)stream, f32io);
+}
+
+int mvg_conv_dgrad_bf16(const mvg_conv_desc *d, const void *dy, const void *wgt_crsk, void *dx, const void *mask,
+                        const void *addend, void *stream) {
+  return dgrad_bf16_impl(d, dy, wgt_crsk, dx, mask, addend, stream, false);
+}
+
+static mvg_conv_desc linear_desc_bf16(int rows, int fin, int fout) {
+  mvg_conv_desc d = {1, rows, 1, 1, fin, fout, 1, 1, 1, 0, 1, 1};
+  return d;
+}
+
+int mvg_linear_fprop_mixed(const float *x, const void *w_bf16, const float *bias, int relu, float *y, int rows, int fin, int fout,
+                           void *stream) {
+  const mvg_conv_desc d = linear_desc_bf16(rows, fin, fout);
+  return fprop_bf16_impl(&d, x, w_bf16, y, bias, relu, nullptr, stream, true);
+}
+
+int mvg_linear_dgrad_mixed(const float *dy, const void *wt_bf16, const float *mask, const float *addend, float *dx, int rows,
+                           int fin, int fout, void *stream) {
+  const mvg_conv_desc d = linear_desc_bf16(rows, fin, fout);
+  return dgrad_bf16_impl(&d, dy, wt_bf16, dx, mask, addend, stream, true);
 }
 
 static void wgrad_bf16_tile(const mvg_conv_desc *d, int &bm, int &bn) {
@@ -827,9 +948,11 @@ int mvg_conv_wgrad_splits_bf16(const mvg_conv_desc *d) {
   return (int)want;
 }
 
-int mvg_conv_wgrad_bf16(const mvg_conv_desc *d, const void *x, const void *dy, float *dw, float *workspace, int splits,
-                        int accumulate, void *stream) {
+static int wgrad_bf16_impl(const mvg_conv_desc *d, const void *x, const void *dy, float *dw, float *db, float *workspace,
+                           int splits, int accumulate, void *stream, bool f32in) {
   if (validate_bf16(d)) return 2;
+  const long long EB = f32in ? 4 : 2;
+  MVG_REQUIRE(!db || f32in, "wgrad_bf16: the bias gradient rides on the fp32-operand form only");
   MVG_REQUIRE(splits >= 1, "wgrad_bf16: splits < 1");
   MVG_REQUIRE(splits == 1 || workspace != nullptr, "wgrad_bf16: workspace required for splits > 1");
   WgradParams p;
@@ -849,13 +972,13 @@ int mvg_conv_wgrad_bf16(const mvg_conv_desc *d, const void *x, const void *dy, f
   p.ncols = d->r * d->s * d->cin;
   p.pixels = (long long)d->groups * d->n * d->ho * d->wo;
   p.pixels_per_split = ((p.pixels + splits - 1) / splits + 63) / 64 * 64;
-  p.x_bytes = 2ll * d->groups * d->n * d->h * d->w * d->cin;
+  p.x_bytes = EB * d->groups * d->n * d->h * d->w * d->cin;
   p.ohw_div = make_fastdiv((unsigned)(d->ho * d->wo));
   p.wo_div = make_fastdiv((unsigned)d->wo);
   p.cin_div = make_fastdiv((unsigned)d->cin);
   p.s_div = make_fastdiv((unsigned)d->s);
-  MVG_REQUIRE(p.pixels_per_split * d->cout * 2ll < 0x7FFFFFF0ll, "wgrad_bf16: split too large for 32-bit offsets");
-  MVG_REQUIRE(2ll * (p.pixels_per_split / (d->ho * d->wo) + 2) * d->h * d->w * d->cin < 0x7FFFFFF0ll,
+  MVG_REQUIRE(p.pixels_per_split * d->cout * EB < 0x7FFFFFF0ll, "wgrad_bf16: split too large for 32-bit offsets");
+  MVG_REQUIRE(EB * (p.pixels_per_split / (d->ho * d->wo) + 2) * d->h * d->w * d->cin < 0x7FFFFFF0ll,
               "wgrad_bf16: split too large for 32-bit offsets");
   int bm, bn;
   wgrad_bf16_tile(d, bm, bn);
@@ -863,6 +986,8 @@ int mvg_conv_wgrad_bf16(const mvg_conv_desc *d, const void *x, const void *dy, f
   p.ntiles = ceil_div(p.ncols, bn);
   p.out = splits == 1 ? dw : workspace;
   p.accumulate = (splits == 1) ? accumulate : 0;
+  float *db_slab = workspace ? workspace + (size_t)splits * d->cout * p.ncols : nullptr;
+  p.db = db ? (splits == 1 ? db : db_slab) : nullptr;
   hipStream_t st = (hipStream_t)stream;
   const bool lin = d->r == 1 && d->s == 1 && d->h == 1 && d->w == 1;
   {
@@ -874,10 +999,11 @@ int mvg_conv_wgrad_bf16(const mvg_conv_desc *d, const void *x, const void *dy, f
     MVG_REQUIRE((long long)p.mtiles * p.ntiles * splits < (1LL << 31), "wgrad_bf16: grid too large");
     dim3 grid(p.mtiles * p.ntiles * splits), block(256);
     const bool incr = (long long)d->ho * d->wo >= 128;       // at most one image wrap per 64-pixel step
-#define MVG_WGRAD_BF16(BM_, BN_)                                                                  \
-  do {                                                                                            \
-    if (incr) hipLaunchKernelGGL((wgrad_bf16_kernel<BM_, BN_, true>), grid, block, 0, st, p);     \
-    else hipLaunchKernelGGL((wgrad_bf16_kernel<BM_, BN_, false>), grid, block, 0, st, p);         \
+#define MVG_WGRAD_BF16(BM_, BN_)                                                                          \
+  do {                                                                                                    \
+    if (f32in) hipLaunchKernelGGL((wgrad_bf16_kernel<BM_, BN_, false, true>), grid, block, 0, st, p);     \
+    else if (incr) hipLaunchKernelGGL((wgrad_bf16_kernel<BM_, BN_, true>), grid, block, 0, st, p);        \
+    else hipLaunchKernelGGL((wgrad_bf16_kernel<BM_, BN_, false>), grid, block, 0, st, p);                 \
   } while (0)
     if (bm == 128 && bn == 128) MVG_WGRAD_BF16(128, 128);
     else if (bm == 64 && bn == 128) MVG_WGRAD_BF16(64, 128);
@@ -895,8 +1021,26 @@ int mvg_conv_wgrad_bf16(const mvg_conv_desc *d, const void *x, const void *dy, f
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, workspace, dw, n / 4, splits, accumulate,
                        lanes);
     if (check_launch("wgrad_reduce")) return 1;
+    if (db) {
+      const long long nb = d->cout;
+      const long long bblocks = (nb / 4 + 256 / lanes - 1) / (256 / lanes);
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)bblocks), dim3(256), 0, st, db_slab, db, nb / 4, splits, accumulate,
+                         lanes);
+      if (check_launch("wgrad_reduce(bias)")) return 1;
+    }
   }
   return 0;
+}
+
+int mvg_conv_wgrad_bf16(const mvg_conv_desc *d, const void *x, const void *dy, float *dw, float *workspace, int splits,
+                        int accumulate, void *stream) {
+  return wgrad_bf16_impl(d, x, dy, dw, nullptr, workspace, splits, accumulate, stream, false);
+}
+
+int mvg_linear_wgrad_mixed(const float *x, const float *dy, float *dw, float *db, int rows, int fin, int fout, float *workspace,
+                           int splits, int accumulate, void *stream) {
+  const mvg_conv_desc d = linear_desc_bf16(rows, fin, fout);
+  return wgrad_bf16_impl(&d, x, dy, dw, db, workspace, splits, accumulate, stream, true);
 }
 
 }  // extern "C"

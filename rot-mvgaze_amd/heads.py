@@ -101,6 +101,13 @@ class _Mlp:
         self._wp: List[Optional[Tensor]] = [None] * n_layers
         self._bp: List[Optional[Tensor]] = [None] * n_layers
         self.in_width = self.fin_p[0]
+        # bf16 path ("mixed"): fp32 tensors, matrix products on the bf16 cores against bf16 weight copies that
+        # forward() makes once per step (w [fout][fin] and its transpose for backward-data)
+        self.mixed = False
+        self._wbf: List[Optional[tuple]] = [None] * n_layers
+
+    def _use_mixed(self, l: int) -> bool:
+        return self.mixed and not self.padded[l] and not (l == self.n - 1 and self.fout[l] <= 4)
 
     def parameters(self):
         out = []
@@ -134,7 +141,11 @@ class _Mlp:
             w, b = self._weights(l)
             last = l == self.n - 1
             y = out if (last and out is not None) else torch.empty(rows, self.fout_p[l], dtype=torch.float32, device=dev)
-            if l == 0 and gen is not None:
+            if self._use_mixed(l):
+                assert gen is None
+                self._wbf[l] = ops.cast_weights_bf16(ConvDesc.linear(1, self.fin_p[l], self.fout_p[l]), w, self.fin_p[l], True)
+                ops.linear_fprop_mixed(cur, self._wbf[l][0], b, not last, y, rows, self.fin_p[l], self.fout_p[l])
+            elif l == 0 and gen is not None:
                 ops.fuser_fprop(gen.img, gen.feat, gen.rel, gen.row_img, gen.row_src, w, b, not last, y, rows, gen.cf, gen.nvec,
                                 self.fout_p[l])
             elif last and self.fout[l] <= 4:
@@ -187,7 +198,9 @@ class _Mlp:
                 def grads(inp=inp, g=g, l=l, fin=fin, fout=fout, aw=aw):
                     # weight AND bias gradient in one launch: the bias gradient (column sums of g) rides on the
                     # kernel that streams g for the weight gradient
-                    if l == 0 and gen is not None:
+                    if self._use_mixed(l):
+                        ops.linear_wgrad_mixed(inp, g, sink.view(self.w[l]), sink.view(self.b[l]), rows, fin, fout, aw)
+                    elif l == 0 and gen is not None:
                         ops.fuser_wgrad(gen.img, gen.feat, gen.rel, gen.row_img, gen.row_src, g, sink.view(self.w[l]),
                                         sink.view(self.b[l]), rows, gen.cf, gen.nvec, fout, aw)
                     else:
@@ -197,12 +210,19 @@ class _Mlp:
                 else:
                     wr.off_path(grads, inp, g)
             # ---- input gradient
+            mixed = self._use_mixed(l)
             if l == 0:
                 dx = dx_out if dx_out is not None else torch.empty(rows, fin, dtype=torch.float32, device=dev)
-                ops.linear_dgrad(g, w, None, dx_addend, dx, rows, fin, fout)
+                if mixed:
+                    ops.linear_dgrad_mixed(g, self._wbf[l][1], None, dx_addend, dx, rows, fin, fout)
+                else:
+                    ops.linear_dgrad(g, w, None, dx_addend, dx, rows, fin, fout)
                 return dx
             dh = torch.empty(rows, fin, dtype=torch.float32, device=dev)
-            ops.linear_dgrad(g, w, hs[l - 1], None, dh, rows, fin, fout)            # (g @ W) * (h > 0)
+            if mixed:
+                ops.linear_dgrad_mixed(g, self._wbf[l][1], hs[l - 1], None, dh, rows, fin, fout)
+            else:
+                ops.linear_dgrad(g, w, hs[l - 1], None, dh, rows, fin, fout)        # (g @ W) * (h > 0)
             g = dh
         raise AssertionError("unreachable")
 
@@ -222,6 +242,7 @@ class FusionHead:
         # MVG_FUSED_INPUT=0: materialise the fuser / head inputs with rotcat kernels instead (A/B switch)
         import os as _os
         self.fused_input = _os.environ.get("MVG_FUSED_INPUT", "1") != "0"
+        self.mixed = False                        # bf16 path: Linear products on the bf16 matrix cores (set by the model per call)
         self.kin = self.fusers[0].in_width            # row length of the fuser input (zero-padded)
         self.hin = self.heads[0].in_width
         self._idx_cache: Dict[Tuple[int, str], dict] = {}
@@ -289,6 +310,8 @@ class FusionHead:
         dev = img_feat.device
         ix = self._indices(V, dev)
         D, I, NV = ix["D"], self.I, NUM_FEAT_VEC
+        for m in [self.lifter] + self.fusers + self.heads:
+            m.mixed = self.mixed
         hl, lifted = self.lifter.forward(img_feat.reshape(V * B, cf))
         rel = torch.empty(D, B, 3, 3, dtype=torch.float32, device=dev)
         ops.relative_rotation(rot.detach().to(torch.float32).contiguous(), ix["vi"], ix["vj"], rel, B, V, D)
@@ -300,7 +323,7 @@ class FusionHead:
         # default / ignore_rotmat variants: rotate + concat run inside the first Linear's operand loader - the
         # fuser input X = [img_feat | R @ F] and the head input [img_feat | F] are never written (the other
         # variants have 9 extra columns / interleaved rows and keep the materialised form)
-        fused_in = self.fused_input and not (self.v.share_feature or self.v.encode_rotmat)
+        fused_in = self.fused_input and not (self.v.share_feature or self.v.encode_rotmat) and not self.mixed
         rt = self._row_tables(V, B, dev) if fused_in else None
         img2d = img_feat.reshape(V * B, cf)
         for it in range(I):

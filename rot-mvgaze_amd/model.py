@@ -314,6 +314,7 @@ class MultiViewGaze(nn.Module):
         if self.compute_dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("compute_dtype must be torch.float32 or torch.bfloat16")
         self._backbone.act_dtype = self.compute_dtype
+        self._head.mixed = self.compute_dtype == torch.bfloat16
         self._sink.active = False
         img_feat = _BackboneFn.apply(self, self.training, len(imgs), *imgs, *self._backbone_params)
         lifted, feats, preds = _HeadFn.apply(self, img_feat, rot, *self._head_params)

@@ -130,6 +130,25 @@ def fuser_wgrad(img_feat, feat, rel, row_img, row_src, dy, dw, db, rows, cf, nve
           "fuser_wgrad")
 
 
+# ---- Linear layers of the fusion block in the bf16 path: fp32 tensors, bf16 matrix product (weights = bf16 copies)
+def linear_fprop_mixed(x, w_bf16, bias, relu, y, rows, fin, fout):
+    check(lib().mvg_linear_fprop_mixed(_p(x), _p(w_bf16), _p(bias), int(relu), _p(y), rows, fin, fout, _s()), "linear_fprop_mixed")
+
+
+def linear_dgrad_mixed(dy, wt_bf16, mask, addend, dx, rows, fin, fout):
+    check(lib().mvg_linear_dgrad_mixed(_p(dy), _p(wt_bf16), _p(mask), _p(addend), _p(dx), rows, fin, fout, _s()), "linear_dgrad_mixed")
+
+
+def linear_wgrad_mixed(x, dy, dw, db, rows, fin, fout, accumulate=False):
+    d = ConvDesc.linear(rows, fin, fout)
+    splits = lib().mvg_conv_wgrad_splits_bf16(C.byref(d))
+    if splits < 1:
+        check(1, "conv_wgrad_splits_bf16")
+    ws = torch.empty(splits * (fout * fin + fout), dtype=torch.float32, device=x.device) if splits > 1 else None
+    check(lib().mvg_linear_wgrad_mixed(_p(x), _p(dy), _p(dw), _p(db), rows, fin, fout, _p(ws), splits, int(accumulate), _s()),
+          "linear_wgrad_mixed")
+
+
 def _linear_ws(x: Tensor, rows: int, fin: int, fout: int):
     n = lib().mvg_linear_workspace_floats(rows, fin, fout)
     return torch.empty(n, dtype=torch.float32, device=x.device), n

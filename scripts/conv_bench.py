@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-shape throughput of the implicit-GEMM conv kernels over the ResNet-18/50 layer shapes
-(synthetic data, N images per group x G groups).  Usage: conv_bench.py [depth] [N] [G] [iters]"""
+(synthetic data, N images per group x G groups).  Usage: conv_bench.py [depth] [N] [G] [iters] [f32|bf16]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -14,13 +14,15 @@ depth = int(sys.argv[1]) if len(sys.argv) > 1 else 18
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 G = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 20
+bf16 = len(sys.argv) > 5 and sys.argv[5] == "bf16"
+adt = torch.bfloat16 if bf16 else torch.float32
 dev = torch.device("cuda:0")
 spec = backbone_spec(depth)
 # walk the net to get input sizes
 shapes = {}
 H = 224
 c = spec.stem
-shapes[(4, c.cout, c.k, c.stride, c.pad, H)] = 1
+shapes[(8 if bf16 else 4, c.cout, c.k, c.stride, c.pad, H)] = 1
 H = (H + 2 * c.pad - c.k) // c.stride + 1
 H = (H + 2 - 3) // 2 + 1
 for blk in spec.blocks:
@@ -43,21 +45,22 @@ def timeit(fn):
     return (time.perf_counter() - t0) / iters
 
 tot = {"fprop": [0, 0], "dgrad": [0, 0], "wgrad": [0, 0]}
-print(f"ResNet-{depth}  N={N} G={G}")
+print(f"ResNet-{depth}  N={N} G={G}  {'bf16' if bf16 else 'fp32'}")
 print(f"{'cin':>5} {'cout':>5} k s {'hw':>4} cnt | {'fprop ms':>9} {'TF':>6} | {'dgrad ms':>9} {'TF':>6} | {'wgrad ms':>9} {'TF':>6}")
 for (cin, cout, k, st, pad, h), cnt in shapes.items():
     d = ConvDesc.make(G, N, h, h, cin, cout, k, st, pad)
-    x = torch.randn(G, N, h, h, cin, device=dev)
-    w = torch.randn(cout, k, k, cin, device=dev) * 0.05
-    y = torch.empty(G, N, d.ho, d.wo, cout, device=dev)
-    P, rpp = ops.conv_stats_partials(d)
+    x = torch.randn(G, N, h, h, cin, device=dev).to(adt)
+    w32 = torch.randn(cout, k, k, cin, device=dev) * 0.05
+    w, wt = ops.cast_weights_bf16(d, w32, cin, True) if bf16 else (w32, w32)
+    y = torch.empty(G, N, d.ho, d.wo, cout, device=dev, dtype=adt)
+    P, rpp = ops.conv_stats_partials(d, bf16)
     stats = torch.empty(G, P, 2, cout, device=dev)
-    gy = torch.randn_like(y)
+    gy = torch.randn(y.shape, device=dev).to(adt)
     dx = torch.empty_like(x)
-    dw = torch.empty_like(w)
+    dw = torch.empty_like(w32)
     flops = 2.0 * G * N * d.ho * d.wo * cout * k * k * cin
     tf = timeit(lambda: ops.conv_fprop(d, x, w, y, None, False, stats))
-    td = timeit(lambda: ops.conv_dgrad(d, gy, w, dx)) if cin > 4 else float("nan")
+    td = timeit(lambda: ops.conv_dgrad(d, gy, wt, dx)) if cin > 8 else float("nan")
     tw = timeit(lambda: ops.conv_wgrad(d, x, gy, dw))
     print(f"{cin:5d} {cout:5d} {k} {st} {h:4d} {cnt:3d} | {tf*1e3:9.3f} {flops/tf/1e12:6.1f} | {td*1e3:9.3f} {flops/td/1e12:6.1f} | {tw*1e3:9.3f} {flops/tw/1e12:6.1f}")
     for name, t in (("fprop", tf), ("dgrad", td), ("wgrad", tw)):

@@ -159,6 +159,38 @@ def test_bf16_conv_fprop_dgrad_wgrad(case):
     close(dw2[..., :cin_src], 2 * dw_ref, 2e-5, "wgrad accumulate")
 
 
+@pytest.mark.parametrize("rows,fin,fout,relu", [(3584, 3584, 3584, True), (384, 2048, 1536, False), (70, 3584, 512, True),
+                                                (1000, 512, 1536, True)])
+def test_mixed_linear_fp32_tensors_bf16_products(rows, fin, fout, relu):
+    """mvg_linear_*_mixed: fp32 tensors in memory, operands rounded to bf16 in the loaders, fp32 accumulation and
+    fp32 results == float64 arithmetic on the rounded operands to fp32 accumulation noise (no output rounding)."""
+    from rot_mvgaze_amd import ops
+    from rot_mvgaze_amd._lib import ConvDesc
+    x, w, b = rnd((rows, fin), 1), rnd((fout, fin), 2, "w", fin ** -0.5), rnd((fout,), 3, "b")
+    xq, wq = bf(x).double(), bf(w).double()
+    xr, wr, br = xq.clone().requires_grad_(True), wq.clone().requires_grad_(True), b.double().requires_grad_(True)
+    pre = F.linear(xr, wr, br)
+    xd, wd, bd = x.to(dev()), w.to(dev()), b.to(dev())
+    wk, wt = ops.cast_weights_bf16(ConvDesc.linear(1, fin, fout), wd, fin, True)
+    y = torch.full((rows, fout), float("nan"), device=dev())
+    ops.linear_fprop_mixed(xd, wk, bd, relu, y, rows, fin, fout)
+    close(y, F.relu(pre) if relu else pre, 2e-5, "fprop")
+    gy = rnd((rows, fout), 4)
+    g = gy.to(dev()) * (y > 0) if relu else gy.to(dev())
+    gq = bf(g).double().cpu()                                  # the backward kernels round dy the same way
+    mask, add = rnd((rows, fin), 8).to(dev()), rnd((rows, fin), 9).to(dev())
+    dx = add.clone()
+    ops.linear_dgrad_mixed(g, wt, mask, dx, dx, rows, fin, fout)
+    close(dx, (gq @ wq) * (mask.cpu() > 0) + add.cpu().double(), 2e-5, "dgrad (mask + addend)")
+    dw, db = torch.full((fout, fin), float("nan"), device=dev()), torch.full((fout,), float("nan"), device=dev())
+    ops.linear_wgrad_mixed(xd, g, dw, db, rows, fin, fout, False)
+    close(dw, gq.T @ xq, 2e-5, "wgrad")
+    close(db, g.double().cpu().sum(0), 1e-5, "bias gradient (fp32 column sums)")
+    ops.linear_wgrad_mixed(xd, g, dw, db, rows, fin, fout, True)
+    close(dw, 2 * (gq.T @ xq), 2e-5, "wgrad accumulate")
+    close(db, 2 * g.double().cpu().sum(0), 1e-5, "bias gradient accumulate")
+
+
 @pytest.mark.parametrize("G,rows,C,residual", [(2, 3000, 64, False), (3, 777, 256, True), (1, 50, 2048, True)])
 def test_bf16_batchnorm_passes(G, rows, C, residual):
     """bn_apply / bn_bwd_reduce / bn_bwd_apply with bf16 activations == the fp32 kernels fed with the same
