@@ -173,8 +173,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T *__restrict__ y, 
                                                        const T *__restrict__ residual,
                                                        const float *__restrict__ res_scale,
                                                        const float *__restrict__ res_shift, int relu,
-                                                       T *__restrict__ out, long long n4_per_group, int c4n, int c) {
+                                                       T *__restrict__ out, long long nw_per_group, int cwn, int c) {
   typedef Elem<T> E;
+  constexpr int W = E::W;                 // float4 groups per 16-byte access (fp32: 1, bf16: 2)
   // res_scale / res_shift: the residual is the RAW output of the block's downsample conv and its BatchNorm
   // is applied here (the normalised downsample map is never written: resnet.py:88-93,137-145)
   const float4 *rs4 = res_scale ? reinterpret_cast<const float4 *>(res_scale + (long long)blockIdx.y * c) : nullptr;
@@ -182,38 +183,43 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T *__restrict__ y, 
   const int g = blockIdx.y;
   const float4 *sc4 = reinterpret_cast<const float4 *>(scale + (long long)g * c);
   const float4 *sh4 = reinterpret_cast<const float4 *>(shift + (long long)g * c);
-  const long long base = (long long)g * n4_per_group;
+  const long long base = (long long)g * nw_per_group;
   const long long stride = (long long)gridDim.x * 256;
   long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  int cq = (int)(i % c4n);
-  const int step = (int)(stride % c4n);
-  for (; i < n4_per_group; i += stride) {
-    const float4 v = E::ld4(y, base + i);
-    const float4 a = sc4[cq], b = sh4[cq];
-    // explicit fma: the backward kernels rebuild the ReLU mask from y with the same expression
-    float4 o = make_float4(__builtin_fmaf(v.x, a.x, b.x), __builtin_fmaf(v.y, a.y, b.y), __builtin_fmaf(v.z, a.z, b.z),
-                           __builtin_fmaf(v.w, a.w, b.w));
-    if (residual) {
-      float4 r = E::ld4(residual, base + i);
-      if (rs4) {
-        const float4 ra = rs4[cq], rb = rh4[cq];
-        r = make_float4(__builtin_fmaf(r.x, ra.x, rb.x), __builtin_fmaf(r.y, ra.y, rb.y), __builtin_fmaf(r.z, ra.z, rb.z),
-                        __builtin_fmaf(r.w, ra.w, rb.w));
+  int cq = (int)(i % cwn);
+  const int step = (int)(stride % cwn);
+  for (; i < nw_per_group; i += stride) {
+    float4 v[W], r[W], o[W];
+    E::ldw(y, base + i, v);
+    if (residual) E::ldw(residual, base + i, r);
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      const float4 a = sc4[cq * W + w], b = sh4[cq * W + w];
+      // explicit fma: the backward kernels rebuild the ReLU mask from y with the same expression
+      o[w] = make_float4(__builtin_fmaf(v[w].x, a.x, b.x), __builtin_fmaf(v[w].y, a.y, b.y), __builtin_fmaf(v[w].z, a.z, b.z),
+                         __builtin_fmaf(v[w].w, a.w, b.w));
+      if (residual) {
+        float4 rr = r[w];
+        if (rs4) {
+          const float4 ra = rs4[cq * W + w], rb = rh4[cq * W + w];
+          rr = make_float4(__builtin_fmaf(rr.x, ra.x, rb.x), __builtin_fmaf(rr.y, ra.y, rb.y), __builtin_fmaf(rr.z, ra.z, rb.z),
+                           __builtin_fmaf(rr.w, ra.w, rb.w));
+        }
+        o[w].x += rr.x;
+        o[w].y += rr.y;
+        o[w].z += rr.z;
+        o[w].w += rr.w;
       }
-      o.x += r.x;
-      o.y += r.y;
-      o.z += r.z;
-      o.w += r.w;
+      if (relu) {
+        o[w].x = fmaxf(o[w].x, 0.f);
+        o[w].y = fmaxf(o[w].y, 0.f);
+        o[w].z = fmaxf(o[w].z, 0.f);
+        o[w].w = fmaxf(o[w].w, 0.f);
+      }
     }
-    if (relu) {
-      o.x = fmaxf(o.x, 0.f);
-      o.y = fmaxf(o.y, 0.f);
-      o.z = fmaxf(o.z, 0.f);
-      o.w = fmaxf(o.w, 0.f);
-    }
-    E::st4(out, base + i, o);
+    E::stw(out, base + i, o);
     cq += step;
-    if (cq >= c4n) cq -= c4n;
+    if (cq >= cwn) cq -= cwn;
   }
 }
 
@@ -226,79 +232,114 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *g, const T 
                                                             const float *__restrict__ invstd,
                                                             const float *__restrict__ mscale,
                                                             const float *__restrict__ mshift, long long rows,
-                                                            long long rows_per_chunk, int c, int c4n, int cw,
+                                                            long long rows_per_chunk, int c, int cwn, int cw,
                                                             float *__restrict__ partial, int chunks, T *dz_out) {
-  __shared__ float4 sh[2][256];
+  typedef Elem<T> E;
+  constexpr int W = E::W;                 // float4 groups per 16-byte access; a "column" below is one such access
+  __shared__ float4 sh[2][256][W];
   const int grp = blockIdx.z;
   const int rl = threadIdx.x / cw, cl = threadIdx.x % cw;
   const int nrl = 256 / cw;
   const int cq = blockIdx.y * cw + cl;
-  const bool cok = cq < c4n;
-  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  const bool cok = cq < cwn;
+  float4 s1[W], s2[W];
+#pragma unroll
+  for (int w = 0; w < W; ++w) s1[w] = s2[w] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (cok) {
-    const float4 mu = reinterpret_cast<const float4 *>(mean + (long long)grp * c)[cq];
-    const float4 is = reinterpret_cast<const float4 *>(invstd + (long long)grp * c)[cq];
-    float4 ma = make_float4(0.f, 0.f, 0.f, 0.f), mb = ma;
-    if (mscale) {
-      ma = reinterpret_cast<const float4 *>(mscale + (long long)grp * c)[cq];
-      mb = reinterpret_cast<const float4 *>(mshift + (long long)grp * c)[cq];
+    float4 mu[W], is[W], ma[W], mb[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      mu[w] = reinterpret_cast<const float4 *>(mean + (long long)grp * c)[cq * W + w];
+      is[w] = reinterpret_cast<const float4 *>(invstd + (long long)grp * c)[cq * W + w];
+      ma[w] = mb[w] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (mscale) {
+        ma[w] = reinterpret_cast<const float4 *>(mscale + (long long)grp * c)[cq * W + w];
+        mb[w] = reinterpret_cast<const float4 *>(mshift + (long long)grp * c)[cq * W + w];
+      }
     }
     const long long r0 = (long long)blockIdx.x * rows_per_chunk;
     long long r1 = r0 + rows_per_chunk;
     if (r1 > rows) r1 = rows;
-    const long long gbase = (long long)grp * rows * c4n;
-    // two rows per iteration with independent loads (the trip count is a runtime value, so the
+    const long long gbase = (long long)grp * rows * cwn;
+    // several rows per iteration with independent loads (the trip count is a runtime value, so the
     // compiler keeps a single row in flight otherwise: latency-bound at 2.9 TB/s)
-    auto row = [&](long long r, float4 &a1, float4 &a2) {
-      const long long off = gbase + r * c4n + cq;
-      float4 d = Elem<T>::ld4(g, off);
-      const float4 v = Elem<T>::ld4(y, off);
-      if (act) {
-        const float4 a = Elem<T>::ld4(act, off);
-        d.x = a.x > 0.f ? d.x : 0.f;
-        d.y = a.y > 0.f ? d.y : 0.f;
-        d.z = a.z > 0.f ? d.z : 0.f;
-        d.w = a.w > 0.f ? d.w : 0.f;
-      } else if (mscale) {       // ReLU without residual: out > 0 <=> fma(y, scale, shift) > 0 (bn_apply_kernel)
-        d.x = __builtin_fmaf(v.x, ma.x, mb.x) > 0.f ? d.x : 0.f;
-        d.y = __builtin_fmaf(v.y, ma.y, mb.y) > 0.f ? d.y : 0.f;
-        d.z = __builtin_fmaf(v.z, ma.z, mb.z) > 0.f ? d.z : 0.f;
-        d.w = __builtin_fmaf(v.w, ma.w, mb.w) > 0.f ? d.w : 0.f;
+    auto row = [&](long long r, float4 (&a1)[W], float4 (&a2)[W]) {
+      const long long off = gbase + r * cwn + cq;
+      float4 d[W], v[W], a[W];
+      E::ldw(g, off, d);
+      E::ldw(y, off, v);
+      if (act) E::ldw(act, off, a);
+#pragma unroll
+      for (int w = 0; w < W; ++w) {
+        if (act) {
+          d[w].x = a[w].x > 0.f ? d[w].x : 0.f;
+          d[w].y = a[w].y > 0.f ? d[w].y : 0.f;
+          d[w].z = a[w].z > 0.f ? d[w].z : 0.f;
+          d[w].w = a[w].w > 0.f ? d[w].w : 0.f;
+        } else if (mscale) {       // ReLU without residual: out > 0 <=> fma(y, scale, shift) > 0 (bn_apply_kernel)
+          d[w].x = __builtin_fmaf(v[w].x, ma[w].x, mb[w].x) > 0.f ? d[w].x : 0.f;
+          d[w].y = __builtin_fmaf(v[w].y, ma[w].y, mb[w].y) > 0.f ? d[w].y : 0.f;
+          d[w].z = __builtin_fmaf(v[w].z, ma[w].z, mb[w].z) > 0.f ? d[w].z : 0.f;
+          d[w].w = __builtin_fmaf(v[w].w, ma[w].w, mb[w].w) > 0.f ? d[w].w : 0.f;
+        }
+        a1[w].x += d[w].x;
+        a1[w].y += d[w].y;
+        a1[w].z += d[w].z;
+        a1[w].w += d[w].w;
+        a2[w].x += d[w].x * ((v[w].x - mu[w].x) * is[w].x);
+        a2[w].y += d[w].y * ((v[w].y - mu[w].y) * is[w].y);
+        a2[w].z += d[w].z * ((v[w].z - mu[w].z) * is[w].z);
+        a2[w].w += d[w].w * ((v[w].w - mu[w].w) * is[w].w);
       }
-      if (dz_out) Elem<T>::st4(dz_out, off, d);      // the masked gradient (may alias g): the apply pass then needs no mask
-      a1.x += d.x;
-      a1.y += d.y;
-      a1.z += d.z;
-      a1.w += d.w;
-      a2.x += d.x * ((v.x - mu.x) * is.x);
-      a2.y += d.y * ((v.y - mu.y) * is.y);
-      a2.z += d.z * ((v.z - mu.z) * is.z);
-      a2.w += d.w * ((v.w - mu.w) * is.w);
+      if (dz_out) E::stw(dz_out, off, d);      // the masked gradient (may alias g): the apply pass then needs no mask
     };
-    float4 t1 = make_float4(0.f, 0.f, 0.f, 0.f), t2 = t1, u1 = t1, u2 = t1, w1 = t1, w2 = t1;
+    constexpr int U = W == 1 ? 4 : 2;          // rows in flight per thread (64 bytes of each tensor)
+    float4 t1[U - 1][W], t2[U - 1][W];
+#pragma unroll
+    for (int u = 0; u < U - 1; ++u)
+#pragma unroll
+      for (int w = 0; w < W; ++w) t1[u][w] = t2[u][w] = make_float4(0.f, 0.f, 0.f, 0.f);
     long long r = r0 + rl;
-    for (; r + 3 * (long long)nrl < r1; r += 4 * (long long)nrl) {
+    for (; r + (U - 1) * (long long)nrl < r1; r += U * (long long)nrl) {
       row(r, s1, s2);
-      row(r + nrl, t1, t2);
-      row(r + 2 * (long long)nrl, u1, u2);
-      row(r + 3 * (long long)nrl, w1, w2);
+#pragma unroll
+      for (int u = 1; u < U; ++u) row(r + u * (long long)nrl, t1[u - 1], t2[u - 1]);
     }
     for (; r < r1; r += nrl) row(r, s1, s2);
-    s1.x += t1.x + (u1.x + w1.x); s1.y += t1.y + (u1.y + w1.y); s1.z += t1.z + (u1.z + w1.z); s1.w += t1.w + (u1.w + w1.w);
-    s2.x += t2.x + (u2.x + w2.x); s2.y += t2.y + (u2.y + w2.y); s2.z += t2.z + (u2.z + w2.z); s2.w += t2.w + (u2.w + w2.w);
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      if constexpr (U == 4) {
+        s1[w].x += t1[0][w].x + (t1[1][w].x + t1[2][w].x); s1[w].y += t1[0][w].y + (t1[1][w].y + t1[2][w].y);
+        s1[w].z += t1[0][w].z + (t1[1][w].z + t1[2][w].z); s1[w].w += t1[0][w].w + (t1[1][w].w + t1[2][w].w);
+        s2[w].x += t2[0][w].x + (t2[1][w].x + t2[2][w].x); s2[w].y += t2[0][w].y + (t2[1][w].y + t2[2][w].y);
+        s2[w].z += t2[0][w].z + (t2[1][w].z + t2[2][w].z); s2[w].w += t2[0][w].w + (t2[1][w].w + t2[2][w].w);
+      } else {
+        s1[w].x += t1[0][w].x; s1[w].y += t1[0][w].y; s1[w].z += t1[0][w].z; s1[w].w += t1[0][w].w;
+        s2[w].x += t2[0][w].x; s2[w].y += t2[0][w].y; s2[w].z += t2[0][w].z; s2[w].w += t2[0][w].w;
+      }
+    }
   }
-  sh[0][threadIdx.x] = s1;
-  sh[1][threadIdx.x] = s2;
+#pragma unroll
+  for (int w = 0; w < W; ++w) {
+    sh[0][threadIdx.x][w] = s1[w];
+    sh[1][threadIdx.x][w] = s2[w];
+  }
   __syncthreads();
   if (rl == 0 && cok) {
     for (int k = 1; k < nrl; ++k) {
-      const float4 a = sh[0][k * cw + cl], b = sh[1][k * cw + cl];
-      s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
-      s2.x += b.x; s2.y += b.y; s2.z += b.z; s2.w += b.w;
+#pragma unroll
+      for (int w = 0; w < W; ++w) {
+        const float4 a = sh[0][k * cw + cl][w], b = sh[1][k * cw + cl][w];
+        s1[w].x += a.x; s1[w].y += a.y; s1[w].z += a.z; s1[w].w += a.w;
+        s2[w].x += b.x; s2[w].y += b.y; s2[w].z += b.z; s2[w].w += b.w;
+      }
     }
     float4 *p = reinterpret_cast<float4 *>(partial + (((long long)grp * chunks + blockIdx.x) * 2) * c);
-    p[cq] = s1;
-    p[c4n + cq] = s2;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      p[cq * W + w] = s1[w];
+      p[c / 4 + cq * W + w] = s2[w];
+    }
   }
 }
 
@@ -353,47 +394,52 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
                                                            const float *__restrict__ s1, const float *__restrict__ s2,
                                                            const float *__restrict__ mscale,
                                                            const float *__restrict__ mshift,
-                                                           long long n4_per_group, float inv_rows, int c4n, int c,
+                                                           long long nw_per_group, float inv_rows, int cwn, int c,
                                                            T *__restrict__ dy, T *__restrict__ dz_out) {
   typedef Elem<T> E;
+  constexpr int W = E::W;
   const int grp = blockIdx.y;
   const float4 *mu4 = reinterpret_cast<const float4 *>(mean + (long long)grp * c);
   const float4 *is4 = reinterpret_cast<const float4 *>(invstd + (long long)grp * c);
   const float4 *ga4 = reinterpret_cast<const float4 *>(gamma);
   const float4 *a4 = reinterpret_cast<const float4 *>(s1 + (long long)grp * c);
   const float4 *b4 = reinterpret_cast<const float4 *>(s2 + (long long)grp * c);
-  const long long base = (long long)grp * n4_per_group;
+  const long long base = (long long)grp * nw_per_group;
   const long long stride = (long long)gridDim.x * 256;
   long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  int cq = (int)(i % c4n);
-  const int step = (int)(stride % c4n);
-  for (; i < n4_per_group; i += stride) {
-    float4 d = E::ld4(g, base + i);
-    const float4 v = E::ld4(y, base + i);
-    if (act) {
-      const float4 a = E::ld4(act, base + i);
-      d.x = a.x > 0.f ? d.x : 0.f;
-      d.y = a.y > 0.f ? d.y : 0.f;
-      d.z = a.z > 0.f ? d.z : 0.f;
-      d.w = a.w > 0.f ? d.w : 0.f;
-    } else if (mscale) {
-      const float4 ma = reinterpret_cast<const float4 *>(mscale + (long long)grp * c)[cq];
-      const float4 mb = reinterpret_cast<const float4 *>(mshift + (long long)grp * c)[cq];
-      d.x = __builtin_fmaf(v.x, ma.x, mb.x) > 0.f ? d.x : 0.f;
-      d.y = __builtin_fmaf(v.y, ma.y, mb.y) > 0.f ? d.y : 0.f;
-      d.z = __builtin_fmaf(v.z, ma.z, mb.z) > 0.f ? d.z : 0.f;
-      d.w = __builtin_fmaf(v.w, ma.w, mb.w) > 0.f ? d.w : 0.f;
+  int cq = (int)(i % cwn);
+  const int step = (int)(stride % cwn);
+  for (; i < nw_per_group; i += stride) {
+    float4 d[W], v[W], a[W], o[W];
+    E::ldw(g, base + i, d);
+    E::ldw(y, base + i, v);
+    if (act) E::ldw(act, base + i, a);
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      const int ci = cq * W + w;
+      if (act) {
+        d[w].x = a[w].x > 0.f ? d[w].x : 0.f;
+        d[w].y = a[w].y > 0.f ? d[w].y : 0.f;
+        d[w].z = a[w].z > 0.f ? d[w].z : 0.f;
+        d[w].w = a[w].w > 0.f ? d[w].w : 0.f;
+      } else if (mscale) {
+        const float4 ma = reinterpret_cast<const float4 *>(mscale + (long long)grp * c)[ci];
+        const float4 mb = reinterpret_cast<const float4 *>(mshift + (long long)grp * c)[ci];
+        d[w].x = __builtin_fmaf(v[w].x, ma.x, mb.x) > 0.f ? d[w].x : 0.f;
+        d[w].y = __builtin_fmaf(v[w].y, ma.y, mb.y) > 0.f ? d[w].y : 0.f;
+        d[w].z = __builtin_fmaf(v[w].z, ma.z, mb.z) > 0.f ? d[w].z : 0.f;
+        d[w].w = __builtin_fmaf(v[w].w, ma.w, mb.w) > 0.f ? d[w].w : 0.f;
+      }
+      const float4 mu = mu4[ci], is = is4[ci], ga = ga4[ci], sa = a4[ci], sb = b4[ci];
+      o[w].x = ga.x * is.x * (d[w].x - sa.x * inv_rows - (v[w].x - mu.x) * is.x * (sb.x * inv_rows));
+      o[w].y = ga.y * is.y * (d[w].y - sa.y * inv_rows - (v[w].y - mu.y) * is.y * (sb.y * inv_rows));
+      o[w].z = ga.z * is.z * (d[w].z - sa.z * inv_rows - (v[w].z - mu.z) * is.z * (sb.z * inv_rows));
+      o[w].w = ga.w * is.w * (d[w].w - sa.w * inv_rows - (v[w].w - mu.w) * is.w * (sb.w * inv_rows));
     }
-    const float4 mu = mu4[cq], is = is4[cq], ga = ga4[cq], sa = a4[cq], sb = b4[cq];
-    float4 o;
-    o.x = ga.x * is.x * (d.x - sa.x * inv_rows - (v.x - mu.x) * is.x * (sb.x * inv_rows));
-    o.y = ga.y * is.y * (d.y - sa.y * inv_rows - (v.y - mu.y) * is.y * (sb.y * inv_rows));
-    o.z = ga.z * is.z * (d.z - sa.z * inv_rows - (v.z - mu.z) * is.z * (sb.z * inv_rows));
-    o.w = ga.w * is.w * (d.w - sa.w * inv_rows - (v.w - mu.w) * is.w * (sb.w * inv_rows));
-    if (dz_out) E::st4(dz_out, base + i, d);
-    E::st4(dy, base + i, o);
+    if (dz_out) E::stw(dz_out, base + i, d);
+    E::stw(dy, base + i, o);
     cq += step;
-    if (cq >= c4n) cq -= c4n;
+    if (cq >= cwn) cq -= cwn;
   }
 }
 
@@ -660,9 +706,11 @@ static int bn_apply_impl(const T *y, const float *scale, const float *shift, con
               "bn_apply: res_scale / res_shift go together and need a residual");
   hipStream_t st = (hipStream_t)stream;
   const long long n4 = rows_per_group * (c / 4);
+  constexpr int W = Elem<T>::W;
+  MVG_REQUIRE(c % (4 * W) == 0, "bn_apply: c must be a multiple of %d", 4 * W);
   ProfScope ps(MVG_K_BN_APPLY, st, 0.0, 4.0 * Elem<T>::kBytes * groups * (double)n4 * (residual ? 3 : 2));
-  hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(grid_for(n4), groups), dim3(256), 0, st, y, scale, shift, residual, res_scale,
-                     res_shift, relu, out, n4, c / 4, c);
+  hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(grid_for(n4 / W), groups), dim3(256), 0, st, y, scale, shift, residual, res_scale,
+                     res_shift, relu, out, n4 / W, c / 4 / W, c);
   return check_launch("bn_apply");
 }
 
@@ -676,9 +724,11 @@ static int bn_bwd_reduce_impl(const T *g, const T *act, const T *y, const float 
   MVG_REQUIRE(c % 4 == 0, "bn_bwd_reduce: c %% 4 != 0");
   MVG_REQUIRE(workspace != nullptr, "bn_bwd_reduce: workspace required");
   hipStream_t st = (hipStream_t)stream;
-  const int c4n = c / 4;
+  constexpr int W = Elem<T>::W;
+  MVG_REQUIRE(c % (4 * W) == 0, "bn_bwd_reduce: c must be a multiple of %d", 4 * W);
+  const int c4n = c / 4 / W;                 // 16-byte column groups per row
   const int cw = c4n < 256 ? c4n : 256;
-  MVG_REQUIRE(256 % cw == 0, "bn_bwd_reduce: c/4 must divide 256 or be a multiple of it (c=%d)", c);
+  MVG_REQUIRE(256 % cw == 0, "bn_bwd_reduce: c/%d must divide 256 or be a multiple of it (c=%d)", 4 * W, c);
   const int chunks = bwd_chunks(groups, rows_per_group, c);
   const long long rpc = (rows_per_group + chunks - 1) / chunks;
   ProfScope ps(MVG_K_BN_BWD_REDUCE, st, 0.0, Elem<T>::kBytes * groups * (double)rows_per_group * c * ((act ? 3 : 2) + (dz_out ? 1 : 0)));
@@ -699,9 +749,11 @@ static int bn_bwd_apply_impl(const T *g, const T *act, const T *y, const float *
   MVG_REQUIRE(c % 4 == 0, "bn_bwd_apply: c %% 4 != 0");
   hipStream_t st = (hipStream_t)stream;
   const long long n4 = rows_per_group * (c / 4);
+  constexpr int W = Elem<T>::W;
+  MVG_REQUIRE(c % (4 * W) == 0, "bn_bwd_apply: c must be a multiple of %d", 4 * W);
   ProfScope ps(MVG_K_BN_BWD_APPLY, st, 0.0, 4.0 * Elem<T>::kBytes * groups * (double)n4 * ((act ? 4 : 3) + (dz_out ? 1 : 0)));
-  hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid_for(n4), groups), dim3(256), 0, st, g, act, y, mean, invstd, gamma, s1, s2,
-                     relu_scale, relu_shift, n4, 1.0f / (float)rows_per_group, c / 4, c, dy, dz_out);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid_for(n4 / W), groups), dim3(256), 0, st, g, act, y, mean, invstd, gamma, s1, s2,
+                     relu_scale, relu_shift, n4 / W, 1.0f / (float)rows_per_group, c / 4 / W, c, dy, dz_out);
   return check_launch("bn_bwd_apply");
 }
 

@@ -18,9 +18,14 @@ __device__ __forceinline__ unsigned bf16_pack2(float a, float b) {       // roun
 template <typename T>
 struct Elem;
 
+// W = float4 groups per 16-byte access: the streaming passes move 16 bytes per lane in both storage types
+// (fp32: 4 channels, bf16: 8 channels); ldw / stw address W-group units.
 template <>
 struct Elem<float> {
   static constexpr double kBytes = 4.0;
+  static constexpr int W = 1;
+  static __device__ __forceinline__ void ldw(const float *p, long long iw, float4 (&v)[1]) { v[0] = reinterpret_cast<const float4 *>(p)[iw]; }
+  static __device__ __forceinline__ void stw(float *p, long long iw, const float4 (&v)[1]) { reinterpret_cast<float4 *>(p)[iw] = v[0]; }
   static __device__ __forceinline__ float4 ld4(const float *p, long long i4) { return reinterpret_cast<const float4 *>(p)[i4]; }
   static __device__ __forceinline__ void st4(float *p, long long i4, float4 v) { reinterpret_cast<float4 *>(p)[i4] = v; }
   static __device__ __forceinline__ float ld1(const float *p, long long i) { return p[i]; }
@@ -29,6 +34,16 @@ struct Elem<float> {
 template <>
 struct Elem<bf16_t> {
   static constexpr double kBytes = 2.0;
+  static constexpr int W = 2;
+  static __device__ __forceinline__ void ldw(const bf16_t *p, long long iw, float4 (&v)[2]) {
+    const uint4 u = reinterpret_cast<const uint4 *>(p)[iw];
+    v[0] = make_float4(bf16_lo(u.x), bf16_hi(u.x), bf16_lo(u.y), bf16_hi(u.y));
+    v[1] = make_float4(bf16_lo(u.z), bf16_hi(u.z), bf16_lo(u.w), bf16_hi(u.w));
+  }
+  static __device__ __forceinline__ void stw(bf16_t *p, long long iw, const float4 (&v)[2]) {
+    reinterpret_cast<uint4 *>(p)[iw] = make_uint4(bf16_pack2(v[0].x, v[0].y), bf16_pack2(v[0].z, v[0].w), bf16_pack2(v[1].x, v[1].y),
+                                                  bf16_pack2(v[1].z, v[1].w));
+  }
   static __device__ __forceinline__ float4 ld4(const bf16_t *p, long long i4) {
     const uint2 u = reinterpret_cast<const uint2 *>(p)[i4];
     return make_float4(bf16_lo(u.x), bf16_hi(u.x), bf16_lo(u.y), bf16_hi(u.y));
