@@ -69,8 +69,11 @@ class Backbone:
         # the reference); bf16 = BASELINE config C5's "bf16 MFMA path" (fp32 master weights, statistics, gradients)
         self.act_dtype = torch.float32
         # BatchNorm-backward reduce pass fused into the epilogue of the backward-data launch that produces the
-        # unit's output gradient (fp32 path, stride-1 producers): MVG_BN_FUSE=0 runs the separate pass instead
-        self.fuse_bn_reduce = os.environ.get("MVG_BN_FUSE", "1") != "0"
+        # unit's output gradient (fp32 path, stride-1 producers): MVG_BN_FUSE=1 switches it on.  Default OFF:
+        # measured at C3 the fused launches cost more than the pass they replace (backward-data 41.7 -> 50.6 ms,
+        # reduce pass 13.4 -> 7.2 ms: the stream-K workgroups reach their epilogues together, so the extra dword
+        # loads of y / act are not hidden under other workgroups' MFMAs)
+        self.fuse_bn_reduce = os.environ.get("MVG_BN_FUSE", "0") == "1"
 
     @property
     def bf16(self) -> bool:
