@@ -496,6 +496,24 @@ def test_gradient_arena_slices_are_16_byte_aligned():
         assert off % 4 == 0 and p.data_ptr() % 16 == 0 and m._grad_views[id(p)].data_ptr() % 16 == 0
 
 
+@pytest.mark.parametrize("depth", [18, 50])
+def test_fused_bn_backward_reduce_switch_gives_the_same_step(depth):
+    """MVG_BN_FUSE=1 (backward-data launches deliver the BatchNorm-backward sums of the unit they feed; off by
+    default because it measured slower) computes the same step: identical forward, gradients to summation-order noise."""
+    grads = []
+    for fuse in (False, True):
+        m = build(depth)
+        m.ensure_layout()
+        m._backbone.fuse_bn_reduce = fuse
+        d = m(inputs(4, 96, seed=3))
+        loss = metrics()(d)
+        loss.backward()
+        grads.append((loss.item(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}))
+    assert grads[0][0] == grads[1][0]
+    for k, g in grads[0][1].items():
+        rel_close(grads[1][1][k], g.cpu().numpy(), 2e-4, "fused vs separate reduce: " + k)
+
+
 def test_gradient_accumulation_and_zero_grad():
     m = build(18)
     d = m(inputs(3, 64))
