@@ -123,9 +123,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=25.0, help="data-parallel gradient bucket size")
-    ap.add_argument("--reserved-cus", type=int, default=int(os.environ.get("MVG_RESERVED_CUS", "12")),
+    # one-rank RCCL rehearsal at C3 (MVG_FORCE_DIST=1, profiles/README.md): plain 159.2 ms; 0 reserved CUs / 4 channels
+    # 163.3; 4 / 4 165.0; 8 / 8 165.3; 12 / 8 166.1.  The gradient stream is 358 MB per ~160 ms step: a few GB/s, far
+    # below what 4 channels move over xGMI, so the default keeps RCCL small (one workgroup per channel).
+    ap.add_argument("--reserved-cus", type=int, default=int(os.environ.get("MVG_RESERVED_CUS", "4")),
                     help="N > 1: CUs the persistent conv grids leave to the RCCL kernels")
-    ap.add_argument("--nccl-channels", type=int, default=int(os.environ.get("NCCL_MAX_NCHANNELS", "8")),
+    ap.add_argument("--nccl-channels", type=int, default=int(os.environ.get("NCCL_MAX_NCHANNELS", "4")),
                     help="N > 1: NCCL_MAX_NCHANNELS for the gradient all-reduce")
     ap.add_argument("--no-optimizer", action="store_true", help="time forward+loss+backward only (no Adam step)")
     ap.add_argument("--no-overlap", action="store_true",
@@ -153,7 +156,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     force_dist = os.environ.get("MVG_FORCE_DIST") == "1"      # rehearse the RCCL path with one rank
+    saved_stdout = None
     if world > 1 or force_dist:
+        # RCCL prints a version banner on stdout when the communicator comes up; the contract is ONE JSON line on
+        # stdout, so everything until the final print goes to stderr
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         if world > 1:
             assert int(os.environ.get("WORLD_SIZE", "1")) == world, "launch with torch.distributed.run (see docstring)"
         else:
@@ -347,7 +356,12 @@ def main():
                        "model_tflops": round(value * sample_flops(depth, V) / 1e12, 2)},
             "roofline": roofline, "roofline_fusion": roofline_fusion, "cpu_baseline": cpu, "kernel_families": families,
         }
-        print(json.dumps(line))
+        sys.stdout.flush()
+        if saved_stdout is not None:
+            os.dup2(saved_stdout, 1)
+        print(json.dumps(line), flush=True)
+        if saved_stdout is not None:
+            os.dup2(2, 1)
     if world > 1 or force_dist:
         dist.destroy_process_group()
 

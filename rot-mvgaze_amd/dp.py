@@ -34,9 +34,10 @@ class GradAllReducer:
         self.bucket_bytes = int(bucket_mb * (1 << 20))
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.force = force            # run the collectives even with one rank (rehearsal of the RCCL path)
-        self.reserved_cus = int(os.environ.get("MVG_RESERVED_CUS", "12")) if reserved_cus is None else int(reserved_cus)
+        self.reserved_cus = int(os.environ.get("MVG_RESERVED_CUS", "4")) if reserved_cus is None else int(reserved_cus)
         self._built_for = None
         self._side: Optional[torch.cuda.Stream] = None
+        self._native_avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         model._on_grads_ready = self._on_ready
         model._on_backward_done = self._on_done
         # Everything that changes how a backward runs (the stream the backward-weight kernels use, the
@@ -61,7 +62,8 @@ class GradAllReducer:
         # The conv kernels run as persistent stream-K grids sized to fill every CU; an RCCL kernel that
         # is resident when one starts would push part of that grid into a second round (2x the kernel
         # time).  Plan the grids for a few CUs less and keep RCCL to a few channels (the gradient
-        # stream needs ~15 GB/s of bus bandwidth at C2 / C4, a fraction of what 8 channels move).
+        # stream needs a few GB/s of bus bandwidth, a fraction of what 4 channels move; bench.py --help has the
+        # one-rank rehearsal figures behind the defaults).
         from . import ops
         ops.set_reserved_cus(self.reserved_cus)
         # backward-weight kernels on a LOWEST-priority stream finish last, which would hold every
@@ -130,9 +132,12 @@ class GradAllReducer:
                 ev.record(st)
                 self._side.wait_event(ev)
             with torch.cuda.stream(self._side):
-                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg)
-                if self.average:
-                    buf.mul_(1.0 / self.world)
+                if self.average and self._native_avg:
+                    dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.pg)      # RCCL averages in the collective
+                else:
+                    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg)
+                    if self.average:
+                        buf.mul_(1.0 / self.world)
         else:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg)
             if self.average:
