@@ -33,6 +33,153 @@ __device__ __forceinline__ unsigned pack_bf2(float a, float b) {          // rou
 
 constexpr int BF_BM = 128, BF_BK = 64, BF_LDK = BF_BK + 8;
 
+// Epilogue shared by the bf16 GEMM kernels: BN partial statistics from the fp32 accumulators, then the tile goes
+// through LDS (fp32, the operand buffers are free after the K loop) so that global stores are 16-byte vectors along
+// the channel axis, with bias / ReLU / mask / addend applied in fp32 and ONE rounding to bf16 (F32IO: fp32 stores).
+template <int BN, bool DGRAD, bool F32IO>
+__device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmClass &c, f32x16 (&acc)[BF_BM / 2 / 32][BN / 2 / 32],
+                                              unsigned short *smem, int tid, int g, int mtile, int ntile) {
+  constexpr int BM = BF_BM, WGM = 2, WGN = 2;
+  constexpr int WTM = BM / WGM, WTN = BN / WGN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int LDO = BN + 4;                // fp32 staging tile
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int ohw = c.out_h * c.out_w;
+  const long long row_base = (long long)mtile * BM + wm * WTM;
+  if (!DGRAD && p.stats) {
+    // per-wave partial over its WTM rows: column sum and sum of squares centred on the partial's own mean
+    long long cnt_ll = c.rows_per_group - row_base;
+    const int cnt = cnt_ll <= 0 ? 0 : (cnt_ll > WTM ? WTM : (int)cnt_ll);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = ntile * BN + wn * WTN + j * 32 + li;
+      float csum = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int r = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          csum += (r < cnt) ? acc[i][j][e] : 0.f;
+        }
+      csum += __shfl_xor(csum, 32, 64);
+      const float mean = cnt > 0 ? csum / (float)cnt : 0.f;
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int r = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          const float dlt = acc[i][j][e] - mean;
+          q += (r < cnt) ? dlt * dlt : 0.f;
+        }
+      q += __shfl_xor(q, 32, 64);
+      if (lh == 0 && col < p.ncols) {
+        const long long P = (long long)c.mtiles_per_group * WGM;
+        const long long pi = (long long)mtile * WGM + wm;
+        float *st = p.stats + (((long long)g * P + pi) * 2) * p.ncols;
+        st[col] = csum;
+        st[p.ncols + col] = q;
+      }
+    }
+  }
+  // accumulators -> fp32 tile in LDS (the operand buffers are free: the K loop ended with a barrier)
+  float *ot = reinterpret_cast<float *>(smem);
+  int *rowoff = reinterpret_cast<int *>(ot + BM * LDO);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        ot[(wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * LDO + wn * WTN + j * 32 + li] = acc[i][j][e];
+  // element offset of every tile row inside its group's output tensor (-1: beyond the end)
+  for (int r = tid; r < BM; r += 256) {
+    const long long m = (long long)mtile * BM + r;
+    int off = -1;
+    if (m < c.rows_per_group) {
+      if (DGRAD && p.cls_step == 2) {
+        const int rr = (int)m;
+        const int img = (int)fdiv((unsigned)rr, c.ohw_div), rem = rr - img * ohw;
+        const int y2 = (int)fdiv((unsigned)rem, c.ow_div), x2 = rem - y2 * c.out_w;
+        off = ((img * p.full_h + 2 * y2 + c.cls_py) * p.full_w + 2 * x2 + c.cls_px) * p.ncols;
+      } else {
+        off = (int)m * p.ncols;
+      }
+    }
+    rowoff[r] = off;
+  }
+  __syncthreads();
+  const long long gelems = DGRAD ? (long long)p.imgs_per_group * p.full_h * p.full_w * p.ncols
+                                 : c.rows_per_group * (long long)p.ncols;
+  unsigned short *out_g = reinterpret_cast<unsigned short *>(p.out) + (long long)g * gelems;
+  const unsigned short *add_g = p.addend ? reinterpret_cast<const unsigned short *>(p.addend) + (long long)g * gelems : nullptr;
+  const unsigned short *mask_g = p.mask ? reinterpret_cast<const unsigned short *>(p.mask) + (long long)g * gelems : nullptr;
+  float *out_f = p.out + (long long)g * gelems;
+  const float *add_f = p.addend ? p.addend + (long long)g * gelems : nullptr;
+  const float *mask_f = p.mask ? p.mask + (long long)g * gelems : nullptr;
+  constexpr int CV = BN / 8;                 // 16-byte output vectors per tile row
+#pragma unroll
+  for (int it = 0; it < BM * CV / 256; ++it) {
+    const int v = tid + it * 256;
+    const int r = v / CV, cv = v - r * CV;
+    const int col = ntile * BN + cv * 8;
+    const int off = rowoff[r];
+    if (off < 0 || col >= p.ncols) continue;
+    const float4 lo = *reinterpret_cast<const float4 *>(ot + r * LDO + cv * 8);
+    const float4 hi = *reinterpret_cast<const float4 *>(ot + r * LDO + cv * 8 + 4);
+    float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    if (!DGRAD && p.bias) {
+      const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + col), b1 = *reinterpret_cast<const float4 *>(p.bias + col + 4);
+      x[0] += b0.x; x[1] += b0.y; x[2] += b0.z; x[3] += b0.w; x[4] += b1.x; x[5] += b1.y; x[6] += b1.z; x[7] += b1.w;
+    }
+    if (!DGRAD && p.relu) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) x[k] = fmaxf(x[k], 0.f);
+    }
+    if constexpr (F32IO) {
+      if (mask_f) {
+        const float4 m0 = *reinterpret_cast<const float4 *>(mask_f + off + col), m1 = *reinterpret_cast<const float4 *>(mask_f + off + col + 4);
+        const float mm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = mm[k] > 0.f ? x[k] : 0.f;
+      }
+      if (add_f) {
+        const float4 a0 = *reinterpret_cast<const float4 *>(add_f + off + col), a1 = *reinterpret_cast<const float4 *>(add_f + off + col + 4);
+        x[0] += a0.x; x[1] += a0.y; x[2] += a0.z; x[3] += a0.w; x[4] += a1.x; x[5] += a1.y; x[6] += a1.z; x[7] += a1.w;
+      }
+      *reinterpret_cast<float4 *>(out_f + off + col) = make_float4(x[0], x[1], x[2], x[3]);
+      *reinterpret_cast<float4 *>(out_f + off + col + 4) = make_float4(x[4], x[5], x[6], x[7]);
+      continue;
+    }
+    if (mask_g) {
+      const u32x4 m = *reinterpret_cast<const u32x4 *>(mask_g + off + col);
+      const unsigned mm[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        x[2 * k] = bf_lo(mm[k]) > 0.f ? x[2 * k] : 0.f;
+        x[2 * k + 1] = bf_hi(mm[k]) > 0.f ? x[2 * k + 1] : 0.f;
+      }
+    }
+    if (add_g) {
+      const u32x4 a = *reinterpret_cast<const u32x4 *>(add_g + off + col);
+      const unsigned aa[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        x[2 * k] += bf_lo(aa[k]);
+        x[2 * k + 1] += bf_hi(aa[k]);
+      }
+    }
+    u32x4 o;
+    o.x = pack_bf2(x[0], x[1]);
+    o.y = pack_bf2(x[2], x[3]);
+    o.z = pack_bf2(x[4], x[5]);
+    o.w = pack_bf2(x[6], x[7]);
+    *reinterpret_cast<u32x4 *>(out_g + off + col) = o;
+  }
+}
+
 // F32IO (the fusion block's Linear layers in the bf16 path): the gathered operand, the output and the epilogue
 // operands (mask, addend) are fp32 in memory - only the matrix product runs in bf16: the loader reads 32 bytes
 // per 8 k, rounds to bf16 on the way into LDS, the epilogue stores fp32.  The weights are the bf16 copies.
@@ -247,137 +394,163 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(IgemmParams p) {
   }
 
   // ---- epilogue -------------------------------------------------------------------------------
-  const long long row_base = (long long)mtile * BM + wm * WTM;
-  if (!DGRAD && p.stats) {
-    // per-wave partial over its WTM rows: column sum and sum of squares centred on the partial's own mean
-    long long cnt_ll = c.rows_per_group - row_base;
-    const int cnt = cnt_ll <= 0 ? 0 : (cnt_ll > WTM ? WTM : (int)cnt_ll);
+  bf16_epilogue<BN, DGRAD, F32IO>(p, c, acc, smem, tid, g, mtile, ntile);
+}
+
+// ------------------------------------------------------------------------------------------
+// LDS-DMA form of the same GEMM (uniform-tap shapes, bf16 operands): the loader is `buffer_load_dwordx4 ... lds`
+// - global memory straight into LDS, no staging registers, no ds_write (a ds_write_b128 costs ~13 LDS cycles
+// per wave-instruction: eight of them per thread and K-step held the register-staged kernel's LDS pipe busier
+// than its matrix pipe).  The DMA writes lane l of a wave-instruction at base + 16*l, so the image is
+// lane-linear: unpadded 128-byte rows, eight rows per wave-instruction, and the bank spread comes from the
+// SOURCE side (cdna_hip_programming.md 5): the lane that fills 16-byte slot p of row r fetches chunk
+// p ^ ((r >> 1) & 7) of that row's K-step, and a fragment read of chunk cc goes to slot cc ^ ((r >> 1) & 7):
+// the 16 rows of a ds_read_b128 lane group then cover 16 different 16-byte bank slots (rows r and r + 1
+// differ in the 128-byte half, the XOR spreads the other eight).  Out-of-range taps / rows / columns use the
+// descriptor's range check: the DMA writes zeros.  Two LDS buffers, the next K-step's DMA is issued before
+// this K-step's MFMAs; vmcnt(0) + barrier per K-step, two workgroups per CU cover each other's waits.
+// ------------------------------------------------------------------------------------------
+template <int BN, bool DGRAD>
+__global__ __launch_bounds__(256, 2) void igemm_bf16_dma_kernel(IgemmParams p) {
+  constexpr int BM = BF_BM, BK = BF_BK, WGM = 2, WGN = 2;
+  constexpr int WTM = BM / WGM, WTN = BN / WGN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int ROW = BK;                     // elements per (unpadded) LDS row = 128 bytes
+  constexpr int A_PASSES = BM / 32, B_PASSES = BN / 32;      // 32 rows (8 rows x 4 waves) per pass
+  constexpr int A_ELEMS = BM * ROW, B_ELEMS = BN * ROW;
+  constexpr int LDO = BN + 4;
+  constexpr int OP_ELEMS = 2 * (A_ELEMS + B_ELEMS);           // ushort
+  constexpr int EPI_ELEMS = (BM * LDO * 4 + BM * 4) / 2;
+  constexpr int SMEM = OP_ELEMS > EPI_ELEMS ? OP_ELEMS : EPI_ELEMS;
+  __shared__ __attribute__((aligned(16))) unsigned short smem[SMEM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int nwg = gridDim.x;
+  const int wg_all = p.no_remap ? (int)blockIdx.x : xcd_remap(blockIdx.x, nwg);
+  int ci = 0;
+  for (int i = 1; i < p.ncls; ++i) ci += wg_all >= p.cls[i].tile0;
+  const IgemmClass &c = p.cls[ci];
+  const int wg = wg_all - c.tile0;
+  const int ntile = wg % p.ntiles;
+  const int mt_all = wg / p.ntiles;
+  const int g = mt_all / c.mtiles_per_group;
+  const int mtile = mt_all - g * c.mtiles_per_group;
+  const int KT = c.KT;
+  const int ohw = c.out_h * c.out_w;
+
+  // this lane fills slot (tid & 7) of row (tid >> 3) of every 32-row pass with source chunk a_kv
+  const int r_in_pass = tid >> 3;
+  const int a_kv = (tid & 7) ^ ((tid >> 4) & 7);              // (row >> 1) & 7 with row = 32 i + (tid >> 3)
+  unsigned a_base[A_PASSES], a_vmask[A_PASSES], b_base[B_PASSES];
+  bool b_ok[B_PASSES];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = ntile * BN + wn * WTN + j * 32 + li;
-      float csum = 0.f;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int r = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-          csum += (r < cnt) ? acc[i][j][e] : 0.f;
-        }
-      csum += __shfl_xor(csum, 32, 64);
-      const float mean = cnt > 0 ? csum / (float)cnt : 0.f;
-      float q = 0.f;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int r = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-          const float dlt = acc[i][j][e] - mean;
-          q += (r < cnt) ? dlt * dlt : 0.f;
-        }
-      q += __shfl_xor(q, 32, 64);
-      if (lh == 0 && col < p.ncols) {
-        const long long P = (long long)c.mtiles_per_group * WGM;
-        const long long pi = (long long)mtile * WGM + wm;
-        float *st = p.stats + (((long long)g * P + pi) * 2) * p.ncols;
-        st[col] = csum;
-        st[p.ncols + col] = q;
-      }
+  for (int i = 0; i < A_PASSES; ++i) {
+    const long long m = (long long)mtile * BM + r_in_pass + i * 32;
+    const bool ok = m < c.rows_per_group;
+    const int mm = ok ? (int)m : 0;
+    const int img = (int)fdiv((unsigned)mm, c.ohw_div);
+    const int rem = mm - img * ohw;
+    const int oy = (int)fdiv((unsigned)rem, c.ow_div), ox = rem - oy * c.out_w;
+    const int y0 = DGRAD ? oy + c.cls_cy : oy * p.stride - p.pad;
+    const int x0 = DGRAD ? ox + c.cls_cx : ox * p.stride - p.pad;
+    a_base[i] = (unsigned)(img * p.src_img_stride * 2) + (unsigned)((y0 * p.src_w + x0) * p.src_c) * 2u + (unsigned)a_kv * 16u;
+    unsigned msk = 0;
+    for (int t = 0; t < c.ntaps; ++t) {
+      const int fr = (int)fdiv((unsigned)t, c.tap_ns_div), fs = t - fr * c.tap_ns;
+      const int iy = DGRAD ? y0 - fr : y0 + fr;
+      const int ix = DGRAD ? x0 - fs : x0 + fs;
+      msk |= (unsigned)(((unsigned)iy < (unsigned)p.src_h) & ((unsigned)ix < (unsigned)p.src_w)) << t;
     }
+    a_vmask[i] = ok ? msk : 0u;
   }
-  // accumulators -> fp32 tile in LDS (the operand buffers are free: the K loop ended with a barrier)
-  float *ot = reinterpret_cast<float *>(smem);
-  int *rowoff = reinterpret_cast<int *>(ot + BM * LDO);
+#pragma unroll
+  for (int i = 0; i < B_PASSES; ++i) {
+    const int n = ntile * BN + r_in_pass + i * 32;
+    b_ok[i] = n < p.ncols;
+    b_base[i] = ((unsigned)n * (unsigned)p.b_row_len + (unsigned)a_kv * 8u) * 2u;
+  }
+  const __amdgpu_buffer_rsrc_t rs_a =
+      make_rsrc(reinterpret_cast<const unsigned short *>(p.a) + (long long)g * p.imgs_per_group * p.src_img_stride, p.a_group_bytes);
+  const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(p.b, p.b_bytes);
+  typedef __attribute__((address_space(3))) void *lds_vp;
+
+  auto issue = [&](int kt, int buf) {
+    int kstart = kt * BK;
+    if (c.korder) {
+      const int cblk = (int)fdiv((unsigned)kt, c.per_div), rem = kt - cblk * c.ntaps;
+      kstart = (rem << p.src_c_shift) + cblk * BK;
+    }
+    const int ks = __builtin_amdgcn_readfirstlane(kstart);
+    const int tap_u = c.ntaps > 1 ? (ks >> p.src_c_shift) : 0;
+    const int chb = ks - (tap_u << p.src_c_shift);
+    const int fru = (int)fdiv((unsigned)tap_u, c.tap_ns_div), fsu = tap_u - fru * c.tap_ns;
+    const int disp = (fru * p.src_w + fsu) * p.src_c;
+    const unsigned sdelta = (unsigned)(((DGRAD ? -disp : disp) + chb) * 2);
+    unsigned kb = (unsigned)ks * 2u;
+    if (DGRAD) {
+      const int btap = (c.tap_r0 + p.tap_step * fru) * p.s + c.tap_s0 + p.tap_step * fsu;
+      kb = (unsigned)(btap * p.src_c + chb) * 2u;
+    }
+    unsigned short *As = smem + buf * (A_ELEMS + B_ELEMS) + wave * 8 * ROW;       // this wave's 8 rows of pass 0 (wave-uniform)
+    unsigned short *Bs = smem + buf * (A_ELEMS + B_ELEMS) + A_ELEMS + wave * 8 * ROW;
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+      const bool ok = ((a_vmask[i] >> tap_u) & 1u) != 0u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_vp)(As + i * 32 * ROW), 16, (int)pred_off(a_base[i] + sdelta, ok), 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < B_PASSES; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_vp)(Bs + i * 32 * ROW), 16, (int)pred_off(b_base[i] + kb, b_ok[i]), 0, 0, 0);
+  };
+
+  f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e)
-        ot[(wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * LDO + wn * WTN + j * 32 + li] = acc[i][j][e];
-  // element offset of every tile row inside its group's output tensor (-1: beyond the end)
-  for (int r = tid; r < BM; r += 256) {
-    const long long m = (long long)mtile * BM + r;
-    int off = -1;
-    if (m < c.rows_per_group) {
-      if (DGRAD && p.cls_step == 2) {
-        const int rr = (int)m;
-        const int img = (int)fdiv((unsigned)rr, c.ohw_div), rem = rr - img * ohw;
-        const int y2 = (int)fdiv((unsigned)rem, c.ow_div), x2 = rem - y2 * c.out_w;
-        off = ((img * p.full_h + 2 * y2 + c.cls_py) * p.full_w + 2 * x2 + c.cls_px) * p.ncols;
-      } else {
-        off = (int)m * p.ncols;
-      }
-    }
-    rowoff[r] = off;
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // fragment addresses: row R, chunk cc = 2 kg + lh -> slot cc ^ ((R >> 1) & 7)
+  int a_row[TM], b_row[TN], a_sw[TM], b_sw[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    a_row[i] = (wm * WTM + i * 32 + li) * ROW;
+    a_sw[i] = ((wm * WTM + i * 32 + li) >> 1) & 7;
   }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    b_row[j] = (wn * WTN + j * 32 + li) * ROW;
+    b_sw[j] = ((wn * WTN + j * 32 + li) >> 1) & 7;
+  }
+
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  const long long gelems = DGRAD ? (long long)p.imgs_per_group * p.full_h * p.full_w * p.ncols
-                                 : c.rows_per_group * (long long)p.ncols;
-  unsigned short *out_g = reinterpret_cast<unsigned short *>(p.out) + (long long)g * gelems;
-  const unsigned short *add_g = p.addend ? reinterpret_cast<const unsigned short *>(p.addend) + (long long)g * gelems : nullptr;
-  const unsigned short *mask_g = p.mask ? reinterpret_cast<const unsigned short *>(p.mask) + (long long)g * gelems : nullptr;
-  float *out_f = p.out + (long long)g * gelems;
-  const float *add_f = p.addend ? p.addend + (long long)g * gelems : nullptr;
-  const float *mask_f = p.mask ? p.mask + (long long)g * gelems : nullptr;
-  constexpr int CV = BN / 8;                 // 16-byte output vectors per tile row
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < KT) issue(kt + 1, cur ^ 1);
+    const unsigned short *As = smem + cur * (A_ELEMS + B_ELEMS);
+    const unsigned short *Bs = As + A_ELEMS;
 #pragma unroll
-  for (int it = 0; it < BM * CV / 256; ++it) {
-    const int v = tid + it * 256;
-    const int r = v / CV, cv = v - r * CV;
-    const int col = ntile * BN + cv * 8;
-    const int off = rowoff[r];
-    if (off < 0 || col >= p.ncols) continue;
-    const float4 lo = *reinterpret_cast<const float4 *>(ot + r * LDO + cv * 8);
-    const float4 hi = *reinterpret_cast<const float4 *>(ot + r * LDO + cv * 8 + 4);
-    float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    if (!DGRAD && p.bias) {
-      const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + col), b1 = *reinterpret_cast<const float4 *>(p.bias + col + 4);
-      x[0] += b0.x; x[1] += b0.y; x[2] += b0.z; x[3] += b0.w; x[4] += b1.x; x[5] += b1.y; x[6] += b1.z; x[7] += b1.w;
-    }
-    if (!DGRAD && p.relu) {
+    for (int kg = 0; kg < BK / 16; ++kg) {
+      bf16x8 av[TM], bv[TN];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) x[k] = fmaxf(x[k], 0.f);
-    }
-    if constexpr (F32IO) {
-      if (mask_f) {
-        const float4 m0 = *reinterpret_cast<const float4 *>(mask_f + off + col), m1 = *reinterpret_cast<const float4 *>(mask_f + off + col + 4);
-        const float mm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+      for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const bf16x8 *>(As + a_row[i] + (((2 * kg + lh) ^ a_sw[i]) << 3));
 #pragma unroll
-        for (int k = 0; k < 8; ++k) x[k] = mm[k] > 0.f ? x[k] : 0.f;
-      }
-      if (add_f) {
-        const float4 a0 = *reinterpret_cast<const float4 *>(add_f + off + col), a1 = *reinterpret_cast<const float4 *>(add_f + off + col + 4);
-        x[0] += a0.x; x[1] += a0.y; x[2] += a0.z; x[3] += a0.w; x[4] += a1.x; x[5] += a1.y; x[6] += a1.z; x[7] += a1.w;
-      }
-      *reinterpret_cast<float4 *>(out_f + off + col) = make_float4(x[0], x[1], x[2], x[3]);
-      *reinterpret_cast<float4 *>(out_f + off + col + 4) = make_float4(x[4], x[5], x[6], x[7]);
-      continue;
-    }
-    if (mask_g) {
-      const u32x4 m = *reinterpret_cast<const u32x4 *>(mask_g + off + col);
-      const unsigned mm[4] = {m.x, m.y, m.z, m.w};
+      for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const bf16x8 *>(Bs + b_row[j] + (((2 * kg + lh) ^ b_sw[j]) << 3));
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        x[2 * k] = bf_lo(mm[k]) > 0.f ? x[2 * k] : 0.f;
-        x[2 * k + 1] = bf_hi(mm[k]) > 0.f ? x[2 * k + 1] : 0.f;
-      }
-    }
-    if (add_g) {
-      const u32x4 a = *reinterpret_cast<const u32x4 *>(add_g + off + col);
-      const unsigned aa[4] = {a.x, a.y, a.z, a.w};
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        x[2 * k] += bf_lo(aa[k]);
-        x[2 * k + 1] += bf_hi(aa[k]);
-      }
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
-    u32x4 o;
-    o.x = pack_bf2(x[0], x[1]);
-    o.y = pack_bf2(x[2], x[3]);
-    o.z = pack_bf2(x[4], x[5]);
-    o.w = pack_bf2(x[6], x[7]);
-    *reinterpret_cast<u32x4 *>(out_g + off + col) = o;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the next K-step's DMA has landed
+    __syncthreads();                                         // ... for every wave, and everyone is done reading `cur`
   }
+  bf16_epilogue<BN, DGRAD, false>(p, c, acc, smem, tid, g, mtile, ntile);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -673,6 +846,16 @@ static int validate_bf16(const mvg_conv_desc *d) {
   return 0;
 }
 
+// MVG_BF16_DMA=0: the register-staged kernel for every shape (A/B switch)
+static bool bf16_dma_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("MVG_BF16_DMA");
+    v = (e && !strcmp(e, "0")) ? 0 : 1;
+  }
+  return v == 1;
+}
+
 template <bool DGRAD>
 static int launch_igemm_bf16(IgemmParams &p, hipStream_t st, bool f32io = false) {
   const int bn = p.ncols >= 128 ? 128 : 64;
@@ -703,6 +886,9 @@ static int launch_igemm_bf16(IgemmParams &p, hipStream_t st, bool f32io = false)
       if (fasta) hipLaunchKernelGGL((igemm_bf16_kernel<64, DGRAD, true, true>), grid, block, 0, st, p);
       else hipLaunchKernelGGL((igemm_bf16_kernel<64, DGRAD, false, true>), grid, block, 0, st, p);
     }
+  } else if (fasta && bf16_dma_enabled()) {
+    if (bn == 128) hipLaunchKernelGGL((igemm_bf16_dma_kernel<128, DGRAD>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((igemm_bf16_dma_kernel<64, DGRAD>), grid, block, 0, st, p);
   } else if (bn == 128) {
     if (fasta) hipLaunchKernelGGL((igemm_bf16_kernel<128, DGRAD, true>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((igemm_bf16_kernel<128, DGRAD, false>), grid, block, 0, st, p);
