@@ -187,6 +187,23 @@ int mvg_bn_eval_affine(int groups, int c, const float *gamma, const float *beta,
 int mvg_bn_apply(const float *y, const float *scale, const float *shift, const float *residual,
                  const float *res_scale, const float *res_shift, int relu, float *out, int groups,
                  int64_t rows_per_group, int c, void *stream);
+/* mvg_bn_apply for a residual unit (relu = 1) that also records the ReLU mask: relu_bits holds one byte per
+ * 16-byte access of `out` (bit k = element k > 0; groups*rows*c/4 bytes in fp32, /8 in bf16).
+ * mvg_bn_bwd_reduce_bits takes the mask from those bytes instead of `act`: 1/16 of the bytes of reading the
+ * activation again (resnet.py:93-94,145-146 under autograd: the ReLU after the residual add). */
+int mvg_bn_apply_bits(const float *y, const float *scale, const float *shift, const float *residual,
+                      const float *res_scale, const float *res_shift, float *out, uint8_t *relu_bits, int groups,
+                      int64_t rows_per_group, int c, void *stream);
+int mvg_bn_bwd_reduce_bits(const float *g, const uint8_t *relu_bits, const float *y, const float *mean,
+                           const float *invstd, int groups, int64_t rows_per_group, int c, float *s1, float *s2,
+                           float *dgamma, float *dbeta, int accumulate, float *workspace, float *dz_out, void *stream);
+int mvg_bn_apply_bits_bf16(const uint16_t *y, const float *scale, const float *shift, const uint16_t *residual,
+                           const float *res_scale, const float *res_shift, uint16_t *out, uint8_t *relu_bits,
+                           int groups, int64_t rows_per_group, int c, void *stream);
+int mvg_bn_bwd_reduce_bits_bf16(const uint16_t *g, const uint8_t *relu_bits, const uint16_t *y, const float *mean,
+                                const float *invstd, int groups, int64_t rows_per_group, int c, float *s1,
+                                float *s2, float *dgamma, float *dbeta, int accumulate, float *workspace,
+                                uint16_t *dz_out, void *stream);
 /* Backward, step 1: per (group, channel) s1 = sum(dz), s2 = sum(dz * xhat), xhat = (y - mean) * invstd,
  * dz = g masked by the unit's ReLU.  The mask comes from `act` (the unit's output: act > 0) or, for
  * a ReLU without residual, from (relu_scale, relu_shift) = the scale/shift mvg_bn_apply used:

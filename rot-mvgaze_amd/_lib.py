@@ -69,6 +69,10 @@ SIGNATURES = {
     "mvg_bn_eval_affine": (_I, [_I, _I, _P, _P, _P, _P, _F, _P, _P, _P]),
     "mvg_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _I, _I64, _I, _P]),
     "mvg_bn_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
+    "mvg_bn_apply_bits": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _P]),
+    "mvg_bn_bwd_reduce_bits": (_I, [_P, _P, _P, _P, _P, _I, _I64, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
+    "mvg_bn_apply_bits_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _P]),
+    "mvg_bn_bwd_reduce_bits_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I64, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
     "mvg_bn_bwd_workspace_floats": (C.c_size_t, [_I, _I64, _I]),
     "mvg_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _P, _P, _P]),
     "mvg_maxpool3x3s2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

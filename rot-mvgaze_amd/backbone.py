@@ -44,9 +44,10 @@ class GradSink:
 class _Unit:
     """Saved state of one conv + BN (+ReLU) (+residual) for the backward pass."""
     __slots__ = ("spec", "desc", "x_in", "y", "out", "mean", "invstd", "relu", "rows", "w", "trained", "pool",
-                 "relu_affine", "fused_s12")
+                 "relu_affine", "fused_s12", "relu_bits")
 
     def __init__(self):
+        self.relu_bits = None     # residual units: the ReLU mask as one byte per 16-byte access (ops.bn_apply_bits)
         self.fused_s12 = None     # BatchNorm-backward sums delivered by the backward-data launch that produced this unit's gradient
 
 
@@ -74,6 +75,9 @@ class Backbone:
         # reduce pass 13.4 -> 7.2 ms: the stream-K workgroups reach their epilogues together, so the extra dword
         # loads of y / act are not hidden under other workgroups' MFMAs)
         self.fuse_bn_reduce = os.environ.get("MVG_BN_FUSE", "0") == "1"
+        # residual units record their ReLU mask as bits in the forward apply pass; the backward reduce pass reads
+        # those (1/16 of the activation's bytes) instead of the activation.  MVG_BN_BITS=0: read the activation.
+        self.relu_bits = os.environ.get("MVG_BN_BITS", "1") != "0"
 
     @property
     def bf16(self) -> bool:
@@ -158,7 +162,11 @@ class Backbone:
             ops.bn_relu_maxpool_fwd(y, scale, shift, out, argmax, G, N, d.ho, d.wo, c.cout, hp, wp_)
         else:
             out = torch.empty_like(y) if keep else y            # inference: normalise in place
-            ops.bn_apply(y, scale, shift, residual, relu, out, G, rows, c.cout, residual_affine)
+            bits = None
+            if keep and relu and residual is not None and self.relu_bits:
+                bits = ops.bn_apply_bits(y, scale, shift, residual, out, G, rows, c.cout, residual_affine)
+            else:
+                ops.bn_apply(y, scale, shift, residual, relu, out, G, rows, c.cout, residual_affine)
         if keep:
             u = _Unit()
             u.spec, u.desc, u.x_in, u.y, u.out, u.mean, u.invstd, u.relu, u.rows, u.w = \
@@ -168,6 +176,8 @@ class Backbone:
             u.relu_affine = (scale, shift) if (relu and residual is None and not pool) else None
             if pool:
                 u.pool = (argmax, scale, shift, d.ho, d.wo, hp, wp_)
+            else:
+                u.relu_bits = bits
             tape.append(u)
         return (out, argmax) if pool else out
 
@@ -267,8 +277,12 @@ class Backbone:
         if need_dz:
             # the reduce pass writes the masked gradient dz over g: the apply pass then reads (dz, y) only - no
             # second look at the ReLU mask, no second dz store - and the residual branch takes dz from g
-            ops.bn_bwd_reduce(g, act, u.y, u.mean, u.invstd, G, u.rows, c.cout, s12[0], s12[1], sink.view(gp), sink.view(bp),
-                              acc, ra, dz_out=g)
+            if u.relu_bits is not None:
+                ops.bn_bwd_reduce_bits(g, u.relu_bits, u.y, u.mean, u.invstd, G, u.rows, c.cout, s12[0], s12[1], sink.view(gp),
+                                       sink.view(bp), acc, dz_out=g)
+            else:
+                ops.bn_bwd_reduce(g, act, u.y, u.mean, u.invstd, G, u.rows, c.cout, s12[0], s12[1], sink.view(gp),
+                                  sink.view(bp), acc, ra, dz_out=g)
             dy = torch.empty_like(g)
             ops.bn_bwd_apply(g, None, u.y, u.mean, u.invstd, gp.detach(), s12[0], s12[1], G, u.rows, c.cout, dy, None, None)
             return dy, g

@@ -173,9 +173,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T *__restrict__ y, 
                                                        const T *__restrict__ residual,
                                                        const float *__restrict__ res_scale,
                                                        const float *__restrict__ res_shift, int relu,
-                                                       T *__restrict__ out, long long nw_per_group, int cwn, int c) {
+                                                       T *__restrict__ out, long long nw_per_group, int cwn, int c,
+                                                       unsigned char *__restrict__ relu_bits) {
   typedef Elem<T> E;
   constexpr int W = E::W;                 // float4 groups per 16-byte access (fp32: 1, bf16: 2)
+  // relu_bits (optional): one byte per 16-byte access, bit k = (element k of the access came out > 0) - the
+  // ReLU mask of a residual unit for its backward reduce pass, at 1/16 of the bytes of reading `out` again
   // res_scale / res_shift: the residual is the RAW output of the block's downsample conv and its BatchNorm
   // is applied here (the normalised downsample map is never written: resnet.py:88-93,137-145)
   const float4 *rs4 = res_scale ? reinterpret_cast<const float4 *>(res_scale + (long long)blockIdx.y * c) : nullptr;
@@ -218,6 +221,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T *__restrict__ y, 
       }
     }
     E::stw(out, base + i, o);
+    if (relu_bits) {
+      unsigned m = 0;
+#pragma unroll
+      for (int w = 0; w < W; ++w)
+        m |= ((o[w].x > 0.f ? 1u : 0u) | (o[w].y > 0.f ? 2u : 0u) | (o[w].z > 0.f ? 4u : 0u) | (o[w].w > 0.f ? 8u : 0u)) << (4 * w);
+      relu_bits[base + i] = (unsigned char)m;
+    }
     cq += step;
     if (cq >= cwn) cq -= cwn;
   }
@@ -233,7 +243,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *g, const T 
                                                             const float *__restrict__ mscale,
                                                             const float *__restrict__ mshift, long long rows,
                                                             long long rows_per_chunk, int c, int cwn, int cw,
-                                                            float *__restrict__ partial, int chunks, T *dz_out) {
+                                                            float *__restrict__ partial, int chunks, T *dz_out,
+                                                            const unsigned char *__restrict__ relu_bits) {
   typedef Elem<T> E;
   constexpr int W = E::W;                 // float4 groups per 16-byte access; a "column" below is one such access
   __shared__ float4 sh[2][256][W];
@@ -269,9 +280,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *g, const T 
       E::ldw(g, off, d);
       E::ldw(y, off, v);
       if (act) E::ldw(act, off, a);
+      const unsigned mb8 = relu_bits ? (unsigned)relu_bits[off] : 0u;
 #pragma unroll
       for (int w = 0; w < W; ++w) {
-        if (act) {
+        if (relu_bits) {               // the mask bn_apply recorded (bit k of the byte = element k of this access > 0)
+          const unsigned m4 = mb8 >> (4 * w);
+          d[w].x = (m4 & 1u) ? d[w].x : 0.f;
+          d[w].y = (m4 & 2u) ? d[w].y : 0.f;
+          d[w].z = (m4 & 4u) ? d[w].z : 0.f;
+          d[w].w = (m4 & 8u) ? d[w].w : 0.f;
+        } else if (act) {
           d[w].x = a[w].x > 0.f ? d[w].x : 0.f;
           d[w].y = a[w].y > 0.f ? d[w].y : 0.f;
           d[w].z = a[w].z > 0.f ? d[w].z : 0.f;
@@ -700,7 +718,8 @@ int mvg_bn_eval_affine(int groups, int c, const float *gamma, const float *beta,
 
 template <typename T>
 static int bn_apply_impl(const T *y, const float *scale, const float *shift, const T *residual, const float *res_scale,
-                         const float *res_shift, int relu, T *out, int groups, int64_t rows_per_group, int c, void *stream) {
+                         const float *res_shift, int relu, T *out, int groups, int64_t rows_per_group, int c, void *stream,
+                         uint8_t *relu_bits = nullptr) {
   MVG_REQUIRE(c % 4 == 0, "bn_apply: c %% 4 != 0");
   MVG_REQUIRE((res_scale == nullptr) == (res_shift == nullptr) && (residual || !res_scale),
               "bn_apply: res_scale / res_shift go together and need a residual");
@@ -710,7 +729,7 @@ static int bn_apply_impl(const T *y, const float *scale, const float *shift, con
   MVG_REQUIRE(c % (4 * W) == 0, "bn_apply: c must be a multiple of %d", 4 * W);
   ProfScope ps(MVG_K_BN_APPLY, st, 0.0, 4.0 * Elem<T>::kBytes * groups * (double)n4 * (residual ? 3 : 2));
   hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(grid_for(n4 / W), groups), dim3(256), 0, st, y, scale, shift, residual, res_scale,
-                     res_shift, relu, out, n4 / W, c / 4 / W, c);
+                     res_shift, relu, out, n4 / W, c / 4 / W, c, relu_bits);
   return check_launch("bn_apply");
 }
 
@@ -718,8 +737,9 @@ template <typename T>
 static int bn_bwd_reduce_impl(const T *g, const T *act, const T *y, const float *mean, const float *invstd,
                               const float *relu_scale, const float *relu_shift, int groups, int64_t rows_per_group, int c,
                               float *s1, float *s2, float *dgamma, float *dbeta, int accumulate, float *workspace, T *dz_out,
-                              void *stream) {
-  MVG_REQUIRE(!(act && relu_scale), "bn_bwd_reduce: give the ReLU mask either as act or as (relu_scale, relu_shift)");
+                              void *stream, const uint8_t *relu_bits = nullptr) {
+  MVG_REQUIRE(!(act && relu_scale) && !(relu_bits && (act || relu_scale)),
+              "bn_bwd_reduce: give the ReLU mask ONE way: act, (relu_scale, relu_shift) or relu_bits");
   MVG_REQUIRE((relu_scale == nullptr) == (relu_shift == nullptr), "bn_bwd_reduce: relu_scale and relu_shift go together");
   MVG_REQUIRE(c % 4 == 0, "bn_bwd_reduce: c %% 4 != 0");
   MVG_REQUIRE(workspace != nullptr, "bn_bwd_reduce: workspace required");
@@ -733,7 +753,7 @@ static int bn_bwd_reduce_impl(const T *g, const T *act, const T *y, const float 
   const long long rpc = (rows_per_group + chunks - 1) / chunks;
   ProfScope ps(MVG_K_BN_BWD_REDUCE, st, 0.0, Elem<T>::kBytes * groups * (double)rows_per_group * c * ((act ? 3 : 2) + (dz_out ? 1 : 0)));
   hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(chunks, ceil_div(c4n, cw), groups), dim3(256), 0, st, g, act, y, mean, invstd,
-                     relu_scale, relu_shift, (long long)rows_per_group, rpc, c, c4n, cw, workspace, chunks, dz_out);
+                     relu_scale, relu_shift, (long long)rows_per_group, rpc, c, c4n, cw, workspace, chunks, dz_out, relu_bits);
   if (check_launch("bn_bwd_reduce")) return 1;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(c, 16)), dim3(1024), 0, st, workspace, groups, chunks, c, s1, s2,
                      dgamma, dbeta, accumulate);
@@ -865,5 +885,27 @@ size_t mvg_bn_bwd_workspace_floats(int groups, int64_t rows_per_group, int c) {
 MVG_BN_FACES(, float)
 MVG_BN_FACES(_bf16, uint16_t)
 #undef MVG_BN_FACES
+
+// residual units: bn_apply also records the ReLU mask as one byte per 16-byte access (groups * rows * c / 4 bytes
+// in fp32, / 8 in bf16) and the backward reduce pass reads those bytes instead of the activation
+#define MVG_BN_BITS_FACES(SUFFIX, T)                                                                                          \
+  int mvg_bn_apply_bits##SUFFIX(const T *y, const float *scale, const float *shift, const T *residual,                      \
+                                const float *res_scale, const float *res_shift, T *out, uint8_t *relu_bits, int groups,      \
+                                int64_t rows_per_group, int c, void *stream) {                                               \
+    MVG_REQUIRE(relu_bits != nullptr, "bn_apply_bits: relu_bits is required");                                               \
+    return bn_apply_impl<T>(y, scale, shift, residual, res_scale, res_shift, 1, out, groups, rows_per_group, c, stream,      \
+                            relu_bits);                                                                                      \
+  }                                                                                                                          \
+  int mvg_bn_bwd_reduce_bits##SUFFIX(const T *g, const uint8_t *relu_bits, const T *y, const float *mean,                   \
+                                     const float *invstd, int groups, int64_t rows_per_group, int c, float *s1, float *s2,   \
+                                     float *dgamma, float *dbeta, int accumulate, float *workspace, T *dz_out,               \
+                                     void *stream) {                                                                         \
+    MVG_REQUIRE(relu_bits != nullptr, "bn_bwd_reduce_bits: relu_bits is required");                                          \
+    return bn_bwd_reduce_impl<T>(g, nullptr, y, mean, invstd, nullptr, nullptr, groups, rows_per_group, c, s1, s2, dgamma,   \
+                                 dbeta, accumulate, workspace, dz_out, stream, relu_bits);                                   \
+  }
+MVG_BN_BITS_FACES(, float)
+MVG_BN_BITS_FACES(_bf16, uint16_t)
+#undef MVG_BN_BITS_FACES
 
 }  // extern "C"

@@ -187,6 +187,23 @@ def bn_apply(y, scale, shift, residual, relu, out, groups, rows_per_group, c, re
                                  rows_per_group, c, _s()), "bn_apply")
 
 
+def bn_apply_bits(y, scale, shift, residual, out, groups, rows_per_group, c, residual_affine=None):
+    """bn_apply (+ residual, ReLU) that also returns the ReLU mask as one byte per 16-byte access of `out`."""
+    per = 8 if y.dtype == torch.bfloat16 else 4
+    bits = torch.empty(groups * rows_per_group * c // per, dtype=torch.uint8, device=y.device)
+    rs, rh = residual_affine if residual_affine is not None else (None, None)
+    check(_fn("mvg_bn_apply_bits", y)(_p(y), _p(scale), _p(shift), _p(residual), _p(rs), _p(rh), _p(out), _p(bits), groups,
+                                      rows_per_group, c, _s()), "bn_apply_bits")
+    return bits
+
+
+def bn_bwd_reduce_bits(g, bits, y, mean, invstd, groups, rows_per_group, c, s1, s2, dgamma, dbeta, accumulate, dz_out=None):
+    n = lib().mvg_bn_bwd_workspace_floats(groups, rows_per_group, c)
+    ws = torch.empty(n, dtype=torch.float32, device=g.device)
+    check(_fn("mvg_bn_bwd_reduce_bits", g)(_p(g), _p(bits), _p(y), _p(mean), _p(invstd), groups, rows_per_group, c, _p(s1), _p(s2),
+                                           _p(dgamma), _p(dbeta), int(accumulate), _p(ws), _p(dz_out), _s()), "bn_bwd_reduce_bits")
+
+
 def bn_bwd_reduce(g, act, y, mean, invstd, groups, rows_per_group, c, s1, s2, dgamma, dbeta, accumulate, relu_affine=None,
                   dz_out=None):
     """relu_affine = (scale, shift) of the forward bn_apply: ReLU mask rebuilt from y (units without residual).

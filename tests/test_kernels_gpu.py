@@ -351,6 +351,18 @@ def test_bn_apply_and_backward(G, N, H, W, C, relu, res):
         dy4 = torch.empty_like(dy)
         ops.bn_bwd_apply(g4, None, yd, mean, invstd, gd, s1c, s2c, G, rows, C, dy4, None, None)
         assert torch.equal(dy4, dy)
+    if res and relu:
+        # ... and with the mask carried as bits (one byte per 16-byte access, written by the forward apply pass)
+        out5 = torch.empty_like(out)
+        bits = ops.bn_apply_bits(yd, scale, shift, r.to(dev()), out5, G, rows, C)
+        assert torch.equal(out5, out) and bits.numel() == G * rows * C // 4
+        want_bits = ((out > 0).reshape(-1, 4).to(torch.uint8) * torch.tensor([1, 2, 4, 8], dtype=torch.uint8, device=dev())).sum(1)
+        assert torch.equal(bits, want_bits.to(torch.uint8))
+        g5 = god.clone()
+        s1d, s2d, dgd, dbd = (torch.empty_like(t) for t in (s1, s2, dgamma, dbeta))
+        ops.bn_bwd_reduce_bits(g5, bits, yd, mean, invstd, G, rows, C, s1d, s2d, dgd, dbd, False, dz_out=g5)
+        assert torch.equal(s1d, s1) and torch.equal(s2d, s2) and torch.equal(dgd, dgamma) and torch.equal(dbd, dbeta)
+        assert torch.equal(g5, dz)
     if res:
         # residual given as the RAW output of the downsample conv + its BatchNorm's (scale, shift)
         rs = (rnd((G, C), 11, "rs") * 0.2 + 1).to(dev())

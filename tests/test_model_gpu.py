@@ -514,6 +514,25 @@ def test_fused_bn_backward_reduce_switch_gives_the_same_step(depth):
         rel_close(grads[1][1][k], g.cpu().numpy(), 2e-4, "fused vs separate reduce: " + k)
 
 
+@pytest.mark.parametrize("depth,dtype", [(18, torch.float32), (50, torch.float32), (50, torch.bfloat16)])
+def test_relu_mask_bits_give_the_same_step_as_reading_the_activation(depth, dtype):
+    """Residual units hand their ReLU mask to the backward as bits (MVG_BN_BITS, default on): the same mask the
+    activation gives, so every gradient is bit-identical to the run that reads the activation."""
+    grads = []
+    for bits in (False, True):
+        m = build(depth)
+        m.compute_dtype = dtype
+        m.ensure_layout()
+        m._backbone.relu_bits = bits
+        d = m(inputs(4, 96, seed=5))
+        loss = metrics()(d)
+        loss.backward()
+        grads.append((loss.item(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}))
+    assert grads[0][0] == grads[1][0]
+    for k, g in grads[0][1].items():
+        assert torch.equal(grads[1][1][k], g), "mask bits vs activation: " + k
+
+
 def test_gradient_accumulation_and_zero_grad():
     m = build(18)
     d = m(inputs(3, 64))
