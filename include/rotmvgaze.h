@@ -439,6 +439,26 @@ int mvg_avgpool_bwd_bf16(const float *dy, uint16_t *dx, int n, int hw, int c, vo
 /* fp32 NCHW images (rot_mv.py:188-189) -> bf16 NHWC with the channels zero-padded to 8 */
 int mvg_nchw_to_nhwc8_bf16(const float *src, uint16_t *dst, int n, int c, int h, int w, void *stream);
 
+/* ---- "split" operands: fp32-accurate convolutions on the bf16 matrix cores (csrc/conv_split.hip) ----------------
+ * An fp32 tensor in "s3" format holds every value as the exact sum of three bf16 pieces; channels go in chunks
+ * of 8 with the three pieces of a chunk adjacent (6 bytes per element; n elements = 6 n bytes).  Six bf16 MFMAs
+ * per 16 k reproduce the fp32 product to fp32 rounding (conv_split.hip header), so these entries serve the same
+ * 1e-4 parity path as mvg_conv_fprop / _dgrad / _wgrad (resnet.py:31-47: F.conv2d forward and its autograd
+ * backward) - outputs (y, dx, dw) are plain fp32.  Shapes: cin, cout multiples of 32, r*s <= 32 (everything in
+ * the backbone but the 3-channel stem). */
+int mvg_split_f32(const float *x, void *out_s3, int64_t n, void *stream);           /* n % 8 == 0 */
+int mvg_merge_s3(const void *x_s3, float *out, int64_t n, void *stream);            /* exact inverse */
+/* fp32 KRSC weights -> s3 KRSC (fprop) and, when w_crsk_s3 != NULL, the s3 transposed copy CRSK (dgrad) */
+int mvg_split_weights(const mvg_conv_desc *d, const float *w, void *w_krsc_s3, void *w_crsk_s3, void *stream);
+/* partial-statistics geometry of mvg_conv_fprop_split (like mvg_conv_stats_partials) */
+int mvg_conv_stats_partials_split(const mvg_conv_desc *d, int32_t *rows_per_partial);
+int mvg_conv_fprop_split(const mvg_conv_desc *d, const void *x_s3, const void *w_s3, float *y, float *stats, void *stream);
+int mvg_conv_dgrad_split(const mvg_conv_desc *d, const void *dy_s3, const void *w_crsk_s3, float *dx, const float *addend,
+                         void *stream);
+int mvg_conv_wgrad_splits_split(const mvg_conv_desc *d);   /* pixel-split count; workspace = splits * cout*r*s*cin floats */
+int mvg_conv_wgrad_split(const mvg_conv_desc *d, const void *x_s3, const void *dy_s3, float *dw, float *workspace, int splits,
+                         int accumulate, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,14 @@ SIGNATURES = {
     "mvg_bn_eval_affine": (_I, [_I, _I, _P, _P, _P, _P, _F, _P, _P, _P]),
     "mvg_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _I, _I64, _I, _P]),
     "mvg_bn_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
+    "mvg_split_f32": (_I, [_P, _P, _I64, _P]),
+    "mvg_merge_s3": (_I, [_P, _P, _I64, _P]),
+    "mvg_split_weights": (_I, [_D, _P, _P, _P, _P]),
+    "mvg_conv_stats_partials_split": (_I, [_D, C.POINTER(C.c_int32)]),
+    "mvg_conv_fprop_split": (_I, [_D, _P, _P, _P, _P, _P]),
+    "mvg_conv_dgrad_split": (_I, [_D, _P, _P, _P, _P, _P]),
+    "mvg_conv_wgrad_splits_split": (_I, [_D]),
+    "mvg_conv_wgrad_split": (_I, [_D, _P, _P, _P, _P, _I, _I, _P]),
     "mvg_bn_apply_bits": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _P]),
     "mvg_bn_bwd_reduce_bits": (_I, [_P, _P, _P, _P, _P, _I, _I64, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
     "mvg_bn_apply_bits_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _P]),

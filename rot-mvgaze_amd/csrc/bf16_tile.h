@@ -1,0 +1,182 @@
+// bf16 matrix-core helpers shared by conv_bf16.hip (bf16 storage) and conv_split.hip (fp32 values held as three
+// bf16 pieces): vector types, packing, and the LDS-staged tile epilogue.  Static / inline only (conv_shared.h).
+#pragma once
+#include "conv_shared.h"
+
+namespace mvg {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float bf_lo(unsigned v) { return __uint_as_float(v << 16); }
+__device__ __forceinline__ float bf_hi(unsigned v) { return __uint_as_float(v & 0xFFFF0000u); }
+__device__ __forceinline__ unsigned pack_bf2(float a, float b) {          // round-to-nearest-even, NaN-safe (plain casts)
+  const __bf16 x = (__bf16)a, y = (__bf16)b;
+  return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+}
+
+// Epilogue shared by the bf16 GEMM kernels: BN partial statistics from the fp32 accumulators, then the tile goes
+// through LDS (fp32, the operand buffers are free after the K loop) so that global stores are 16-byte vectors along
+// the channel axis, with bias / ReLU / mask / addend applied in fp32 and ONE rounding to bf16 (F32IO: fp32 stores).
+// Workgroup = WGM x 2 waves (WGM * 128 threads), wave tile (BM / WGM) x (BN / 2).
+template <int BM, int BN, int WGM, bool DGRAD, bool F32IO>
+__device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmClass &c, f32x16 (&acc)[BM / WGM / 32][BN / 2 / 32],
+                                              unsigned short *smem, int tid, int g, int mtile, int ntile) {
+  constexpr int WGN = 2, NT = WGM * WGN * 64;
+  constexpr int WTM = BM / WGM, WTN = BN / WGN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int LDO = BN + 4;                // fp32 staging tile
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int ohw = c.out_h * c.out_w;
+  const long long row_base = (long long)mtile * BM + wm * WTM;
+  if (!DGRAD && p.stats) {
+    // per-wave partial over its WTM rows: column sum and sum of squares centred on the partial's own mean
+    long long cnt_ll = c.rows_per_group - row_base;
+    const int cnt = cnt_ll <= 0 ? 0 : (cnt_ll > WTM ? WTM : (int)cnt_ll);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = ntile * BN + wn * WTN + j * 32 + li;
+      float csum = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int r = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          csum += (r < cnt) ? acc[i][j][e] : 0.f;
+        }
+      csum += __shfl_xor(csum, 32, 64);
+      const float mean = cnt > 0 ? csum / (float)cnt : 0.f;
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int r = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          const float dlt = acc[i][j][e] - mean;
+          q += (r < cnt) ? dlt * dlt : 0.f;
+        }
+      q += __shfl_xor(q, 32, 64);
+      if (lh == 0 && col < p.ncols) {
+        const long long P = (long long)c.mtiles_per_group * WGM;
+        const long long pi = (long long)mtile * WGM + wm;
+        float *st = p.stats + (((long long)g * P + pi) * 2) * p.ncols;
+        st[col] = csum;
+        st[p.ncols + col] = q;
+      }
+    }
+  }
+  // accumulators -> fp32 tile in LDS (the operand buffers are free: the K loop ended with a barrier)
+  float *ot = reinterpret_cast<float *>(smem);
+  int *rowoff = reinterpret_cast<int *>(ot + BM * LDO);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        ot[(wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * LDO + wn * WTN + j * 32 + li] = acc[i][j][e];
+  // element offset of every tile row inside its group's output tensor (-1: beyond the end)
+  for (int r = tid; r < BM; r += NT) {
+    const long long m = (long long)mtile * BM + r;
+    int off = -1;
+    if (m < c.rows_per_group) {
+      if (DGRAD && p.cls_step == 2) {
+        const int rr = (int)m;
+        const int img = (int)fdiv((unsigned)rr, c.ohw_div), rem = rr - img * ohw;
+        const int y2 = (int)fdiv((unsigned)rem, c.ow_div), x2 = rem - y2 * c.out_w;
+        off = ((img * p.full_h + 2 * y2 + c.cls_py) * p.full_w + 2 * x2 + c.cls_px) * p.ncols;
+      } else {
+        off = (int)m * p.ncols;
+      }
+    }
+    rowoff[r] = off;
+  }
+  __syncthreads();
+  const long long gelems = DGRAD ? (long long)p.imgs_per_group * p.full_h * p.full_w * p.ncols
+                                 : c.rows_per_group * (long long)p.ncols;
+  unsigned short *out_g = reinterpret_cast<unsigned short *>(p.out) + (long long)g * gelems;
+  const unsigned short *add_g = p.addend ? reinterpret_cast<const unsigned short *>(p.addend) + (long long)g * gelems : nullptr;
+  const unsigned short *mask_g = p.mask ? reinterpret_cast<const unsigned short *>(p.mask) + (long long)g * gelems : nullptr;
+  float *out_f = p.out + (long long)g * gelems;
+  const float *add_f = p.addend ? p.addend + (long long)g * gelems : nullptr;
+  const float *mask_f = p.mask ? p.mask + (long long)g * gelems : nullptr;
+  constexpr int CV = BN / 8;                 // 16-byte output vectors per tile row
+#pragma unroll
+  for (int it = 0; it < BM * CV / NT; ++it) {
+    const int v = tid + it * NT;
+    const int r = v / CV, cv = v - r * CV;
+    const int col = ntile * BN + cv * 8;
+    const int off = rowoff[r];
+    if (off < 0 || col >= p.ncols) continue;
+    const float4 lo = *reinterpret_cast<const float4 *>(ot + r * LDO + cv * 8);
+    const float4 hi = *reinterpret_cast<const float4 *>(ot + r * LDO + cv * 8 + 4);
+    float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    if (!DGRAD && p.bias) {
+      const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + col), b1 = *reinterpret_cast<const float4 *>(p.bias + col + 4);
+      x[0] += b0.x; x[1] += b0.y; x[2] += b0.z; x[3] += b0.w; x[4] += b1.x; x[5] += b1.y; x[6] += b1.z; x[7] += b1.w;
+    }
+    if (!DGRAD && p.relu) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) x[k] = fmaxf(x[k], 0.f);
+    }
+    if constexpr (F32IO) {
+      if (mask_f) {
+        const float4 m0 = *reinterpret_cast<const float4 *>(mask_f + off + col), m1 = *reinterpret_cast<const float4 *>(mask_f + off + col + 4);
+        const float mm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = mm[k] > 0.f ? x[k] : 0.f;
+      }
+      if (add_f) {
+        const float4 a0 = *reinterpret_cast<const float4 *>(add_f + off + col), a1 = *reinterpret_cast<const float4 *>(add_f + off + col + 4);
+        x[0] += a0.x; x[1] += a0.y; x[2] += a0.z; x[3] += a0.w; x[4] += a1.x; x[5] += a1.y; x[6] += a1.z; x[7] += a1.w;
+      }
+      *reinterpret_cast<float4 *>(out_f + off + col) = make_float4(x[0], x[1], x[2], x[3]);
+      *reinterpret_cast<float4 *>(out_f + off + col + 4) = make_float4(x[4], x[5], x[6], x[7]);
+      continue;
+    }
+    if (mask_g) {
+      const u32x4 m = *reinterpret_cast<const u32x4 *>(mask_g + off + col);
+      const unsigned mm[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        x[2 * k] = bf_lo(mm[k]) > 0.f ? x[2 * k] : 0.f;
+        x[2 * k + 1] = bf_hi(mm[k]) > 0.f ? x[2 * k + 1] : 0.f;
+      }
+    }
+    if (add_g) {
+      const u32x4 a = *reinterpret_cast<const u32x4 *>(add_g + off + col);
+      const unsigned aa[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        x[2 * k] += bf_lo(aa[k]);
+        x[2 * k + 1] += bf_hi(aa[k]);
+      }
+    }
+    u32x4 o;
+    o.x = pack_bf2(x[0], x[1]);
+    o.y = pack_bf2(x[2], x[3]);
+    o.z = pack_bf2(x[4], x[5]);
+    o.w = pack_bf2(x[6], x[7]);
+    *reinterpret_cast<u32x4 *>(out_g + off + col) = o;
+  }
+}
+
+// Transposing fragment read (ds_read_b64_tr_b16) from a pixel-major [k][m] LDS image with row pitch `ld` elements:
+// the A / B fragment of v_mfma_f32_32x32x16_bf16 for rows m0 .. m0+31, k0 .. k0+15 (cdna_hip_programming.md T10).
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned short *img, int ld, int k0, int m0, int lane) {
+  // lane 4q+p of a 16-lane group supplies the address of block row q (k), columns 4p..4p+3 (m); it receives
+  // column (lane & 15) of the 4 rows.  Groups: (lane>>4)&1 -> m half of the 32-row MFMA block, lane>>5 -> k half.
+  const int t = lane & 15, q = t >> 2, pq = t & 3;
+  const int mh = (lane >> 4) & 1, kh = lane >> 5;
+  const unsigned short *a = img + (k0 + 8 * kh + q) * ld + m0 + 16 * mh + 4 * pq;
+  typedef s16x4 __attribute__((address_space(3))) * lds_p;
+  const s16x4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a));
+  const s16x4 y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a + 4 * ld));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 z = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+  return __builtin_bit_cast(bf16x8, z);
+}
+
+}  // namespace mvg

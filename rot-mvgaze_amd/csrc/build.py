@@ -6,7 +6,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["api.hip", "conv_igemm.hip", "conv_bf16.hip", "bn.hip", "pool.hip", "fusion.hip", "pair_index.cpp"]
+SOURCES = ["api.hip", "conv_igemm.hip", "conv_bf16.hip", "conv_split.hip", "bn.hip", "pool.hip", "fusion.hip", "pair_index.cpp"]
 LIB = os.path.join(HERE, "librotmvgaze_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
          "-fno-gpu-rdc"]
@@ -16,7 +16,7 @@ def _stale(obj, src):
     if not os.path.exists(obj):
         return True
     deps = [src, os.path.join(HERE, "common.h"), os.path.join(HERE, "conv_shared.h"),
-            os.path.join(HERE, "elem.h"), os.path.join(HERE, "..", "..", "include", "rotmvgaze.h"),
+            os.path.join(HERE, "elem.h"), os.path.join(HERE, "bf16_tile.h"), os.path.join(HERE, "..", "..", "include", "rotmvgaze.h"),
             os.path.abspath(__file__)]
     return any(os.path.exists(d) and os.path.getmtime(d) > os.path.getmtime(obj) for d in deps)
 

@@ -1,0 +1,831 @@
+// fp32-accurate convolution / linear kernels on the gfx950 bf16 matrix cores ("split" operands).
+//
+// An fp32 value is the exact sum of three bf16 pieces, a = a1 + a2 + a3 (a1 = bf16(a), a2 = bf16(a - a1),
+// a3 = bf16(a - a1 - a2): 3 x 8 significand bits, same exponent range as fp32).  A product of two pieces is exact
+// in fp32, so
+//     a * b  =  a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a2 b2 + a3 b1)  + O(2^-24 |a b|)
+// six bf16 MFMAs (v_mfma_f32_32x32x16_bf16, fp32 accumulation) per 16 k reproduce the fp32 product to fp32
+// rounding: measured against fp64 on 2048 x 256..4608 GEMMs the result is as close as (or closer than) the fp32
+// MFMA kernel's (rel. L2 0.7-3.4e-7 vs 1.5-4.1e-7).  Six bf16 MFMAs of 16 k cost 6 x 32 cycles,
+// the eight fp32 MFMAs (32x32x2) they replace 8 x 64: the matrix pipe needs 2.7x less time per fp32-accurate
+// product.  This is the 1e-4 parity path's arithmetic, NOT the reduced-precision bf16 path of conv_bf16.hip.
+//
+// Operand format "s3" (written by the producers: bn.hip's apply passes, split_weights below): channels in chunks
+// of 8, the three pieces of a chunk adjacent - element (row, c, piece) at ushort offset
+//     ((row * C/8 + c/8) * 3 + piece) * 8 + c % 8            (48 contiguous bytes per 8 channels, 6 bytes/element)
+//
+// Kernel (fprop and dgrad, uniform-tap shapes with channels % 32 == 0): 512 threads = 8 waves as 4 x 2, tile
+// 256 x BN x 32, wave tile 64 x (BN/2); loader = LDS-DMA (`buffer_load_dwordx4 ... lds`, one wave-instruction =
+// 16 rows x 64 bytes of one piece), LDS image per stage: piece-major, unpadded 64-byte rows, bank spread from the
+// source side (the lane that fills 16-byte slot s of row r fetches chunk s ^ ((r >> 2) & 3); a fragment read of
+// chunk cc goes to slot cc ^ ((r >> 2) & 3): the 16 rows of a ds_read_b128 lane group cover 16 different 16-byte
+// bank slots).  Two stages (2 x 72 KB): the next K-step's DMA is issued before this K-step's 48 MFMAs per wave.
+// fp32 output through the LDS-staged epilogue of bf16_tile.h (BN statistics partials, addend).
+#include "bf16_tile.h"
+
+namespace mvg {
+
+constexpr int SP_BM = 256, SP_BK = 32;
+
+__device__ __forceinline__ void split3(float v, unsigned short &p1, unsigned short &p2, unsigned short &p3) {
+  const __bf16 h1 = (__bf16)v;
+  float r = v - (float)h1;
+  const __bf16 h2 = (__bf16)r;
+  r -= (float)h2;
+  const __bf16 h3 = (__bf16)r;
+  p1 = __builtin_bit_cast(unsigned short, h1);
+  p2 = __builtin_bit_cast(unsigned short, h2);
+  p3 = __builtin_bit_cast(unsigned short, h3);
+}
+
+// 8 consecutive fp32 values -> the chunk's three 16-byte piece vectors
+__device__ __forceinline__ void split3_chunk(const float (&v)[8], u32x4 &q1, u32x4 &q2, u32x4 &q3) {
+  unsigned short a[8], b[8], c[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) split3(v[k], a[k], b[k], c[k]);
+  q1 = u32x4{(unsigned)a[0] | ((unsigned)a[1] << 16), (unsigned)a[2] | ((unsigned)a[3] << 16), (unsigned)a[4] | ((unsigned)a[5] << 16),
+             (unsigned)a[6] | ((unsigned)a[7] << 16)};
+  q2 = u32x4{(unsigned)b[0] | ((unsigned)b[1] << 16), (unsigned)b[2] | ((unsigned)b[3] << 16), (unsigned)b[4] | ((unsigned)b[5] << 16),
+             (unsigned)b[6] | ((unsigned)b[7] << 16)};
+  q3 = u32x4{(unsigned)c[0] | ((unsigned)c[1] << 16), (unsigned)c[2] | ((unsigned)c[3] << 16), (unsigned)c[4] | ((unsigned)c[5] << 16),
+             (unsigned)c[6] | ((unsigned)c[7] << 16)};
+}
+
+// fp32 [n8 * 8] -> s3 (layout plumbing for tests and for tensors no kernel writes in s3 directly)
+__global__ __launch_bounds__(256) void split_f32_kernel(const float4 *__restrict__ x, u32x4 *__restrict__ out, long long n8) {
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += stride) {
+    const float4 lo = x[2 * i], hi = x[2 * i + 1];
+    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    u32x4 q1, q2, q3;
+    split3_chunk(v, q1, q2, q3);
+    out[3 * i] = q1;
+    out[3 * i + 1] = q2;
+    out[3 * i + 2] = q3;
+  }
+}
+
+// s3 -> fp32 (exact: the three pieces sum without rounding)
+__global__ __launch_bounds__(256) void merge_s3_kernel(const u32x4 *__restrict__ x, float4 *__restrict__ out, long long n8) {
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += stride) {
+    const u32x4 q1 = x[3 * i], q2 = x[3 * i + 1], q3 = x[3 * i + 2];
+    const unsigned a[4] = {q1.x, q1.y, q1.z, q1.w}, b[4] = {q2.x, q2.y, q2.z, q2.w}, c[4] = {q3.x, q3.y, q3.z, q3.w};
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[2 * k] = (bf_lo(a[k]) + bf_lo(b[k])) + bf_lo(c[k]);
+      v[2 * k + 1] = (bf_hi(a[k]) + bf_hi(b[k])) + bf_hi(c[k]);
+    }
+    out[2 * i] = make_float4(v[0], v[1], v[2], v[3]);
+    out[2 * i + 1] = make_float4(v[4], v[5], v[6], v[7]);
+  }
+}
+
+// fp32 KRSC weights -> s3 KRSC ([cout][rs*cin]) and, optionally, the s3 transposed copy the backward-data kernel
+// reads (CRSK: [cin][rs*cout]).  One thread per (row, tap, 8-channel chunk) of each output.
+__global__ __launch_bounds__(256) void split_weights_kernel(const float *__restrict__ w, u32x4 *__restrict__ wk, u32x4 *__restrict__ wt,
+                                                            int cout, int rs, int cin) {
+  const int c8n = cin / 8, o8n = cout / 8;
+  const long long nk = (long long)cout * rs * c8n, nt = wt ? (long long)cin * rs * o8n : 0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nk + nt; i += (long long)gridDim.x * 256) {
+    float v[8];
+    u32x4 *dst;
+    if (i < nk) {
+      const float4 *src = reinterpret_cast<const float4 *>(w + i * 8);          // (o, tap, c8) is the KRSC order itself
+      const float4 lo = src[0], hi = src[1];
+      v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+      dst = wk + 3 * i;
+    } else {
+      const long long j = i - nk;
+      const int o8 = (int)(j % o8n);
+      const long long t = j / o8n;
+      const int tap = (int)(t % rs), c = (int)(t / rs);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = w[((long long)(o8 * 8 + k) * rs + tap) * cin + c];
+      dst = wt + 3 * j;
+    }
+    u32x4 q1, q2, q3;
+    split3_chunk(v, q1, q2, q3);
+    dst[0] = q1;
+    dst[1] = q2;
+    dst[2] = q3;
+  }
+}
+
+template <int BN, bool DGRAD>
+__global__ __launch_bounds__(512, 1) void igemm_split_kernel(IgemmParams p) {
+  constexpr int BM = SP_BM, BK = SP_BK, WGM = 4, WGN = 2;
+  constexpr int WTM = BM / WGM, WTN = BN / WGN;               // 64 x (BN / 2)
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int ROW = BK;                                     // elements per LDS row (64 bytes)
+  constexpr int A_ELEMS = BM * ROW, B_ELEMS = BN * ROW;       // one piece
+  constexpr int STAGE = 3 * (A_ELEMS + B_ELEMS);
+  constexpr int A_GROUPS = BM / 16 / 8;                       // 16-row DMA groups per wave
+  constexpr int B_GROUPS = BN / 16;                           // ... in total (waves 0 .. B_GROUPS-1 take one each)
+  constexpr int LDO = BN + 4;
+  constexpr int EPI_ELEMS = (BM * LDO * 4 + BM * 4) / 2;
+  constexpr int SMEM = 2 * STAGE > EPI_ELEMS ? 2 * STAGE : EPI_ELEMS;
+  __shared__ __attribute__((aligned(16))) unsigned short smem[SMEM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int nwg = gridDim.x;
+  const int wg_all = p.no_remap ? (int)blockIdx.x : xcd_remap(blockIdx.x, nwg);
+  int ci = 0;
+  for (int i = 1; i < p.ncls; ++i) ci += wg_all >= p.cls[i].tile0;
+  const IgemmClass &c = p.cls[ci];
+  const int wg = wg_all - c.tile0;
+  const int ntile = wg % p.ntiles;
+  const int mt_all = wg / p.ntiles;
+  const int g = mt_all / c.mtiles_per_group;
+  const int mtile = mt_all - g * c.mtiles_per_group;
+  const int KT = c.KT;
+  const int ohw = c.out_h * c.out_w;
+
+  // DMA lane map: lane l of a wave-instruction fills 16-byte slot (l & 3) of row (l >> 2) of a 16-row group
+  // with source chunk a_kv; wave w owns A row groups w and w + 8, and B row group w (when w < B_GROUPS)
+  const int r_in_grp = lane >> 2;
+  const int a_kv = (lane & 3) ^ ((lane >> 4) & 3);            // (row >> 2) & 3 with row = 16 * group + (lane >> 2)
+  unsigned a_base[A_GROUPS], a_vmask[A_GROUPS];
+#pragma unroll
+  for (int i = 0; i < A_GROUPS; ++i) {
+    const long long m = (long long)mtile * BM + (wave + 8 * i) * 16 + r_in_grp;
+    const bool ok = m < c.rows_per_group;
+    const int mm = ok ? (int)m : 0;
+    const int img = (int)fdiv((unsigned)mm, c.ohw_div);
+    const int rem = mm - img * ohw;
+    const int oy = (int)fdiv((unsigned)rem, c.ow_div), ox = rem - oy * c.out_w;
+    const int y0 = DGRAD ? oy + c.cls_cy : oy * p.stride - p.pad;
+    const int x0 = DGRAD ? ox + c.cls_cx : ox * p.stride - p.pad;
+    a_base[i] = (unsigned)(img * p.src_img_stride * 6) + (unsigned)((y0 * p.src_w + x0) * p.src_c) * 6u + (unsigned)a_kv * 48u;
+    unsigned msk = 0;
+    for (int t = 0; t < c.ntaps; ++t) {
+      const int fr = (int)fdiv((unsigned)t, c.tap_ns_div), fs = t - fr * c.tap_ns;
+      const int iy = DGRAD ? y0 - fr : y0 + fr;
+      const int ix = DGRAD ? x0 - fs : x0 + fs;
+      msk |= (unsigned)(((unsigned)iy < (unsigned)p.src_h) & ((unsigned)ix < (unsigned)p.src_w)) << t;
+    }
+    a_vmask[i] = ok ? msk : 0u;
+  }
+  const int bn_row = ntile * BN + wave * 16 + r_in_grp;
+  const bool b_ok = (wave < B_GROUPS) & (bn_row < p.ncols);
+  const unsigned b_base = ((unsigned)bn_row * (unsigned)p.b_row_len) * 6u + (unsigned)a_kv * 48u;
+  const __amdgpu_buffer_rsrc_t rs_a =
+      make_rsrc(reinterpret_cast<const char *>(p.a) + (long long)g * p.imgs_per_group * p.src_img_stride * 6, p.a_group_bytes);
+  const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(p.b, p.b_bytes);
+  typedef __attribute__((address_space(3))) void *lds_vp;
+
+  auto issue = [&](int kt, int buf) {
+    int kstart = kt * BK;
+    if (c.korder) {
+      const int cblk = (int)fdiv((unsigned)kt, c.per_div), rem = kt - cblk * c.ntaps;
+      kstart = (rem << p.src_c_shift) + cblk * BK;
+    }
+    const int ks = __builtin_amdgcn_readfirstlane(kstart);
+    const int tap_u = c.ntaps > 1 ? (ks >> p.src_c_shift) : 0;
+    const int chb = ks - (tap_u << p.src_c_shift);
+    const int fru = (int)fdiv((unsigned)tap_u, c.tap_ns_div), fsu = tap_u - fru * c.tap_ns;
+    const int disp = (fru * p.src_w + fsu) * p.src_c;
+    const unsigned sdelta = (unsigned)(((DGRAD ? -disp : disp) + chb) * 6);
+    unsigned kb = (unsigned)ks * 6u;
+    if (DGRAD) {
+      const int btap = (c.tap_r0 + p.tap_step * fru) * p.s + c.tap_s0 + p.tap_step * fsu;
+      kb = (unsigned)(btap * p.src_c + chb) * 6u;
+    }
+    unsigned short *st = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < A_GROUPS; ++i) {
+      const bool ok = ((a_vmask[i] >> tap_u) & 1u) != 0u;
+      const unsigned off = a_base[i] + sdelta;
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_vp)(st + pc * A_ELEMS + (wave + 8 * i) * 16 * ROW), 16,
+                                                 (int)pred_off(off + 16u * pc, ok), 0, 0, 0);
+    }
+    if (wave < B_GROUPS) {
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_vp)(st + 3 * A_ELEMS + pc * B_ELEMS + wave * 16 * ROW), 16,
+                                                 (int)pred_off(b_base + kb + 16u * pc, b_ok), 0, 0, 0);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // fragment addresses: row R, chunk cc = 2 kg + lh -> slot cc ^ ((R >> 2) & 3)
+  int a_row[TM], b_row[TN], a_sw[TM], b_sw[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int R = wm * WTM + i * 32 + li;
+    a_row[i] = R * ROW;
+    a_sw[i] = (R >> 2) & 3;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int R = wn * WTN + j * 32 + li;
+    b_row[j] = R * ROW;
+    b_sw[j] = (R >> 2) & 3;
+  }
+
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < KT) issue(kt + 1, cur ^ 1);
+    const unsigned short *As = smem + cur * STAGE;
+    const unsigned short *Bs = As + 3 * A_ELEMS;
+#pragma unroll
+    for (int kg = 0; kg < BK / 16; ++kg) {
+      bf16x8 av[3][TM], bv[3][TN];
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          av[pc][i] = *reinterpret_cast<const bf16x8 *>(As + pc * A_ELEMS + a_row[i] + (((2 * kg + lh) ^ a_sw[i]) << 3));
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          bv[pc][j] = *reinterpret_cast<const bf16x8 *>(Bs + pc * B_ELEMS + b_row[j] + (((2 * kg + lh) ^ b_sw[j]) << 3));
+      }
+      // smallest terms first: (a1 b3, a3 b1, a2 b2), (a1 b2, a2 b1), a1 b1
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][i], bv[2][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[2][i], bv[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1][i], bv[1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][i], bv[1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1][i], bv[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][i], bv[0][j], acc[i][j], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the next K-step's DMA has landed
+    __syncthreads();                                         // ... for every wave, and everyone is done reading `cur`
+  }
+  bf16_epilogue<BM, BN, WGM, DGRAD, true>(p, c, acc, smem, tid, g, mtile, ntile);
+}
+
+// ------------------------------------------------------------------------------------------
+// wgrad: dw[o][tap][c] = sum over pixels of dy[pix][o] * x[pix at tap][c] with both operands in s3.  Like the bf16
+// kernel (conv_bf16.hip): M = cout, N = (tap, c), K = pixels split into slabs; the LDS images stay pixel-major
+// [piece][k][m] (rows padded by 32 elements) and the fragments come from ds_read_b64_tr_b16.  A K-step is 16
+// pixels: 30 KB per stage, two stages, two workgroups per CU; a thread's three piece vectors of one 8-channel chunk
+// are 48 contiguous bytes in memory.
+// ------------------------------------------------------------------------------------------
+template <int BM, int BN, bool INCR>
+__global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradParams p) {
+  constexpr int BK = 16, WGM = 2, WGN = 2;
+  constexpr int WTM = BM / WGM, WTN = BN / WGN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int LDA = BM + 32, LDB = BN + 32;
+  constexpr int MV = BM / 8, NVB = BN / 8;
+  constexpr int A_TPR = 256 / BK;                       // threads per k-row (16)
+  constexpr int A_CPT = MV / A_TPR > 0 ? MV / A_TPR : 1;   // chunks per thread
+  constexpr int B_CPT = NVB / A_TPR > 0 ? NVB / A_TPR : 1;
+  constexpr int A_ELEMS = BK * LDA, B_ELEMS = BK * LDB;    // one piece
+  constexpr int STAGE = 3 * (A_ELEMS + B_ELEMS);
+  __shared__ __attribute__((aligned(16))) unsigned short smem[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int tiles = p.mtiles * p.ntiles;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = logical / tiles;
+  const int tile = logical - split * tiles;
+  const int ntile = tile % p.ntiles, mtile = tile / p.ntiles;
+  const long long m_begin = (long long)split * p.pixels_per_split;
+  long long m_end = m_begin + p.pixels_per_split;
+  if (m_end > p.pixels) m_end = p.pixels;
+  const int m_count = m_end > m_begin ? (int)(m_end - m_begin) : 0;
+  const int ohw = p.ho * p.wo;
+  const long long img0 = m_begin / ohw;
+  const unsigned rem0 = (unsigned)(m_begin - img0 * ohw);
+
+  const char *dy = reinterpret_cast<const char *>(p.dy);
+  const char *x = reinterpret_cast<const char *>(p.x);
+  const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(dy + m_begin * p.cout * 6, 6ll * m_count * p.cout);
+  const long long x_img_elems = (long long)p.h * p.w * p.cin;
+  const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(x + img0 * x_img_elems * 6, p.x_bytes - 6ll * img0 * x_img_elems);
+  // both loaders: pixel row i_row = tid / 16, chunk lane i_v0 = tid % 16 (+ 16 per extra chunk)
+  const int i_row = tid / A_TPR, i_v0 = tid % A_TPR;
+  unsigned a_off[A_CPT];
+  bool a_on[A_CPT];
+#pragma unroll
+  for (int j = 0; j < A_CPT; ++j) {
+    const int cv = i_v0 + j * A_TPR;
+    const int col = mtile * BM + cv * 8;
+    a_on[j] = cv < MV;
+    a_off[j] = (a_on[j] && col < p.cout) ? (unsigned)(i_row * p.cout + col) * 6u : 0x80000000u;
+  }
+  int i_dy[B_CPT], i_dx[B_CPT];
+  unsigned i_tconst[B_CPT];
+  bool i_cok[B_CPT], b_on[B_CPT];
+#pragma unroll
+  for (int j = 0; j < B_CPT; ++j) {
+    const int cv = i_v0 + j * A_TPR;
+    const int col = ntile * BN + cv * 8;
+    b_on[j] = cv < NVB;
+    i_cok[j] = b_on[j] && col < p.ncols;
+    const int tap = (int)fdiv((unsigned)(i_cok[j] ? col : 0), p.cin_div);
+    const int cc = (i_cok[j] ? col : 0) - tap * p.cin;
+    const int fr = (int)fdiv((unsigned)tap, p.s_div), fs = tap - fr * p.s;
+    i_dy[j] = fr - p.pad;
+    i_dx[j] = fs - p.pad;
+    i_tconst[j] = (unsigned)((i_dy[j] * p.w + i_dx[j]) * p.cin + cc) * 6u;
+  }
+  const unsigned row_bytes = (unsigned)(p.stride * p.w * p.cin) * 6u, col_bytes = (unsigned)(p.stride * p.cin) * 6u;
+  const unsigned img_bytes = (unsigned)x_img_elems * 6u;
+  int s_oy = 0, s_ox = 0;
+  unsigned s_imgoff = 0;
+  if (INCR) {
+    const unsigned pix = rem0 + (unsigned)i_row;
+    const unsigned img = fdiv(pix, p.ohw_div);
+    const unsigned rem = pix - img * (unsigned)ohw;
+    const unsigned oy = fdiv(rem, p.wo_div);
+    s_oy = (int)oy;
+    s_ox = (int)(rem - oy * (unsigned)p.wo);
+    s_imgoff = img * img_bytes;
+  }
+  u32x4 a_reg[A_CPT][3], b_reg[B_CPT][3];
+  auto load_tiles = [&](int kt) {
+#pragma unroll
+    for (int j = 0; j < A_CPT; ++j) {
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc)             // rows >= m_count: beyond the descriptor = zeros
+        a_reg[j][pc] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_off[j] + 16u * pc, 0, 0);
+      a_off[j] += (unsigned)(BK * p.cout) * 6u;
+    }
+    const bool mok = kt * BK + i_row < m_count;
+    int oy, ox;
+    unsigned imgoff;
+    if constexpr (INCR) {
+      oy = s_oy;
+      ox = s_ox;
+      imgoff = s_imgoff;
+    } else {
+      const unsigned pix = rem0 + (unsigned)(kt * BK + i_row);
+      const unsigned img = fdiv(pix, p.ohw_div);
+      const unsigned rem = pix - img * (unsigned)ohw;
+      const unsigned uy = fdiv(rem, p.wo_div);
+      oy = (int)uy;
+      ox = (int)(rem - uy * (unsigned)p.wo);
+      imgoff = img * img_bytes;
+    }
+    const int iy0 = oy * p.stride, ix0 = ox * p.stride;
+    const unsigned pixoff = imgoff + (unsigned)oy * row_bytes + (unsigned)ox * col_bytes;
+#pragma unroll
+    for (int j = 0; j < B_CPT; ++j) {
+      const bool ok = mok & i_cok[j] & ((unsigned)(iy0 + i_dy[j]) < (unsigned)p.h) & ((unsigned)(ix0 + i_dx[j]) < (unsigned)p.w);
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc)
+        b_reg[j][pc] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, pred_off(pixoff + i_tconst[j] + 16u * pc, ok), 0, 0);
+    }
+    if constexpr (INCR) {
+      // advance BK pixels: columns wrap into rows, rows into the next image (at most once: ho*wo >= 2*BK)
+      unsigned nx = (unsigned)s_ox + BK;
+      const unsigned q = fdiv(nx, p.wo_div);
+      nx -= q * (unsigned)p.wo;
+      s_ox = (int)nx;
+      const int noy = s_oy + (int)q;
+      const bool wrap = noy >= p.ho;
+      s_oy = wrap ? noy - p.ho : noy;
+      s_imgoff += wrap ? img_bytes : 0u;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    unsigned short *As = smem + buf * STAGE;
+    unsigned short *Bs = As + 3 * A_ELEMS;
+#pragma unroll
+    for (int j = 0; j < A_CPT; ++j)
+      if (a_on[j]) {
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+          *reinterpret_cast<u32x4 *>(As + pc * A_ELEMS + i_row * LDA + (i_v0 + j * A_TPR) * 8) = a_reg[j][pc];
+      }
+#pragma unroll
+    for (int j = 0; j < B_CPT; ++j)
+      if (b_on[j]) {
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+          *reinterpret_cast<u32x4 *>(Bs + pc * B_ELEMS + i_row * LDB + (i_v0 + j * A_TPR) * 8) = b_reg[j][pc];
+      }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int KT = (m_count + BK - 1) / BK;
+  load_tiles(0);
+  store_tiles(0);
+  load_tiles(1);
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    store_tiles(cur ^ 1);
+    load_tiles(kt + 2);
+    const unsigned short *As = smem + cur * STAGE;
+    const unsigned short *Bs = As + 3 * A_ELEMS;
+    bf16x8 av[3][TM], bv[3][TN];
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av[pc][i] = tr_frag(As + pc * A_ELEMS, LDA, 0, wm * WTM + i * 32, lane);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bv[pc][j] = tr_frag(Bs + pc * B_ELEMS, LDB, 0, wn * WTN + j * 32, lane);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][i], bv[2][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[2][i], bv[0][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1][i], bv[1][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][i], bv[1][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1][i], bv[0][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][i], bv[0][j], acc[i][j], 0, 0, 0);
+      }
+    __syncthreads();
+  }
+
+  float *out = p.out + (long long)split * p.cout * p.ncols;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = ntile * BN + wn * WTN + j * 32 + li;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = mtile * BM + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (row < p.cout && col < p.ncols) {
+          const long long off = (long long)row * p.ncols + col;
+          float v = acc[i][j][e];
+          if (p.accumulate) v += out[off];
+          out[off] = v;
+        }
+      }
+    }
+}
+
+// A stride-2 parity class without taps: dx = addend (or zero) on that class's pixels (float4 vectors)
+__global__ __launch_bounds__(256) void dgrad_empty_class_split_kernel(float4 *__restrict__ dx, const float4 *__restrict__ addend,
+                                                                      long long n, int sub_h, int sub_w, int full_h, int full_w,
+                                                                      int c4, int py, int px) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int cc = (int)(i % c4);
+    long long t = i / c4;
+    const int x2 = (int)(t % sub_w);
+    t /= sub_w;
+    const int y2 = (int)(t % sub_h);
+    const long long img = t / sub_h;
+    const long long off = ((img * full_h + 2 * y2 + py) * full_w + 2 * x2 + px) * c4 + cc;
+    dx[off] = addend ? addend[off] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static int validate_split(const mvg_conv_desc *d) {
+  if (validate(d)) return 2;
+  MVG_REQUIRE(d->cin % 32 == 0 && d->cout % 32 == 0, "split conv: cin and cout must be multiples of 32 (got %d, %d)", d->cin,
+              d->cout);
+  MVG_REQUIRE(d->r * d->s <= 32, "split conv: at most 32 filter taps");
+  return 0;
+}
+
+template <bool DGRAD>
+static int launch_igemm_split(IgemmParams &p, hipStream_t st) {
+  const int bn = p.ncols >= 128 ? 128 : 64;
+  p.ntiles = ceil_div(p.ncols, bn);
+  p.splits = 1;
+  p.sk_tiles = 0;
+  long long tiles = 0;
+  for (int i = 0; i < p.ncls; ++i) {
+    IgemmClass &c = p.cls[i];
+    c.mtiles_per_group = ceil_div(c.rows_per_group, SP_BM);
+    c.KT = c.ktotal > 0 ? ceil_div(c.ktotal, SP_BK) : 1;
+    c.korder = c.ntaps > 1 ? 1 : 0;
+    c.per_div = make_fastdiv((unsigned)(c.ntaps > 0 ? c.ntaps : 1));
+    c.tile0 = (int)tiles;
+    c.unit0 = 0;
+    tiles += (long long)p.groups * c.mtiles_per_group * p.ntiles;
+    MVG_REQUIRE(c.ntaps >= 1 && c.ntaps <= 32 && c.ktotal % SP_BK == 0, "split conv: class shape not covered");
+  }
+  MVG_REQUIRE(tiles < (1LL << 31), "split conv: grid too large");
+  if (tiles <= 0) return 0;
+  dim3 grid((unsigned)tiles), block(512);
+  if (bn == 128) hipLaunchKernelGGL((igemm_split_kernel<128, DGRAD>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL((igemm_split_kernel<64, DGRAD>), grid, block, 0, st, p);
+  return check_launch(DGRAD ? "conv_dgrad_split" : "conv_fprop_split");
+}
+
+}  // namespace mvg
+
+using namespace mvg;
+
+extern "C" {
+
+int mvg_split_f32(const float *x, void *out_s3, int64_t n, void *stream) {
+  MVG_REQUIRE(x && out_s3 && n >= 0 && n % 8 == 0, "split_f32: null argument or n %% 8 != 0");
+  if (n == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(MVG_K_LAYOUT, st, 0.0, 10.0 * (double)n);
+  long long blocks = (n / 8 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(split_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float4 *)x, (u32x4 *)out_s3, (long long)(n / 8));
+  return check_launch("split_f32");
+}
+
+int mvg_merge_s3(const void *x_s3, float *out, int64_t n, void *stream) {
+  MVG_REQUIRE(x_s3 && out && n >= 0 && n % 8 == 0, "merge_s3: null argument or n %% 8 != 0");
+  if (n == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(MVG_K_LAYOUT, st, 0.0, 10.0 * (double)n);
+  long long blocks = (n / 8 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(merge_s3_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const u32x4 *)x_s3, (float4 *)out, (long long)(n / 8));
+  return check_launch("merge_s3");
+}
+
+int mvg_split_weights(const mvg_conv_desc *d, const float *w, void *w_krsc_s3, void *w_crsk_s3, void *stream) {
+  MVG_REQUIRE(d && w && w_krsc_s3, "split_weights: null argument");
+  if (validate_split(d)) return 2;
+  hipStream_t st = (hipStream_t)stream;
+  const long long total = (long long)d->cout * d->r * d->s * d->cin;
+  ProfScope ps(MVG_K_LAYOUT, st, 0.0, (w_crsk_s3 ? 20.0 : 10.0) * (double)total);
+  long long blocks = ((w_crsk_s3 ? 2 : 1) * total / 8 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, st, w, (u32x4 *)w_krsc_s3, (u32x4 *)w_crsk_s3, d->cout,
+                     d->r * d->s, d->cin);
+  return check_launch("split_weights");
+}
+
+int mvg_conv_stats_partials_split(const mvg_conv_desc *d, int32_t *rows_per_partial) {
+  if (validate_split(d)) return -1;
+  const long long rows = (long long)d->n * d->ho * d->wo;
+  if (rows_per_partial) *rows_per_partial = SP_BM / 4;
+  return ceil_div(rows, SP_BM) * 4;
+}
+
+int mvg_conv_fprop_split(const mvg_conv_desc *d, const void *x_s3, const void *w_s3, float *y, float *stats, void *stream) {
+  if (validate_split(d)) return 2;
+  IgemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.a = (const float *)x_s3;
+  p.b = (const float *)w_s3;
+  p.out = y;
+  p.stats = stats;
+  p.groups = d->groups;
+  p.out_h = d->ho;
+  p.out_w = d->wo;
+  p.src_h = d->h;
+  p.src_w = d->w;
+  p.src_c = d->cin;
+  p.src_c_shift = (d->r * d->s > 1) ? ilog2_exact(d->cin) : 0;
+  p.ncols = d->cout;
+  p.r = d->r;
+  p.s = d->s;
+  p.rs = d->r * d->s;
+  p.stride = d->stride;
+  p.pad = d->pad;
+  p.ktotal = d->r * d->s * d->cin;
+  p.b_row_len = p.ktotal;
+  p.cin = d->cin;
+  p.rows_per_group = (long long)d->n * d->ho * d->wo;
+  p.src_img_stride = (long long)d->h * d->w * d->cin;
+  p.imgs_per_group = d->n;
+  p.ntaps = d->r * d->s;
+  p.tap_ns = d->s;
+  p.tap_step = 1;
+  p.cls_step = 1;
+  p.a_group_bytes = 6ll * d->n * p.src_img_stride;
+  p.b_bytes = 6ll * d->cout * p.ktotal;
+  MVG_REQUIRE(p.a_group_bytes < 0x7FFFFFF0ll && p.b_bytes < 0x7FFFFFF0ll, "split conv: a group / the weights exceed 2 GiB");
+  MVG_REQUIRE(p.rows_per_group * (long long)d->cout < (1ll << 31), "split conv: a group of the output exceeds 2^31 elements");
+  p.tap_ns_div = make_fastdiv((unsigned)p.tap_ns);
+  p.ohw_div = make_fastdiv((unsigned)(p.out_h * p.out_w));
+  p.ow_div = make_fastdiv((unsigned)p.out_w);
+  const double flops = 2.0 * d->groups * (double)p.rows_per_group * d->cout * d->r * d->s * d->cin;
+  const double bytes = 6.0 * (d->groups * (double)d->n * d->h * d->w * d->cin + (double)d->cout * d->r * d->s * d->cin) +
+                       4.0 * d->groups * (double)p.rows_per_group * d->cout;
+  const bool lin = d->r == 1 && d->s == 1 && d->h == 1 && d->w == 1;
+  ProfScope ps(lin ? MVG_K_LINEAR_FPROP : MVG_K_CONV_FPROP, (hipStream_t)stream, flops, bytes);
+  p.ncls = 1;
+  class_from_params(p.cls[0], p);
+  return launch_igemm_split<false>(p, (hipStream_t)stream);
+}
+
+int mvg_conv_dgrad_split(const mvg_conv_desc *d, const void *dy_s3, const void *w_crsk_s3, float *dx, const float *addend,
+                         void *stream) {
+  if (validate_split(d)) return 2;
+  IgemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.a = (const float *)dy_s3;
+  p.b = (const float *)w_crsk_s3;
+  p.out = dx;
+  p.addend = addend;
+  p.groups = d->groups;
+  p.out_h = d->h;
+  p.out_w = d->w;
+  p.src_h = d->ho;
+  p.src_w = d->wo;
+  p.src_c = d->cout;
+  p.src_c_shift = (d->r * d->s > 1) ? ilog2_exact(d->cout) : 0;
+  p.ncols = d->cin;
+  p.r = d->r;
+  p.s = d->s;
+  p.rs = d->r * d->s;
+  p.stride = d->stride;
+  p.pad = d->pad;
+  p.ktotal = d->r * d->s * d->cout;
+  p.b_row_len = d->r * d->s * d->cout;
+  p.cin = d->cin;
+  p.src_img_stride = (long long)d->ho * d->wo * d->cout;
+  p.imgs_per_group = d->n;
+  p.full_h = d->h;
+  p.full_w = d->w;
+  p.a_group_bytes = 6ll * d->n * p.src_img_stride;
+  p.b_bytes = 6ll * d->cin * p.b_row_len;
+  MVG_REQUIRE(p.a_group_bytes < 0x7FFFFFF0ll && p.b_bytes < 0x7FFFFFF0ll, "split conv: a group / the weights exceed 2 GiB");
+  MVG_REQUIRE((long long)d->n * d->h * d->w * d->cin < (1ll << 31), "split conv: a group of dx exceeds 2^31 elements");
+  const double flops = 2.0 * d->groups * (double)d->n * d->ho * d->wo * d->cout * d->r * d->s * d->cin;
+  const double bytes = 6.0 * (d->groups * (double)d->n * d->ho * d->wo * d->cout + (double)d->cout * d->r * d->s * d->cin) +
+                       4.0 * d->groups * (double)d->n * d->h * d->w * d->cin;
+  const bool lin = d->r == 1 && d->s == 1 && d->h == 1 && d->w == 1;
+  ProfScope ps(lin ? MVG_K_LINEAR_DGRAD : MVG_K_CONV_DGRAD, (hipStream_t)stream, flops, bytes);
+  const int step = d->stride;
+  IgemmParams m = p;
+  m.ncls = 0;
+  int cls_k[4];
+  for (int py = 0; py < step; ++py)
+    for (int px = 0; px < step; ++px) {
+      const int sub_h = (d->h - py + step - 1) / step, sub_w = (d->w - px + step - 1) / step;
+      if (sub_h <= 0 || sub_w <= 0) continue;
+      const int r0 = (py + d->pad) % step, s0 = (px + d->pad) % step;
+      const int nr = r0 < d->r ? (d->r - r0 + step - 1) / step : 0;
+      const int ns = s0 < d->s ? (d->s - s0 + step - 1) / step : 0;
+      IgemmParams q = p;
+      q.out_h = sub_h;
+      q.out_w = sub_w;
+      q.rows_per_group = (long long)d->n * sub_h * sub_w;
+      q.ntaps = nr * ns;
+      q.tap_ns = ns > 0 ? ns : 1;
+      q.tap_ns_div = make_fastdiv((unsigned)q.tap_ns);
+      q.ohw_div = make_fastdiv((unsigned)(sub_h * sub_w));
+      q.ow_div = make_fastdiv((unsigned)sub_w);
+      q.tap_r0 = r0;
+      q.tap_s0 = s0;
+      q.tap_step = step;
+      q.ktotal = nr * ns * d->cout;
+      q.cls_step = step;
+      q.cls_py = py;
+      q.cls_px = px;
+      q.cls_cy = (py + d->pad - r0) / step;
+      q.cls_cx = (px + d->pad - s0) / step;
+      if (q.ntaps == 0) {
+        if (addend != dx || !addend) {                 // nothing to do when the caller accumulates in place
+          const long long n = (long long)d->groups * d->n * sub_h * sub_w * (d->cin / 4);
+          long long blocks = (n + 255) / 256;
+          if (blocks > 4096) blocks = 4096;
+          hipLaunchKernelGGL(dgrad_empty_class_split_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4 *)dx,
+                             (const float4 *)addend, n, sub_h, sub_w, d->h, d->w, d->cin / 4, py, px);
+          if (check_launch("dgrad_split(empty class)")) return 1;
+        }
+        continue;
+      }
+      if (m.ncls == 0) {
+        m.tap_step = step;
+        m.cls_step = step;
+        m.rows_per_group = q.rows_per_group;
+        m.ktotal = q.ktotal;
+        m.out_h = q.out_h;
+        m.out_w = q.out_w;
+      }
+      cls_k[m.ncls] = q.ktotal;
+      class_from_params(m.cls[m.ncls++], q);
+    }
+  if (m.ncls == 0) return 0;
+  for (int i = 1; i < m.ncls; ++i)                       // longest class first
+    for (int j = i; j > 0 && cls_k[j] > cls_k[j - 1]; --j) {
+      const IgemmClass tc = m.cls[j];
+      m.cls[j] = m.cls[j - 1];
+      m.cls[j - 1] = tc;
+      const int tk = cls_k[j];
+      cls_k[j] = cls_k[j - 1];
+      cls_k[j - 1] = tk;
+    }
+  m.no_remap = m.ncls > 1;
+  return launch_igemm_split<true>(m, (hipStream_t)stream);
+}
+
+static void wgrad_split_tile(const mvg_conv_desc *d, int &bm, int &bn) {
+  const int ncols = d->r * d->s * d->cin;
+  bm = d->cout >= 128 ? 128 : 64;
+  bn = ncols >= 128 ? 128 : 64;
+}
+
+int mvg_conv_wgrad_splits_split(const mvg_conv_desc *d) {
+  if (validate_split(d)) return -1;
+  int bm, bn;
+  wgrad_split_tile(d, bm, bn);
+  const int ncols = d->r * d->s * d->cin;
+  const long long tiles = (long long)ceil_div(d->cout, bm) * ceil_div(ncols, bn);
+  const long long pixels = (long long)d->groups * d->n * d->ho * d->wo;
+  const int cus = compute_cus();
+  long long want = (2LL * cus) / tiles;                    // one resident round at two workgroups per CU
+  long long maxs = pixels / 256;                           // at least 256 pixels (16 K-steps) per split
+  if (maxs < 1) maxs = 1;
+  if (want > maxs) want = maxs;
+  if (want < 1) want = 1;
+  if (want > 1024) want = 1024;
+  return (int)want;
+}
+
+int mvg_conv_wgrad_split(const mvg_conv_desc *d, const void *x_s3, const void *dy_s3, float *dw, float *workspace, int splits,
+                         int accumulate, void *stream) {
+  if (validate_split(d)) return 2;
+  MVG_REQUIRE(splits >= 1, "wgrad_split: splits < 1");
+  MVG_REQUIRE(splits == 1 || workspace != nullptr, "wgrad_split: workspace required for splits > 1");
+  WgradParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = (const float *)x_s3;
+  p.dy = (const float *)dy_s3;
+  p.h = d->h;
+  p.w = d->w;
+  p.cin = d->cin;
+  p.cout = d->cout;
+  p.r = d->r;
+  p.s = d->s;
+  p.stride = d->stride;
+  p.pad = d->pad;
+  p.ho = d->ho;
+  p.wo = d->wo;
+  p.ncols = d->r * d->s * d->cin;
+  p.pixels = (long long)d->groups * d->n * d->ho * d->wo;
+  p.pixels_per_split = ((p.pixels + splits - 1) / splits + 15) / 16 * 16;
+  p.x_bytes = 6ll * d->groups * d->n * d->h * d->w * d->cin;
+  p.ohw_div = make_fastdiv((unsigned)(d->ho * d->wo));
+  p.wo_div = make_fastdiv((unsigned)d->wo);
+  p.cin_div = make_fastdiv((unsigned)d->cin);
+  p.s_div = make_fastdiv((unsigned)d->s);
+  MVG_REQUIRE(p.pixels_per_split * d->cout * 6 < 0x7FFFFFF0ll, "wgrad_split: split too large for 32-bit offsets");
+  MVG_REQUIRE(6ll * (p.pixels_per_split / (d->ho * d->wo) + 2) * d->h * d->w * d->cin < 0x7FFFFFF0ll,
+              "wgrad_split: split too large for 32-bit offsets");
+  int bm, bn;
+  wgrad_split_tile(d, bm, bn);
+  p.mtiles = ceil_div(d->cout, bm);
+  p.ntiles = ceil_div(p.ncols, bn);
+  p.out = splits == 1 ? dw : workspace;
+  p.accumulate = (splits == 1) ? accumulate : 0;
+  hipStream_t st = (hipStream_t)stream;
+  const bool lin = d->r == 1 && d->s == 1 && d->h == 1 && d->w == 1;
+  {
+    const double flops = 2.0 * (double)p.pixels * d->cout * d->r * d->s * d->cin;
+    const double bytes = 6.0 * ((double)d->groups * d->n * d->h * d->w * d->cin + (double)p.pixels * d->cout) +
+                         4.0 * (double)d->cout * d->r * d->s * d->cin;
+    ProfScope ps(lin ? MVG_K_LINEAR_WGRAD : MVG_K_CONV_WGRAD, st, flops, bytes);
+    MVG_REQUIRE((long long)p.mtiles * p.ntiles * splits < (1LL << 31), "wgrad_split: grid too large");
+    dim3 grid(p.mtiles * p.ntiles * splits), block(256);
+    const bool incr = (long long)d->ho * d->wo >= 32;        // at most one image wrap per 16-pixel step
+#define MVG_WGRAD_SPLIT(BM_, BN_)                                                                  \
+  do {                                                                                             \
+    if (incr) hipLaunchKernelGGL((wgrad_split_kernel<BM_, BN_, true>), grid, block, 0, st, p);     \
+    else hipLaunchKernelGGL((wgrad_split_kernel<BM_, BN_, false>), grid, block, 0, st, p);         \
+  } while (0)
+    if (bm == 128 && bn == 128) MVG_WGRAD_SPLIT(128, 128);
+    else if (bm == 64 && bn == 128) MVG_WGRAD_SPLIT(64, 128);
+    else if (bm == 128 && bn == 64) MVG_WGRAD_SPLIT(128, 64);
+    else MVG_WGRAD_SPLIT(64, 64);
+#undef MVG_WGRAD_SPLIT
+    if (check_launch("conv_wgrad_split")) return 1;
+  }
+  if (splits > 1) {
+    const long long n = (long long)d->cout * p.ncols;
+    ProfScope ps(MVG_K_WGRAD_REDUCE, st, 0.0, 4.0 * n * (splits + 1));
+    const int lanes = splits >= 32 ? 16 : (splits >= 8 ? 4 : 1);
+    const long long blocks = (n / 4 + 256 / lanes - 1) / (256 / lanes);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, workspace, dw, n / 4, splits, accumulate, lanes);
+    if (check_launch("wgrad_reduce")) return 1;
+  }
+  return 0;
+}
+
+}  // extern "C"

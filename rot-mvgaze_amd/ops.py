@@ -130,6 +130,56 @@ def fuser_wgrad(img_feat, feat, rel, row_img, row_src, dy, dw, db, rows, cf, nve
           "fuser_wgrad")
 
 
+# ---- "split" operands: fp32 values as three bf16 pieces, fp32-accurate products on the bf16 matrix cores
+def split_f32(x: Tensor) -> Tensor:
+    """fp32 [..., C] (C % 8 == 0) -> s3 tensor [..., C/8, 3, 8] bf16 (the three pieces sum to x exactly)."""
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] % 8 == 0
+    out = torch.empty(*x.shape[:-1], x.shape[-1] // 8, 3, 8, dtype=torch.bfloat16, device=x.device)
+    check(lib().mvg_split_f32(_p(x), _p(out), x.numel(), _s()), "split_f32")
+    return out
+
+
+def merge_s3(x: Tensor) -> Tensor:
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.shape[-2:] == (3, 8)
+    out = torch.empty(*x.shape[:-3], x.shape[-3] * 8, dtype=torch.float32, device=x.device)
+    check(lib().mvg_merge_s3(_p(x), _p(out), out.numel(), _s()), "merge_s3")
+    return out
+
+
+def split_weights(d: ConvDesc, w: Tensor, need_transposed: bool = True):
+    """fp32 KRSC weights -> (s3 KRSC, s3 CRSK or None)."""
+    rs = d.r * d.s
+    wk = torch.empty(d.cout, rs * d.cin // 8, 3, 8, dtype=torch.bfloat16, device=w.device)
+    wt = torch.empty(d.cin, rs * d.cout // 8, 3, 8, dtype=torch.bfloat16, device=w.device) if need_transposed else None
+    check(lib().mvg_split_weights(C.byref(d), _p(w), _p(wk), _p(wt), _s()), "split_weights")
+    return wk, wt
+
+
+def conv_stats_partials_split(d: ConvDesc):
+    rpp = C.c_int32(0)
+    n = lib().mvg_conv_stats_partials_split(C.byref(d), C.byref(rpp))
+    if n < 0:
+        check(1, "conv_stats_partials_split")
+    return n, rpp.value
+
+
+def conv_fprop_split(d: ConvDesc, x_s3: Tensor, w_s3: Tensor, y: Tensor, stats: Optional[Tensor] = None):
+    check(lib().mvg_conv_fprop_split(C.byref(d), _p(x_s3), _p(w_s3), _p(y), _p(stats), _s()), "conv_fprop_split")
+
+
+def conv_dgrad_split(d: ConvDesc, dy_s3: Tensor, wt_s3: Tensor, dx: Tensor, addend: Optional[Tensor] = None):
+    check(lib().mvg_conv_dgrad_split(C.byref(d), _p(dy_s3), _p(wt_s3), _p(dx), _p(addend), _s()), "conv_dgrad_split")
+
+
+def conv_wgrad_split(d: ConvDesc, x_s3: Tensor, dy_s3: Tensor, dw: Tensor, accumulate: bool = False):
+    splits = lib().mvg_conv_wgrad_splits_split(C.byref(d))
+    if splits < 1:
+        check(1, "conv_wgrad_splits_split")
+    ws = torch.empty(splits * dw.numel(), dtype=torch.float32, device=dw.device) if splits > 1 else None
+    check(lib().mvg_conv_wgrad_split(C.byref(d), _p(x_s3), _p(dy_s3), _p(dw), _p(ws), splits, int(accumulate), _s()),
+          "conv_wgrad_split")
+
+
 # ---- Linear layers of the fusion block in the bf16 path: fp32 tensors, bf16 matrix product (weights = bf16 copies)
 def linear_fprop_mixed(x, w_bf16, bias, relu, y, rows, fin, fout):
     check(lib().mvg_linear_fprop_mixed(_p(x), _p(w_bf16), _p(bias), int(relu), _p(y), rows, fin, fout, _s()), "linear_fprop_mixed")
