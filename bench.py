@@ -287,11 +287,23 @@ def main():
             with open(cands[-1]) as f:
                 tj = json.load(f)
             traffic, traffic_src = tj["traffic_bytes_per_launch"], os.path.relpath(cands[-1], ROOT)
-        peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
+        # fp32 training steps run the split-operand kernels (conv_split.hip: six bf16 MFMAs per fp32-accurate product),
+        # so their matrix-pipe ceiling is the bf16 MFMA peak / 6 (fp32-equivalent FLOP/s); MVG_SPLIT=0: the fp32 MFMA
+        split = (not bf16) and args.mode == "train" and bb is not None and getattr(bb, "split", False)
+        peak = PEAK_BF16_MFMA_TFLOPS if bf16 else (PEAK_BF16_MFMA_TFLOPS / 6.0 if split else PEAK_FP32_MFMA_TFLOPS)
+        kernels = "bf16" if bf16 else ("split" if split else "fp32mfma")
+        if traffic is not None and tj.get("kernels", "fp32mfma") != kernels:
+            traffic, traffic_src = None, None           # the committed counters belong to another kernel family
         roofline = {"bound": "mfma",
                     "kernel": ("igemm_bf16_kernel/wgrad_bf16_kernel (bf16 MFMA implicit-GEMM conv: fprop+dgrad+wgrad)" if bf16 else
+                               "igemm_split_kernel/wgrad_split_kernel (fp32-accurate implicit-GEMM conv on the bf16 MFMA, six MFMAs "
+                               "per product; the 3-channel stem on the fp32 MFMA: fprop+dgrad+wgrad)" if split else
                                "igemm_kernel/wgrad_kernel (fp32 MFMA implicit-GEMM conv: fprop+dgrad+wgrad)"),
-                    "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                    "peak_basis": ("dense bf16 MFMA 2500 TFLOP/s" if bf16 else
+                                   "dense bf16 MFMA 2500 TFLOP/s / 6 MFMAs per fp32-accurate product = 416.7 fp32-equivalent TFLOP/s"
+                                   if split else "dense fp32 MFMA (v_mfma_f32_32x32x2_f32) 157.3 TFLOP/s"),
+                    "frac_of_fp32_mfma_peak": None if bf16 else round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic,
                     "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE*2 + WRITE_SIZE, separate passes)",
                     "traffic_source": traffic_src,

@@ -455,6 +455,21 @@ int mvg_conv_stats_partials_split(const mvg_conv_desc *d, int32_t *rows_per_part
 int mvg_conv_fprop_split(const mvg_conv_desc *d, const void *x_s3, const void *w_s3, float *y, float *stats, void *stream);
 int mvg_conv_dgrad_split(const mvg_conv_desc *d, const void *dy_s3, const void *w_crsk_s3, float *dx, const float *addend,
                          void *stream);
+/* The BatchNorm passes on the split path: the conv output y and every gradient g stay fp32; what the next conv
+ * reads is written in s3 - the normalised activation (mvg_bn_apply_split, residual = the previous block's s3 output
+ * when residual_s3 != 0, else the raw fp32 downsample output with its res_scale / res_shift), the stem's pooled map
+ * (mvg_bn_relu_maxpool_fwd_split) and dy (mvg_bn_bwd_apply_split: g already masked, or the mask from relu_scale /
+ * relu_shift).  relu_bits as in mvg_bn_apply_bits (1 byte per 4 channels).  mvg_avgpool_fwd_split pools an s3 map. */
+int mvg_bn_apply_split(const float *y, const float *scale, const float *shift, const void *residual, int residual_s3,
+                       const float *res_scale, const float *res_shift, int relu, void *out_s3, uint8_t *relu_bits,
+                       int groups, int64_t rows_per_group, int c, void *stream);
+int mvg_bn_bwd_apply_split(const float *g, const float *y, const float *mean, const float *invstd, const float *gamma,
+                           const float *s1, const float *s2, const float *relu_scale, const float *relu_shift,
+                           int groups, int64_t rows_per_group, int c, void *dy_s3, void *stream);
+int mvg_bn_relu_maxpool_fwd_split(const float *y, const float *scale, const float *shift, void *pooled_s3,
+                                  uint8_t *argmax, int groups, int n_per_group, int h, int w, int c, int ho, int wo,
+                                  void *stream);
+int mvg_avgpool_fwd_split(const void *x_s3, float *y, int n, int hw, int c, void *stream);
 int mvg_conv_wgrad_splits_split(const mvg_conv_desc *d);   /* pixel-split count; workspace = splits * cout*r*s*cin floats */
 int mvg_conv_wgrad_split(const mvg_conv_desc *d, const void *x_s3, const void *dy_s3, float *dw, float *workspace, int splits,
                          int accumulate, void *stream);

@@ -44,9 +44,10 @@ class GradSink:
 class _Unit:
     """Saved state of one conv + BN (+ReLU) (+residual) for the backward pass."""
     __slots__ = ("spec", "desc", "x_in", "y", "out", "mean", "invstd", "relu", "rows", "w", "trained", "pool",
-                 "relu_affine", "fused_s12", "relu_bits")
+                 "relu_affine", "fused_s12", "relu_bits", "split")
 
     def __init__(self):
+        self.split = False        # conv operands (x_in, out, dy, w) in s3, split-operand kernels (conv_split.hip)
         self.relu_bits = None     # residual units: the ReLU mask as one byte per 16-byte access (ops.bn_apply_bits)
         self.fused_s12 = None     # BatchNorm-backward sums delivered by the backward-data launch that produced this unit's gradient
 
@@ -78,6 +79,10 @@ class Backbone:
         # residual units record their ReLU mask as bits in the forward apply pass; the backward reduce pass reads
         # those (1/16 of the activation's bytes) instead of the activation.  MVG_BN_BITS=0: read the activation.
         self.relu_bits = os.environ.get("MVG_BN_BITS", "1") != "0"
+        # fp32 training steps on the split-operand kernels (conv_split.hip): every conv but the 3-channel stem reads its
+        # operands as three bf16 pieces per fp32 value and runs six bf16 MFMAs per product - fp32-accurate (the 1e-4
+        # parity path), 1.2-1.7x the fp32-MFMA kernels.  MVG_SPLIT=0: the fp32-MFMA kernels everywhere.
+        self.split = os.environ.get("MVG_SPLIT", "1") != "0"
 
     @property
     def bf16(self) -> bool:
@@ -111,7 +116,15 @@ class Backbone:
         cin = (8 if bf else 4) if c.cin == 3 else c.cin
         d = ConvDesc.make(G, N, H, W, cin, c.cout, c.k, c.stride, c.pad)
         dev = x.device
-        if bf:
+        # split path: training steps of the fp32 model; sp_in = this conv reads s3 operands (all but the stem),
+        # sp_out = its consumers do (every unit: the stem's pooled map feeds layer1)
+        sp_out = self.split and training and not bf
+        sp_in = sp_out and c.cin != 3
+        if sp_in:
+            wsrc = self.p[c.name + ".weight"].detach()
+            assert wsrc.is_contiguous(memory_format=torch.channels_last) or (c.k == 1 and wsrc.is_contiguous())
+            w, w_t = ops.split_weights(d, wsrc, need_transposed=tape is not None)
+        elif bf:
             # one cast of the fp32 master weights per step: KRSC for fprop, CRSK (transposed) for backward-data
             wsrc = self.p[c.name + ".weight"].detach()
             assert wsrc.is_contiguous(memory_format=torch.channels_last) or (c.k == 1 and wsrc.is_contiguous())
@@ -126,9 +139,12 @@ class Backbone:
         mean, invstd, scale, shift = aff[0], aff[1], aff[2], aff[3]
 
         def fprop(stats_buf):
-            ops.conv_fprop(d, x, w, y, None, False, stats_buf)
+            if sp_in:
+                ops.conv_fprop_split(d, x, w, y, stats_buf)
+            else:
+                ops.conv_fprop(d, x, w, y, None, False, stats_buf)
         if training:
-            P, rpp = ops.conv_stats_partials(d, bf)
+            P, rpp = ops.conv_stats_partials_split(d) if sp_in else ops.conv_stats_partials(d, bf)
             stats = torch.empty(G, P, 2, c.cout, dtype=torch.float32, device=dev)
             fprop(stats)
             ops.bn_finalize(stats, G, P, rpp, rows, c.cout, gamma, beta, rm, rv, BN_MOMENTUM, BN_EPS, mean, invstd,
@@ -149,17 +165,26 @@ class Backbone:
             if keep:
                 u = _Unit()
                 u.spec, u.desc, u.x_in, u.y, u.out, u.mean, u.invstd, u.relu, u.rows, u.w = \
-                    c, d, x, y, None, mean, invstd, False, rows, (w_t if bf else w)
+                    c, d, x, y, None, mean, invstd, False, rows, (w_t if (bf or sp_in) else w)
                 u.trained = training
+                u.split = sp_in
                 u.relu_affine = None
                 tape.append(u)
             return y, (scale, shift)
         if pool:
             assert relu and residual is None
             hp, wp_ = (d.ho + 2 - 3) // 2 + 1, (d.wo + 2 - 3) // 2 + 1
-            out = torch.empty(G, N, hp, wp_, c.cout, dtype=self.act_dtype, device=dev)
             argmax = torch.empty(G, N, hp, wp_, c.cout, dtype=torch.uint8, device=dev)
-            ops.bn_relu_maxpool_fwd(y, scale, shift, out, argmax, G, N, d.ho, d.wo, c.cout, hp, wp_)
+            if sp_out:
+                out = ops.s3_empty(G, N, hp, wp_, c.cout, device=dev)
+                ops.bn_relu_maxpool_fwd_split(y, scale, shift, out, argmax, G, N, d.ho, d.wo, c.cout, hp, wp_)
+            else:
+                out = torch.empty(G, N, hp, wp_, c.cout, dtype=self.act_dtype, device=dev)
+                ops.bn_relu_maxpool_fwd(y, scale, shift, out, argmax, G, N, d.ho, d.wo, c.cout, hp, wp_)
+        elif sp_out:
+            out = ops.s3_empty(G, N, d.ho, d.wo, c.cout, device=dev)
+            bits = ops.bn_apply_split(y, scale, shift, residual, relu, out, G, rows, c.cout, residual_affine,
+                                      want_bits=keep and relu and residual is not None)
         else:
             out = torch.empty_like(y) if keep else y            # inference: normalise in place
             bits = None
@@ -170,8 +195,9 @@ class Backbone:
         if keep:
             u = _Unit()
             u.spec, u.desc, u.x_in, u.y, u.out, u.mean, u.invstd, u.relu, u.rows, u.w = \
-                c, d, x, y, (None if pool else out), mean, invstd, relu, rows, (w_t if bf else w)
+                c, d, x, y, (None if pool else out), mean, invstd, relu, rows, (w_t if (bf or sp_in) else w)
             u.trained = training
+            u.split = sp_in
             # ReLU without residual: the backward rebuilds the mask from y (saves reading `out` twice)
             u.relu_affine = (scale, shift) if (relu and residual is None and not pool) else None
             if pool:
@@ -251,7 +277,10 @@ class Backbone:
             x = out
             Hc, Wc = out.shape[2], out.shape[3]
         feat = torch.empty(V, B, self.fc_dim, dtype=torch.float32, device=dev)
-        ops.avgpool_fwd(x, feat, V * B, Hc * Wc, self.fc_dim)
+        if x.dtype == torch.bfloat16 and not self.bf16:             # s3 activation of the split path
+            ops.avgpool_fwd_split(x, feat, V * B, Hc * Wc, self.fc_dim)
+        else:
+            ops.avgpool_fwd(x, feat, V * B, Hc * Wc, self.fc_dim)
         if keep_tape:
             tape["final_hw"] = (Hc, Wc)
         return feat, tape
@@ -274,6 +303,19 @@ class Backbone:
         act = u.out if (u.relu and ra is None) else None
         acc = sink.accumulate(gp)
         assert acc == sink.accumulate(bp)
+        if u.split:
+            # split path: g and y are fp32, dy goes to the conv kernels in s3; residual units carry their mask as bits
+            assert not (u.relu and ra is None) or u.relu_bits is not None
+            if u.relu_bits is not None:
+                ops.bn_bwd_reduce_bits(g, u.relu_bits, u.y, u.mean, u.invstd, G, u.rows, c.cout, s12[0], s12[1], sink.view(gp),
+                                       sink.view(bp), acc, dz_out=g)
+            else:
+                ops.bn_bwd_reduce(g, None, u.y, u.mean, u.invstd, G, u.rows, c.cout, s12[0], s12[1], sink.view(gp), sink.view(bp),
+                                  acc, ra)
+            dy = ops.s3_empty(*u.y.shape, device=g.device)
+            ops.bn_bwd_apply_split(g, u.y, u.mean, u.invstd, gp.detach(), s12[0], s12[1], G, u.rows, c.cout, dy,
+                                   None if u.relu_bits is not None else ra)
+            return dy, (g if need_dz else None)
         if need_dz:
             # the reduce pass writes the masked gradient dz over g: the apply pass then reads (dz, y) only - no
             # second look at the ReLU mask, no second dz store - and the residual branch takes dz from g
@@ -319,14 +361,16 @@ class Backbone:
             self._wgrad(u, dy, sink)
         dx = None
         if need_dx:
-            dx = torch.empty_like(u.x_in)
+            dx = torch.empty(ops.s3_shape(u.x_in), dtype=torch.float32, device=dy.device) if u.split else torch.empty_like(u.x_in)
             self._dgrad(u, dy, dx, addend, fuse_for, sink)
         return dx
 
     def _wgrad(self, u: _Unit, dy: Tensor, sink: GradSink):
         c = u.spec
         wp = self.p[c.name + ".weight"]
-        if c.cin == 3:
+        if u.split:
+            ops.conv_wgrad_split(u.desc, u.x_in, dy, sink.view(wp), sink.accumulate(wp))
+        elif c.cin == 3:
             dw4 = torch.empty(c.cout, c.k, c.k, u.desc.cin, dtype=torch.float32, device=dy.device)
             ops.conv_wgrad(u.desc, u.x_in, dy, dw4, False)
             gv = sink.view(wp).permute(0, 2, 3, 1)
@@ -342,6 +386,9 @@ class Backbone:
         """dx = backward-data of unit u (+ addend).  fuse_for = the unit whose OUTPUT gradient dx is, when dx
         is final with this launch: its ReLU mask is applied and its BatchNorm-backward sums (s1, s2, dgamma,
         dbeta) are produced by the same launch (mvg_conv_dgrad_bnreduce) instead of a pass over (g, act, y)."""
+        if u.split:
+            ops.conv_dgrad_split(u.desc, dy, u.w, dx, addend)
+            return
         if fuse_for is not None and self.fuse_bn_reduce and not self.bf16 and u.desc.stride == 1:
             U, c = fuse_for, fuse_for.spec
             gp, bp = self.p[c.bn + ".weight"], self.p[c.bn + ".bias"]

@@ -167,16 +167,19 @@ __global__ void bn_eval_affine_kernel(int groups, int c, const float *gamma, con
 }
 
 // ---- apply: out = [relu](y*scale + shift [+ residual]) -------------------------------------
-template <typename T>
+// TO / TR: storage of the output and of the residual when they differ from y's (the split path: y fp32 from the conv,
+// out in s3 for the next conv, residual s3 (identity) or fp32 (raw downsample output)); same access width as T.
+template <typename T, typename TO = T, typename TR = T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T *__restrict__ y, const float *__restrict__ scale,
                                                        const float *__restrict__ shift,
-                                                       const T *__restrict__ residual,
+                                                       const TR *__restrict__ residual,
                                                        const float *__restrict__ res_scale,
                                                        const float *__restrict__ res_shift, int relu,
-                                                       T *__restrict__ out, long long nw_per_group, int cwn, int c,
+                                                       TO *__restrict__ out, long long nw_per_group, int cwn, int c,
                                                        unsigned char *__restrict__ relu_bits) {
   typedef Elem<T> E;
   constexpr int W = E::W;                 // float4 groups per 16-byte access (fp32: 1, bf16: 2)
+  static_assert(Elem<TO>::W == W && Elem<TR>::W == W, "bn_apply: mixed storage types need the same access width");
   // relu_bits (optional): one byte per 16-byte access, bit k = (element k of the access came out > 0) - the
   // ReLU mask of a residual unit for its backward reduce pass, at 1/16 of the bytes of reading `out` again
   // res_scale / res_shift: the residual is the RAW output of the block's downsample conv and its BatchNorm
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T *__restrict__ y, 
   for (; i < nw_per_group; i += stride) {
     float4 v[W], r[W], o[W];
     E::ldw(y, base + i, v);
-    if (residual) E::ldw(residual, base + i, r);
+    if (residual) Elem<TR>::ldw(residual, base + i, r);
 #pragma unroll
     for (int w = 0; w < W; ++w) {
       const float4 a = sc4[cq * W + w], b = sh4[cq * W + w];
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T *__restrict__ y, 
         o[w].w = fmaxf(o[w].w, 0.f);
       }
     }
-    E::stw(out, base + i, o);
+    Elem<TO>::stw(out, base + i, o);
     if (relu_bits) {
       unsigned m = 0;
 #pragma unroll
@@ -403,7 +406,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float *__re
   }
 }
 
-template <typename T>
+template <typename T, typename TO = T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__ g, const T *__restrict__ act,
                                                            const T *__restrict__ y,
                                                            const float *__restrict__ mean,
@@ -413,9 +416,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
                                                            const float *__restrict__ mscale,
                                                            const float *__restrict__ mshift,
                                                            long long nw_per_group, float inv_rows, int cwn, int c,
-                                                           T *__restrict__ dy, T *__restrict__ dz_out) {
+                                                           TO *__restrict__ dy, T *__restrict__ dz_out) {
   typedef Elem<T> E;
   constexpr int W = E::W;
+  static_assert(Elem<TO>::W == W, "bn_bwd_apply: mixed storage types need the same access width");
   const int grp = blockIdx.y;
   const float4 *mu4 = reinterpret_cast<const float4 *>(mean + (long long)grp * c);
   const float4 *is4 = reinterpret_cast<const float4 *>(invstd + (long long)grp * c);
@@ -455,7 +459,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
       o[w].w = ga.w * is.w * (d[w].w - sa.w * inv_rows - (v[w].w - mu.w) * is.w * (sb.w * inv_rows));
     }
     if (dz_out) E::stw(dz_out, base + i, d);
-    E::stw(dy, base + i, o);
+    Elem<TO>::stw(dy, base + i, o);
     cq += step;
     if (cq >= cwn) cq -= cwn;
   }
@@ -473,9 +477,9 @@ __device__ __forceinline__ float4 bn_relu4(float4 v, float4 a, float4 b) {
 
 // grid = (ceil(wo*c4n / 256), images*ho): one thread = one (image, oy, ox, 4 channels), no per-thread
 // divisions by runtime values except ox/cq.  First maximum in (kh, kw) scan order (ATen's rule).
-template <typename T>
+template <typename T, typename TO = T>
 __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const T *__restrict__ y, const float *__restrict__ scale,
-                                                                  const float *__restrict__ shift, T *__restrict__ pooled,
+                                                                  const float *__restrict__ shift, TO *__restrict__ pooled,
                                                                   uchar4 *__restrict__ argmax, int n_per_group, int h, int w,
                                                                   int c4n, int ho, int wo) {
   const int t = blockIdx.x * 256 + threadIdx.x;
@@ -511,7 +515,7 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const T *__res
     }
   }
   const long long o = (((long long)n * ho + oy) * wo + ox) * c4n + cq;
-  Elem<T>::st4(pooled, o, best);
+  Elem<TO>::st4(pooled, o, best);
   argmax[o] = idx;
 }
 
@@ -716,9 +720,9 @@ int mvg_bn_eval_affine(int groups, int c, const float *gamma, const float *beta,
 
 }  // extern "C" (templated implementations below)
 
-template <typename T>
-static int bn_apply_impl(const T *y, const float *scale, const float *shift, const T *residual, const float *res_scale,
-                         const float *res_shift, int relu, T *out, int groups, int64_t rows_per_group, int c, void *stream,
+template <typename T, typename TO = T, typename TR = T>
+static int bn_apply_impl(const T *y, const float *scale, const float *shift, const TR *residual, const float *res_scale,
+                         const float *res_shift, int relu, TO *out, int groups, int64_t rows_per_group, int c, void *stream,
                          uint8_t *relu_bits = nullptr) {
   MVG_REQUIRE(c % 4 == 0, "bn_apply: c %% 4 != 0");
   MVG_REQUIRE((res_scale == nullptr) == (res_shift == nullptr) && (residual || !res_scale),
@@ -727,8 +731,9 @@ static int bn_apply_impl(const T *y, const float *scale, const float *shift, con
   const long long n4 = rows_per_group * (c / 4);
   constexpr int W = Elem<T>::W;
   MVG_REQUIRE(c % (4 * W) == 0, "bn_apply: c must be a multiple of %d", 4 * W);
-  ProfScope ps(MVG_K_BN_APPLY, st, 0.0, 4.0 * Elem<T>::kBytes * groups * (double)n4 * (residual ? 3 : 2));
-  hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(grid_for(n4 / W), groups), dim3(256), 0, st, y, scale, shift, residual, res_scale,
+  ProfScope ps(MVG_K_BN_APPLY, st, 0.0,
+               4.0 * groups * (double)n4 * (Elem<T>::kBytes + Elem<TO>::kBytes + (residual ? Elem<TR>::kBytes : 0.0)));
+  hipLaunchKernelGGL((bn_apply_kernel<T, TO, TR>), dim3(grid_for(n4 / W), groups), dim3(256), 0, st, y, scale, shift, residual, res_scale,
                      res_shift, relu, out, n4 / W, c / 4 / W, c, relu_bits);
   return check_launch("bn_apply");
 }
@@ -760,10 +765,10 @@ static int bn_bwd_reduce_impl(const T *g, const T *act, const T *y, const float 
   return check_launch("bn_bwd_finalize");
 }
 
-template <typename T>
+template <typename T, typename TO = T>
 static int bn_bwd_apply_impl(const T *g, const T *act, const T *y, const float *mean, const float *invstd, const float *gamma,
                              const float *s1, const float *s2, const float *relu_scale, const float *relu_shift, int groups,
-                             int64_t rows_per_group, int c, T *dy, T *dz_out, void *stream) {
+                             int64_t rows_per_group, int c, TO *dy, T *dz_out, void *stream) {
   MVG_REQUIRE(!(act && relu_scale), "bn_bwd_apply: give the ReLU mask either as act or as (relu_scale, relu_shift)");
   MVG_REQUIRE((relu_scale == nullptr) == (relu_shift == nullptr), "bn_bwd_apply: relu_scale and relu_shift go together");
   MVG_REQUIRE(c % 4 == 0, "bn_bwd_apply: c %% 4 != 0");
@@ -771,22 +776,24 @@ static int bn_bwd_apply_impl(const T *g, const T *act, const T *y, const float *
   const long long n4 = rows_per_group * (c / 4);
   constexpr int W = Elem<T>::W;
   MVG_REQUIRE(c % (4 * W) == 0, "bn_bwd_apply: c must be a multiple of %d", 4 * W);
-  ProfScope ps(MVG_K_BN_BWD_APPLY, st, 0.0, 4.0 * Elem<T>::kBytes * groups * (double)n4 * ((act ? 4 : 3) + (dz_out ? 1 : 0)));
-  hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid_for(n4 / W), groups), dim3(256), 0, st, g, act, y, mean, invstd, gamma, s1, s2,
+  ProfScope ps(MVG_K_BN_BWD_APPLY, st, 0.0,
+               4.0 * groups * (double)n4 * (Elem<T>::kBytes * ((act ? 3 : 2) + (dz_out ? 1 : 0)) + Elem<TO>::kBytes));
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<T, TO>), dim3(grid_for(n4 / W), groups), dim3(256), 0, st, g, act, y, mean, invstd, gamma, s1, s2,
                      relu_scale, relu_shift, n4 / W, 1.0f / (float)rows_per_group, c / 4 / W, c, dy, dz_out);
   return check_launch("bn_bwd_apply");
 }
 
-template <typename T>
-static int bn_relu_maxpool_fwd_impl(const T *y, const float *scale, const float *shift, T *pooled, uint8_t *argmax, int groups,
+template <typename T, typename TO = T>
+static int bn_relu_maxpool_fwd_impl(const T *y, const float *scale, const float *shift, TO *pooled, uint8_t *argmax, int groups,
                                     int n_per_group, int h, int w, int c, int ho, int wo, void *stream) {
   MVG_REQUIRE(c % 4 == 0, "bn_relu_maxpool: c %% 4 != 0");
   MVG_REQUIRE(ho == (h + 2 - 3) / 2 + 1 && wo == (w + 2 - 3) / 2 + 1, "bn_relu_maxpool: bad output size");
   const long long total = (long long)groups * n_per_group * ho * wo * (c / 4);
   hipStream_t st = (hipStream_t)stream;
-  ProfScope ps(MVG_K_POOL, st, 0.0, Elem<T>::kBytes * ((double)groups * n_per_group * h * w * c + (double)total * 4) + (double)total * 4);
+  ProfScope ps(MVG_K_POOL, st, 0.0,
+               Elem<T>::kBytes * (double)groups * n_per_group * h * w * c + Elem<TO>::kBytes * (double)total * 4 + (double)total * 4);
   MVG_REQUIRE((long long)groups * n_per_group * ho < 65536, "bn_relu_maxpool: images*ho must fit grid.y");
-  hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel<T>, dim3(ceil_div((long long)wo * (c / 4), 256), groups * n_per_group * ho),
+  hipLaunchKernelGGL((bn_relu_maxpool_fwd_kernel<T, TO>), dim3(ceil_div((long long)wo * (c / 4), 256), groups * n_per_group * ho),
                      dim3(256), 0, st, y, scale, shift, pooled, (uchar4 *)argmax, n_per_group, h, w, c / 4, ho, wo);
   return check_launch("bn_relu_maxpool_fwd");
 }
@@ -904,6 +911,34 @@ MVG_BN_FACES(_bf16, uint16_t)
     return bn_bwd_reduce_impl<T>(g, nullptr, y, mean, invstd, nullptr, nullptr, groups, rows_per_group, c, s1, s2, dgamma,   \
                                  dbeta, accumulate, workspace, dz_out, stream, relu_bits);                                   \
   }
+// ---- split path (conv_split.hip): conv outputs and gradients fp32, conv INPUTS (activations, dy) in s3 ----------
+int mvg_bn_apply_split(const float *y, const float *scale, const float *shift, const void *residual, int residual_s3,
+                       const float *res_scale, const float *res_shift, int relu, void *out_s3, uint8_t *relu_bits, int groups,
+                       int64_t rows_per_group, int c, void *stream) {
+  MVG_REQUIRE(c % 8 == 0, "bn_apply_split: c %% 8 != 0");
+  MVG_REQUIRE(!(residual_s3 && res_scale), "bn_apply_split: an s3 residual is already normalised (no res_scale / res_shift)");
+  if (residual && residual_s3)
+    return bn_apply_impl<float, s3_t, s3_t>(y, scale, shift, (const s3_t *)residual, nullptr, nullptr, relu, (s3_t *)out_s3, groups,
+                                            rows_per_group, c, stream, relu_bits);
+  return bn_apply_impl<float, s3_t, float>(y, scale, shift, (const float *)residual, res_scale, res_shift, relu, (s3_t *)out_s3,
+                                           groups, rows_per_group, c, stream, relu_bits);
+}
+
+int mvg_bn_bwd_apply_split(const float *g, const float *y, const float *mean, const float *invstd, const float *gamma,
+                           const float *s1, const float *s2, const float *relu_scale, const float *relu_shift, int groups,
+                           int64_t rows_per_group, int c, void *dy_s3, void *stream) {
+  MVG_REQUIRE(c % 8 == 0, "bn_bwd_apply_split: c %% 8 != 0");
+  return bn_bwd_apply_impl<float, s3_t>(g, nullptr, y, mean, invstd, gamma, s1, s2, relu_scale, relu_shift, groups, rows_per_group,
+                                        c, (s3_t *)dy_s3, nullptr, stream);
+}
+
+int mvg_bn_relu_maxpool_fwd_split(const float *y, const float *scale, const float *shift, void *pooled_s3, uint8_t *argmax,
+                                  int groups, int n_per_group, int h, int w, int c, int ho, int wo, void *stream) {
+  MVG_REQUIRE(c % 8 == 0, "bn_relu_maxpool_fwd_split: c %% 8 != 0");
+  return bn_relu_maxpool_fwd_impl<float, s3_t>(y, scale, shift, (s3_t *)pooled_s3, argmax, groups, n_per_group, h, w, c, ho, wo,
+                                               stream);
+}
+
 MVG_BN_BITS_FACES(, float)
 MVG_BN_BITS_FACES(_bf16, uint16_t)
 #undef MVG_BN_BITS_FACES

@@ -22,21 +22,11 @@
 // bank slots).  Two stages (2 x 72 KB): the next K-step's DMA is issued before this K-step's 48 MFMAs per wave.
 // fp32 output through the LDS-staged epilogue of bf16_tile.h (BN statistics partials, addend).
 #include "bf16_tile.h"
+#include "elem.h"
 
 namespace mvg {
 
 constexpr int SP_BM = 256, SP_BK = 32;
-
-__device__ __forceinline__ void split3(float v, unsigned short &p1, unsigned short &p2, unsigned short &p3) {
-  const __bf16 h1 = (__bf16)v;
-  float r = v - (float)h1;
-  const __bf16 h2 = (__bf16)r;
-  r -= (float)h2;
-  const __bf16 h3 = (__bf16)r;
-  p1 = __builtin_bit_cast(unsigned short, h1);
-  p2 = __builtin_bit_cast(unsigned short, h2);
-  p3 = __builtin_bit_cast(unsigned short, h3);
-}
 
 // 8 consecutive fp32 values -> the chunk's three 16-byte piece vectors
 __device__ __forceinline__ void split3_chunk(const float (&v)[8], u32x4 &q1, u32x4 &q2, u32x4 &q3) {

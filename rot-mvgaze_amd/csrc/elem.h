@@ -54,4 +54,47 @@ struct Elem<bf16_t> {
   static __device__ __forceinline__ float ld1(const bf16_t *p, long long i) { return __uint_as_float((unsigned)p[i] << 16); }
 };
 
+// "s3" storage (conv_split.hip): an fp32 value as the exact sum of three bf16 pieces; channels in chunks of 8 with
+// the three pieces of a chunk adjacent (48 bytes).  The streaming passes address 4-channel groups like fp32: group
+// i4 is half (i4 & 1) of chunk (i4 >> 1), i.e. three 8-byte accesses 16 bytes apart.
+struct s3_t {
+  unsigned short v;
+};
+
+__device__ __forceinline__ void split3(float v, unsigned short &p1, unsigned short &p2, unsigned short &p3) {
+  const __bf16 h1 = (__bf16)v;
+  float r = v - (float)h1;
+  const __bf16 h2 = (__bf16)r;
+  r -= (float)h2;
+  const __bf16 h3 = (__bf16)r;
+  p1 = __builtin_bit_cast(unsigned short, h1);
+  p2 = __builtin_bit_cast(unsigned short, h2);
+  p3 = __builtin_bit_cast(unsigned short, h3);
+}
+
+template <>
+struct Elem<s3_t> {
+  static constexpr double kBytes = 6.0;
+  static constexpr int W = 1;
+  static __device__ __forceinline__ float4 ld4(const s3_t *p, long long i4) {
+    const uint2 *q = reinterpret_cast<const uint2 *>(p) + (i4 >> 1) * 6 + (i4 & 1);
+    const uint2 a = q[0], b = q[2], c = q[4];
+    return make_float4((bf16_lo(a.x) + bf16_lo(b.x)) + bf16_lo(c.x), (bf16_hi(a.x) + bf16_hi(b.x)) + bf16_hi(c.x),
+                       (bf16_lo(a.y) + bf16_lo(b.y)) + bf16_lo(c.y), (bf16_hi(a.y) + bf16_hi(b.y)) + bf16_hi(c.y));
+  }
+  static __device__ __forceinline__ void st4(s3_t *p, long long i4, float4 v) {
+    unsigned short a[4], b[4], c[4];
+    split3(v.x, a[0], b[0], c[0]);
+    split3(v.y, a[1], b[1], c[1]);
+    split3(v.z, a[2], b[2], c[2]);
+    split3(v.w, a[3], b[3], c[3]);
+    uint2 *q = reinterpret_cast<uint2 *>(p) + (i4 >> 1) * 6 + (i4 & 1);
+    q[0] = make_uint2((unsigned)a[0] | ((unsigned)a[1] << 16), (unsigned)a[2] | ((unsigned)a[3] << 16));
+    q[2] = make_uint2((unsigned)b[0] | ((unsigned)b[1] << 16), (unsigned)b[2] | ((unsigned)b[3] << 16));
+    q[4] = make_uint2((unsigned)c[0] | ((unsigned)c[1] << 16), (unsigned)c[2] | ((unsigned)c[3] << 16));
+  }
+  static __device__ __forceinline__ void ldw(const s3_t *p, long long iw, float4 (&v)[1]) { v[0] = ld4(p, iw); }
+  static __device__ __forceinline__ void stw(s3_t *p, long long iw, const float4 (&v)[1]) { st4(p, iw, v[0]); }
+};
+
 }  // namespace mvg

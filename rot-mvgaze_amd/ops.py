@@ -180,6 +180,42 @@ def conv_wgrad_split(d: ConvDesc, x_s3: Tensor, dy_s3: Tensor, dw: Tensor, accum
           "conv_wgrad_split")
 
 
+def s3_empty(*shape, device) -> Tensor:
+    """An uninitialised s3 tensor for fp32 shape [..., C] (C % 8 == 0): bf16 [..., C/8, 3, 8]."""
+    assert shape[-1] % 8 == 0
+    return torch.empty(*shape[:-1], shape[-1] // 8, 3, 8, dtype=torch.bfloat16, device=device)
+
+
+def s3_shape(x_s3: Tensor):
+    return tuple(x_s3.shape[:-3]) + (x_s3.shape[-3] * 8,)
+
+
+def bn_apply_split(y, scale, shift, residual, relu, out_s3, groups, rows_per_group, c, residual_affine=None, want_bits=False):
+    """y fp32 -> normalised (+ residual) (ReLU) activation in s3.  residual: an s3 tensor (identity) or the raw fp32
+    downsample output with residual_affine = its (scale, shift).  want_bits: also return the ReLU mask bytes."""
+    bits = torch.empty(groups * rows_per_group * c // 4, dtype=torch.uint8, device=y.device) if want_bits else None
+    rs, rh = residual_affine if residual_affine is not None else (None, None)
+    res_s3 = residual is not None and residual.dtype == torch.bfloat16
+    check(lib().mvg_bn_apply_split(_p(y), _p(scale), _p(shift), _p(residual), int(res_s3), _p(rs), _p(rh), int(relu), _p(out_s3),
+                                   _p(bits), groups, rows_per_group, c, _s()), "bn_apply_split")
+    return bits
+
+
+def bn_bwd_apply_split(g, y, mean, invstd, gamma, s1, s2, groups, rows_per_group, c, dy_s3, relu_affine=None):
+    rs, rh = relu_affine if relu_affine is not None else (None, None)
+    check(lib().mvg_bn_bwd_apply_split(_p(g), _p(y), _p(mean), _p(invstd), _p(gamma), _p(s1), _p(s2), _p(rs), _p(rh), groups,
+                                       rows_per_group, c, _p(dy_s3), _s()), "bn_bwd_apply_split")
+
+
+def bn_relu_maxpool_fwd_split(y, scale, shift, pooled_s3, argmax, groups, n_per_group, h, w, c, ho, wo):
+    check(lib().mvg_bn_relu_maxpool_fwd_split(_p(y), _p(scale), _p(shift), _p(pooled_s3), _p(argmax), groups, n_per_group, h, w, c,
+                                              ho, wo, _s()), "bn_relu_maxpool_fwd_split")
+
+
+def avgpool_fwd_split(x_s3, y, n, hw, c):
+    check(lib().mvg_avgpool_fwd_split(_p(x_s3), _p(y), n, hw, c, _s()), "avgpool_fwd_split")
+
+
 # ---- Linear layers of the fusion block in the bf16 path: fp32 tensors, bf16 matrix product (weights = bf16 copies)
 def linear_fprop_mixed(x, w_bf16, bias, relu, y, rows, fin, fout):
     check(lib().mvg_linear_fprop_mixed(_p(x), _p(w_bf16), _p(bias), int(relu), _p(y), rows, fin, fout, _s()), "linear_fprop_mixed")

@@ -99,8 +99,20 @@ def check_outputs(data, g, prefix, tol):
                       f"{prefix}.iter_{i}.{k}")
 
 
+# The fp32 model's training convs run on one of two kernel families, both held to the same bounds: "split" (default:
+# fp32 values as three bf16 pieces, six bf16 MFMAs per product, conv_split.hip) and "fp32mfma" (MVG_SPLIT=0: the
+# v_mfma_f32_32x32x2_f32 kernels of conv_igemm.hip, which also serve the stem, the Linears and inference).
+KERNELS = ["split", "fp32mfma"]
+
+
+def select_kernels(monkeypatch, kernels):
+    monkeypatch.setenv("MVG_SPLIT", "1" if kernels == "split" else "0")
+
+
+@pytest.mark.parametrize("kernels", KERNELS)
 @pytest.mark.parametrize("depth,batch,hw", [(18, 3, 64), (50, 3, 64), (18, 2, 224), (50, 2, 224)])
-def test_against_reference_golden(golden_dir, depth, batch, hw):
+def test_against_reference_golden(golden_dir, monkeypatch, depth, batch, hw, kernels):
+    select_kernels(monkeypatch, kernels)
     g = np.load(os.path.join(golden_dir, f"model_r{depth}_b{batch}_hw{hw}.npz"))
     # ---- eval
     m = build(depth, train=False)
@@ -230,7 +242,11 @@ def _captured_masks(m, V=2):
 
     def unit_mask(u, v):
         if u.out is not None:
-            return u.out[v] > 0
+            o = u.out[v].contiguous()
+            if o.dtype == torch.bfloat16:           # split path: the activation is stored as three bf16 pieces (exact sum)
+                from rot_mvgaze_amd import ops
+                o = ops.merge_s3(o)
+            return o > 0
         # fused stem: the normalised map is not stored; the kernels use fma(y, scale, shift) > 0, whose
         # sign equals the sign of the exact value (evaluated here in fp64)
         scale, shift = u.pool[1], u.pool[2]
@@ -252,11 +268,13 @@ def _captured_masks(m, V=2):
 @pytest.mark.parametrize("depth,batch,hw,gtol", [(18, 4, 96, GTOL), (50, 2, 160, 2 * GTOL), (18, 2, 224, GTOL),
                                                  (50, 3, 64, 1e-3),    # 12-sample BatchNorm in layer4
                                                  (18, 64, 224, GTOL / 2)])   # the benchmark configuration C2 at full size
-def test_backward_strict_with_imposed_relu_pattern(depth, batch, hw, gtol):
+@pytest.mark.parametrize("kernels", KERNELS)
+def test_backward_strict_with_imposed_relu_pattern(monkeypatch, depth, batch, hw, gtol, kernels):
     """Every parameter gradient (and d/d img) against the fp64 oracle evaluated with the SAME
     ReLU activation pattern as the HIP forward (oracle._relu): isolates the backward kernels from
     the handful of boundary ReLU decisions that fp32 reduction order flips."""
     from oracle import restatement as R
+    select_kernels(monkeypatch, kernels)
     m = build(depth)
     m._debug_keep_tapes = True
     data = inputs(batch, hw, seed=99)
@@ -504,6 +522,7 @@ def test_fused_bn_backward_reduce_switch_gives_the_same_step(depth):
     for fuse in (False, True):
         m = build(depth)
         m.ensure_layout()
+        m._backbone.split = False           # the fusion is a feature of the fp32-MFMA backward-data kernel
         m._backbone.fuse_bn_reduce = fuse
         d = m(inputs(4, 96, seed=3))
         loss = metrics()(d)
@@ -523,6 +542,7 @@ def test_relu_mask_bits_give_the_same_step_as_reading_the_activation(depth, dtyp
         m = build(depth)
         m.compute_dtype = dtype
         m.ensure_layout()
+        m._backbone.split = False           # the split path always carries the mask as bits
         m._backbone.relu_bits = bits
         d = m(inputs(4, 96, seed=5))
         loss = metrics()(d)
@@ -531,6 +551,26 @@ def test_relu_mask_bits_give_the_same_step_as_reading_the_activation(depth, dtyp
     assert grads[0][0] == grads[1][0]
     for k, g in grads[0][1].items():
         assert torch.equal(grads[1][1][k], g), "mask bits vs activation: " + k
+
+
+@pytest.mark.parametrize("depth,batch,hw", [(18, 4, 96), (50, 3, 128)])
+def test_split_and_fp32_mfma_kernels_give_the_same_step(depth, batch, hw):
+    """The two conv kernel families of the fp32 model are both fp32-accurate: same loss to 1e-5, gradients to the
+    ReLU-flip bound (they round differently, so a boundary ReLU may fall on either side)."""
+    runs = []
+    for split in (True, False):
+        m = build(depth)
+        m.ensure_layout()
+        m._backbone.split = split
+        d = m(inputs(batch, hw, seed=11))
+        loss = metrics()(d)
+        loss.backward()
+        runs.append((loss.item(), d["iter_2"]["pred_gaze_1"].detach().clone(),
+                     {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}))
+    rel_close(runs[0][0], runs[1][0], 1e-5, "loss, split vs fp32-MFMA kernels")
+    rel_close(runs[0][1], runs[1][1].cpu().numpy(), TOL, "pred, split vs fp32-MFMA kernels")
+    for k, g in runs[1][2].items():
+        l2_close(runs[0][2][k], g.cpu().numpy(), GTOL_L2_FLIPS_DEEP, "split vs fp32-MFMA kernels: " + k)   # two flip-noisy runs
 
 
 def test_gradient_accumulation_and_zero_grad():
