@@ -18,8 +18,9 @@ __device__ __forceinline__ unsigned pack_bf2(float a, float b) {          // rou
 // Epilogue shared by the bf16 GEMM kernels: BN partial statistics from the fp32 accumulators, then the tile goes
 // through LDS (fp32, the operand buffers are free after the K loop) so that global stores are 16-byte vectors along
 // the channel axis, with bias / ReLU / mask / addend applied in fp32 and ONE rounding to bf16 (F32IO: fp32 stores).
-// Workgroup = WGM x 2 waves (WGM * 128 threads), wave tile (BM / WGM) x (BN / 2).
-template <int BM, int BN, int WGM, bool DGRAD, bool F32IO>
+// Workgroup = WGM x 2 waves (WGM * 128 threads), wave tile (BM / WGM) x (BN / 2).  PASSES > 1: the staging tile
+// holds BM / PASSES rows at a time (the wave rows take turns), for kernels whose LDS is smaller than the full tile.
+template <int BM, int BN, int WGM, bool DGRAD, bool F32IO, int PASSES = 1>
 __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmClass &c, f32x16 (&acc)[BM / WGM / 32][BN / 2 / 32],
                                               unsigned short *smem, int tid, int g, int mtile, int ntile) {
   constexpr int WGN = 2, NT = WGM * WGN * 64;
@@ -59,7 +60,7 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
         }
       q += __shfl_xor(q, 32, 64);
       if (lh == 0 && col < p.ncols) {
-        const long long P = (long long)c.mtiles_per_group * WGM;
+        const long long P = p.stats_partials ? p.stats_partials : (long long)c.mtiles_per_group * WGM;
         const long long pi = (long long)mtile * WGM + wm;
         float *st = p.stats + (((long long)g * P + pi) * 2) * p.ncols;
         st[col] = csum;
@@ -68,15 +69,10 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
     }
   }
   // accumulators -> fp32 tile in LDS (the operand buffers are free: the K loop ended with a barrier)
+  static_assert(WGM % PASSES == 0, "bf16_epilogue: the wave rows must divide into the passes");
+  constexpr int PR = BM / PASSES;              // rows per pass
   float *ot = reinterpret_cast<float *>(smem);
-  int *rowoff = reinterpret_cast<int *>(ot + BM * LDO);
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e)
-        ot[(wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * LDO + wn * WTN + j * 32 + li] = acc[i][j][e];
+  int *rowoff = reinterpret_cast<int *>(ot + PR * LDO);
   // element offset of every tile row inside its group's output tensor (-1: beyond the end)
   for (int r = tid; r < BM; r += NT) {
     const long long m = (long long)mtile * BM + r;
@@ -93,7 +89,6 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
     }
     rowoff[r] = off;
   }
-  __syncthreads();
   const long long gelems = DGRAD ? (long long)p.imgs_per_group * p.full_h * p.full_w * p.ncols
                                  : c.rows_per_group * (long long)p.ncols;
   unsigned short *out_g = reinterpret_cast<unsigned short *>(p.out) + (long long)g * gelems;
@@ -104,14 +99,28 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
   const float *mask_f = p.mask ? p.mask + (long long)g * gelems : nullptr;
   constexpr int CV = BN / 8;                 // 16-byte output vectors per tile row
 #pragma unroll
-  for (int it = 0; it < BM * CV / NT; ++it) {
+  for (int ph = 0; ph < PASSES; ++ph) {
+  if (PASSES > 1 && ph > 0) __syncthreads();                  // the previous pass's rows have been read
+  if (wm / (WGM / PASSES) == ph) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          ot[((wm % (WGM / PASSES)) * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * LDO + wn * WTN + j * 32 + li] = acc[i][j][e];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < PR * CV / NT; ++it) {
     const int v = tid + it * NT;
-    const int r = v / CV, cv = v - r * CV;
+    const int rl = v / CV, cv = v - rl * CV;
+    const int r = ph * PR + rl;
     const int col = ntile * BN + cv * 8;
     const int off = rowoff[r];
     if (off < 0 || col >= p.ncols) continue;
-    const float4 lo = *reinterpret_cast<const float4 *>(ot + r * LDO + cv * 8);
-    const float4 hi = *reinterpret_cast<const float4 *>(ot + r * LDO + cv * 8 + 4);
+    const float4 lo = *reinterpret_cast<const float4 *>(ot + rl * LDO + cv * 8);
+    const float4 hi = *reinterpret_cast<const float4 *>(ot + rl * LDO + cv * 8 + 4);
     float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     if (!DGRAD && p.bias) {
       const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + col), b1 = *reinterpret_cast<const float4 *>(p.bias + col + 4);
@@ -161,6 +170,7 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
     o.w = pack_bf2(x[6], x[7]);
     *reinterpret_cast<u32x4 *>(out_g + off + col) = o;
   }
+  }  // passes
 }
 
 // Transposing fragment read (ds_read_b64_tr_b16) from a pixel-major [k][m] LDS image with row pitch `ld` elements:

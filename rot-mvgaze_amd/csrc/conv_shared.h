@@ -123,6 +123,7 @@ struct IgemmParams {
   int ncls;
   IgemmClass cls[4];         // per-class view (one class unless this is a stride-2 dgrad)
   int b_row_len;             // bf16 kernels: elements per row of the (k-contiguous) weight operand
+  int stats_partials;        // bf16_epilogue: partials per group of `stats` as the caller allocated it (0: mtiles * wave rows)
   // Backward-data fused with the BatchNorm-backward REDUCE pass of the unit whose output gradient this
   // launch produces (fp32 kernels, stride-1 launches): the epilogue masks the gradient by that unit's ReLU
   // (bn_act > 0, or fma(bn_y, bn_rscale, bn_rshift) > 0, or no mask), stores the masked gradient and adds up,

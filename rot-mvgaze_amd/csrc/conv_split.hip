@@ -27,6 +27,7 @@
 namespace mvg {
 
 constexpr int SP_BM = 256, SP_BK = 32;
+constexpr int SP_SMALL_K = 4096;      // GEMM K below this: the 128-row, three-workgroups-per-CU kernel (measured per shape)
 
 // 8 consecutive fp32 values -> the chunk's three 16-byte piece vectors
 __device__ __forceinline__ void split3_chunk(const float (&v)[8], u32x4 &q1, u32x4 &q2, u32x4 &q3) {
@@ -265,6 +266,172 @@ __global__ __launch_bounds__(512, 1) void igemm_split_kernel(IgemmParams p) {
   bf16_epilogue<BM, BN, WGM, DGRAD, true>(p, c, acc, smem, tid, g, mtile, ntile);
 }
 
+// The same GEMM for short-K and HBM-bound shapes: tile 128 x BN x 32, 256 threads = 4 waves as 2 x 2 (the same
+// 64 x (BN/2) wave tile), ONE 48 KB stage and three workgroups per CU.  With 1x1 convs of K = 64..512 a tile is a
+// few K-steps between a cold prologue and a 64 KB epilogue: one big workgroup per CU runs those phases in lock step
+// with every other CU (the HBM idles during the K loops and saturates during the epilogues); three small workgroups
+// per CU drift apart and cover each other's DMA waits and epilogues (cdna_hip_programming.md: at 2-3 blocks/CU the
+// wave-level overlap already captures what a deeper software pipeline would add).  The epilogue stages 64 rows at a
+// time (34 KB).
+template <int BN, bool DGRAD>
+__global__ __launch_bounds__(256, 3) void igemm_split_small_kernel(IgemmParams p) {
+  constexpr int BM = 128, BK = SP_BK, WGM = 2, WGN = 2;
+  constexpr int WTM = BM / WGM, WTN = BN / WGN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int ROW = BK;
+  constexpr int A_ELEMS = BM * ROW, B_ELEMS = BN * ROW;       // one piece
+  constexpr int STAGE = 3 * (A_ELEMS + B_ELEMS);
+  constexpr int A_GROUPS = BM / 16 / 4;                       // 16-row DMA groups per wave (2)
+  constexpr int B_GROUPS = BN / 16 / 4;                       // (2 or 1)
+  constexpr int LDO = BN + 4;
+  constexpr int EPI_ELEMS = ((BM / 2) * LDO * 4 + BM * 4) / 2;
+  constexpr int SMEM = STAGE > EPI_ELEMS ? STAGE : EPI_ELEMS;
+  __shared__ __attribute__((aligned(16))) unsigned short smem[SMEM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int nwg = gridDim.x;
+  const int wg_all = p.no_remap ? (int)blockIdx.x : xcd_remap(blockIdx.x, nwg);
+  int ci = 0;
+  for (int i = 1; i < p.ncls; ++i) ci += wg_all >= p.cls[i].tile0;
+  const IgemmClass &c = p.cls[ci];
+  const int wg = wg_all - c.tile0;
+  const int ntile = wg % p.ntiles;
+  const int mt_all = wg / p.ntiles;
+  const int g = mt_all / c.mtiles_per_group;
+  const int mtile = mt_all - g * c.mtiles_per_group;
+  const int KT = c.KT;
+  const int ohw = c.out_h * c.out_w;
+
+  const int r_in_grp = lane >> 2;
+  const int a_kv = (lane & 3) ^ ((lane >> 4) & 3);
+  unsigned a_base[A_GROUPS], a_vmask[A_GROUPS], b_base[B_GROUPS];
+  bool b_ok[B_GROUPS];
+#pragma unroll
+  for (int i = 0; i < A_GROUPS; ++i) {
+    const long long m = (long long)mtile * BM + (wave + 4 * i) * 16 + r_in_grp;
+    const bool ok = m < c.rows_per_group;
+    const int mm = ok ? (int)m : 0;
+    const int img = (int)fdiv((unsigned)mm, c.ohw_div);
+    const int rem = mm - img * ohw;
+    const int oy = (int)fdiv((unsigned)rem, c.ow_div), ox = rem - oy * c.out_w;
+    const int y0 = DGRAD ? oy + c.cls_cy : oy * p.stride - p.pad;
+    const int x0 = DGRAD ? ox + c.cls_cx : ox * p.stride - p.pad;
+    a_base[i] = (unsigned)(img * p.src_img_stride * 6) + (unsigned)((y0 * p.src_w + x0) * p.src_c) * 6u + (unsigned)a_kv * 48u;
+    unsigned msk = 0;
+    for (int t = 0; t < c.ntaps; ++t) {
+      const int fr = (int)fdiv((unsigned)t, c.tap_ns_div), fs = t - fr * c.tap_ns;
+      const int iy = DGRAD ? y0 - fr : y0 + fr;
+      const int ix = DGRAD ? x0 - fs : x0 + fs;
+      msk |= (unsigned)(((unsigned)iy < (unsigned)p.src_h) & ((unsigned)ix < (unsigned)p.src_w)) << t;
+    }
+    a_vmask[i] = ok ? msk : 0u;
+  }
+#pragma unroll
+  for (int i = 0; i < B_GROUPS; ++i) {
+    const int n = ntile * BN + (wave + 4 * i) * 16 + r_in_grp;
+    b_ok[i] = n < p.ncols;
+    b_base[i] = ((unsigned)n * (unsigned)p.b_row_len) * 6u + (unsigned)a_kv * 48u;
+  }
+  const __amdgpu_buffer_rsrc_t rs_a =
+      make_rsrc(reinterpret_cast<const char *>(p.a) + (long long)g * p.imgs_per_group * p.src_img_stride * 6, p.a_group_bytes);
+  const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(p.b, p.b_bytes);
+  typedef __attribute__((address_space(3))) void *lds_vp;
+
+  auto issue = [&](int kt) {
+    int kstart = kt * BK;
+    if (c.korder) {
+      const int cblk = (int)fdiv((unsigned)kt, c.per_div), rem = kt - cblk * c.ntaps;
+      kstart = (rem << p.src_c_shift) + cblk * BK;
+    }
+    const int ks = __builtin_amdgcn_readfirstlane(kstart);
+    const int tap_u = c.ntaps > 1 ? (ks >> p.src_c_shift) : 0;
+    const int chb = ks - (tap_u << p.src_c_shift);
+    const int fru = (int)fdiv((unsigned)tap_u, c.tap_ns_div), fsu = tap_u - fru * c.tap_ns;
+    const int disp = (fru * p.src_w + fsu) * p.src_c;
+    const unsigned sdelta = (unsigned)(((DGRAD ? -disp : disp) + chb) * 6);
+    unsigned kb = (unsigned)ks * 6u;
+    if (DGRAD) {
+      const int btap = (c.tap_r0 + p.tap_step * fru) * p.s + c.tap_s0 + p.tap_step * fsu;
+      kb = (unsigned)(btap * p.src_c + chb) * 6u;
+    }
+#pragma unroll
+    for (int i = 0; i < A_GROUPS; ++i) {
+      const bool ok = ((a_vmask[i] >> tap_u) & 1u) != 0u;
+      const unsigned off = a_base[i] + sdelta;
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_vp)(smem + pc * A_ELEMS + (wave + 4 * i) * 16 * ROW), 16,
+                                                 (int)pred_off(off + 16u * pc, ok), 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < B_GROUPS; ++i) {
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_vp)(smem + 3 * A_ELEMS + pc * B_ELEMS + (wave + 4 * i) * 16 * ROW), 16,
+                                                 (int)pred_off(b_base[i] + kb + 16u * pc, b_ok[i]), 0, 0, 0);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  int a_row[TM], b_row[TN], a_sw[TM], b_sw[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int R = wm * WTM + i * 32 + li;
+    a_row[i] = R * ROW;
+    a_sw[i] = (R >> 2) & 3;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int R = wn * WTN + j * 32 + li;
+    b_row[j] = R * ROW;
+    b_sw[j] = (R >> 2) & 3;
+  }
+
+  const unsigned short *As = smem;
+  const unsigned short *Bs = smem + 3 * A_ELEMS;
+  for (int kt = 0; kt < KT; ++kt) {
+    issue(kt);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int kg = 0; kg < BK / 16; ++kg) {
+      bf16x8 av[3][TM], bv[3][TN];
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          av[pc][i] = *reinterpret_cast<const bf16x8 *>(As + pc * A_ELEMS + a_row[i] + (((2 * kg + lh) ^ a_sw[i]) << 3));
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          bv[pc][j] = *reinterpret_cast<const bf16x8 *>(Bs + pc * B_ELEMS + b_row[j] + (((2 * kg + lh) ^ b_sw[j]) << 3));
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][i], bv[2][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[2][i], bv[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1][i], bv[1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][i], bv[1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1][i], bv[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][i], bv[0][j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();                                         // everyone is done reading before the next DMA lands
+  }
+  bf16_epilogue<BM, BN, WGM, DGRAD, true, 2>(p, c, acc, smem, tid, g, mtile, ntile);
+}
+
 // ------------------------------------------------------------------------------------------
 // wgrad: dw[o][tap][c] = sum over pixels of dy[pix][o] * x[pix at tap][c] with both operands in s3.  Like the bf16
 // kernel (conv_bf16.hip): M = cout, N = (tap, c), K = pixels split into slabs; the LDS images stay pixel-major
@@ -501,16 +668,37 @@ static int validate_split(const mvg_conv_desc *d) {
   return 0;
 }
 
+// 0: by shape (default), 1: always the 256-row kernel, 2: always the 128-row kernel (A/B switch: MVG_SPLIT_TILE)
+static int split_tile_env() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("MVG_SPLIT_TILE");
+    v = e ? atoi(e) : 0;
+    if (v < 0 || v > 2) v = 0;
+  }
+  return v;
+}
+
+// rows per statistics partial: both kernels produce 64-row (one wave tile) partials, mtiles * (BM / 64) per group
+static int split_bm(const IgemmParams &p) {
+  const int env = split_tile_env();
+  if (env) return env == 1 ? 256 : 128;
+  int kmax = 0;
+  for (int i = 0; i < p.ncls; ++i) kmax = p.cls[i].ktotal > kmax ? p.cls[i].ktotal : kmax;
+  return kmax >= SP_SMALL_K ? 256 : 128;
+}
+
 template <bool DGRAD>
 static int launch_igemm_split(IgemmParams &p, hipStream_t st) {
   const int bn = p.ncols >= 128 ? 128 : 64;
+  const int bm = split_bm(p);
   p.ntiles = ceil_div(p.ncols, bn);
   p.splits = 1;
   p.sk_tiles = 0;
   long long tiles = 0;
   for (int i = 0; i < p.ncls; ++i) {
     IgemmClass &c = p.cls[i];
-    c.mtiles_per_group = ceil_div(c.rows_per_group, SP_BM);
+    c.mtiles_per_group = ceil_div(c.rows_per_group, bm);
     c.KT = c.ktotal > 0 ? ceil_div(c.ktotal, SP_BK) : 1;
     c.korder = c.ntaps > 1 ? 1 : 0;
     c.per_div = make_fastdiv((unsigned)(c.ntaps > 0 ? c.ntaps : 1));
@@ -521,9 +709,15 @@ static int launch_igemm_split(IgemmParams &p, hipStream_t st) {
   }
   MVG_REQUIRE(tiles < (1LL << 31), "split conv: grid too large");
   if (tiles <= 0) return 0;
-  dim3 grid((unsigned)tiles), block(512);
-  if (bn == 128) hipLaunchKernelGGL((igemm_split_kernel<128, DGRAD>), grid, block, 0, st, p);
-  else hipLaunchKernelGGL((igemm_split_kernel<64, DGRAD>), grid, block, 0, st, p);
+  if (bm == 256) {
+    dim3 grid((unsigned)tiles), block(512);
+    if (bn == 128) hipLaunchKernelGGL((igemm_split_kernel<128, DGRAD>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((igemm_split_kernel<64, DGRAD>), grid, block, 0, st, p);
+  } else {
+    dim3 grid((unsigned)tiles), block(256);
+    if (bn == 128) hipLaunchKernelGGL((igemm_split_small_kernel<128, DGRAD>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((igemm_split_small_kernel<64, DGRAD>), grid, block, 0, st, p);
+  }
   return check_launch(DGRAD ? "conv_dgrad_split" : "conv_fprop_split");
 }
 
@@ -571,7 +765,9 @@ int mvg_split_weights(const mvg_conv_desc *d, const float *w, void *w_krsc_s3, v
 int mvg_conv_stats_partials_split(const mvg_conv_desc *d, int32_t *rows_per_partial) {
   if (validate_split(d)) return -1;
   const long long rows = (long long)d->n * d->ho * d->wo;
-  if (rows_per_partial) *rows_per_partial = SP_BM / 4;
+  if (rows_per_partial) *rows_per_partial = 64;               // one wave tile of rows, whichever kernel runs
+  // the 256-row kernel writes 4 partials per tile (the last tile's may lie beyond the rows: count 0), the 128-row
+  // kernel 2: size for the larger count, bn_finalize ignores partials that start beyond the rows
   return ceil_div(rows, SP_BM) * 4;
 }
 
@@ -618,6 +814,7 @@ int mvg_conv_fprop_split(const mvg_conv_desc *d, const void *x_s3, const void *w
                        4.0 * d->groups * (double)p.rows_per_group * d->cout;
   const bool lin = d->r == 1 && d->s == 1 && d->h == 1 && d->w == 1;
   ProfScope ps(lin ? MVG_K_LINEAR_FPROP : MVG_K_CONV_FPROP, (hipStream_t)stream, flops, bytes);
+  p.stats_partials = ceil_div(p.rows_per_group, SP_BM) * 4;    // = mvg_conv_stats_partials_split, whichever kernel runs
   p.ncls = 1;
   class_from_params(p.cls[0], p);
   return launch_igemm_split<false>(p, (hipStream_t)stream);
