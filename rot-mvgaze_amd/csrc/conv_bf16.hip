@@ -253,8 +253,10 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(IgemmParams p) {
 // descriptor's range check: the DMA writes zeros.  Two LDS buffers, the next K-step's DMA is issued before
 // this K-step's MFMAs; vmcnt(0) + barrier per K-step, two workgroups per CU cover each other's waits.
 // ------------------------------------------------------------------------------------------
-template <int BN, bool DGRAD>
-__global__ __launch_bounds__(256, 2) void igemm_bf16_dma_kernel(IgemmParams p) {
+// STAGES = 1 (short K: a tile is a few K-steps between a cold prologue and the epilogue): one 32 KB stage, the
+// epilogue staged in two passes (34 KB), four workgroups per CU that cover each other's DMA waits and epilogues.
+template <int BN, bool DGRAD, int STAGES = 2>
+__global__ __launch_bounds__(256, STAGES == 1 ? 4 : 2) void igemm_bf16_dma_kernel(IgemmParams p) {
   constexpr int BM = BF_BM, BK = BF_BK, WGM = 2, WGN = 2;
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -262,8 +264,9 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_dma_kernel(IgemmParams p) {
   constexpr int A_PASSES = BM / 32, B_PASSES = BN / 32;      // 32 rows (8 rows x 4 waves) per pass
   constexpr int A_ELEMS = BM * ROW, B_ELEMS = BN * ROW;
   constexpr int LDO = BN + 4;
-  constexpr int OP_ELEMS = 2 * (A_ELEMS + B_ELEMS);           // ushort
-  constexpr int EPI_ELEMS = (BM * LDO * 4 + BM * 4) / 2;
+  constexpr int OP_ELEMS = STAGES * (A_ELEMS + B_ELEMS);      // ushort
+  constexpr int EPI_PASSES = STAGES == 1 ? 2 : 1;
+  constexpr int EPI_ELEMS = ((BM / EPI_PASSES) * LDO * 4 + BM * 4) / 2;
   constexpr int SMEM = OP_ELEMS > EPI_ELEMS ? OP_ELEMS : EPI_ELEMS;
   __shared__ __attribute__((aligned(16))) unsigned short smem[SMEM];
 
@@ -370,12 +373,20 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_dma_kernel(IgemmParams p) {
     b_sw[j] = ((wn * WTN + j * 32 + li) >> 1) & 7;
   }
 
-  issue(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  if constexpr (STAGES == 2) {
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
   for (int kt = 0; kt < KT; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < KT) issue(kt + 1, cur ^ 1);
+    const int cur = STAGES == 2 ? (kt & 1) : 0;
+    if constexpr (STAGES == 2) {
+      if (kt + 1 < KT) issue(kt + 1, cur ^ 1);
+    } else {
+      issue(kt, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
     const unsigned short *As = smem + cur * (A_ELEMS + B_ELEMS);
     const unsigned short *Bs = As + A_ELEMS;
 #pragma unroll
@@ -390,10 +401,10 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_dma_kernel(IgemmParams p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the next K-step's DMA has landed
+    if constexpr (STAGES == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the next K-step's DMA has landed
     __syncthreads();                                         // ... for every wave, and everyone is done reading `cur`
   }
-  bf16_epilogue<BF_BM, BN, 2, DGRAD, false>(p, c, acc, smem, tid, g, mtile, ntile);
+  bf16_epilogue<BF_BM, BN, 2, DGRAD, false, EPI_PASSES>(p, c, acc, smem, tid, g, mtile, ntile);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -717,7 +728,20 @@ static int launch_igemm_bf16(IgemmParams &p, hipStream_t st, bool f32io = false)
       else hipLaunchKernelGGL((igemm_bf16_kernel<64, DGRAD, false, true>), grid, block, 0, st, p);
     }
   } else if (fasta && bf16_dma_enabled()) {
-    if (bn == 128) hipLaunchKernelGGL((igemm_bf16_dma_kernel<128, DGRAD>), grid, block, 0, st, p);
+    int kmax = 0;
+    for (int i = 0; i < p.ncls; ++i) kmax = p.cls[i].ktotal > kmax ? p.cls[i].ktotal : kmax;
+    // GEMM K below this runs the one-stage, four-workgroups-per-CU form: measured faster at every ResNet-50 shape
+    // (C5: fprop 10.4 -> 8.4 ms, dgrad 9.5 -> 7.5 ms), so the default is "always"; MVG_BF16_ONE_STAGE_K=0 restores
+    // the two-stage form everywhere (A/B switch)
+    static int one_stage_k = -1;
+    if (one_stage_k < 0) {
+      const char *e = getenv("MVG_BF16_ONE_STAGE_K");
+      one_stage_k = e ? atoi(e) : 0x7FFFFFFF;
+    }
+    if (kmax < one_stage_k) {
+      if (bn == 128) hipLaunchKernelGGL((igemm_bf16_dma_kernel<128, DGRAD, 1>), grid, block, 0, st, p);
+      else hipLaunchKernelGGL((igemm_bf16_dma_kernel<64, DGRAD, 1>), grid, block, 0, st, p);
+    } else if (bn == 128) hipLaunchKernelGGL((igemm_bf16_dma_kernel<128, DGRAD>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((igemm_bf16_dma_kernel<64, DGRAD>), grid, block, 0, st, p);
   } else if (bn == 128) {
     if (fasta) hipLaunchKernelGGL((igemm_bf16_kernel<128, DGRAD, true>), grid, block, 0, st, p);
