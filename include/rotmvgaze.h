@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MVG_ABI_VERSION 5
+#define MVG_ABI_VERSION 6
 
 /* ---------------------------------------------------------------- library */
 int mvg_abi_version(void);

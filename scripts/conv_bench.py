@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-shape throughput of the implicit-GEMM conv kernels over the ResNet-18/50 layer shapes
-(synthetic data, N images per group x G groups).  Usage: conv_bench.py [depth] [N] [G] [iters] [f32|bf16]"""
+(synthetic data, N images per group x G groups).  Usage: conv_bench.py [depth] [N] [G] [iters] [f32|bf16|split]   (split: the fp32-accurate split-operand kernels; the stem stays fp32)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -15,6 +15,7 @@ N = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 G = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 20
 bf16 = len(sys.argv) > 5 and sys.argv[5] == "bf16"
+split = len(sys.argv) > 5 and sys.argv[5] == "split"
 adt = torch.bfloat16 if bf16 else torch.float32
 dev = torch.device("cuda:0")
 spec = backbone_spec(depth)
@@ -45,7 +46,7 @@ def timeit(fn):
     return (time.perf_counter() - t0) / iters
 
 tot = {"fprop": [0, 0], "dgrad": [0, 0], "wgrad": [0, 0]}
-print(f"ResNet-{depth}  N={N} G={G}  {'bf16' if bf16 else 'fp32'}")
+print(f"ResNet-{depth}  N={N} G={G}  {'bf16' if bf16 else ('fp32 values, split-operand kernels' if split else 'fp32')}")
 print(f"{'cin':>5} {'cout':>5} k s {'hw':>4} cnt | {'fprop ms':>9} {'TF':>6} | {'dgrad ms':>9} {'TF':>6} | {'wgrad ms':>9} {'TF':>6}")
 for (cin, cout, k, st, pad, h), cnt in shapes.items():
     d = ConvDesc.make(G, N, h, h, cin, cout, k, st, pad)
@@ -59,9 +60,18 @@ for (cin, cout, k, st, pad, h), cnt in shapes.items():
     dx = torch.empty_like(x)
     dw = torch.empty_like(w32)
     flops = 2.0 * G * N * d.ho * d.wo * cout * k * k * cin
-    tf = timeit(lambda: ops.conv_fprop(d, x, w, y, None, False, stats))
-    td = timeit(lambda: ops.conv_dgrad(d, gy, wt, dx)) if cin > 8 else float("nan")
-    tw = timeit(lambda: ops.conv_wgrad(d, x, gy, dw))
+    if split and cin > 8:
+        xs, gys = ops.split_f32(x), ops.split_f32(gy)
+        wk, wts = ops.split_weights(d, w32, True)
+        Ps, _ = ops.conv_stats_partials_split(d)
+        stats_s = torch.empty(G, Ps, 2, cout, device=dev)
+        tf = timeit(lambda: ops.conv_fprop_split(d, xs, wk, y, stats_s))
+        td = timeit(lambda: ops.conv_dgrad_split(d, gys, wts, dx))
+        tw = timeit(lambda: ops.conv_wgrad_split(d, xs, gys, dw))
+    else:
+        tf = timeit(lambda: ops.conv_fprop(d, x, w, y, None, False, stats))
+        td = timeit(lambda: ops.conv_dgrad(d, gy, wt, dx)) if cin > 8 else float("nan")
+        tw = timeit(lambda: ops.conv_wgrad(d, x, gy, dw))
     print(f"{cin:5d} {cout:5d} {k} {st} {h:4d} {cnt:3d} | {tf*1e3:9.3f} {flops/tf/1e12:6.1f} | {td*1e3:9.3f} {flops/td/1e12:6.1f} | {tw*1e3:9.3f} {flops/tw/1e12:6.1f}")
     for name, t in (("fprop", tf), ("dgrad", td), ("wgrad", tw)):
         if t == t:

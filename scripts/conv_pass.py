@@ -2,7 +2,7 @@
 """Run every convolution op of ONE training step of a workload exactly once (fprop with BN partial
 statistics, dgrad, wgrad per layer, in network order) - the launch set bench.py's `roofline`
 averages over - so that `rocprofv3 --pmc` totals divide into per-op HBM traffic.
-Usage: conv_pass.py [depth] [N per view] [views]"""
+Usage: conv_pass.py [depth] [N per view] [views] [f32|split]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -15,6 +15,7 @@ from rot_mvgaze_amd.arch import backbone_spec
 depth = int(sys.argv[1]) if len(sys.argv) > 1 else 18
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 G = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+split = len(sys.argv) > 4 and sys.argv[4] == "split"
 dev = torch.device("cuda:0")
 spec = backbone_spec(depth)
 layers = []
@@ -43,13 +44,26 @@ for (cin, cout, k, st, pad, h, need_dx) in layers:
     stats = torch.empty(G, P, 2, cout, device=dev)
     gy = torch.randn_like(y)
     dw = torch.empty_like(w)
-    ops.conv_fprop(d, x, w, y, None, False, stats)
-    ops.conv_wgrad(d, x, gy, dw)
-    n_ops += 2
-    if need_dx:
-        dx = torch.randn_like(x)
-        ops.conv_dgrad(d, gy, w, dx, None, dx)       # in-place addend, like the residual branches
-        n_ops += 1
+    if split and cin > 4:
+        xs, gys = ops.split_f32(x), ops.split_f32(gy)
+        wk, wts = ops.split_weights(d, w, True)
+        Ps, _ = ops.conv_stats_partials_split(d)
+        stats_s = torch.empty(G, Ps, 2, cout, device=dev)
+        ops.conv_fprop_split(d, xs, wk, y, stats_s)
+        ops.conv_wgrad_split(d, xs, gys, dw)
+        n_ops += 2
+        if need_dx:
+            dx = torch.randn_like(x)
+            ops.conv_dgrad_split(d, gys, wts, dx, dx)
+            n_ops += 1
+    else:
+        ops.conv_fprop(d, x, w, y, None, False, stats)
+        ops.conv_wgrad(d, x, gy, dw)
+        n_ops += 2
+        if need_dx:
+            dx = torch.randn_like(x)
+            ops.conv_dgrad(d, gy, w, dx, None, dx)       # in-place addend, like the residual branches
+            n_ops += 1
     flops += 2.0 * G * N * d.ho * d.wo * cout * k * k * cin * (3 if need_dx else 2)
     torch.cuda.synchronize()
     del x, y, gy, stats
