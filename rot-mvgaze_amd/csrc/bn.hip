@@ -465,6 +465,126 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
   }
 }
 
+// ---- split path: the passes that write s3, one 8-channel chunk per lane -------------------------------
+// (fp32 tensors as two float4 per lane, the s3 tensor as the chunk's three 16-byte pieces; the generic kernels
+// with Elem<s3_t> move 4 channels per lane as three 8-byte accesses and reach 4.2-4.5 TB/s where the fp32 forms
+// reach 5.1-5.3.)  A lane's channel chunk is fixed whenever the grid stride is a multiple of the chunks per row
+// (every ResNet shape): the per-channel factors are loaded once, outside the row loop.
+struct F8 {
+  float v[8];
+};
+__device__ __forceinline__ F8 ld8(const float *p, long long chunk) {
+  const float4 a = reinterpret_cast<const float4 *>(p)[2 * chunk], b = reinterpret_cast<const float4 *>(p)[2 * chunk + 1];
+  return F8{{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
+}
+__device__ __forceinline__ F8 ld8_s3(const s3_t *p, long long chunk) {
+  const uint4 *q = reinterpret_cast<const uint4 *>(p) + 3 * chunk;
+  const uint4 a = q[0], b = q[1], c = q[2];
+  const unsigned ua[4] = {a.x, a.y, a.z, a.w}, ub[4] = {b.x, b.y, b.z, b.w}, uc[4] = {c.x, c.y, c.z, c.w};
+  F8 r;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    r.v[2 * k] = (bf16_lo(ua[k]) + bf16_lo(ub[k])) + bf16_lo(uc[k]);
+    r.v[2 * k + 1] = (bf16_hi(ua[k]) + bf16_hi(ub[k])) + bf16_hi(uc[k]);
+  }
+  return r;
+}
+__device__ __forceinline__ void st8_s3(s3_t *p, long long chunk, const F8 &x) {
+  uint4 q1, q2, q3;
+  split3_chunk(x.v, q1, q2, q3);
+  uint4 *q = reinterpret_cast<uint4 *>(p) + 3 * chunk;
+  q[0] = q1;
+  q[1] = q2;
+  q[2] = q3;
+}
+
+template <bool RES_S3>
+__global__ __launch_bounds__(256) void bn_apply_s3_kernel(const float *__restrict__ y, const float *__restrict__ scale,
+                                                          const float *__restrict__ shift, const void *__restrict__ residual,
+                                                          const float *__restrict__ res_scale,
+                                                          const float *__restrict__ res_shift, int relu, s3_t *__restrict__ out,
+                                                          long long n8_per_group, int c8n, int c,
+                                                          unsigned short *__restrict__ relu_bits) {
+  const int g = blockIdx.y;
+  const long long base = (long long)g * n8_per_group;
+  const long long stride = (long long)gridDim.x * 256;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  int cq = (int)(i % c8n);
+  const int step = (int)(stride % c8n);
+  F8 sc = ld8(scale + (long long)g * c, cq), sh = ld8(shift + (long long)g * c, cq), rs, rh;
+  const bool raff = res_scale != nullptr;
+  if (raff) {
+    rs = ld8(res_scale + (long long)g * c, cq);
+    rh = ld8(res_shift + (long long)g * c, cq);
+  }
+  for (; i < n8_per_group; i += stride) {
+    if (step != 0) {                       // (not taken for the ResNet shapes: the stride is a multiple of c8n)
+      sc = ld8(scale + (long long)g * c, cq);
+      sh = ld8(shift + (long long)g * c, cq);
+      if (raff) {
+        rs = ld8(res_scale + (long long)g * c, cq);
+        rh = ld8(res_shift + (long long)g * c, cq);
+      }
+    }
+    const F8 v = ld8(y, base + i);
+    F8 r, o;
+    if (residual) r = RES_S3 ? ld8_s3(reinterpret_cast<const s3_t *>(residual), base + i) : ld8(reinterpret_cast<const float *>(residual), base + i);
+    unsigned m = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float x = __builtin_fmaf(v.v[k], sc.v[k], sh.v[k]);      // the same expressions as bn_apply_kernel (mask rebuild in the backward)
+      if (residual) x += raff ? __builtin_fmaf(r.v[k], rs.v[k], rh.v[k]) : r.v[k];
+      if (relu) x = fmaxf(x, 0.f);
+      o.v[k] = x;
+      m |= (x > 0.f ? 1u : 0u) << (k + (k >= 4 ? 4 : 0));    // two bytes, low nibbles: one byte per 4 channels (bn_bwd_reduce_bits)
+    }
+    st8_s3(out, base + i, o);
+    if (relu_bits) relu_bits[base + i] = (unsigned short)m;
+    cq += step;
+    if (cq >= c8n) cq -= c8n;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_s3_kernel(const float *__restrict__ g, const float *__restrict__ y,
+                                                              const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                              const float *__restrict__ gamma, const float *__restrict__ s1,
+                                                              const float *__restrict__ s2, const float *__restrict__ mscale,
+                                                              const float *__restrict__ mshift, long long n8_per_group,
+                                                              float inv_rows, int c8n, int c, s3_t *__restrict__ dy) {
+  const int grp = blockIdx.y;
+  const long long base = (long long)grp * n8_per_group;
+  const long long stride = (long long)gridDim.x * 256;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  int cq = (int)(i % c8n);
+  const int step = (int)(stride % c8n);
+  const long long gc = (long long)grp * c;
+  F8 mu = ld8(mean + gc, cq), is = ld8(invstd + gc, cq), ga = ld8(gamma, cq), sa = ld8(s1 + gc, cq), sb = ld8(s2 + gc, cq), ma, mb;
+  if (mscale) {
+    ma = ld8(mscale + gc, cq);
+    mb = ld8(mshift + gc, cq);
+  }
+  for (; i < n8_per_group; i += stride) {
+    if (step != 0) {
+      mu = ld8(mean + gc, cq); is = ld8(invstd + gc, cq); ga = ld8(gamma, cq); sa = ld8(s1 + gc, cq); sb = ld8(s2 + gc, cq);
+      if (mscale) {
+        ma = ld8(mscale + gc, cq);
+        mb = ld8(mshift + gc, cq);
+      }
+    }
+    const F8 d = ld8(g, base + i), v = ld8(y, base + i);
+    F8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float dd = d.v[k];
+      if (mscale) dd = __builtin_fmaf(v.v[k], ma.v[k], mb.v[k]) > 0.f ? dd : 0.f;
+      o.v[k] = ga.v[k] * is.v[k] * (dd - sa.v[k] * inv_rows - (v.v[k] - mu.v[k]) * is.v[k] * (sb.v[k] * inv_rows));
+    }
+    st8_s3(dy, base + i, o);
+    cq += step;
+    if (cq >= c8n) cq -= c8n;
+  }
+}
+
 // ---- stem tail: BatchNorm + ReLU + MaxPool2d(3,2,1), fused --------------------------------------
 // The normalised stem activation (B*V x 112 x 112 x 64 floats, 411 MB at C2) is never written:
 // forward reads the conv output once and writes the pooled map + argmax; backward rebuilds the
@@ -652,11 +772,20 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const T *__restr
 }
 
 static int bwd_chunks(int groups, long long rows, int c) {
-  // ~2048 workgroups in total, at least 64 rows per chunk
+  // at least 64 rows per chunk
   const int c4n = c / 4;
   const int cw = c4n < 256 ? c4n : 256;
   const int colblocks = ceil_div(c4n, cw);
-  long long want = 1024 / ((long long)groups * colblocks);
+  // one resident round: the kernel's registers and LDS admit three workgroups per CU; measured at C3's shapes
+  // (scripts/bn_bench.py): 256 / 384 / 512 / 768 / 1024 / 2048 / 4096 workgroups -> 13.7 / 11.2 / 9.7 / 9.4 / 10.7 /
+  // 10.2 / 10.5 ms per step (1024 = a full round plus a third of one).  MVG_BN_REDUCE_WGS overrides.
+  static int total = -1;
+  if (total < 0) {
+    const char *e = getenv("MVG_BN_REDUCE_WGS");
+    total = e ? atoi(e) : 3 * compute_cus();
+    if (total < 64) total = 64;
+  }
+  long long want = total / ((long long)groups * colblocks);
   if (want < 1) want = 1;
   long long maxc = (rows + 63) / 64;
   if (want > maxc) want = maxc;
@@ -917,19 +1046,32 @@ int mvg_bn_apply_split(const float *y, const float *scale, const float *shift, c
                        int64_t rows_per_group, int c, void *stream) {
   MVG_REQUIRE(c % 8 == 0, "bn_apply_split: c %% 8 != 0");
   MVG_REQUIRE(!(residual_s3 && res_scale), "bn_apply_split: an s3 residual is already normalised (no res_scale / res_shift)");
+  MVG_REQUIRE((res_scale == nullptr) == (res_shift == nullptr) && (residual || !res_scale),
+              "bn_apply_split: res_scale / res_shift go together and need a residual");
+  hipStream_t st = (hipStream_t)stream;
+  const long long n8 = rows_per_group * (c / 8);
+  ProfScope ps(MVG_K_BN_APPLY, st, 0.0, 8.0 * groups * (double)n8 * (4.0 + 6.0 + (residual ? (residual_s3 ? 6.0 : 4.0) : 0.0)));
+  const dim3 grid(grid_for(n8), groups), block(256);
   if (residual && residual_s3)
-    return bn_apply_impl<float, s3_t, s3_t>(y, scale, shift, (const s3_t *)residual, nullptr, nullptr, relu, (s3_t *)out_s3, groups,
-                                            rows_per_group, c, stream, relu_bits);
-  return bn_apply_impl<float, s3_t, float>(y, scale, shift, (const float *)residual, res_scale, res_shift, relu, (s3_t *)out_s3,
-                                           groups, rows_per_group, c, stream, relu_bits);
+    hipLaunchKernelGGL(bn_apply_s3_kernel<true>, grid, block, 0, st, y, scale, shift, residual, res_scale, res_shift, relu,
+                       (s3_t *)out_s3, n8, c / 8, c, (unsigned short *)relu_bits);
+  else
+    hipLaunchKernelGGL(bn_apply_s3_kernel<false>, grid, block, 0, st, y, scale, shift, residual, res_scale, res_shift, relu,
+                       (s3_t *)out_s3, n8, c / 8, c, (unsigned short *)relu_bits);
+  return check_launch("bn_apply_split");
 }
 
 int mvg_bn_bwd_apply_split(const float *g, const float *y, const float *mean, const float *invstd, const float *gamma,
                            const float *s1, const float *s2, const float *relu_scale, const float *relu_shift, int groups,
                            int64_t rows_per_group, int c, void *dy_s3, void *stream) {
   MVG_REQUIRE(c % 8 == 0, "bn_bwd_apply_split: c %% 8 != 0");
-  return bn_bwd_apply_impl<float, s3_t>(g, nullptr, y, mean, invstd, gamma, s1, s2, relu_scale, relu_shift, groups, rows_per_group,
-                                        c, (s3_t *)dy_s3, nullptr, stream);
+  MVG_REQUIRE((relu_scale == nullptr) == (relu_shift == nullptr), "bn_bwd_apply_split: relu_scale and relu_shift go together");
+  hipStream_t st = (hipStream_t)stream;
+  const long long n8 = rows_per_group * (c / 8);
+  ProfScope ps(MVG_K_BN_BWD_APPLY, st, 0.0, 8.0 * groups * (double)n8 * 14.0);
+  hipLaunchKernelGGL(bn_bwd_apply_s3_kernel, dim3(grid_for(n8), groups), dim3(256), 0, st, g, y, mean, invstd, gamma, s1, s2,
+                     relu_scale, relu_shift, n8, 1.0f / (float)rows_per_group, c / 8, c, (s3_t *)dy_s3);
+  return check_launch("bn_bwd_apply_split");
 }
 
 int mvg_bn_relu_maxpool_fwd_split(const float *y, const float *scale, const float *shift, void *pooled_s3, uint8_t *argmax,

@@ -29,26 +29,13 @@ namespace mvg {
 constexpr int SP_BM = 256, SP_BK = 32;
 constexpr int SP_SMALL_K = 4096;      // GEMM K below this: the 128-row, three-workgroups-per-CU kernel (measured per shape)
 
-// 8 consecutive fp32 values -> the chunk's three 16-byte piece vectors
-__device__ __forceinline__ void split3_chunk(const float (&v)[8], u32x4 &q1, u32x4 &q2, u32x4 &q3) {
-  unsigned short a[8], b[8], c[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) split3(v[k], a[k], b[k], c[k]);
-  q1 = u32x4{(unsigned)a[0] | ((unsigned)a[1] << 16), (unsigned)a[2] | ((unsigned)a[3] << 16), (unsigned)a[4] | ((unsigned)a[5] << 16),
-             (unsigned)a[6] | ((unsigned)a[7] << 16)};
-  q2 = u32x4{(unsigned)b[0] | ((unsigned)b[1] << 16), (unsigned)b[2] | ((unsigned)b[3] << 16), (unsigned)b[4] | ((unsigned)b[5] << 16),
-             (unsigned)b[6] | ((unsigned)b[7] << 16)};
-  q3 = u32x4{(unsigned)c[0] | ((unsigned)c[1] << 16), (unsigned)c[2] | ((unsigned)c[3] << 16), (unsigned)c[4] | ((unsigned)c[5] << 16),
-             (unsigned)c[6] | ((unsigned)c[7] << 16)};
-}
-
 // fp32 [n8 * 8] -> s3 (layout plumbing for tests and for tensors no kernel writes in s3 directly)
-__global__ __launch_bounds__(256) void split_f32_kernel(const float4 *__restrict__ x, u32x4 *__restrict__ out, long long n8) {
+__global__ __launch_bounds__(256) void split_f32_kernel(const float4 *__restrict__ x, uint4 *__restrict__ out, long long n8) {
   const long long stride = (long long)gridDim.x * 256;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += stride) {
     const float4 lo = x[2 * i], hi = x[2 * i + 1];
     const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    u32x4 q1, q2, q3;
+    uint4 q1, q2, q3;
     split3_chunk(v, q1, q2, q3);
     out[3 * i] = q1;
     out[3 * i + 1] = q2;
@@ -57,10 +44,10 @@ __global__ __launch_bounds__(256) void split_f32_kernel(const float4 *__restrict
 }
 
 // s3 -> fp32 (exact: the three pieces sum without rounding)
-__global__ __launch_bounds__(256) void merge_s3_kernel(const u32x4 *__restrict__ x, float4 *__restrict__ out, long long n8) {
+__global__ __launch_bounds__(256) void merge_s3_kernel(const uint4 *__restrict__ x, float4 *__restrict__ out, long long n8) {
   const long long stride = (long long)gridDim.x * 256;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += stride) {
-    const u32x4 q1 = x[3 * i], q2 = x[3 * i + 1], q3 = x[3 * i + 2];
+    const uint4 q1 = x[3 * i], q2 = x[3 * i + 1], q3 = x[3 * i + 2];
     const unsigned a[4] = {q1.x, q1.y, q1.z, q1.w}, b[4] = {q2.x, q2.y, q2.z, q2.w}, c[4] = {q3.x, q3.y, q3.z, q3.w};
     float v[8];
 #pragma unroll
@@ -75,13 +62,13 @@ __global__ __launch_bounds__(256) void merge_s3_kernel(const u32x4 *__restrict__
 
 // fp32 KRSC weights -> s3 KRSC ([cout][rs*cin]) and, optionally, the s3 transposed copy the backward-data kernel
 // reads (CRSK: [cin][rs*cout]).  One thread per (row, tap, 8-channel chunk) of each output.
-__global__ __launch_bounds__(256) void split_weights_kernel(const float *__restrict__ w, u32x4 *__restrict__ wk, u32x4 *__restrict__ wt,
+__global__ __launch_bounds__(256) void split_weights_kernel(const float *__restrict__ w, uint4 *__restrict__ wk, uint4 *__restrict__ wt,
                                                             int cout, int rs, int cin) {
   const int c8n = cin / 8, o8n = cout / 8;
   const long long nk = (long long)cout * rs * c8n, nt = wt ? (long long)cin * rs * o8n : 0;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nk + nt; i += (long long)gridDim.x * 256) {
     float v[8];
-    u32x4 *dst;
+    uint4 *dst;
     if (i < nk) {
       const float4 *src = reinterpret_cast<const float4 *>(w + i * 8);          // (o, tap, c8) is the KRSC order itself
       const float4 lo = src[0], hi = src[1];
@@ -96,7 +83,7 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float *__restr
       for (int k = 0; k < 8; ++k) v[k] = w[((long long)(o8 * 8 + k) * rs + tap) * cin + c];
       dst = wt + 3 * j;
     }
-    u32x4 q1, q2, q3;
+    uint4 q1, q2, q3;
     split3_chunk(v, q1, q2, q3);
     dst[0] = q1;
     dst[1] = q2;
@@ -734,7 +721,7 @@ int mvg_split_f32(const float *x, void *out_s3, int64_t n, void *stream) {
   ProfScope ps(MVG_K_LAYOUT, st, 0.0, 10.0 * (double)n);
   long long blocks = (n / 8 + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(split_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float4 *)x, (u32x4 *)out_s3, (long long)(n / 8));
+  hipLaunchKernelGGL(split_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float4 *)x, (uint4 *)out_s3, (long long)(n / 8));
   return check_launch("split_f32");
 }
 
@@ -745,7 +732,7 @@ int mvg_merge_s3(const void *x_s3, float *out, int64_t n, void *stream) {
   ProfScope ps(MVG_K_LAYOUT, st, 0.0, 10.0 * (double)n);
   long long blocks = (n / 8 + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(merge_s3_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const u32x4 *)x_s3, (float4 *)out, (long long)(n / 8));
+  hipLaunchKernelGGL(merge_s3_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const uint4 *)x_s3, (float4 *)out, (long long)(n / 8));
   return check_launch("merge_s3");
 }
 
@@ -757,7 +744,7 @@ int mvg_split_weights(const mvg_conv_desc *d, const float *w, void *w_krsc_s3, v
   ProfScope ps(MVG_K_LAYOUT, st, 0.0, (w_crsk_s3 ? 20.0 : 10.0) * (double)total);
   long long blocks = ((w_crsk_s3 ? 2 : 1) * total / 8 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, st, w, (u32x4 *)w_krsc_s3, (u32x4 *)w_crsk_s3, d->cout,
+  hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, st, w, (uint4 *)w_krsc_s3, (uint4 *)w_crsk_s3, d->cout,
                      d->r * d->s, d->cin);
   return check_launch("split_weights");
 }

@@ -72,6 +72,19 @@ __device__ __forceinline__ void split3(float v, unsigned short &p1, unsigned sho
   p3 = __builtin_bit_cast(unsigned short, h3);
 }
 
+// 8 consecutive fp32 values -> the chunk's three 16-byte piece vectors
+__device__ __forceinline__ void split3_chunk(const float (&v)[8], uint4 &q1, uint4 &q2, uint4 &q3) {
+  unsigned short a[8], b[8], c[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) split3(v[k], a[k], b[k], c[k]);
+  q1 = make_uint4((unsigned)a[0] | ((unsigned)a[1] << 16), (unsigned)a[2] | ((unsigned)a[3] << 16), (unsigned)a[4] | ((unsigned)a[5] << 16),
+             (unsigned)a[6] | ((unsigned)a[7] << 16));
+  q2 = make_uint4((unsigned)b[0] | ((unsigned)b[1] << 16), (unsigned)b[2] | ((unsigned)b[3] << 16), (unsigned)b[4] | ((unsigned)b[5] << 16),
+             (unsigned)b[6] | ((unsigned)b[7] << 16));
+  q3 = make_uint4((unsigned)c[0] | ((unsigned)c[1] << 16), (unsigned)c[2] | ((unsigned)c[3] << 16), (unsigned)c[4] | ((unsigned)c[5] << 16),
+             (unsigned)c[6] | ((unsigned)c[7] << 16));
+}
+
 template <>
 struct Elem<s3_t> {
   static constexpr double kBytes = 6.0;

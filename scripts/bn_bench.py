@@ -1,43 +1,66 @@
 #!/usr/bin/env python3
-"""BatchNorm kernel timings at the ResNet-18 C2 activation sizes (V=2, B=64)."""
+"""Achieved HBM rate of the BatchNorm streaming passes on the ResNet-50 tensor shapes of one workload
+(synthetic data).  Usage: bn_bench.py [N per view] [views] [f32|split]   (split: the passes that write s3)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import rot_mvgaze_amd
 from rot_mvgaze_amd import ops
-from rot_mvgaze_amd._lib import ConvDesc
 
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+G = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+split = len(sys.argv) > 3 and sys.argv[3] == "split"
 dev = torch.device("cuda:0")
-G, N = 2, 64
 
-def timeit(fn, iters=20):
+def timeit(fn, iters=10):
     fn(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(iters): fn()
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / iters * 1e6
+    return (time.perf_counter() - t0) / iters
 
-print(f"{'hw':>4} {'c':>4} | {'finalize':>9} {'apply':>9} {'apply+res':>9} {'bwd_red':>9} {'bwd_red(y)':>10} {'bwd_app':>9} {'bwd_app(y)':>10}   (us; GB/s in brackets)")
-for hw, c in ((56, 64), (28, 128), (14, 256), (7, 512)):
+print(f"N={N} G={G} {'split (s3 outputs)' if split else 'fp32'}: pass, ms, GB/s (algorithmic bytes)")
+tot = {}
+for hw, C, cnt_plain, cnt_res in [(56, 64, 7, 0), (56, 256, 0, 3), (28, 128, 8, 0), (28, 512, 0, 4), (14, 256, 12, 0), (14, 1024, 0, 6),
+                                  (7, 512, 6, 0), (7, 2048, 0, 3)]:
     rows = N * hw * hw
-    d = ConvDesc.make(G, N, hw, hw, c, c, 3, 1, 1)
-    P, rpp = ops.conv_stats_partials(d)
-    stats = torch.rand(G, P, 2, c, device=dev)
-    y = torch.randn(G, rows, c, device=dev); out = torch.empty_like(y); res = torch.randn_like(y); g = torch.randn_like(y)
-    dy = torch.empty_like(y)
-    gamma = torch.ones(c, device=dev); beta = torch.zeros(c, device=dev)
-    rm = torch.zeros(c, device=dev); rv = torch.ones(c, device=dev)
-    aff = torch.empty(4, G, c, device=dev)
-    s12 = torch.empty(2, G, c, device=dev); dg = torch.empty(c, device=dev); db = torch.empty(c, device=dev)
-    t_fin = timeit(lambda: ops.bn_finalize(stats, G, P, rpp, rows, c, gamma, beta, rm, rv, 0.1, 1e-5, aff[0], aff[1], aff[2], aff[3]))
-    aff[0].zero_(); aff[1].fill_(1.0); aff[2].fill_(1.0); aff[3].zero_()
-    t_app = timeit(lambda: ops.bn_apply(y, aff[2], aff[3], None, True, out, G, rows, c))
-    t_appr = timeit(lambda: ops.bn_apply(y, aff[2], aff[3], res, True, out, G, rows, c))
-    t_red = timeit(lambda: ops.bn_bwd_reduce(g, out, y, aff[0], aff[1], G, rows, c, s12[0], s12[1], dg, db, False))
-    t_redy = timeit(lambda: ops.bn_bwd_reduce(g, None, y, aff[0], aff[1], G, rows, c, s12[0], s12[1], dg, db, False, (aff[2], aff[3])))
-    t_ba = timeit(lambda: ops.bn_bwd_apply(g, out, y, aff[0], aff[1], gamma, s12[0], s12[1], G, rows, c, dy, None))
-    t_bay = timeit(lambda: ops.bn_bwd_apply(g, None, y, aff[0], aff[1], gamma, s12[0], s12[1], G, rows, c, dy, None, (aff[2], aff[3])))
-    nb = y.numel() * 4
-    gb = lambda k, t: f"{t:7.1f}[{k * nb / t / 1e3:4.0f}]"
-    print(f"{hw:4d} {c:4d} | {t_fin:9.1f} {gb(2, t_app)} {gb(3, t_appr)} {gb(3, t_red)} {gb(2, t_redy)} {gb(4, t_ba)} {gb(3, t_bay)}", flush=True)
+    n = G * rows * C
+    y = torch.randn(G, rows, C, device=dev)
+    g = torch.randn(G, rows, C, device=dev)
+    scale, shift = torch.rand(G, C, device=dev) + 0.5, torch.randn(G, C, device=dev) * 0.3
+    mean, invstd = torch.randn(G, C, device=dev) * 0.1, torch.rand(G, C, device=dev) + 0.5
+    gamma = torch.rand(C, device=dev) + 0.5
+    s1, s2 = torch.randn(G, C, device=dev), torch.randn(G, C, device=dev)
+    dg, db = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    res = cnt_res > 0
+    cnt = cnt_plain + cnt_res
+    if split:
+        out = ops.s3_empty(G, rows, C, device=dev)
+        r = ops.split_f32(torch.randn(G, rows, C, device=dev)) if res else None
+        t_apply = timeit(lambda: ops.bn_apply_split(y, scale, shift, r, True, out, G, rows, C, None, want_bits=res))
+        b_apply = n * (4 + 6 + (6.25 if res else 0))
+        dy = ops.s3_empty(G, rows, C, device=dev)
+        t_bapply = timeit(lambda: ops.bn_bwd_apply_split(g, y, mean, invstd, gamma, s1, s2, G, rows, C, dy, None if res else (scale, shift)))
+        b_bapply = n * 14
+    else:
+        out = torch.empty_like(y)
+        r = torch.randn(G, rows, C, device=dev) if res else None
+        t_apply = timeit(lambda: (ops.bn_apply_bits(y, scale, shift, r, out, G, rows, C) if res else ops.bn_apply(y, scale, shift, None, True, out, G, rows, C)))
+        b_apply = n * (8 + (4.25 if res else 0))
+        dy = torch.empty_like(g)
+        t_bapply = timeit(lambda: ops.bn_bwd_apply(g, None, y, mean, invstd, gamma, s1, s2, G, rows, C, dy, None, None if res else (scale, shift)))
+        b_bapply = n * 12
+    if res:
+        bits = torch.randint(0, 255, (n // 4,), dtype=torch.uint8, device=dev)
+        t_red = timeit(lambda: ops.bn_bwd_reduce_bits(g, bits, y, mean, invstd, G, rows, C, s1, s2, dg, db, False, dz_out=g))
+        b_red = n * 12.25
+    else:
+        t_red = timeit(lambda: ops.bn_bwd_reduce(g, None, y, mean, invstd, G, rows, C, s1, s2, dg, db, False, (scale, shift)))
+        b_red = n * 8
+    print(f"hw{hw:3d} C{C:5d} x{cnt:2d} {'res' if res else '   '} | apply {t_apply*1e3:6.3f} ms {b_apply/t_apply/1e9:6.0f} | bwd_reduce {t_red*1e3:6.3f} ms {b_red/t_red/1e9:6.0f} | bwd_apply {t_bapply*1e3:6.3f} ms {b_bapply/t_bapply/1e9:6.0f}")
+    for k, t, b in (("apply", t_apply, b_apply), ("bwd_reduce", t_red, b_red), ("bwd_apply", t_bapply, b_bapply)):
+        a = tot.setdefault(k, [0.0, 0.0]); a[0] += t * cnt; a[1] += b * cnt
+for k, (t, b) in tot.items():
+    print(f"{k}: {t*1e3:.2f} ms per step, {b/t/1e9:.0f} GB/s")
+print(f"all: {sum(v[0] for v in tot.values())*1e3:.2f} ms")
