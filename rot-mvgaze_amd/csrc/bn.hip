@@ -194,20 +194,37 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T *__restrict__ y, 
   long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   int cq = (int)(i % cwn);
   const int step = (int)(stride % cwn);
+  // a lane keeps its channel group whenever the grid stride is a multiple of the groups per row (every ResNet
+  // shape): with bf16 storage (W = 2) the per-channel factors are then loaded once, outside the row loop
+  // (C5: bn_bwd_apply 8.0 -> 7.5 ms)
+  float4 pa[W], pb[W], pra[W], prb[W];
+  auto load_factors = [&]() {
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      pa[w] = sc4[cq * W + w];
+      pb[w] = sh4[cq * W + w];
+      if (rs4) {
+        pra[w] = rs4[cq * W + w];
+        prb[w] = rh4[cq * W + w];
+      }
+    }
+  };
+  load_factors();
   for (; i < nw_per_group; i += stride) {
+    if (W == 1 || step != 0) load_factors();      // fp32 (W = 1) measured 3-6 % faster reloading: fewer live registers
     float4 v[W], r[W], o[W];
     E::ldw(y, base + i, v);
     if (residual) Elem<TR>::ldw(residual, base + i, r);
 #pragma unroll
     for (int w = 0; w < W; ++w) {
-      const float4 a = sc4[cq * W + w], b = sh4[cq * W + w];
+      const float4 a = pa[w], b = pb[w];
       // explicit fma: the backward kernels rebuild the ReLU mask from y with the same expression
       o[w] = make_float4(__builtin_fmaf(v[w].x, a.x, b.x), __builtin_fmaf(v[w].y, a.y, b.y), __builtin_fmaf(v[w].z, a.z, b.z),
                          __builtin_fmaf(v[w].w, a.w, b.w));
       if (residual) {
         float4 rr = r[w];
         if (rs4) {
-          const float4 ra = rs4[cq * W + w], rb = rh4[cq * W + w];
+          const float4 ra = pra[w], rb = prb[w];
           rr = make_float4(__builtin_fmaf(rr.x, ra.x, rb.x), __builtin_fmaf(rr.y, ra.y, rb.y), __builtin_fmaf(rr.z, ra.z, rb.z),
                            __builtin_fmaf(rr.w, ra.w, rb.w));
         }
@@ -431,28 +448,44 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
   long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   int cq = (int)(i % cwn);
   const int step = (int)(stride % cwn);
+  float4 pmu[W], pis[W], pga[W], psa[W], psb[W], pma[W], pmb[W];
+  auto load_factors = [&]() {
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      const int ci = cq * W + w;
+      pmu[w] = mu4[ci];
+      pis[w] = is4[ci];
+      pga[w] = ga4[ci];
+      psa[w] = a4[ci];
+      psb[w] = b4[ci];
+      if (mscale) {
+        pma[w] = reinterpret_cast<const float4 *>(mscale + (long long)grp * c)[ci];
+        pmb[w] = reinterpret_cast<const float4 *>(mshift + (long long)grp * c)[ci];
+      }
+    }
+  };
+  load_factors();
   for (; i < nw_per_group; i += stride) {
+    if (W == 1 || step != 0) load_factors();
     float4 d[W], v[W], a[W], o[W];
     E::ldw(g, base + i, d);
     E::ldw(y, base + i, v);
     if (act) E::ldw(act, base + i, a);
 #pragma unroll
     for (int w = 0; w < W; ++w) {
-      const int ci = cq * W + w;
       if (act) {
         d[w].x = a[w].x > 0.f ? d[w].x : 0.f;
         d[w].y = a[w].y > 0.f ? d[w].y : 0.f;
         d[w].z = a[w].z > 0.f ? d[w].z : 0.f;
         d[w].w = a[w].w > 0.f ? d[w].w : 0.f;
       } else if (mscale) {
-        const float4 ma = reinterpret_cast<const float4 *>(mscale + (long long)grp * c)[ci];
-        const float4 mb = reinterpret_cast<const float4 *>(mshift + (long long)grp * c)[ci];
+        const float4 ma = pma[w], mb = pmb[w];
         d[w].x = __builtin_fmaf(v[w].x, ma.x, mb.x) > 0.f ? d[w].x : 0.f;
         d[w].y = __builtin_fmaf(v[w].y, ma.y, mb.y) > 0.f ? d[w].y : 0.f;
         d[w].z = __builtin_fmaf(v[w].z, ma.z, mb.z) > 0.f ? d[w].z : 0.f;
         d[w].w = __builtin_fmaf(v[w].w, ma.w, mb.w) > 0.f ? d[w].w : 0.f;
       }
-      const float4 mu = mu4[ci], is = is4[ci], ga = ga4[ci], sa = a4[ci], sb = b4[ci];
+      const float4 mu = pmu[w], is = pis[w], ga = pga[w], sa = psa[w], sb = psb[w];
       o[w].x = ga.x * is.x * (d[w].x - sa.x * inv_rows - (v[w].x - mu.x) * is.x * (sb.x * inv_rows));
       o[w].y = ga.y * is.y * (d[w].y - sa.y * inv_rows - (v[w].y - mu.y) * is.y * (sb.y * inv_rows));
       o[w].z = ga.z * is.z * (d[w].z - sa.z * inv_rows - (v[w].z - mu.z) * is.z * (sb.z * inv_rows));
