@@ -26,6 +26,15 @@
 
 namespace mvg {
 
+// acc[i][j] += the six piece products of fragments av[piece][i], bv[piece][j]; product-major (consecutive MFMAs go
+// to different accumulators), smallest terms first: (a1 b3, a3 b1, a2 b2), (a1 b2, a2 b1), a1 b1
+#define SPLIT_ONE(PA, PB, av, bv, acc)                                                                         \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)                \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[PA][i], bv[PB][j], acc[i][j], 0, 0, 0);
+#define SPLIT_PRODUCTS(av, bv, acc)                                                                            \
+  SPLIT_ONE(0, 2, av, bv, acc) SPLIT_ONE(2, 0, av, bv, acc) SPLIT_ONE(1, 1, av, bv, acc) SPLIT_ONE(0, 1, av, bv, acc) \
+  SPLIT_ONE(1, 0, av, bv, acc) SPLIT_ONE(0, 0, av, bv, acc)
+
 constexpr int SP_BM = 256, SP_BK = 32;
 constexpr int SP_SMALL_K = 4096;      // GEMM K below this: the 128-row, three-workgroups-per-CU kernel (measured per shape)
 
@@ -234,18 +243,7 @@ __global__ __launch_bounds__(512, 1) void igemm_split_kernel(IgemmParams p) {
         for (int j = 0; j < TN; ++j)
           bv[pc][j] = *reinterpret_cast<const bf16x8 *>(Bs + pc * B_ELEMS + b_row[j] + (((2 * kg + lh) ^ b_sw[j]) << 3));
       }
-      // smallest terms first: (a1 b3, a3 b1, a2 b2), (a1 b2, a2 b1), a1 b1
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][i], bv[2][j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[2][i], bv[0][j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1][i], bv[1][j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][i], bv[1][j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1][i], bv[0][j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][i], bv[0][j], acc[i][j], 0, 0, 0);
-        }
+      SPLIT_PRODUCTS(av, bv, acc)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the next K-step's DMA has landed
     __syncthreads();                                         // ... for every wave, and everyone is done reading `cur`
@@ -402,17 +400,7 @@ __global__ __launch_bounds__(256, 3) void igemm_split_small_kernel(IgemmParams p
         for (int j = 0; j < TN; ++j)
           bv[pc][j] = *reinterpret_cast<const bf16x8 *>(Bs + pc * B_ELEMS + b_row[j] + (((2 * kg + lh) ^ b_sw[j]) << 3));
       }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][i], bv[2][j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[2][i], bv[0][j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1][i], bv[1][j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][i], bv[1][j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1][i], bv[0][j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][i], bv[0][j], acc[i][j], 0, 0, 0);
-        }
+      SPLIT_PRODUCTS(av, bv, acc)
     }
     __syncthreads();                                         // everyone is done reading before the next DMA lands
   }
@@ -594,17 +582,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradParams p) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) bv[pc][j] = tr_frag(Bs + pc * B_ELEMS, LDB, 0, wn * WTN + j * 32, lane);
     }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][i], bv[2][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[2][i], bv[0][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1][i], bv[1][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][i], bv[1][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1][i], bv[0][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][i], bv[0][j], acc[i][j], 0, 0, 0);
-      }
+    SPLIT_PRODUCTS(av, bv, acc)
     __syncthreads();
   }
 
