@@ -53,6 +53,8 @@ class _Unit:
 
 
 class Backbone:
+    _guard_scale = 1          # tests raise it to exercise the 2 GiB guard of the split path without a 2 GiB tensor
+
     def __init__(self, depth: int, params: Dict[str, Tensor], prefix: str = "_feat_extractor.0."):
         self.spec: BackboneSpec = backbone_spec(depth, prefix)
         self.p = params                      # name -> Parameter / buffer (live objects)
@@ -83,6 +85,7 @@ class Backbone:
         # operands as three bf16 pieces per fp32 value and runs six bf16 MFMAs per product - fp32-accurate (the 1e-4
         # parity path), 1.2-1.7x the fp32-MFMA kernels.  MVG_SPLIT=0: the fp32-MFMA kernels everywhere.
         self.split = os.environ.get("MVG_SPLIT", "1") != "0"
+        self._split_now = self.split          # per forward call: off when a view's largest s3 tensor would exceed 2 GiB
 
     @property
     def bf16(self) -> bool:
@@ -118,7 +121,7 @@ class Backbone:
         dev = x.device
         # split path: training steps of the fp32 model; sp_in = this conv reads s3 operands (all but the stem),
         # sp_out = its consumers do (every unit: the stem's pooled map feeds layer1)
-        sp_out = self.split and training and not bf
+        sp_out = self._split_now and training and not bf
         sp_in = sp_out and c.cin != 3
         if sp_in:
             wsrc = self.p[c.name + ".weight"].detach()
@@ -243,6 +246,11 @@ class Backbone:
             else:
                 assert im.dtype == torch.float32
                 ops.nchw_to_nhwc4(im.detach().contiguous(), x0[v], B, 3, H, W)
+        # The split kernels address one view of an s3 tensor (6 bytes per element) with 32-bit offsets: the largest one
+        # (layer1's output: (H/4) x (W/4) x 64 or 256 channels per image) must stay below 2 GiB, or this call runs on the
+        # fp32-MFMA kernels (4 bytes per element: B < 668 instead of B < 445 per view at 224 x 224 with ResNet-50)
+        biggest_view_elems = B * ((H + 3) // 4) * ((W + 3) // 4) * self.spec.blocks[0].convs[-1].cout
+        self._split_now = self.split and 6 * biggest_view_elems * self._guard_scale < 0x7FFFFFF0
         tape: Optional[dict] = {"units": [], "blocks": [], "V": V, "B": B} if keep_tape else None
         ulist = tape["units"] if keep_tape else None
         if training:

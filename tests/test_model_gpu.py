@@ -573,6 +573,23 @@ def test_split_and_fp32_mfma_kernels_give_the_same_step(depth, batch, hw):
         l2_close(runs[0][2][k], g.cpu().numpy(), GTOL_L2_FLIPS_DEEP, "split vs fp32-MFMA kernels: " + k)   # two flip-noisy runs
 
 
+def test_split_kernels_step_aside_when_a_view_would_not_fit_32_bit_offsets(monkeypatch):
+    """One view of the largest s3 tensor (6 bytes per element) must stay below 2 GiB; beyond that the call runs on the
+    fp32-MFMA kernels.  Exercised by scaling the guard's size estimate, not by allocating 2 GiB."""
+    import rot_mvgaze_amd.backbone as B
+    m = build(18)
+    m.ensure_layout()
+    bb = m._backbone
+    assert bb.split
+    d = m(inputs(2, 64, seed=1))
+    assert bb._split_now
+    monkeypatch.setattr(B.Backbone, "_guard_scale", 10 ** 6)
+    d2 = m(inputs(2, 64, seed=1))
+    assert not bb._split_now
+    rel_close(d2["iter_2"]["pred_gaze_1"], d["iter_2"]["pred_gaze_1"].detach().cpu().numpy(), TOL, "pred with and without the split kernels")
+    metrics()(d2).backward()                      # and the backward of that call runs on the fp32-MFMA kernels too
+
+
 def test_gradient_accumulation_and_zero_grad():
     m = build(18)
     d = m(inputs(3, 64))
