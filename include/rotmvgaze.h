@@ -470,6 +470,16 @@ int mvg_bn_relu_maxpool_fwd_split(const float *y, const float *scale, const floa
                                   uint8_t *argmax, int groups, int n_per_group, int h, int w, int c, int ho, int wo,
                                   void *stream);
 int mvg_avgpool_fwd_split(const void *x_s3, float *y, int n, int hw, int c, void *stream);
+/* mvg_conv_dgrad_split fused with the BatchNorm-backward reduce pass of the unit whose output gradient dx is (stride-1
+ * launches): dx is stored masked by that unit's ReLU (bn_bits from mvg_bn_apply_split, or fma(bn_y, relu_scale,
+ * relu_shift) > 0, or no mask) and s1 / s2 / dgamma / dbeta come out of the same launch + a finalize (like
+ * mvg_conv_dgrad_bnreduce).  partials: groups * mvg_conv_dgrad_bn_partials_split(d) * 2 * cin floats. */
+int mvg_conv_dgrad_bn_partials_split(const mvg_conv_desc *d);
+int mvg_conv_dgrad_split_bnreduce(const mvg_conv_desc *d, const void *dy_s3, const void *w_crsk_s3, float *dx,
+                                  const float *addend, const float *bn_y, const uint8_t *bn_bits, const float *bn_mean,
+                                  const float *bn_invstd, const float *relu_scale, const float *relu_shift,
+                                  float *partials, float *s1, float *s2, float *dgamma, float *dbeta, int accumulate,
+                                  void *stream);
 int mvg_conv_wgrad_splits_split(const mvg_conv_desc *d);   /* pixel-split count; workspace = splits * cout*r*s*cin floats */
 int mvg_conv_wgrad_split(const mvg_conv_desc *d, const void *x_s3, const void *dy_s3, float *dw, float *workspace, int splits,
                          int accumulate, void *stream);

@@ -98,6 +98,25 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
   const float *add_f = p.addend ? p.addend + (long long)g * gelems : nullptr;
   const float *mask_f = p.mask ? p.mask + (long long)g * gelems : nullptr;
   constexpr int CV = BN / 8;                 // 16-byte output vectors per tile row
+  // Backward-data fused with the BatchNorm-backward REDUCE pass of the unit whose output gradient this launch produces
+  // (fp32 results, stride-1 launches; IgemmParams::bn_*): the gradient is masked by that unit's ReLU here, stored
+  // masked, and s1 = sum(dz), s2 = sum(dz * xhat) are added up per thread (its 8 channels are fixed: NT % CV == 0),
+  // per workgroup through LDS, and written as one partial per (group, row tile) for bn_bwd_finalize.
+  const bool bnf = DGRAD && F32IO && p.bn_part != nullptr;
+  float bn_mu[8], bn_is[8], bn_ra[8], bn_rb[8], bn_s1[8], bn_s2[8];
+  const bool bn_aff = bnf && p.bn_rscale != nullptr;
+  if (bnf) {
+    const int col0 = ntile * BN + (tid % CV) * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const bool ok = col0 + k < p.ncols;
+      bn_mu[k] = ok ? p.bn_mean[(long long)g * p.ncols + col0 + k] : 0.f;
+      bn_is[k] = ok ? p.bn_invstd[(long long)g * p.ncols + col0 + k] : 0.f;
+      bn_ra[k] = (ok && bn_aff) ? p.bn_rscale[(long long)g * p.ncols + col0 + k] : 0.f;
+      bn_rb[k] = (ok && bn_aff) ? p.bn_rshift[(long long)g * p.ncols + col0 + k] : 0.f;
+      bn_s1[k] = bn_s2[k] = 0.f;
+    }
+  }
 #pragma unroll
   for (int ph = 0; ph < PASSES; ++ph) {
   if (PASSES > 1 && ph > 0) __syncthreads();                  // the previous pass's rows have been read
@@ -141,6 +160,23 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
         const float4 a0 = *reinterpret_cast<const float4 *>(add_f + off + col), a1 = *reinterpret_cast<const float4 *>(add_f + off + col + 4);
         x[0] += a0.x; x[1] += a0.y; x[2] += a0.z; x[3] += a0.w; x[4] += a1.x; x[5] += a1.y; x[6] += a1.z; x[7] += a1.w;
       }
+      if (bnf) {
+        const float *yg = p.bn_y + (long long)g * gelems + off + col;
+        const float4 y0 = *reinterpret_cast<const float4 *>(yg), y1 = *reinterpret_cast<const float4 *>(yg + 4);
+        const float yy[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+        unsigned bits = 0xFFu;                      // no ReLU on that unit: every element passes
+        if (p.bn_bits) {
+          const unsigned short two = *reinterpret_cast<const unsigned short *>(p.bn_bits + (((long long)g * gelems + off + col) >> 2));
+          bits = (two & 0xFu) | ((two >> 4) & 0xF0u);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const bool on = bn_aff ? (__builtin_fmaf(yy[k], bn_ra[k], bn_rb[k]) > 0.f) : (((bits >> k) & 1u) != 0u);
+          x[k] = on ? x[k] : 0.f;
+          bn_s1[k] += x[k];
+          bn_s2[k] += x[k] * ((yy[k] - bn_mu[k]) * bn_is[k]);
+        }
+      }
       *reinterpret_cast<float4 *>(out_f + off + col) = make_float4(x[0], x[1], x[2], x[3]);
       *reinterpret_cast<float4 *>(out_f + off + col + 4) = make_float4(x[4], x[5], x[6], x[7]);
       continue;
@@ -171,6 +207,26 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
     *reinterpret_cast<u32x4 *>(out_g + off + col) = o;
   }
   }  // passes
+  if (bnf) {
+    constexpr int RL = NT / CV;                // threads (row lanes) per 8-channel column group
+    __syncthreads();                           // the staging tile has been read out
+    float *red = reinterpret_cast<float *>(smem);           // [2][RL][BN]
+    const int cvt = tid % CV, rlt = tid / CV;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      red[(0 * RL + rlt) * BN + cvt * 8 + k] = bn_s1[k];
+      red[(1 * RL + rlt) * BN + cvt * 8 + k] = bn_s2[k];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 2 * BN; idx += NT) {
+      const int which = idx / BN, cc = idx - which * BN;
+      const int colr = ntile * BN + cc;
+      if (colr >= p.ncols) continue;
+      float t = 0.f;
+      for (int r = 0; r < RL; ++r) t += red[(which * RL + r) * BN + cc];       // fixed order
+      p.bn_part[(((long long)g * c.mtiles_per_group + mtile) * 2 + which) * p.ncols + colr] = t;
+    }
+  }
 }
 
 // Transposing fragment read (ds_read_b64_tr_b16) from a pixel-major [k][m] LDS image with row pitch `ld` elements:

@@ -785,8 +785,15 @@ int mvg_conv_fprop_split(const mvg_conv_desc *d, const void *x_s3, const void *w
   return launch_igemm_split<false>(p, (hipStream_t)stream);
 }
 
-int mvg_conv_dgrad_split(const mvg_conv_desc *d, const void *dy_s3, const void *w_crsk_s3, float *dx, const float *addend,
-                         void *stream) {
+struct SplitBnFuse {       // fused BatchNorm-backward reduce of the unit whose output gradient dx is (IgemmParams::bn_*)
+  const float *y;
+  const uint8_t *bits;
+  const float *mean, *invstd, *rscale, *rshift;
+  float *part;
+};
+
+static int dgrad_split_impl(const mvg_conv_desc *d, const void *dy_s3, const void *w_crsk_s3, float *dx, const float *addend,
+                            void *stream, const SplitBnFuse *bnf) {
   if (validate_split(d)) return 2;
   IgemmParams p;
   memset(&p, 0, sizeof(p));
@@ -794,6 +801,15 @@ int mvg_conv_dgrad_split(const mvg_conv_desc *d, const void *dy_s3, const void *
   p.b = (const float *)w_crsk_s3;
   p.out = dx;
   p.addend = addend;
+  if (bnf) {
+    p.bn_y = bnf->y;
+    p.bn_bits = bnf->bits;
+    p.bn_mean = bnf->mean;
+    p.bn_invstd = bnf->invstd;
+    p.bn_rscale = bnf->rscale;
+    p.bn_rshift = bnf->rshift;
+    p.bn_part = bnf->part;
+  }
   p.groups = d->groups;
   p.out_h = d->h;
   p.out_w = d->w;
@@ -886,6 +902,37 @@ int mvg_conv_dgrad_split(const mvg_conv_desc *d, const void *dy_s3, const void *
     }
   m.no_remap = m.ncls > 1;
   return launch_igemm_split<true>(m, (hipStream_t)stream);
+}
+
+int mvg_conv_dgrad_split(const mvg_conv_desc *d, const void *dy_s3, const void *w_crsk_s3, float *dx, const float *addend,
+                         void *stream) {
+  return dgrad_split_impl(d, dy_s3, w_crsk_s3, dx, addend, stream, nullptr);
+}
+
+// row tiles per group of the backward-data launch = partials per group of the fused reduce (0: not fusable)
+int mvg_conv_dgrad_bn_partials_split(const mvg_conv_desc *d) {
+  if (validate_split(d)) return -1;
+  if (d->stride != 1) return 0;                         // parity-class launches scatter their rows: not fused
+  IgemmParams q;
+  memset(&q, 0, sizeof(q));
+  q.ncls = 1;
+  q.cls[0].ktotal = d->r * d->s * d->cout;
+  return ceil_div((long long)d->n * d->h * d->w, split_bm(q));
+}
+
+int mvg_conv_dgrad_split_bnreduce(const mvg_conv_desc *d, const void *dy_s3, const void *w_crsk_s3, float *dx, const float *addend,
+                                  const float *bn_y, const uint8_t *bn_bits, const float *bn_mean, const float *bn_invstd,
+                                  const float *relu_scale, const float *relu_shift, float *partials, float *s1, float *s2,
+                                  float *dgamma, float *dbeta, int accumulate, void *stream) {
+  MVG_REQUIRE(bn_y && bn_mean && bn_invstd && partials && s1 && s2, "dgrad_split_bnreduce: null argument");
+  MVG_REQUIRE(!(bn_bits && relu_scale) && ((relu_scale == nullptr) == (relu_shift == nullptr)),
+              "dgrad_split_bnreduce: give the ReLU mask either as bits or as (relu_scale, relu_shift)");
+  const int P = mvg_conv_dgrad_bn_partials_split(d);
+  MVG_REQUIRE(P > 0, "dgrad_split_bnreduce: this shape cannot be fused (stride %d)", d ? d->stride : -1);
+  const SplitBnFuse f = {bn_y, bn_bits, bn_mean, bn_invstd, relu_scale, relu_shift, partials};
+  if (dgrad_split_impl(d, dy_s3, w_crsk_s3, dx, addend, stream, &f)) return 1;
+  ProfScope ps(MVG_K_BN_BWD_REDUCE, (hipStream_t)stream, 0.0, 8.0 * d->groups * (double)P * d->cin);
+  return bn_bwd_finalize_launch(partials, d->groups, P, d->cin, s1, s2, dgamma, dbeta, accumulate, (hipStream_t)stream);
 }
 
 static void wgrad_split_tile(const mvg_conv_desc *d, int &bm, int &bn) {

@@ -171,6 +171,24 @@ def conv_dgrad_split(d: ConvDesc, dy_s3: Tensor, wt_s3: Tensor, dx: Tensor, adde
     check(lib().mvg_conv_dgrad_split(C.byref(d), _p(dy_s3), _p(wt_s3), _p(dx), _p(addend), _s()), "conv_dgrad_split")
 
 
+def conv_dgrad_bn_partials_split(d: ConvDesc) -> int:
+    n = lib().mvg_conv_dgrad_bn_partials_split(C.byref(d))
+    if n < 0:
+        check(1, "conv_dgrad_bn_partials_split")
+    return n
+
+
+def conv_dgrad_split_bnreduce(d: ConvDesc, dy_s3, wt_s3, dx, addend, bn_y, bn_bits, bn_mean, bn_invstd, relu_affine, s1, s2, dgamma,
+                              dbeta, accumulate: bool):
+    """conv_dgrad_split + the BatchNorm-backward reduce pass of the unit whose output gradient dx is, in one launch."""
+    P = conv_dgrad_bn_partials_split(d)
+    part = torch.empty(d.groups * P * 2 * d.cin, dtype=torch.float32, device=dx.device)
+    rs, rh = relu_affine if relu_affine is not None else (None, None)
+    check(lib().mvg_conv_dgrad_split_bnreduce(C.byref(d), _p(dy_s3), _p(wt_s3), _p(dx), _p(addend), _p(bn_y), _p(bn_bits), _p(bn_mean),
+                                              _p(bn_invstd), _p(rs), _p(rh), _p(part), _p(s1), _p(s2), _p(dgamma), _p(dbeta),
+                                              int(accumulate), _s()), "conv_dgrad_split_bnreduce")
+
+
 def conv_wgrad_split(d: ConvDesc, x_s3: Tensor, dy_s3: Tensor, dw: Tensor, accumulate: bool = False):
     splits = lib().mvg_conv_wgrad_splits_split(C.byref(d))
     if splits < 1:

@@ -533,6 +533,25 @@ def test_fused_bn_backward_reduce_switch_gives_the_same_step(depth):
         rel_close(grads[1][1][k], g.cpu().numpy(), 2e-4, "fused vs separate reduce: " + k)
 
 
+@pytest.mark.parametrize("depth", [18, 50])
+def test_split_path_fused_bn_backward_reduce_switch_gives_the_same_step(depth):
+    """MVG_BN_FUSE_SPLIT: the split backward-data launches deliver the BatchNorm-backward sums of the unit they feed.
+    Same forward, same masks, gradients to summation-order noise."""
+    grads = []
+    for fuse in (False, True):
+        m = build(depth)
+        m.ensure_layout()
+        assert m._backbone.split
+        m._backbone.fuse_bn_split = fuse
+        d = m(inputs(4, 96, seed=3))
+        loss = metrics()(d)
+        loss.backward()
+        grads.append((loss.item(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}))
+    assert grads[0][0] == grads[1][0]
+    for k, g in grads[0][1].items():
+        rel_close(grads[1][1][k], g.cpu().numpy(), 2e-4, "fused vs separate reduce (split path): " + k)
+
+
 @pytest.mark.parametrize("depth,dtype", [(18, torch.float32), (50, torch.float32), (50, torch.bfloat16)])
 def test_relu_mask_bits_give_the_same_step_as_reading_the_activation(depth, dtype):
     """Residual units hand their ReLU mask to the backward as bits (MVG_BN_BITS, default on): the same mask the

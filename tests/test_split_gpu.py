@@ -163,6 +163,51 @@ def test_stem_tail_writing_s3_matches_the_fp32_kernel():
     assert torch.equal(ops.merge_s3(out), want) and torch.equal(am, am_want)
 
 
+@pytest.mark.parametrize("case", [(2, 3, 14, 256, 256, 3, 1, 1), (3, 2, 14, 1024, 256, 1, 1, 0), (2, 3, 56, 64, 64, 3, 1, 1),
+                                  (1, 2, 56, 64, 256, 1, 1, 0), (2, 7, 7, 512, 512, 3, 1, 1), (2, 5, 9, 128, 160, 1, 1, 0)],
+                         ids=lambda c: "g%d_n%d_h%d_%dto%d_k%d" % c[:6])
+@pytest.mark.parametrize("mask", ["bits", "affine", "none"])
+def test_split_dgrad_fused_with_bn_backward_reduce(case, mask):
+    """mvg_conv_dgrad_split_bnreduce == mvg_conv_dgrad_split followed by the reduce pass over its result: the same
+    masked gradient bit for bit, the same sums to summation order."""
+    from rot_mvgaze_amd import ops
+    from rot_mvgaze_amd._lib import ConvDesc
+    G, N, h, cin, cout, k, st, pad = case
+    torch.manual_seed(sum(case) + len(mask))
+    d = ConvDesc.make(G, N, h, h, cin, cout, k, st, pad)
+    rows = N * h * h
+    w = torch.randn(cout, k, k, cin, device=dev()) * (1.0 / (k * k * cout) ** 0.5)
+    gy = torch.randn(G, N, d.ho, d.wo, cout, device=dev())
+    add = torch.randn(G, N, h, h, cin, device=dev())
+    _, wt = ops.split_weights(d, w, True)
+    gys = ops.split_f32(gy)
+    # the unit whose output gradient dx is: its conv output y, statistics, and ReLU mask
+    y = torch.randn(G, rows, cin, device=dev()) * 1.5 + 0.3
+    mean, invstd = torch.randn(G, cin, device=dev()) * 0.1 + 0.3, torch.rand(G, cin, device=dev()) + 0.4
+    scale, shift = torch.rand(G, cin, device=dev()) + 0.5, torch.randn(G, cin, device=dev()) * 0.3
+    bits = torch.randint(0, 16, (G * rows * cin // 4,), dtype=torch.uint8, device=dev()) if mask == "bits" else None
+    ra = (scale, shift) if mask == "affine" else None
+    # reference: two launches
+    dx_ref = torch.empty(G, N, h, h, cin, device=dev())
+    ops.conv_dgrad_split(d, gys, wt, dx_ref, add)
+    s_ref = [torch.empty(G, cin, device=dev()) for _ in range(2)]
+    dg_ref, db_ref = torch.full((cin,), 0.5, device=dev()), torch.full((cin,), -0.25, device=dev())
+    g2 = dx_ref.view(G, rows, cin)
+    if bits is not None:
+        ops.bn_bwd_reduce_bits(g2, bits, y, mean, invstd, G, rows, cin, s_ref[0], s_ref[1], dg_ref, db_ref, True, dz_out=g2)
+    else:
+        ops.bn_bwd_reduce(g2, None, y, mean, invstd, G, rows, cin, s_ref[0], s_ref[1], dg_ref, db_ref, True, ra, dz_out=g2)
+    # fused
+    dx = torch.empty_like(dx_ref)
+    s = [torch.empty(G, cin, device=dev()) for _ in range(2)]
+    dg, db = torch.full((cin,), 0.5, device=dev()), torch.full((cin,), -0.25, device=dev())
+    ops.conv_dgrad_split_bnreduce(d, gys, wt, dx, add, y, bits, mean, invstd, ra, s[0], s[1], dg, db, True)
+    assert torch.equal(dx, dx_ref), "masked gradient"
+    for got, want, name in ((s[0], s_ref[0], "s1"), (s[1], s_ref[1], "s2"), (dg, dg_ref, "dgamma"), (db, db_ref, "dbeta")):
+        err = (got - want).abs().max().item()
+        assert err <= 2e-5 * max(want.abs().max().item(), 1.0) * (rows ** 0.5), f"{name}: {err:.3e}"
+
+
 def test_split_kernels_reject_shapes_they_do_not_cover():
     from rot_mvgaze_amd import ops
     from rot_mvgaze_amd._lib import ConvDesc
