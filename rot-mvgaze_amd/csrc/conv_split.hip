@@ -20,7 +20,9 @@
 // source side (the lane that fills 16-byte slot s of row r fetches chunk s ^ ((r >> 2) & 3); a fragment read of
 // chunk cc goes to slot cc ^ ((r >> 2) & 3): the 16 rows of a ds_read_b128 lane group cover 16 different 16-byte
 // bank slots).  Two stages (2 x 72 KB): the next K-step's DMA is issued before this K-step's 48 MFMAs per wave.
-// fp32 output through the LDS-staged epilogue of bf16_tile.h (BN statistics partials, addend).
+// fp32 output through the LDS-staged epilogue of bf16_tile.h (BN statistics partials, addend; backward-data can carry
+// the BatchNorm-backward reduce pass of the unit it feeds: mvg_conv_dgrad_split_bnreduce).  The default for K < 4096
+// is igemm_split_small_kernel below (128-row tiles, one stage, three workgroups per CU).
 #include "bf16_tile.h"
 #include "elem.h"
 
