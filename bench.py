@@ -289,7 +289,8 @@ def main():
             traffic, traffic_src = tj["traffic_bytes_per_launch"], os.path.relpath(cands[-1], ROOT)
         # fp32 training steps run the split-operand kernels (conv_split.hip: six bf16 MFMAs per fp32-accurate product),
         # so their matrix-pipe ceiling is the bf16 MFMA peak / 6 (fp32-equivalent FLOP/s); MVG_SPLIT=0: the fp32 MFMA
-        split = (not bf16) and args.mode == "train" and bb is not None and getattr(bb, "split", False)
+        split = (not bf16) and bb is not None and getattr(bb, "split", False) and \
+            (args.mode == "train" or getattr(bb, "split_eval", False))
         peak = PEAK_BF16_MFMA_TFLOPS if bf16 else (PEAK_BF16_MFMA_TFLOPS / 6.0 if split else PEAK_FP32_MFMA_TFLOPS)
         kernels = "bf16" if bf16 else ("split" if split else "fp32mfma")
         if traffic is not None and tj.get("kernels", "fp32mfma") != kernels:
@@ -355,7 +356,7 @@ def main():
             "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
             "config": {"workload": desc, "backbone": f"ResNet-{depth}", "views": V, "batch_per_gpu": B,
                        "global_batch": B * world, "image": "3x224x224", "parallelism": f"dp{world}" + ("" if os.environ.get("MVG_DIST_BACKEND", "nccl") == "nccl" else " (REHEARSAL: gloo, ranks share devices - not a measurement)"),
-                       "timed_region": ("inference forward (BN folded into conv epilogues)" if args.mode == "eval" else
+                       "timed_region": ("inference forward under torch.no_grad() (BN folded into the conv epilogues)" if args.mode == "eval" else
                                         "forward + loss + backward" + (" + RCCL gradient all-reduce" if world > 1 else "") +
                                         ("" if args.no_optimizer else " + fused Adam step")),
                        "weights": "random init, seed 0 (kaiming-normal convs, default Linear)",

@@ -453,6 +453,12 @@ int mvg_split_weights(const mvg_conv_desc *d, const float *w, void *w_krsc_s3, v
 /* partial-statistics geometry of mvg_conv_fprop_split (like mvg_conv_stats_partials) */
 int mvg_conv_stats_partials_split(const mvg_conv_desc *d, int32_t *rows_per_partial);
 int mvg_conv_fprop_split(const mvg_conv_desc *d, const void *x_s3, const void *w_s3, float *y, float *stats, void *stream);
+/* inference forward with BatchNorm folded into the epilogue (like mvg_conv_fprop_affine): out = relu?(conv * scale +
+ * shift (+ residual)); residual fp32 or s3 (residual_s3), the result fp32 or s3 (out_s3) - in s3 the next conv reads
+ * it directly (resnet.py:60-75,113-133 in eval mode) */
+int mvg_conv_fprop_split_affine(const mvg_conv_desc *d, const void *x_s3, const void *w_s3, void *out, int out_s3,
+                                const float *scale, const float *shift, const void *residual, int residual_s3, int relu,
+                                void *stream);
 int mvg_conv_dgrad_split(const mvg_conv_desc *d, const void *dy_s3, const void *w_crsk_s3, float *dx, const float *addend,
                          void *stream);
 /* The BatchNorm passes on the split path: the conv output y and every gradient g stay fp32; what the next conv

@@ -74,6 +74,7 @@ SIGNATURES = {
     "mvg_split_weights": (_I, [_D, _P, _P, _P, _P]),
     "mvg_conv_stats_partials_split": (_I, [_D, C.POINTER(C.c_int32)]),
     "mvg_conv_fprop_split": (_I, [_D, _P, _P, _P, _P, _P]),
+    "mvg_conv_fprop_split_affine": (_I, [_D, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P]),
     "mvg_conv_dgrad_split": (_I, [_D, _P, _P, _P, _P, _P]),
     "mvg_bn_apply_split": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _I, _I64, _I, _P]),
     "mvg_bn_bwd_apply_split": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _P, _P]),

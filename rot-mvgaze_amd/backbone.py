@@ -91,6 +91,7 @@ class Backbone:
         # one partial per row tile.  C3: backward-data 27.3 -> 31.1 ms, reduce passes 10.8 -> 5.4 ms, 1 000 -> 1 034
         # samples/s.  MVG_BN_FUSE_SPLIT=0: separate reduce passes.
         self.fuse_bn_split = os.environ.get("MVG_BN_FUSE_SPLIT", "1") != "0"
+        self.split_eval = os.environ.get("MVG_SPLIT_EVAL", "1") != "0"      # inference forward on the split kernels too
         self._split_now = self.split          # per forward call: off when a view's largest s3 tensor would exceed 2 GiB
 
     @property
@@ -161,9 +162,20 @@ class Backbone:
         elif tape is None and not bf:
             # inference: BN (running statistics) + residual + ReLU folded into the conv epilogue
             ops.bn_eval_affine(1, c.cout, gamma, beta, rm, rv, BN_EPS, scale[:1], shift[:1])
+            sp_eval = self._split_now and self.split_eval
+            if sp_eval and c.cin != 3:
+                # ... on the split kernels: the epilogue writes the next conv's s3 operand directly (the downsample
+                # branch, read only as a residual, stays fp32)
+                wsrc = self.p[c.name + ".weight"].detach()
+                assert wsrc.is_contiguous(memory_format=torch.channels_last) or (c.k == 1 and wsrc.is_contiguous())
+                wk, _ = ops.split_weights(d, wsrc, need_transposed=False)
+                out = ops.s3_empty(G, N, d.ho, d.wo, c.cout, device=dev) if relu else y
+                ops.conv_fprop_split_affine(d, x, wk, out, scale[0], shift[0], residual, relu)
+                return out
             ops.conv_fprop_affine(d, x, w, y, scale[0], shift[0], residual, relu)
             if pool:
-                return self._pool_plain(y, G, N, d.ho, d.wo, c.cout)
+                pooled, am = self._pool_plain(y, G, N, d.ho, d.wo, c.cout)
+                return (ops.split_f32(pooled), am) if sp_eval else (pooled, am)
             return y
         else:
             fprop(None)

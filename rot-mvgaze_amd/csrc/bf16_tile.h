@@ -15,6 +15,25 @@ __device__ __forceinline__ unsigned pack_bf2(float a, float b) {          // rou
   return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
 }
 
+// fp32 x[8] -> the three bf16 pieces of an s3 chunk (conv_split.hip's operand format; elem.h has the uint4 flavour)
+__device__ __forceinline__ void split3_store(const float (&x)[8], u32x4 &q1, u32x4 &q2, u32x4 &q3) {
+  unsigned a[8], b[8], c[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const __bf16 h1 = (__bf16)x[k];
+    float r = x[k] - (float)h1;
+    const __bf16 h2 = (__bf16)r;
+    r -= (float)h2;
+    const __bf16 h3 = (__bf16)r;
+    a[k] = __builtin_bit_cast(unsigned short, h1);
+    b[k] = __builtin_bit_cast(unsigned short, h2);
+    c[k] = __builtin_bit_cast(unsigned short, h3);
+  }
+  q1 = u32x4{a[0] | (a[1] << 16), a[2] | (a[3] << 16), a[4] | (a[5] << 16), a[6] | (a[7] << 16)};
+  q2 = u32x4{b[0] | (b[1] << 16), b[2] | (b[3] << 16), b[4] | (b[5] << 16), b[6] | (b[7] << 16)};
+  q3 = u32x4{c[0] | (c[1] << 16), c[2] | (c[3] << 16), c[4] | (c[5] << 16), c[6] | (c[7] << 16)};
+}
+
 // Epilogue shared by the bf16 GEMM kernels: BN partial statistics from the fp32 accumulators, then the tile goes
 // through LDS (fp32, the operand buffers are free after the K loop) so that global stores are 16-byte vectors along
 // the channel axis, with bias / ReLU / mask / addend applied in fp32 and ONE rounding to bf16 (F32IO: fp32 stores).
@@ -141,22 +160,54 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
     const float4 lo = *reinterpret_cast<const float4 *>(ot + rl * LDO + cv * 8);
     const float4 hi = *reinterpret_cast<const float4 *>(ot + rl * LDO + cv * 8 + 4);
     float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    if (!DGRAD && F32IO && p.scale) {          // inference: BatchNorm folded into a per-channel affine
+      const float4 s0 = *reinterpret_cast<const float4 *>(p.scale + col), s1 = *reinterpret_cast<const float4 *>(p.scale + col + 4);
+      x[0] *= s0.x; x[1] *= s0.y; x[2] *= s0.z; x[3] *= s0.w; x[4] *= s1.x; x[5] *= s1.y; x[6] *= s1.z; x[7] *= s1.w;
+    }
     if (!DGRAD && p.bias) {
       const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + col), b1 = *reinterpret_cast<const float4 *>(p.bias + col + 4);
       x[0] += b0.x; x[1] += b0.y; x[2] += b0.z; x[3] += b0.w; x[4] += b1.x; x[5] += b1.y; x[6] += b1.z; x[7] += b1.w;
     }
-    if (!DGRAD && p.relu) {
+    if (!DGRAD && p.relu && !(F32IO && p.addend)) {       // (forward with a residual: the ReLU follows the add, below)
 #pragma unroll
       for (int k = 0; k < 8; ++k) x[k] = fmaxf(x[k], 0.f);
     }
     if constexpr (F32IO) {
-      if (mask_f) {
+      if (!DGRAD && p.addend) {                // forward residual (fp32, or s3: the previous block's output), then ReLU
+        if (p.addend_s3) {
+          const u32x4 *q = reinterpret_cast<const u32x4 *>(p.addend) + (((long long)g * gelems + off + col) >> 3) * 3;
+          const u32x4 a = q[0], b = q[1], c3 = q[2];
+          const unsigned ua[4] = {a.x, a.y, a.z, a.w}, ub[4] = {b.x, b.y, b.z, b.w}, uc[4] = {c3.x, c3.y, c3.z, c3.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            x[2 * k] += (bf_lo(ua[k]) + bf_lo(ub[k])) + bf_lo(uc[k]);
+            x[2 * k + 1] += (bf_hi(ua[k]) + bf_hi(ub[k])) + bf_hi(uc[k]);
+          }
+        } else {
+          const float4 a0 = *reinterpret_cast<const float4 *>(add_f + off + col), a1 = *reinterpret_cast<const float4 *>(add_f + off + col + 4);
+          x[0] += a0.x; x[1] += a0.y; x[2] += a0.z; x[3] += a0.w; x[4] += a1.x; x[5] += a1.y; x[6] += a1.z; x[7] += a1.w;
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) x[k] = fmaxf(x[k], 0.f);
+        }
+      }
+      if (!DGRAD && p.out_s3) {                // the next conv's operand, written directly (one chunk per lane)
+        u32x4 q1, q2, q3;
+        split3_store(x, q1, q2, q3);
+        u32x4 *dst = reinterpret_cast<u32x4 *>(p.out) + (((long long)g * gelems + off + col) >> 3) * 3;
+        dst[0] = q1;
+        dst[1] = q2;
+        dst[2] = q3;
+        continue;
+      }
+      if (DGRAD && mask_f) {
         const float4 m0 = *reinterpret_cast<const float4 *>(mask_f + off + col), m1 = *reinterpret_cast<const float4 *>(mask_f + off + col + 4);
         const float mm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
 #pragma unroll
         for (int k = 0; k < 8; ++k) x[k] = mm[k] > 0.f ? x[k] : 0.f;
       }
-      if (add_f) {
+      if (DGRAD && add_f) {
         const float4 a0 = *reinterpret_cast<const float4 *>(add_f + off + col), a1 = *reinterpret_cast<const float4 *>(add_f + off + col + 4);
         x[0] += a0.x; x[1] += a0.y; x[2] += a0.z; x[3] += a0.w; x[4] += a1.x; x[5] += a1.y; x[6] += a1.z; x[7] += a1.w;
       }

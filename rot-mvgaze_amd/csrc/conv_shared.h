@@ -131,6 +131,9 @@ struct IgemmParams {
   // bn_part [groups][P][2][ncols] (P = row partials per group, like the forward statistics).
   const float *bn_y, *bn_act, *bn_mean, *bn_invstd, *bn_rscale, *bn_rshift;
   float *bn_part;
+  // split kernels, inference forward (BatchNorm folded: y = acc * scale + bias (+ residual) [relu]): the residual
+  // and / or the result in s3 (the next conv's operand format) instead of fp32
+  int addend_s3, out_s3;
   const unsigned char *bn_bits;   // split kernels: the unit's ReLU mask as bits (one byte per 4 channels, mvg_bn_apply_split) instead of bn_act
   // Cross-view fusion (igemm_kernel AMODE = 1, Linear forward): the A operand is never materialised - row m of
   //   X = [ img_feat[rc_row_img[m]] (rc_cf floats) | rc_rel[m] (3x3) @ feat[rc_row_src[m]] (3 x rc_nvec, axis-major) ]

@@ -738,14 +738,29 @@ int mvg_conv_stats_partials_split(const mvg_conv_desc *d, int32_t *rows_per_part
   return ceil_div(rows, SP_BM) * 4;
 }
 
-int mvg_conv_fprop_split(const mvg_conv_desc *d, const void *x_s3, const void *w_s3, float *y, float *stats, void *stream) {
+struct SplitAffine {       // inference forward: y = acc * scale + shift (+ residual) [relu], result fp32 or s3
+  const float *scale, *shift;
+  const void *residual;
+  int residual_s3, relu, out_s3;
+};
+
+static int fprop_split_impl(const mvg_conv_desc *d, const void *x_s3, const void *w_s3, void *y, float *stats, void *stream,
+                            const SplitAffine *aff) {
   if (validate_split(d)) return 2;
   IgemmParams p;
   memset(&p, 0, sizeof(p));
   p.a = (const float *)x_s3;
   p.b = (const float *)w_s3;
-  p.out = y;
+  p.out = (float *)y;
   p.stats = stats;
+  if (aff) {
+    p.scale = aff->scale;
+    p.bias = aff->shift;
+    p.addend = (const float *)aff->residual;
+    p.addend_s3 = aff->residual_s3;
+    p.relu = aff->relu;
+    p.out_s3 = aff->out_s3;
+  }
   p.groups = d->groups;
   p.out_h = d->ho;
   p.out_w = d->wo;
@@ -785,6 +800,18 @@ int mvg_conv_fprop_split(const mvg_conv_desc *d, const void *x_s3, const void *w
   p.ncls = 1;
   class_from_params(p.cls[0], p);
   return launch_igemm_split<false>(p, (hipStream_t)stream);
+}
+
+int mvg_conv_fprop_split(const mvg_conv_desc *d, const void *x_s3, const void *w_s3, float *y, float *stats, void *stream) {
+  return fprop_split_impl(d, x_s3, w_s3, y, stats, stream, nullptr);
+}
+
+int mvg_conv_fprop_split_affine(const mvg_conv_desc *d, const void *x_s3, const void *w_s3, void *out, int out_s3,
+                                const float *scale, const float *shift, const void *residual, int residual_s3, int relu,
+                                void *stream) {
+  MVG_REQUIRE(scale && shift && out, "fprop_split_affine: scale, shift and out are required");
+  const SplitAffine a = {scale, shift, residual, residual_s3, relu, out_s3};
+  return fprop_split_impl(d, x_s3, w_s3, out, nullptr, stream, &a);
 }
 
 struct SplitBnFuse {       // fused BatchNorm-backward reduce of the unit whose output gradient dx is (IgemmParams::bn_*)

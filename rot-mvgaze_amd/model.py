@@ -101,7 +101,10 @@ class _BackboneFn(torch.autograd.Function):
     def forward(ctx, model: "MultiViewGaze", training: bool, n_views: int, *tensors: Tensor):
         imgs = list(tensors[:n_views])
         ctx.set_materialize_grads(False)
-        keep = any(ctx.needs_input_grad)          # False under no_grad / when nothing requires grad
+        # needs_input_grad reports requires_grad of the inputs whatever the grad mode is (and grad mode is always off
+        # inside forward): run_views records the caller's grad mode, so that torch.no_grad() inference takes the
+        # tape-less path (BatchNorm folded into the conv epilogues) even though the parameters require grad
+        keep = model._grad_mode and any(ctx.needs_input_grad)
         feat, tape = model._backbone.forward(imgs, training, keep, model.input_bgr, model.input_size)
         ctx.model, ctx.tape, ctx.n_views = model, tape, n_views
         if model._debug_keep_tapes:
@@ -133,7 +136,7 @@ class _HeadFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model: "MultiViewGaze", img_feat: Tensor, rot: Tensor, *params: Tensor):
         ctx.set_materialize_grads(False)
-        keep = any(ctx.needs_input_grad)
+        keep = model._grad_mode and any(ctx.needs_input_grad)
         lifted, feats, preds, tape = model._head.forward(img_feat.detach().contiguous(), rot, keep, model.training)
         ctx.model, ctx.tape = model, tape
         if model._debug_keep_tapes:
@@ -206,6 +209,7 @@ class MultiViewGaze(nn.Module):
         self._on_backward_done: Optional[Callable[[], None]] = None
         self._layout_sig = None
         self._debug_keep_tapes = False            # tests: keep references to the saved activations
+        self._grad_mode = True                    # the caller's grad mode at the last forward (see _BackboneFn.forward)
         self.input_bgr = False                    # raw uint8 inputs: swap B and R first (dataset color_type 'bgr')
         self.input_size: Optional[int] = 224      # raw uint8 inputs: Resize((S, S), antialias=True), main.py:40,53; None = keep
         self._sink = _ArenaSink(self)
@@ -316,6 +320,7 @@ class MultiViewGaze(nn.Module):
         self._backbone.act_dtype = self.compute_dtype
         self._head.mixed = self.compute_dtype == torch.bfloat16
         self._sink.active = False
+        self._grad_mode = torch.is_grad_enabled()
         img_feat = _BackboneFn.apply(self, self.training, len(imgs), *imgs, *self._backbone_params)
         lifted, feats, preds = _HeadFn.apply(self, img_feat, rot, *self._head_params)
         return img_feat, lifted, feats, preds

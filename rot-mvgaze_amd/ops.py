@@ -167,6 +167,15 @@ def conv_fprop_split(d: ConvDesc, x_s3: Tensor, w_s3: Tensor, y: Tensor, stats: 
     check(lib().mvg_conv_fprop_split(C.byref(d), _p(x_s3), _p(w_s3), _p(y), _p(stats), _s()), "conv_fprop_split")
 
 
+def conv_fprop_split_affine(d: ConvDesc, x_s3: Tensor, w_s3: Tensor, out: Tensor, scale: Tensor, shift: Tensor,
+                            residual: Optional[Tensor], relu: bool):
+    """Inference forward on the split kernels, BatchNorm folded: out = relu?(conv * scale + shift (+ residual)).
+    out / residual: fp32 tensors or s3 tensors (bf16 [..., C/8, 3, 8])."""
+    check(lib().mvg_conv_fprop_split_affine(C.byref(d), _p(x_s3), _p(w_s3), _p(out), int(out.dtype == torch.bfloat16), _p(scale),
+                                            _p(shift), _p(residual), int(residual is not None and residual.dtype == torch.bfloat16),
+                                            int(relu), _s()), "conv_fprop_split_affine")
+
+
 def conv_dgrad_split(d: ConvDesc, dy_s3: Tensor, wt_s3: Tensor, dx: Tensor, addend: Optional[Tensor] = None):
     check(lib().mvg_conv_dgrad_split(C.byref(d), _p(dy_s3), _p(wt_s3), _p(dx), _p(addend), _s()), "conv_dgrad_split")
 

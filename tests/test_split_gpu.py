@@ -208,6 +208,39 @@ def test_split_dgrad_fused_with_bn_backward_reduce(case, mask):
         assert err <= 2e-5 * max(want.abs().max().item(), 1.0) * (rows ** 0.5), f"{name}: {err:.3e}"
 
 
+@pytest.mark.parametrize("case", [(2, 3, 14, 256, 256, 3, 1, 1), (1, 5, 28, 128, 128, 3, 2, 1), (3, 2, 14, 1024, 256, 1, 1, 0),
+                                  (1, 2, 56, 64, 256, 1, 1, 0), (2, 7, 7, 512, 2048, 1, 1, 0), (2, 2, 7, 512, 512, 3, 1, 1)],
+                         ids=lambda c: "g%d_n%d_h%d_%dto%d_k%d_s%d" % c[:7])
+@pytest.mark.parametrize("res", [None, "s3", "fp32"])
+@pytest.mark.parametrize("relu,out_s3", [(True, True), (False, False)])
+def test_split_inference_forward_with_folded_batchnorm(case, res, relu, out_s3):
+    """mvg_conv_fprop_split_affine (out = relu?(conv * scale + shift (+ residual)), result and residual in s3 or fp32)
+    against float64 and against the fp32-MFMA inference kernel mvg_conv_fprop_affine."""
+    from rot_mvgaze_amd import ops
+    from rot_mvgaze_amd._lib import ConvDesc
+    G, N, h, cin, cout, k, st, pad = case
+    torch.manual_seed(sum(case))
+    d = ConvDesc.make(G, N, h, h, cin, cout, k, st, pad)
+    x = torch.relu(torch.randn(G, N, h, h, cin, device=dev()))
+    w = torch.randn(cout, k, k, cin, device=dev()) * (1.0 / (k * k * cin) ** 0.5)
+    scale, shift = torch.rand(cout, device=dev()) + 0.5, torch.randn(cout, device=dev()) * 0.3
+    r = torch.randn(G, N, d.ho, d.wo, cout, device=dev()) if res else None
+    ref = F.conv2d(x.double().view(G * N, h, h, cin).permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), None, st, pad).permute(0, 2, 3, 1)
+    ref = ref.reshape(G, N, d.ho, d.wo, cout) * scale.double() + shift.double()
+    if res:
+        ref = ref + r.double()
+    if relu:
+        ref = torch.relu(ref)
+    want = torch.empty(G, N, d.ho, d.wo, cout, device=dev())
+    ops.conv_fprop_affine(d, x, w, want, scale, shift, r, relu)
+    wk, _ = ops.split_weights(d, w, False)
+    out = ops.s3_empty(G, N, d.ho, d.wo, cout, device=dev()) if out_s3 else torch.empty_like(want)
+    ops.conv_fprop_split_affine(d, ops.split_f32(x), wk, out, scale, shift, ops.split_f32(r) if res == "s3" else r, relu)
+    got = ops.merge_s3(out) if out_s3 else out
+    e_split, e_fp32 = rel_l2(got, ref), rel_l2(want, ref)
+    assert e_split <= SPLIT_VS_F64 and e_split <= SPLIT_VS_FP32_KERNEL * e_fp32 + 1e-7, f"split {e_split:.2e}, fp32-MFMA kernel {e_fp32:.2e}"
+
+
 def test_split_kernels_reject_shapes_they_do_not_cover():
     from rot_mvgaze_amd import ops
     from rot_mvgaze_amd._lib import ConvDesc
