@@ -92,6 +92,7 @@ class Backbone:
         # samples/s.  MVG_BN_FUSE_SPLIT=0: separate reduce passes.
         self.fuse_bn_split = os.environ.get("MVG_BN_FUSE_SPLIT", "1") != "0"
         self.split_eval = os.environ.get("MVG_SPLIT_EVAL", "1") != "0"      # inference forward on the split kernels too
+        self._wk_cache: Dict[str, tuple] = {}     # inference: conv name -> (data_ptr, version, s3 weights)
         self._split_now = self.split          # per forward call: off when a view's largest s3 tensor would exceed 2 GiB
 
     @property
@@ -168,7 +169,14 @@ class Backbone:
                 # branch, read only as a residual, stays fp32)
                 wsrc = self.p[c.name + ".weight"].detach()
                 assert wsrc.is_contiguous(memory_format=torch.channels_last) or (c.k == 1 and wsrc.is_contiguous())
-                wk, _ = ops.split_weights(d, wsrc, need_transposed=False)
+                # the s3 copy of the weights is kept between calls while the parameter is unchanged (its version counter:
+                # load_state_dict, optimizer steps - the fused Adam bumps it explicitly - and broadcasts all move it)
+                hit = self._wk_cache.get(c.name)
+                if hit is not None and hit[0] == wsrc.data_ptr() and hit[1] == wsrc._version:
+                    wk = hit[2]
+                else:
+                    wk, _ = ops.split_weights(d, wsrc, need_transposed=False)
+                    self._wk_cache[c.name] = (wsrc.data_ptr(), wsrc._version, wk)
                 out = ops.s3_empty(G, N, d.ho, d.wo, c.cout, device=dev) if relu else y
                 ops.conv_fprop_split_affine(d, x, wk, out, scale[0], shift[0], residual, relu)
                 return out

@@ -93,6 +93,11 @@ class GradAllReducer:
         with torch.no_grad():
             for t in tensors:
                 dist.broadcast(t, src, group=self.pg)
+            if arena is not None:
+                # the parameters alias the arena through `.data` and keep their own version counters: mark them
+                # modified (the inference path caches split copies of the conv weights keyed on the version)
+                for p_ in m.parameters():
+                    torch.autograd.graph.increment_version(p_)
 
     # bucket = [start, end) element range of the arena + the id of its last parameter
     def _build(self):

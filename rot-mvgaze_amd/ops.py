@@ -478,6 +478,10 @@ def linear_skinny_bwd(dy, x, w, mask, dx, dw, db, rows, k, nout, accumulate=Fals
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step):
     check(lib().mvg_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr, beta1, beta2, eps,
                               weight_decay, step, _s()), "adam_step")
+    # the kernel wrote the parameters (and the moments) through raw pointers: tell autograd's version counters, which
+    # the views of the arena share (saved-tensor checks, and the inference path's cache of split weights, rely on them)
+    for t in (param, exp_avg, exp_avg_sq):
+        torch.autograd.graph.increment_version(t)
 
 
 def gaze_angular_loss(pred, gt, n, row_weight, loss, accumulate=False, dpred=None, theta=None):

@@ -73,6 +73,10 @@ class Adam(torch.optim.Optimizer):
             st["step"] += 1
             ops.adam_step(arena_p, arena_g, st["exp_avg"], st["exp_avg_sq"], float(g["lr"]), float(g["betas"][0]),
                           float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), st["step"])
+            # the parameters alias the arena through `.data` (their own version counters): mark them modified, as an
+            # in-place torch op would (the inference path's cache of split weights keys on the version)
+            for (p, _, _) in entries:
+                torch.autograd.graph.increment_version(p)
         return loss
 
     # The moments live in flat buffers that mirror the model's parameter arena (one launch updates all of

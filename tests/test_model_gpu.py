@@ -905,6 +905,36 @@ def test_training_step_does_not_synchronise_the_host():
         torch.cuda.synchronize()
 
 
+def test_inference_weight_cache_follows_parameter_updates():
+    """The inference path keeps s3 copies of the conv weights between calls; an optimizer step (torch's or the fused
+    one, which writes through raw pointers), load_state_dict or an in-place edit must invalidate them."""
+    from rot_mvgaze_amd.optim import Adam
+    m = build(18)
+    x = inputs(3, 64, seed=4)
+
+    def infer():
+        m.eval()
+        with torch.no_grad():
+            return m(dict(x))["iter_2"]["pred_gaze_1"].clone()
+    p0 = infer()
+    assert torch.equal(infer(), p0) and len(m._backbone._wk_cache) > 0          # second call: cache hits, same result
+    m.train()
+    opt = Adam(m.parameters(), lr=1e-2)
+    metrics()(m(dict(x))).backward()
+    opt.step()
+    p1 = infer()
+    assert not torch.equal(p1, p0), "weights changed by the fused Adam step: the cached copies must not be used"
+    ref = build(18)
+    ref.load_state_dict(m.state_dict())
+    ref.eval()
+    with torch.no_grad():
+        want = ref(dict(x))["iter_2"]["pred_gaze_1"]
+    rel_close(p1, want.cpu().numpy(), 1e-6, "inference after an optimizer step vs a fresh model with the same weights")
+    with torch.no_grad():
+        next(p for n, p in m.named_parameters() if n.endswith("layer1.0.conv1.weight")).mul_(1.5)
+    assert not torch.equal(infer(), p1)
+
+
 def test_view_swap_symmetry_eval():
     m = build(18, train=False)
     with torch.no_grad():
