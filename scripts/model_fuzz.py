@@ -49,7 +49,9 @@ for it in range(cases):
     od = R.model_forward(sd, od, depth, 3, True, variant=v)
     ol = R.iteration_loss(od)
     ol.backward()
-    tol = 1e-4 if B >= 4 else 5e-4
+    # layer4's BatchNorm population per channel is B * (hw / 32)^2: at 4 samples (B = 1, 64 px) ResNet-50's outputs
+    # scatter over 5e-5 .. 9e-4 with BOTH conv kernel families (6 seeds each)
+    tol = 1e-4 if B >= 4 else (2e-3 if B * (hw // 32) ** 2 <= 4 else 5e-4)
     e_loss = abs(loss.item() - ol.item()) / abs(ol.item())
     p_dev, p_ref = data["pred_gaze"].detach().cpu().double(), od["pred_gaze"].detach().double()
     e_pred = ((p_dev - p_ref).abs().max() / p_ref.abs().max()).item()
