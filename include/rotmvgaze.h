@@ -450,6 +450,11 @@ int mvg_split_f32(const float *x, void *out_s3, int64_t n, void *stream);       
 int mvg_merge_s3(const void *x_s3, float *out, int64_t n, void *stream);            /* exact inverse */
 /* fp32 KRSC weights -> s3 KRSC (fprop) and, when w_crsk_s3 != NULL, the s3 transposed copy CRSK (dgrad) */
 int mvg_split_weights(const mvg_conv_desc *d, const float *w, void *w_krsc_s3, void *w_crsk_s3, void *stream);
+/* All weight copies of a training step in one launch.  items_dev: n records in DEVICE memory of
+ *   { const float *w (fp32 KRSC); void *wk; void *wt (NULL: no transposed copy); int32 cout, rs, cin, cin_pad; }  (40 bytes)
+ * mode 1: wk / wt = the s3 KRSC / CRSK copies of mvg_split_weights (cin_pad unused); mode 0: the bf16 KRSC (cin
+ * zero-padded to cin_pad) / CRSK copies of mvg_cast_weights_bf16. */
+int mvg_weights_prep_batch(const void *items_dev, int n, int mode, void *stream);
 /* partial-statistics geometry of mvg_conv_fprop_split (like mvg_conv_stats_partials) */
 int mvg_conv_stats_partials_split(const mvg_conv_desc *d, int32_t *rows_per_partial);
 int mvg_conv_fprop_split(const mvg_conv_desc *d, const void *x_s3, const void *w_s3, float *y, float *stats, void *stream);

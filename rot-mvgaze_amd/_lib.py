@@ -72,6 +72,7 @@ SIGNATURES = {
     "mvg_split_f32": (_I, [_P, _P, _I64, _P]),
     "mvg_merge_s3": (_I, [_P, _P, _I64, _P]),
     "mvg_split_weights": (_I, [_D, _P, _P, _P, _P]),
+    "mvg_weights_prep_batch": (_I, [_P, _I, _I, _P]),
     "mvg_conv_stats_partials_split": (_I, [_D, C.POINTER(C.c_int32)]),
     "mvg_conv_fprop_split": (_I, [_D, _P, _P, _P, _P, _P]),
     "mvg_conv_fprop_split_affine": (_I, [_D, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P]),

@@ -93,6 +93,10 @@ class Backbone:
         self.fuse_bn_split = os.environ.get("MVG_BN_FUSE_SPLIT", "1") != "0"
         self.split_eval = os.environ.get("MVG_SPLIT_EVAL", "1") != "0"      # inference forward on the split kernels too
         self._wk_cache: Dict[str, tuple] = {}     # inference: conv name -> (data_ptr, version, s3 weights)
+        # training: one launch per step makes every conv's bf16 / s3 weight copies (MVG_BATCH_WEIGHT_PREP=0: one per conv)
+        self.batch_weight_prep = os.environ.get("MVG_BATCH_WEIGHT_PREP", "1") != "0"
+        self._wprep: Optional[Dict[str, tuple]] = None
+        self._wprep_state = None
         self._split_now = self.split          # per forward call: off when a view's largest s3 tensor would exceed 2 GiB
 
     @property
@@ -110,6 +114,36 @@ class Backbone:
         assert w.is_contiguous(memory_format=torch.channels_last) or (c.k == 1 and w.is_contiguous()), \
             f"{c.name}.weight must be channels_last (KRSC)"
         return w.detach()
+
+    def _prepare_weights(self, dev) -> Dict[str, tuple]:
+        """The per-step copies of every conv's weights the bf16 / split kernels read (KRSC for fprop, CRSK for
+        backward-data), made by ONE launch: destination buffers and the launch's device-resident table of
+        (source, destinations, shape) records are built once per parameter placement and reused every step."""
+        mode = 0 if self.bf16 else 1
+        convs = [c for c in self.spec.all_convs() if not (mode == 1 and c.cin == 3)]
+        key = (mode, str(dev), tuple(self.p[c.name + ".weight"].data_ptr() for c in convs))
+        if self._wprep_state is None or self._wprep_state[0] != key:
+            out, rows = {}, []
+            for c in convs:
+                wsrc = self.p[c.name + ".weight"]
+                assert wsrc.is_contiguous(memory_format=torch.channels_last) or (c.k == 1 and wsrc.is_contiguous())
+                rs = c.k * c.k
+                if mode == 1:
+                    wk = torch.empty(c.cout, rs * c.cin // 8, 3, 8, dtype=torch.bfloat16, device=dev)
+                    wt = torch.empty(c.cin, rs * c.cout // 8, 3, 8, dtype=torch.bfloat16, device=dev)
+                    cin_pad = c.cin
+                else:
+                    cin_pad = 8 if c.cin == 3 else c.cin
+                    wk = torch.empty(c.cout, c.k, c.k, cin_pad, dtype=torch.bfloat16, device=dev)
+                    wt = None if c.cin == 3 else torch.empty(cin_pad, c.k, c.k, c.cout, dtype=torch.bfloat16, device=dev)
+                out[c.name] = (wk, wt)
+                rows.append([wsrc.data_ptr(), wk.data_ptr(), wt.data_ptr() if wt is not None else 0, c.cout | (rs << 32),
+                             c.cin | (cin_pad << 32)])
+            table = torch.tensor(rows, dtype=torch.int64).to(dev)            # once per placement (a host-to-device copy)
+            self._wprep_state = (key, out, table, len(rows), mode)
+        _, out, table, n, mode = self._wprep_state
+        ops.weights_prep_batch(table, n, mode)
+        return out
 
     def bn_count_buffers(self) -> List[Tensor]:
         return [self.p[c.bn + ".num_batches_tracked"] for c in self.spec.all_convs()]
@@ -131,7 +165,9 @@ class Backbone:
         # sp_out = its consumers do (every unit: the stem's pooled map feeds layer1)
         sp_out = self._split_now and training and not bf
         sp_in = sp_out and c.cin != 3
-        if sp_in:
+        if (sp_in or bf) and self._wprep is not None:
+            w, w_t = self._wprep[c.name]         # this step's copies, made by ONE launch at the start of forward()
+        elif sp_in:
             wsrc = self.p[c.name + ".weight"].detach()
             assert wsrc.is_contiguous(memory_format=torch.channels_last) or (c.k == 1 and wsrc.is_contiguous())
             w, w_t = ops.split_weights(d, wsrc, need_transposed=tape is not None)
@@ -277,6 +313,9 @@ class Backbone:
         # fp32-MFMA kernels (4 bytes per element: B < 668 instead of B < 445 per view at 224 x 224 with ResNet-50)
         biggest_view_elems = B * ((H + 3) // 4) * ((W + 3) // 4) * self.spec.blocks[0].convs[-1].cout
         self._split_now = self.split and 6 * biggest_view_elems * self._guard_scale < 0x7FFFFFF0
+        self._wprep = None
+        if self.batch_weight_prep and (self.bf16 or (self._split_now and training)):
+            self._wprep = self._prepare_weights(dev)
         tape: Optional[dict] = {"units": [], "blocks": [], "V": V, "B": B} if keep_tape else None
         ulist = tape["units"] if keep_tape else None
         if training:

@@ -102,6 +102,64 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float *__restr
   }
 }
 
+// Every conv's weight copies of one training step in ONE launch (grid.y = conv): the per-conv launches were
+// latency-bound (53-72 launches of a few microseconds of work each: 0.7 ms per step on the split path, 1.4 ms on
+// the bf16 path).  mode 1: fp32 KRSC -> s3 KRSC (+ s3 CRSK); mode 0: -> bf16 KRSC (cin zero-padded to cin_pad)
+// (+ bf16 CRSK), the layouts of split_weights_kernel / conv_bf16.hip's cast_weights_bf16_kernel.
+struct WPrepItem {
+  const float *w;
+  void *wk, *wt;
+  int cout, rs, cin, cin_pad;
+};
+
+__global__ __launch_bounds__(256) void weights_prep_batch_kernel(const WPrepItem *__restrict__ items, int mode) {
+  const WPrepItem it = items[blockIdx.y];
+  const float *__restrict__ w = it.w;
+  const int cout = it.cout, rs = it.rs, cin = it.cin;
+  if (mode == 1) {
+    uint4 *wk = reinterpret_cast<uint4 *>(it.wk), *wt = reinterpret_cast<uint4 *>(it.wt);
+    const int c8n = cin / 8, o8n = cout / 8;
+    const long long nk = (long long)cout * rs * c8n, nt = wt ? (long long)cin * rs * o8n : 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nk + nt; i += (long long)gridDim.x * 256) {
+      float v[8];
+      uint4 *dst;
+      if (i < nk) {
+        const float4 *src = reinterpret_cast<const float4 *>(w + i * 8);
+        const float4 lo = src[0], hi = src[1];
+        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+        dst = wk + 3 * i;
+      } else {
+        const long long j = i - nk;
+        const int o8 = (int)(j % o8n);
+        const long long t = j / o8n;
+        const int tap = (int)(t % rs), c = (int)(t / rs);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = w[((long long)(o8 * 8 + k) * rs + tap) * cin + c];
+        dst = wt + 3 * j;
+      }
+      uint4 q1, q2, q3;
+      split3_chunk(v, q1, q2, q3);
+      dst[0] = q1;
+      dst[1] = q2;
+      dst[2] = q3;
+    }
+    return;
+  }
+  unsigned short *wk = reinterpret_cast<unsigned short *>(it.wk), *wt = reinterpret_cast<unsigned short *>(it.wt);
+  const int cin_pad = it.cin_pad;
+  const long long total = (long long)cout * rs * cin_pad;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % cin_pad);
+    const long long t = i / cin_pad;
+    const int tap = (int)(t % rs), o = (int)(t / rs);
+    const float v = c < cin ? w[((long long)o * rs + tap) * cin + c] : 0.f;
+    const __bf16 b = (__bf16)v;
+    const unsigned short u = __builtin_bit_cast(unsigned short, b);
+    wk[i] = u;
+    if (wt) wt[((long long)c * rs + tap) * cout + o] = u;
+  }
+}
+
 template <int BN, bool DGRAD>
 __global__ __launch_bounds__(512, 1) void igemm_split_kernel(IgemmParams p) {
   constexpr int BM = SP_BM, BK = SP_BK, WGM = 4, WGN = 2;
@@ -727,6 +785,14 @@ int mvg_split_weights(const mvg_conv_desc *d, const float *w, void *w_krsc_s3, v
   hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, st, w, (uint4 *)w_krsc_s3, (uint4 *)w_crsk_s3, d->cout,
                      d->r * d->s, d->cin);
   return check_launch("split_weights");
+}
+
+int mvg_weights_prep_batch(const void *items_dev, int n, int mode, void *stream) {
+  MVG_REQUIRE(items_dev != nullptr && n > 0 && (mode == 0 || mode == 1), "weights_prep_batch: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(MVG_K_LAYOUT, st, 0.0, 0.0);
+  hipLaunchKernelGGL(weights_prep_batch_kernel, dim3(64, (unsigned)n), dim3(256), 0, st, (const WPrepItem *)items_dev, mode);
+  return check_launch("weights_prep_batch");
 }
 
 int mvg_conv_stats_partials_split(const mvg_conv_desc *d, int32_t *rows_per_partial) {

@@ -155,6 +155,12 @@ def split_weights(d: ConvDesc, w: Tensor, need_transposed: bool = True):
     return wk, wt
 
 
+def weights_prep_batch(items: Tensor, n: int, mode: int):
+    """items: int64 device tensor [n, 5] = (w ptr, wk ptr, wt ptr or 0, cout | rs << 32, cin | cin_pad << 32)."""
+    assert items.is_cuda and items.dtype == torch.int64 and items.is_contiguous() and items.shape == (n, 5)
+    check(lib().mvg_weights_prep_batch(C.c_void_p(items.data_ptr()), n, mode, _s()), "weights_prep_batch")
+
+
 def conv_stats_partials_split(d: ConvDesc):
     rpp = C.c_int32(0)
     n = lib().mvg_conv_stats_partials_split(C.byref(d), C.byref(rpp))
