@@ -3,8 +3,13 @@
 (+ gradient all-reduce when --gpus > 1), synthetic B x V x 3 x 224 x 224 batches.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps K --warmup W        # self-launching: starts N rank processes itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+
+With --gpus N > 1 and no RANK in the environment, this process never touches the GPU: it starts one
+child process per rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set),
+relays rank 0's single JSON line and exits with the worst child's return code (launch_ranks below).
 
 Prints ONE JSON line (rank 0).  `value` = samples all ranks processed / max-over-ranks time of
 exactly K steps bracketed by barrier + synchronize; inputs are resident in HBM before the timed
@@ -112,6 +117,71 @@ def cpu_baseline(depth, views):
     return out
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(world, argv, script=None, extra_env=None, timeout=None, python=None):
+    """Start `world` rank processes of `script` (default: this file) with `argv`, one per GPU, and wait.
+
+    The caller must not have initialised the GPU (nothing here imports torch): the children are fresh
+    processes, never an exec of this one.  Rank r gets RANK = LOCAL_RANK = r, WORLD_SIZE = world,
+    MASTER_ADDR = 127.0.0.1 and a free MASTER_PORT (what torch.distributed.run would set).  Rank 0's stdout is
+    captured and returned - the contract is ONE JSON line - every other rank's stdout joins stderr.  When a
+    rank fails, the remaining ones (who would wait in a collective forever) are terminated.  Returns
+    (worst return code, rank 0's stdout text)."""
+    import subprocess
+    script = script or os.path.abspath(__file__)
+    env0 = dict(os.environ)
+    env0.update({"WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port()),
+                 "LOCAL_WORLD_SIZE": str(world)})
+    env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this pool
+    env0.update(extra_env or {})
+    procs = []
+    for r in range(world):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([python or sys.executable, script] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno(),
+                                      stderr=None, text=(r == 0) or None))
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = None if timeout is None else time.time() + timeout
+    worst, failed = 0, False
+    alive = set(range(world))
+    while alive:
+        for r in sorted(alive):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            alive.discard(r)
+            if rc != 0:
+                worst = max(worst, rc if rc > 0 else 128 - rc)      # killed by signal s: 128 + s, like a shell
+                failed = True
+        if (failed or (deadline is not None and time.time() > deadline)) and alive:
+            if not failed:
+                worst = 124
+            for r in alive:                   # exactly the processes started above
+                procs[r].terminate()
+            t_kill = time.time() + 10
+            for r in sorted(alive):
+                try:
+                    procs[r].wait(max(0.1, t_kill - time.time()))
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+                    procs[r].wait()
+            alive.clear()
+            break
+        if alive:
+            time.sleep(0.05)
+    reader.join(10)
+    return worst, (out0[0] if out0 else "")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -139,6 +209,13 @@ def main():
                     help="eval = inference forward only (model.eval(), BN folded into the convs; SURVEY §8(f) rank 2)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # bare `python bench.py --gpus N`: become the launcher (no torch / HIP in this process)
+        rc, out = launch_ranks(args.gpus, sys.argv[1:])
+        sys.stdout.write(out)
+        sys.stdout.flush()
+        sys.exit(rc)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -164,7 +241,8 @@ def main():
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         if world > 1:
-            assert int(os.environ.get("WORLD_SIZE", "1")) == world, "launch with torch.distributed.run (see docstring)"
+            assert int(os.environ.get("WORLD_SIZE", "1")) == world, \
+                f"--gpus {world} but WORLD_SIZE={os.environ.get('WORLD_SIZE')}: start N ranks (torch.distributed.run) or none (self-launch)"
         else:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")

@@ -206,7 +206,9 @@ class _Mlp:
                     else:
                         ops.linear_wgrad(inp, g, sink.view(self.w[l]), sink.view(self.b[l]), rows, fin, fout, aw)
                 if l == 0 and gen is not None:
-                    wr.off_path(grads, gen.img, gen.feat, g)
+                    # every per-step tensor the side-stream kernel reads must be recorded on that stream: `rel` is
+                    # a per-forward allocation owned only by this tape (the row tables are cached for the model's life)
+                    wr.off_path(grads, gen.img, gen.feat, g, *([gen.rel] if gen.rel is not None else []))
                 else:
                     wr.off_path(grads, inp, g)
             # ---- input gradient

@@ -23,7 +23,11 @@ Nothing in the reference runs in bf16, so this path has no reference fixture.  I
     "teacher-forced" instead: the unit's recorded bf16 input goes through the unit on the CPU and must
     reproduce the recorded conv output, batch statistics and activation (incl. residual adds, the fused stem
     tail and the final pooling) to bf16 output rounding; the end-to-end distances are reported and
-    sanity-bounded (0.6).
+    sanity-bounded (0.6).  AND, since round 3, ResNet-50 is also held END TO END to the declared 3e-2 on a
+    second, well-conditioned weight recipe (synth.make_state_dict(conditioned=True): the last BatchNorm gamma of
+    every residual block x 0.1, as in a trained / zero-init-residual network), whose own sensitivity to one flipped
+    rounding is 2-6e-3 (measured on the CPU oracle alone, tests/test_oracle_golden.py): predictions and loss at
+    V = 2 / 4 / 8, incl. 224 px (C5's image size).
 
 (c) the distance to the fp32 oracle is REPORTED, with a loose sanity bound only (BF16_VS_FP32_SANITY = 0.6):
     on this benchmark's random-initialised ResNet-50 the storage format itself moves the pooled features by
@@ -400,20 +404,36 @@ def _check_blocks_backward_teacher_forced(m, tape, dfeat):
     assert not bad, "teacher-forced backward: " + "; ".join(f"{w} {e:.2e}" for e, w in sorted(bad, reverse=True)[:6])
 
 
-BF16_MODEL_CASES = [(18, 2, 8, 96), (18, 4, 6, 128), (50, 2, 16, 128), (50, 4, 8, 96), (50, 8, 4, 160)]
+# depth, V, B, hw, weight recipe ("random" = synth.make_state_dict(perturb_bn=True); "conditioned" = ... conditioned=True)
+BF16_MODEL_CASES = [
+    (18, 2, 8, 96, "random"), (18, 4, 6, 128, "random"),
+    (50, 2, 16, 128, "random"), (50, 4, 8, 96, "random"), (50, 8, 4, 160, "random"),
+    (50, 8, 2, 224, "random"),                                   # C5's network at C5's image size
+    (50, 2, 16, 128, "conditioned"), (50, 4, 4, 224, "conditioned"), (50, 8, 2, 224, "conditioned"),
+]
 
 
-@pytest.mark.parametrize("depth,V,B,hw", BF16_MODEL_CASES, ids=[f"r{d}_V{v}_B{b}_hw{h}" for d, v, b, h in BF16_MODEL_CASES])
-def test_bf16_training_step_against_bf16_storage_oracle(depth, V, B, hw):
-    """One training step with compute_dtype = bfloat16 (incl. C5's shapes at reduced batch: ResNet-50, V = 8,
-    224 px) against the CPU oracle with the same storage rounding, at the tolerances declared above; the
-    distance to the fp32 oracle is logged (MVG_TEST_L2_LOG) and sanity-bounded."""
+@pytest.mark.parametrize("depth,V,B,hw,recipe", BF16_MODEL_CASES, ids=[f"r{d}_V{v}_B{b}_hw{h}_{r}" for d, v, b, h, r in BF16_MODEL_CASES])
+def test_bf16_training_step_against_bf16_storage_oracle(depth, V, B, hw, recipe):
+    """One training step with compute_dtype = bfloat16 against the CPU oracle with the same storage rounding, at the
+    tolerances declared above.  Covers C5's network (ResNet-50, V = 8) at C5's image size (224 px: 56 x 56 ... 7 x 7
+    maps through the whole model, 112 fusion-block rows per sample pair set) at reduced batch, and ResNet-50 at V = 4 / 224 px.
+
+    * ResNet-18, and ResNet-50 with the WELL-CONDITIONED weight recipe (synth.make_state_dict(conditioned=True);
+      its conditioning is measured on the CPU oracle alone in tests/test_oracle_golden.py): predictions and loss
+      are ASSERTED end to end at BF16_PRED_TOL / BF16_LOSS_TOL = 3e-2.
+    * ResNet-50 with the benchmark's random-init weights: every conv + BatchNorm unit forward and every residual
+      block backward teacher-forced (part (b) of the module docstring); end to end the distance is reported and
+      sanity-bounded - the network itself turns one flipped rounding into 10-20 % there.
+    The distance to the fp32 oracle is logged (MVG_TEST_L2_LOG) and sanity-bounded in every case."""
     from oracle import restatement as R
     from rot_mvgaze_amd.geometry import rotation_matrix_2d
     from rot_mvgaze_amd.losses import MultiViewIterationLoss
     from rot_mvgaze_amd.model import MultiViewGaze
     m = MultiViewGaze(depth, 3)
-    sdn = synth.make_state_dict(depth, 0, 3, perturb_bn=True)
+    conditioned = recipe == "conditioned"
+    teacher_forced = not conditioned          # the unit-by-unit checks do not depend on the recipe: run them once per shape
+    sdn = synth.make_state_dict(depth, 0, 3, perturb_bn=True, conditioned=conditioned)
     m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sdn.items()})
     m.to(dev()).train()
     m.compute_dtype = torch.bfloat16
@@ -422,19 +442,21 @@ def test_bf16_training_step_against_bf16_storage_oracle(depth, V, B, hw):
     img, hp, gt = (torch.from_numpy(inp[k]) for k in ("img", "head_pose", "gt_gaze"))
     rot_d = rotation_matrix_2d(hp.reshape(-1, 2).to(dev())).reshape(B, V, 3, 3)
     out = m.forward_multiview([img[:, v].contiguous().to(dev()) for v in range(V)], rot_d)
-    _check_units_teacher_forced(m, out["img_feat"])                     # before backward: it releases the activations
+    if teacher_forced:
+        _check_units_teacher_forced(m, out["img_feat"])                 # before backward: it releases the activations
     tape = m._last_backbone_tape
     tape["debug"] = []                                                  # backward records the gradient after every block
     out["img_feat"].retain_grad()
     loss = MultiViewIterationLoss(rel_weight=0.01, reference_decay=1.0, iter_decay=0.5)(out, gt.to(dev()))
     loss.backward()
-    _check_blocks_backward_teacher_forced(m, tape, out["img_feat"].grad)
+    if teacher_forced:
+        _check_blocks_backward_teacher_forced(m, tape, out["img_feat"].grad)
     assert out["img_feat"].dtype == torch.float32                       # the fusion block stays fp32
-    strict = depth == 18                                                # ResNet-50: see (b) in the module docstring
+    strict = depth == 18 or conditioned                                 # random-init ResNet-50: see (b) in the module docstring
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     rot = R.rotation_matrix_2d(hp.reshape(-1, 2)).reshape(B, V, 3, 3)
     log = os.environ.get("MVG_TEST_L2_LOG")
-    tag = f"bf16[r{depth}_V{V}_B{B}_hw{hw}]"
+    tag = f"bf16[r{depth}_V{V}_B{B}_hw{hw}_{recipe}]"
 
     def note(line):
         if log:
@@ -482,11 +504,11 @@ def test_bf16_training_step_against_bf16_storage_oracle(depth, V, B, hw):
         got, ref = params[k].grad.detach().cpu().double().numpy(), leaves[k].grad.double().numpy()
         err = np.linalg.norm((got - ref).ravel()) / (np.linalg.norm(ref.ravel()) + 1e-30)
         note(f"{err:.3e} {BF16_GRAD_L2:.1e} {tag} grad {k}")
-        if strict and "_feat_extractor" not in k:
+        if strict and depth == 18 and "_feat_extractor" not in k:
             assert err <= BF16_GRAD_L2, f"grad {k}: relative L2 {err:.3e}"
     # BN running statistics (fp32, from the fp32 accumulators)
     close(m.state_dict()["_feat_extractor.0.bn1.running_mean"], sd["_feat_extractor.0.bn1.running_mean"], 1e-4, "running_mean")
-    if strict:
+    if depth == 18:
         close(m.state_dict()["_feat_extractor.0.layer4.0.bn2.running_var"], sd["_feat_extractor.0.layer4.0.bn2.running_var"], 2e-2,
               "running_var")
     assert int(m.state_dict()["_feat_extractor.0.bn1.num_batches_tracked"]) == V

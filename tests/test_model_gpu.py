@@ -472,6 +472,31 @@ def test_data_parallel_two_ranks_equals_average_of_independent_steps(tmp_path):
             assert torch.equal(got[k], want[k]), (r, k)
 
 
+def test_bench_self_launch_two_ranks_gloo_rehearsal():
+    """`python bench.py --gpus 2 ...` with NO launcher around it and no RANK in the environment: bench.py starts its two
+    rank processes itself (bench.launch_ranks) and prints exactly one JSON line.  On this one-GPU box the ranks share
+    the device and the gradients travel over gloo (MVG_DIST_BACKEND=gloo): the line says REHEARSAL and is not a
+    measurement; on a multi-GPU node the same command runs over RCCL."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    env["MVG_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--workload", "c2", "--batch", "4", "--no-roofline", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["rccl_ranks"] == 2 and j["config"]["global_batch"] == 8
+    assert "REHEARSAL" in j["config"]["parallelism"] and j["config"]["dp"]["backend"] == "gloo"
+    assert j["value"] > 0 and np.isfinite(j["config"]["loss"])
+
+
 def test_second_backward_through_released_tape_raises():
     m = build(18)
     d = m(inputs(2, 64))
@@ -740,6 +765,69 @@ def test_benchmark_configuration_c4_share_full_size_against_oracle():
                                "_feat_extractor.0.layer2.0.downsample.0.weight", "_feat_extractor.0.layer3.2.conv2.weight",
                                "_feat_extractor.0.layer4.2.conv1.weight", "_lifter._lifter.blocks.1.0.weight",
                                "_img_fusers.2._fuser.blocks.0.0.weight", "_gaze_estimators.0.blocks.0.0.weight"))
+
+
+def test_benchmark_configuration_c3_full_size_against_oracle():
+    """C3 - the workload the headline number is quoted on - at FULL size: ResNet-50, V = 4, B = 128, 224 x 224
+    (512 images, 1536 fusion-block rows, bench.py's weights and inputs; s3 activations of 617 MB per view against
+    the 2 GiB guard of the split kernels, more than 2 GiB across views).  The HIP TRAINING forward against the CPU
+    oracle's forward (batch statistics) on the same inputs: loss and EVERY pair's gaze predictions and fused
+    features of every iteration within the north star's 1e-4 (rot_mv.py:187-269 per pair), and the split-operand
+    kernels must be the ones that ran.  The backward runs at full size too: finite gradients everywhere, and the
+    gradients that do not need a 512-image CPU autograd graph - d loss / d pooled feature of every view and the
+    fusion block's weight gradients, from the oracle's fusion block + loss on the oracle's own pooled features -
+    are compared (relative L2 1e-3: no ReLU of the backbone is involved; the two sides' pooled features differ by up to 1e-4)."""
+    from oracle import restatement as R
+    from rot_mvgaze_amd.arch import backbone_spec
+    from rot_mvgaze_amd.geometry import rotation_matrix_2d
+    from rot_mvgaze_amd.losses import MultiViewIterationLoss
+    from rot_mvgaze_amd.model import MultiViewGaze
+    depth, V, B, hw = 50, 4, 128, 224
+    m = MultiViewGaze(depth, 3)
+    sdn = synth.make_state_dict(depth, 0, 3)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sdn.items()}, strict=True)
+    m.to(dev()).train()
+    inp = synth.make_inputs(B, V, 1234, hw)
+    img, hp, gt = (torch.from_numpy(inp[k]) for k in ("img", "head_pose", "gt_gaze"))
+    rot_d = rotation_matrix_2d(hp.reshape(-1, 2).to(dev())).reshape(B, V, 3, 3)
+    out = m.forward_multiview([img[:, v].contiguous().to(dev()) for v in range(V)], rot_d)
+    assert m._backbone._split_now is True
+    out["img_feat"].retain_grad()
+    loss = MultiViewIterationLoss(rel_weight=0.01, reference_decay=1.0, iter_decay=0.5)(out, gt.to(dev()))
+    loss.backward()
+    for k, p in m.named_parameters():
+        assert p.grad is None or bool(torch.isfinite(p.grad).all()), k
+
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in sdn.items()}
+    spec = backbone_spec(depth)
+    rot = R.rotation_matrix_2d(hp.reshape(-1, 2)).reshape(B, V, 3, 3)
+    with torch.no_grad():
+        feats = [R.backbone_forward(sd, img[:, v], spec, True) for v in range(V)]
+    for v in range(V):
+        rel_close(out["img_feat"][v], feats[v].numpy(), TOL, f"C3 pooled feature of view {v}")
+    feats = [f.requires_grad_(True) for f in feats]
+    head_keys = [k for k in sd if not k.startswith("_feat_extractor") and sd[k].dtype == torch.float32]
+    for k in head_keys:
+        sd[k].requires_grad_(True)
+    lifted = [R.lift(sd, f) for f in feats]
+    oo = {"num_iter": 3, "views": V, "pairs": {}}
+    for (i, j) in R.view_pairs(V):
+        oo["pairs"][(i, j)] = R.fuse_pair(sd, 3, feats[i], feats[j], lifted[i], lifted[j], rot[:, i], rot[:, j])
+    ol = R.multiview_loss(oo, gt, iter_decay=0.5, rel_weight=0.01, reference_decay=1.0)
+    ol.backward()
+    rel_close(loss, ol.item(), TOL, "C3 loss")
+    for pr in R.view_pairs(V):
+        for it in range(3):
+            for k in ("pred_gaze_0", "pred_gaze_1", "feat_0", "feat_1"):
+                rel_close(out["pairs"][pr][f"iter_{it}"][k], oo["pairs"][pr][f"iter_{it}"][k].detach().numpy(), TOL,
+                          f"C3 pair {pr} iter {it} {k}")
+    for v in range(V):
+        l2_close(out["img_feat"].grad[v], feats[v].grad.numpy(), 1e-3, f"C3 d loss / d pooled feature of view {v}")
+    params = dict(m.named_parameters())
+    for k in head_keys:
+        l2_close(params[k].grad, sd[k].grad.numpy(), 1e-3, "C3 grad " + k)
+    assert int(m.state_dict()["_feat_extractor.0.bn1.num_batches_tracked"]) == V
 
 
 def test_fused_adam_matches_torch_adam():
