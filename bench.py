@@ -375,7 +375,7 @@ def main():
             traffic, traffic_src = None, None           # the committed counters belong to another kernel family
         roofline = {"bound": "mfma",
                     "kernel": ("igemm_bf16_kernel/wgrad_bf16_kernel (bf16 MFMA implicit-GEMM conv: fprop+dgrad+wgrad)" if bf16 else
-                               "igemm_split_kernel/wgrad_split_kernel (fp32-accurate implicit-GEMM conv on the bf16 MFMA, six MFMAs "
+                               "igemm_split16_kernel/wgrad_split_kernel (fp32-accurate implicit-GEMM conv on the bf16 MFMA, six MFMAs "
                                "per product; the 3-channel stem on the fp32 MFMA: fprop+dgrad+wgrad)" if split else
                                "igemm_kernel/wgrad_kernel (fp32 MFMA implicit-GEMM conv: fprop+dgrad+wgrad)"),
                     "peak_basis": ("dense bf16 MFMA 2500 TFLOP/s" if bf16 else

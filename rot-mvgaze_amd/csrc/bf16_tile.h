@@ -39,16 +39,22 @@ __device__ __forceinline__ void split3_store(const float (&x)[8], u32x4 &q1, u32
 // the channel axis, with bias / ReLU / mask / addend applied in fp32 and ONE rounding to bf16 (F32IO: fp32 stores).
 // Workgroup = WGM x 2 waves (WGM * 128 threads), wave tile (BM / WGM) x (BN / 2).  PASSES > 1: the staging tile
 // holds BM / PASSES rows at a time (the wave rows take turns), for kernels whose LDS is smaller than the full tile.
-template <int BM, int BN, int WGM, bool DGRAD, bool F32IO, int PASSES = 1>
-__device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmClass &c, f32x16 (&acc)[BM / WGM / 32][BN / 2 / 32],
+// ACC16: the accumulators are 16 x 16 tiles of v_mfma_f32_16x16x32_bf16 (f32x4 acc[WTM / 16][WTN / 16]: column =
+// lane & 15, row = 4 * (lane >> 4) + e) instead of 32 x 32 tiles of v_mfma_f32_32x32x16_bf16 (f32x16 acc[WTM / 32][WTN / 32]:
+// column = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)).
+template <int BM, int BN, int WGM, bool DGRAD, bool F32IO, int PASSES = 1, bool ACC16 = false, class AccT>
+__device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmClass &c, AccT &acc,
                                               unsigned short *smem, int tid, int g, int mtile, int ntile) {
   constexpr int WGN = 2, NT = WGM * WGN * 64;
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
-  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int TS = ACC16 ? 16 : 32, NE = ACC16 ? 4 : 16;      // tile side, accumulator registers per tile
+  constexpr int TM = WTM / TS, TN = WTN / TS;
   constexpr int LDO = BN + 4;                // fp32 staging tile
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
-  const int li = lane & 31, lh = lane >> 5;
+  const int li = ACC16 ? (lane & 15) : (lane & 31), lh = ACC16 ? (lane >> 4) : (lane >> 5);
+  // row of accumulator register e inside its tile
+  auto erow = [&](int e) { return ACC16 ? 4 * lh + e : (e & 3) + 8 * (e >> 2) + 4 * lh; };
   const int ohw = c.out_h * c.out_w;
   const long long row_base = (long long)mtile * BM + wm * WTM;
   if (!DGRAD && p.stats) {
@@ -57,27 +63,29 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
     const int cnt = cnt_ll <= 0 ? 0 : (cnt_ll > WTM ? WTM : (int)cnt_ll);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int col = ntile * BN + wn * WTN + j * 32 + li;
+      const int col = ntile * BN + wn * WTN + j * TS + li;
       float csum = 0.f;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int r = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        for (int e = 0; e < NE; ++e) {
+          const int r = i * TS + erow(e);
           csum += (r < cnt) ? acc[i][j][e] : 0.f;
         }
       csum += __shfl_xor(csum, 32, 64);
+      if (ACC16) csum += __shfl_xor(csum, 16, 64);
       const float mean = cnt > 0 ? csum / (float)cnt : 0.f;
       float q = 0.f;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int r = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        for (int e = 0; e < NE; ++e) {
+          const int r = i * TS + erow(e);
           const float dlt = acc[i][j][e] - mean;
           q += (r < cnt) ? dlt * dlt : 0.f;
         }
       q += __shfl_xor(q, 32, 64);
+      if (ACC16) q += __shfl_xor(q, 16, 64);
       if (lh == 0 && col < p.ncols) {
         const long long P = p.stats_partials ? p.stats_partials : (long long)c.mtiles_per_group * WGM;
         const long long pi = (long long)mtile * WGM + wm;
@@ -145,8 +153,8 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int e = 0; e < 16; ++e)
-          ot[((wm % (WGM / PASSES)) * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * LDO + wn * WTN + j * 32 + li] = acc[i][j][e];
+        for (int e = 0; e < NE; ++e)
+          ot[((wm % (WGM / PASSES)) * WTM + i * TS + erow(e)) * LDO + wn * WTN + j * TS + li] = acc[i][j][e];
   }
   __syncthreads();
 #pragma unroll

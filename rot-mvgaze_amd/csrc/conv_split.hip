@@ -14,15 +14,9 @@
 // of 8, the three pieces of a chunk adjacent - element (row, c, piece) at ushort offset
 //     ((row * C/8 + c/8) * 3 + piece) * 8 + c % 8            (48 contiguous bytes per 8 channels, 6 bytes/element)
 //
-// Kernel (fprop and dgrad, uniform-tap shapes with channels % 32 == 0): 512 threads = 8 waves as 4 x 2, tile
-// 256 x BN x 32, wave tile 64 x (BN/2); loader = LDS-DMA (`buffer_load_dwordx4 ... lds`, one wave-instruction =
-// 16 rows x 64 bytes of one piece), LDS image per stage: piece-major, unpadded 64-byte rows, bank spread from the
-// source side (the lane that fills 16-byte slot s of row r fetches chunk s ^ ((r >> 2) & 3); a fragment read of
-// chunk cc goes to slot cc ^ ((r >> 2) & 3): the 16 rows of a ds_read_b128 lane group cover 16 different 16-byte
-// bank slots).  Two stages (2 x 72 KB): the next K-step's DMA is issued before this K-step's 48 MFMAs per wave.
-// fp32 output through the LDS-staged epilogue of bf16_tile.h (BN statistics partials, addend; backward-data can carry
-// the BatchNorm-backward reduce pass of the unit it feeds: mvg_conv_dgrad_split_bnreduce).  The default for K < 4096
-// is igemm_split_small_kernel below (128-row tiles, one stage, three workgroups per CU).
+// Kernels: igemm_split16_kernel (fprop and dgrad, uniform-tap shapes with channels % 32 == 0; below) and
+// wgrad_split_kernel.  fp32 output through the LDS-staged epilogue of bf16_tile.h (BN statistics partials, addend;
+// backward-data can carry the BatchNorm-backward reduce pass of the unit it feeds: mvg_conv_dgrad_split_bnreduce).
 #include "bf16_tile.h"
 #include "elem.h"
 
@@ -37,8 +31,7 @@ namespace mvg {
   SPLIT_ONE(0, 2, av, bv, acc) SPLIT_ONE(2, 0, av, bv, acc) SPLIT_ONE(1, 1, av, bv, acc) SPLIT_ONE(0, 1, av, bv, acc) \
   SPLIT_ONE(1, 0, av, bv, acc) SPLIT_ONE(0, 0, av, bv, acc)
 
-constexpr int SP_BM = 256, SP_BK = 32;
-constexpr int SP_SMALL_K = 4096;      // GEMM K below this: the 128-row, three-workgroups-per-CU kernel (measured per shape)
+constexpr int SP_BM = 128, SP_BK = 32;
 
 // fp32 [n8 * 8] -> s3 (layout plumbing for tests and for tensors no kernel writes in s3 directly)
 __global__ __launch_bounds__(256) void split_f32_kernel(const float4 *__restrict__ x, uint4 *__restrict__ out, long long n8) {
@@ -160,183 +153,51 @@ __global__ __launch_bounds__(256) void weights_prep_batch_kernel(const WPrepItem
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// igemm_split16_kernel: the 128 x BN x 32 tile on v_mfma_f32_16x16x32_bf16 with a "span" loader.
+//
+// Measured in scripts/kloop_probe.hip (a GEMM sandbox with this tile and a 3x3 conv's operand reuse; MI355X,
+// profiles/r03_kloop_probe.txt) against round 2's kernel (32x32x16 MFMAs, piece-major image), same sync structure (one
+// stage of 48 KB, three workgroups per CU, which cover each other's DMA waits and epilogues):
+//   * loader: +8..19 %.  One LDS-DMA wave-instruction used to fetch, for 16 rows, the four 16-byte chunks of ONE
+//     piece - 64 segments of 16 bytes at a 48-byte stride, three instructions re-touching the same 128-byte lines.
+//     Now an instruction covers 64 CONSECUTIVE 16-byte slots of a row-major LDS image whose rows are the 192
+//     contiguous bytes a row contributes to a K-step (4 chunks x 3 pieces): 5 1/3 rows x 192 contiguous bytes.
+//     The LDS image has no padding (stage = (128 + BN) x 192 bytes, as before): the slot of (chunk cc, piece pc) in
+//     row R is 4 pc + (cc ^ g(R)), g(R) = (-(R >> 2)) & 3, filled by permuting the SOURCE address inside the row's
+//     span (the DMA destination is linear in the lane).  A ds_read_b128 of a fragment is conflict-free for the
+//     16x16x32 operand map (lane: row l & 15, chunk l >> 4) and for the 32x32x16 one (brute-force check in DESIGN.md).
+//   * MFMA shape: +9..10 % on top.  16x16x32 and 32x32x16 need the same cycles per flop and the same LDS reads per
+//     K-step (a 64 x 64 wave tile: 8 fragments per piece either way), but an MFMA-dense loop is clock-limited by
+//     power on this chip and holds a higher clock on the 16x16x32 shape (MI355X_MICROARCH.md, DVFS give-back 7).
+// Row -> address: every lane needs the base offset and tap-validity mask of SIX rows (one per A instruction it
+// issues) instead of two; thread r computes row r's once and the lanes pick theirs up through LDS.
+// ------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define SPLIT16_ONE(PA, PB)                                                                       \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)   \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[PA][i], bv[PB][j], acc[i][j], 0, 0, 0);
+
 template <int BN, bool DGRAD>
-__global__ __launch_bounds__(512, 1) void igemm_split_kernel(IgemmParams p) {
-  constexpr int BM = SP_BM, BK = SP_BK, WGM = 4, WGN = 2;
-  constexpr int WTM = BM / WGM, WTN = BN / WGN;               // 64 x (BN / 2)
-  constexpr int TM = WTM / 32, TN = WTN / 32;
-  constexpr int ROW = BK;                                     // elements per LDS row (64 bytes)
-  constexpr int A_ELEMS = BM * ROW, B_ELEMS = BN * ROW;       // one piece
-  constexpr int STAGE = 3 * (A_ELEMS + B_ELEMS);
-  constexpr int A_GROUPS = BM / 16 / 8;                       // 16-row DMA groups per wave
-  constexpr int B_GROUPS = BN / 16;                           // ... in total (waves 0 .. B_GROUPS-1 take one each)
-  constexpr int LDO = BN + 4;
-  constexpr int EPI_ELEMS = (BM * LDO * 4 + BM * 4) / 2;
-  constexpr int SMEM = 2 * STAGE > EPI_ELEMS ? 2 * STAGE : EPI_ELEMS;
-  __shared__ __attribute__((aligned(16))) unsigned short smem[SMEM];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WGN, wn = wave % WGN;
-  const int li = lane & 31, lh = lane >> 5;
-  const int nwg = gridDim.x;
-  const int wg_all = p.no_remap ? (int)blockIdx.x : xcd_remap(blockIdx.x, nwg);
-  int ci = 0;
-  for (int i = 1; i < p.ncls; ++i) ci += wg_all >= p.cls[i].tile0;
-  const IgemmClass &c = p.cls[ci];
-  const int wg = wg_all - c.tile0;
-  const int ntile = wg % p.ntiles;
-  const int mt_all = wg / p.ntiles;
-  const int g = mt_all / c.mtiles_per_group;
-  const int mtile = mt_all - g * c.mtiles_per_group;
-  const int KT = c.KT;
-  const int ohw = c.out_h * c.out_w;
-
-  // DMA lane map: lane l of a wave-instruction fills 16-byte slot (l & 3) of row (l >> 2) of a 16-row group
-  // with source chunk a_kv; wave w owns A row groups w and w + 8, and B row group w (when w < B_GROUPS)
-  const int r_in_grp = lane >> 2;
-  const int a_kv = (lane & 3) ^ ((lane >> 4) & 3);            // (row >> 2) & 3 with row = 16 * group + (lane >> 2)
-  unsigned a_base[A_GROUPS], a_vmask[A_GROUPS];
-#pragma unroll
-  for (int i = 0; i < A_GROUPS; ++i) {
-    const long long m = (long long)mtile * BM + (wave + 8 * i) * 16 + r_in_grp;
-    const bool ok = m < c.rows_per_group;
-    const int mm = ok ? (int)m : 0;
-    const int img = (int)fdiv((unsigned)mm, c.ohw_div);
-    const int rem = mm - img * ohw;
-    const int oy = (int)fdiv((unsigned)rem, c.ow_div), ox = rem - oy * c.out_w;
-    const int y0 = DGRAD ? oy + c.cls_cy : oy * p.stride - p.pad;
-    const int x0 = DGRAD ? ox + c.cls_cx : ox * p.stride - p.pad;
-    a_base[i] = (unsigned)(img * p.src_img_stride * 6) + (unsigned)((y0 * p.src_w + x0) * p.src_c) * 6u + (unsigned)a_kv * 48u;
-    unsigned msk = 0;
-    for (int t = 0; t < c.ntaps; ++t) {
-      const int fr = (int)fdiv((unsigned)t, c.tap_ns_div), fs = t - fr * c.tap_ns;
-      const int iy = DGRAD ? y0 - fr : y0 + fr;
-      const int ix = DGRAD ? x0 - fs : x0 + fs;
-      msk |= (unsigned)(((unsigned)iy < (unsigned)p.src_h) & ((unsigned)ix < (unsigned)p.src_w)) << t;
-    }
-    a_vmask[i] = ok ? msk : 0u;
-  }
-  const int bn_row = ntile * BN + wave * 16 + r_in_grp;
-  const bool b_ok = (wave < B_GROUPS) & (bn_row < p.ncols);
-  const unsigned b_base = ((unsigned)bn_row * (unsigned)p.b_row_len) * 6u + (unsigned)a_kv * 48u;
-  const __amdgpu_buffer_rsrc_t rs_a =
-      make_rsrc(reinterpret_cast<const char *>(p.a) + (long long)g * p.imgs_per_group * p.src_img_stride * 6, p.a_group_bytes);
-  const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(p.b, p.b_bytes);
-  typedef __attribute__((address_space(3))) void *lds_vp;
-
-  auto issue = [&](int kt, int buf) {
-    int kstart = kt * BK;
-    if (c.korder) {
-      const int cblk = (int)fdiv((unsigned)kt, c.per_div), rem = kt - cblk * c.ntaps;
-      kstart = (rem << p.src_c_shift) + cblk * BK;
-    }
-    const int ks = __builtin_amdgcn_readfirstlane(kstart);
-    const int tap_u = c.ntaps > 1 ? (ks >> p.src_c_shift) : 0;
-    const int chb = ks - (tap_u << p.src_c_shift);
-    const int fru = (int)fdiv((unsigned)tap_u, c.tap_ns_div), fsu = tap_u - fru * c.tap_ns;
-    const int disp = (fru * p.src_w + fsu) * p.src_c;
-    const unsigned sdelta = (unsigned)(((DGRAD ? -disp : disp) + chb) * 6);
-    unsigned kb = (unsigned)ks * 6u;
-    if (DGRAD) {
-      const int btap = (c.tap_r0 + p.tap_step * fru) * p.s + c.tap_s0 + p.tap_step * fsu;
-      kb = (unsigned)(btap * p.src_c + chb) * 6u;
-    }
-    unsigned short *st = smem + buf * STAGE;
-#pragma unroll
-    for (int i = 0; i < A_GROUPS; ++i) {
-      const bool ok = ((a_vmask[i] >> tap_u) & 1u) != 0u;
-      const unsigned off = a_base[i] + sdelta;
-#pragma unroll
-      for (int pc = 0; pc < 3; ++pc)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_vp)(st + pc * A_ELEMS + (wave + 8 * i) * 16 * ROW), 16,
-                                                 (int)pred_off(off + 16u * pc, ok), 0, 0, 0);
-    }
-    if (wave < B_GROUPS) {
-#pragma unroll
-      for (int pc = 0; pc < 3; ++pc)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_vp)(st + 3 * A_ELEMS + pc * B_ELEMS + wave * 16 * ROW), 16,
-                                                 (int)pred_off(b_base + kb + 16u * pc, b_ok), 0, 0, 0);
-    }
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  // fragment addresses: row R, chunk cc = 2 kg + lh -> slot cc ^ ((R >> 2) & 3)
-  int a_row[TM], b_row[TN], a_sw[TM], b_sw[TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int R = wm * WTM + i * 32 + li;
-    a_row[i] = R * ROW;
-    a_sw[i] = (R >> 2) & 3;
-  }
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int R = wn * WTN + j * 32 + li;
-    b_row[j] = R * ROW;
-    b_sw[j] = (R >> 2) & 3;
-  }
-
-  issue(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int kt = 0; kt < KT; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < KT) issue(kt + 1, cur ^ 1);
-    const unsigned short *As = smem + cur * STAGE;
-    const unsigned short *Bs = As + 3 * A_ELEMS;
-#pragma unroll
-    for (int kg = 0; kg < BK / 16; ++kg) {
-      bf16x8 av[3][TM], bv[3][TN];
-#pragma unroll
-      for (int pc = 0; pc < 3; ++pc) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-          av[pc][i] = *reinterpret_cast<const bf16x8 *>(As + pc * A_ELEMS + a_row[i] + (((2 * kg + lh) ^ a_sw[i]) << 3));
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          bv[pc][j] = *reinterpret_cast<const bf16x8 *>(Bs + pc * B_ELEMS + b_row[j] + (((2 * kg + lh) ^ b_sw[j]) << 3));
-      }
-      SPLIT_PRODUCTS(av, bv, acc)
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the next K-step's DMA has landed
-    __syncthreads();                                         // ... for every wave, and everyone is done reading `cur`
-  }
-  bf16_epilogue<BM, BN, WGM, DGRAD, true>(p, c, acc, smem, tid, g, mtile, ntile);
-}
-
-// The same GEMM for short-K and HBM-bound shapes: tile 128 x BN x 32, 256 threads = 4 waves as 2 x 2 (the same
-// 64 x (BN/2) wave tile), ONE 48 KB stage and three workgroups per CU.  With 1x1 convs of K = 64..512 a tile is a
-// few K-steps between a cold prologue and a 64 KB epilogue: one big workgroup per CU runs those phases in lock step
-// with every other CU (the HBM idles during the K loops and saturates during the epilogues); three small workgroups
-// per CU drift apart and cover each other's DMA waits and epilogues (cdna_hip_programming.md: at 2-3 blocks/CU the
-// wave-level overlap already captures what a deeper software pipeline would add).  The epilogue stages 64 rows at a
-// time (34 KB).
-template <int BN, bool DGRAD>
-__global__ __launch_bounds__(256, 3) void igemm_split_small_kernel(IgemmParams p) {
-  constexpr int BM = 128, BK = SP_BK, WGM = 2, WGN = 2;
+__global__ __launch_bounds__(256, 3) void igemm_split16_kernel(IgemmParams p) {
+  constexpr int BM = 128, WGM = 2, WGN = 2, NW = 4;
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
-  constexpr int TM = WTM / 32, TN = WTN / 32;
-  constexpr int ROW = BK;
-  constexpr int A_ELEMS = BM * ROW, B_ELEMS = BN * ROW;       // one piece
-  constexpr int STAGE = 3 * (A_ELEMS + B_ELEMS);
-  constexpr int A_GROUPS = BM / 16 / 4;                       // 16-row DMA groups per wave (2)
-  constexpr int B_GROUPS = BN / 16 / 4;                       // (2 or 1)
+  constexpr int TM = WTM / 16, TN = WTN / 16;
+  constexpr int ROWB = 192, ROWS = BM + BN, STAGE_B = ROWS * ROWB;
+  constexpr int NQ = ROWS * 12 / 64;                          // DMA wave-instructions per stage (48 / 36)
+  constexpr int QA = BM * 12 / 64;                            // ... of which the first 24 fill the A rows
+  constexpr int A_PER = QA / NW, B_PER = (NQ - QA) / NW;      // per wave: 6 and 6 / 3
+  static_assert(QA % NW == 0 && (NQ - QA) % NW == 0, "whole instructions per wave");
   constexpr int LDO = BN + 4;
-  constexpr int EPI_ELEMS = ((BM / 2) * LDO * 4 + BM * 4) / 2;
-  constexpr int SMEM = STAGE > EPI_ELEMS ? STAGE : EPI_ELEMS;
-  __shared__ __attribute__((aligned(16))) unsigned short smem[SMEM];
+  constexpr int EPI_B = (BM / 2) * LDO * 4 + BM * 4;
+  constexpr int INFO_OFF = STAGE_B > EPI_B ? STAGE_B : EPI_B;  // row table behind the stage / the epilogue tile
+  constexpr int SMEM_B = INFO_OFF + BM * 8;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_B];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
-  const int li = lane & 31, lh = lane >> 5;
   const int nwg = gridDim.x;
   const int wg_all = p.no_remap ? (int)blockIdx.x : xcd_remap(blockIdx.x, nwg);
   int ci = 0;
@@ -350,13 +211,10 @@ __global__ __launch_bounds__(256, 3) void igemm_split_small_kernel(IgemmParams p
   const int KT = c.KT;
   const int ohw = c.out_h * c.out_w;
 
-  const int r_in_grp = lane >> 2;
-  const int a_kv = (lane & 3) ^ ((lane >> 4) & 3);
-  unsigned a_base[A_GROUPS], a_vmask[A_GROUPS], b_base[B_GROUPS];
-  bool b_ok[B_GROUPS];
-#pragma unroll
-  for (int i = 0; i < A_GROUPS; ++i) {
-    const long long m = (long long)mtile * BM + (wave + 4 * i) * 16 + r_in_grp;
+  // ---- row table: thread r < 128 -> (byte offset of row r's pixel at tap (0,0) channel 0, bit t = tap t in range)
+  uint2 *rowinfo = reinterpret_cast<uint2 *>(smem + INFO_OFF);
+  if (tid < BM) {
+    const long long m = (long long)mtile * BM + tid;
     const bool ok = m < c.rows_per_group;
     const int mm = ok ? (int)m : 0;
     const int img = (int)fdiv((unsigned)mm, c.ohw_div);
@@ -364,7 +222,7 @@ __global__ __launch_bounds__(256, 3) void igemm_split_small_kernel(IgemmParams p
     const int oy = (int)fdiv((unsigned)rem, c.ow_div), ox = rem - oy * c.out_w;
     const int y0 = DGRAD ? oy + c.cls_cy : oy * p.stride - p.pad;
     const int x0 = DGRAD ? ox + c.cls_cx : ox * p.stride - p.pad;
-    a_base[i] = (unsigned)(img * p.src_img_stride * 6) + (unsigned)((y0 * p.src_w + x0) * p.src_c) * 6u + (unsigned)a_kv * 48u;
+    const unsigned base = (unsigned)(img * p.src_img_stride * 6) + (unsigned)((y0 * p.src_w + x0) * p.src_c) * 6u;
     unsigned msk = 0;
     for (int t = 0; t < c.ntaps; ++t) {
       const int fr = (int)fdiv((unsigned)t, c.tap_ns_div), fs = t - fr * c.tap_ns;
@@ -372,13 +230,27 @@ __global__ __launch_bounds__(256, 3) void igemm_split_small_kernel(IgemmParams p
       const int ix = DGRAD ? x0 - fs : x0 + fs;
       msk |= (unsigned)(((unsigned)iy < (unsigned)p.src_h) & ((unsigned)ix < (unsigned)p.src_w)) << t;
     }
-    a_vmask[i] = ok ? msk : 0u;
+    rowinfo[tid] = make_uint2(base, ok ? msk : 0u);
+  }
+  __syncthreads();
+  // ---- the instructions this wave issues: Q = wave + 4 i; lane -> linear slot 64 Q + lane -> (row, slot in row)
+  unsigned a_base[A_PER], a_vmask[A_PER], b_base[B_PER];
+#pragma unroll
+  for (int i = 0; i < A_PER; ++i) {
+    const int sl = (wave + NW * i) * 64 + lane;
+    const int row = sl / 12, j = sl - row * 12;
+    const int pc = j >> 2, cc = (j & 3) ^ ((-(row >> 2)) & 3);
+    const uint2 ri = rowinfo[row];
+    a_base[i] = ri.x + 16u * (unsigned)(cc * 3 + pc);
+    a_vmask[i] = ri.y;
   }
 #pragma unroll
-  for (int i = 0; i < B_GROUPS; ++i) {
-    const int n = ntile * BN + (wave + 4 * i) * 16 + r_in_grp;
-    b_ok[i] = n < p.ncols;
-    b_base[i] = ((unsigned)n * (unsigned)p.b_row_len) * 6u + (unsigned)a_kv * 48u;
+  for (int i = 0; i < B_PER; ++i) {
+    const int sl = (wave + NW * (A_PER + i)) * 64 + lane - BM * 12;
+    const int row = sl / 12, j = sl - row * 12;                  // (BM >> 2) & 3 == 0: the swizzle of stage row BM + row is g(row)
+    const int pc = j >> 2, cc = (j & 3) ^ ((-(row >> 2)) & 3);
+    const int n = ntile * BN + row;
+    b_base[i] = pred_off(((unsigned)n * (unsigned)p.b_row_len) * 6u + 16u * (unsigned)(cc * 3 + pc), n < p.ncols);
   }
   const __amdgpu_buffer_rsrc_t rs_a =
       make_rsrc(reinterpret_cast<const char *>(p.a) + (long long)g * p.imgs_per_group * p.src_img_stride * 6, p.a_group_bytes);
@@ -386,10 +258,10 @@ __global__ __launch_bounds__(256, 3) void igemm_split_small_kernel(IgemmParams p
   typedef __attribute__((address_space(3))) void *lds_vp;
 
   auto issue = [&](int kt) {
-    int kstart = kt * BK;
+    int kstart = kt * SP_BK;
     if (c.korder) {
       const int cblk = (int)fdiv((unsigned)kt, c.per_div), rem = kt - cblk * c.ntaps;
-      kstart = (rem << p.src_c_shift) + cblk * BK;
+      kstart = (rem << p.src_c_shift) + cblk * SP_BK;
     }
     const int ks = __builtin_amdgcn_readfirstlane(kstart);
     const int tap_u = c.ntaps > 1 ? (ks >> p.src_c_shift) : 0;
@@ -403,68 +275,56 @@ __global__ __launch_bounds__(256, 3) void igemm_split_small_kernel(IgemmParams p
       kb = (unsigned)(btap * p.src_c + chb) * 6u;
     }
 #pragma unroll
-    for (int i = 0; i < A_GROUPS; ++i) {
+    for (int i = 0; i < A_PER; ++i) {
       const bool ok = ((a_vmask[i] >> tap_u) & 1u) != 0u;
-      const unsigned off = a_base[i] + sdelta;
-#pragma unroll
-      for (int pc = 0; pc < 3; ++pc)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_vp)(smem + pc * A_ELEMS + (wave + 4 * i) * 16 * ROW), 16,
-                                                 (int)pred_off(off + 16u * pc, ok), 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_vp)(smem + (wave + NW * i) * 1024), 16, (int)pred_off(a_base[i] + sdelta, ok), 0, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < B_GROUPS; ++i) {
-#pragma unroll
-      for (int pc = 0; pc < 3; ++pc)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_vp)(smem + 3 * A_ELEMS + pc * B_ELEMS + (wave + 4 * i) * 16 * ROW), 16,
-                                                 (int)pred_off(b_base[i] + kb + 16u * pc, b_ok[i]), 0, 0, 0);
-    }
+    for (int i = 0; i < B_PER; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_vp)(smem + (wave + NW * (A_PER + i)) * 1024), 16, (int)(b_base[i] + kb), 0, 0, 0);
   };
 
-  f32x16 acc[TM][TN];
+  f32x4 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
 
-  int a_row[TM], b_row[TN], a_sw[TM], b_sw[TN];
+  // fragment addresses: lane -> row (l & 15) of a 16-row tile, chunk cc = l >> 4 -> slot 4 pc + (cc ^ g(row))
+  const int cc_l = lane >> 4;
+  int a_off[TM], b_off[TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    const int R = wm * WTM + i * 32 + li;
-    a_row[i] = R * ROW;
-    a_sw[i] = (R >> 2) & 3;
+    const int R = wm * WTM + i * 16 + (lane & 15);
+    a_off[i] = R * ROWB + ((cc_l ^ ((-(R >> 2)) & 3)) << 4);
   }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int R = wn * WTN + j * 32 + li;
-    b_row[j] = R * ROW;
-    b_sw[j] = (R >> 2) & 3;
+    const int R = wn * WTN + j * 16 + (lane & 15);
+    b_off[j] = (BM + R) * ROWB + ((cc_l ^ ((-(R >> 2)) & 3)) << 4);
   }
 
-  const unsigned short *As = smem;
-  const unsigned short *Bs = smem + 3 * A_ELEMS;
   for (int kt = 0; kt < KT; ++kt) {
     issue(kt);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-#pragma unroll
-    for (int kg = 0; kg < BK / 16; ++kg) {
+    {
       bf16x8 av[3][TM], bv[3][TN];
 #pragma unroll
       for (int pc = 0; pc < 3; ++pc) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-          av[pc][i] = *reinterpret_cast<const bf16x8 *>(As + pc * A_ELEMS + a_row[i] + (((2 * kg + lh) ^ a_sw[i]) << 3));
+        for (int i = 0; i < TM; ++i) av[pc][i] = *reinterpret_cast<const bf16x8 *>(smem + a_off[i] + pc * 64);
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          bv[pc][j] = *reinterpret_cast<const bf16x8 *>(Bs + pc * B_ELEMS + b_row[j] + (((2 * kg + lh) ^ b_sw[j]) << 3));
+        for (int j = 0; j < TN; ++j) bv[pc][j] = *reinterpret_cast<const bf16x8 *>(smem + b_off[j] + pc * 64);
       }
-      SPLIT_PRODUCTS(av, bv, acc)
+      // smallest terms first: (a1 b3, a3 b1, a2 b2), (a1 b2, a2 b1), a1 b1
+      SPLIT16_ONE(0, 2) SPLIT16_ONE(2, 0) SPLIT16_ONE(1, 1) SPLIT16_ONE(0, 1) SPLIT16_ONE(1, 0) SPLIT16_ONE(0, 0)
     }
     __syncthreads();                                         // everyone is done reading before the next DMA lands
   }
-  bf16_epilogue<BM, BN, WGM, DGRAD, true, 2>(p, c, acc, smem, tid, g, mtile, ntile);
+  bf16_epilogue<BM, BN, WGM, DGRAD, true, 2, true>(p, c, acc, reinterpret_cast<unsigned short *>(smem), tid, g, mtile, ntile);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -693,30 +553,10 @@ static int validate_split(const mvg_conv_desc *d) {
   return 0;
 }
 
-// 0: by shape (default), 1: always the 256-row kernel, 2: always the 128-row kernel (A/B switch: MVG_SPLIT_TILE)
-static int split_tile_env() {
-  static int v = -1;
-  if (v < 0) {
-    const char *e = getenv("MVG_SPLIT_TILE");
-    v = e ? atoi(e) : 0;
-    if (v < 0 || v > 2) v = 0;
-  }
-  return v;
-}
-
-// rows per statistics partial: both kernels produce 64-row (one wave tile) partials, mtiles * (BM / 64) per group
-static int split_bm(const IgemmParams &p) {
-  const int env = split_tile_env();
-  if (env) return env == 1 ? 256 : 128;
-  int kmax = 0;
-  for (int i = 0; i < p.ncls; ++i) kmax = p.cls[i].ktotal > kmax ? p.cls[i].ktotal : kmax;
-  return kmax >= SP_SMALL_K ? 256 : 128;
-}
-
 template <bool DGRAD>
 static int launch_igemm_split(IgemmParams &p, hipStream_t st) {
   const int bn = p.ncols >= 128 ? 128 : 64;
-  const int bm = split_bm(p);
+  const int bm = SP_BM;
   p.ntiles = ceil_div(p.ncols, bn);
   p.splits = 1;
   p.sk_tiles = 0;
@@ -734,15 +574,9 @@ static int launch_igemm_split(IgemmParams &p, hipStream_t st) {
   }
   MVG_REQUIRE(tiles < (1LL << 31), "split conv: grid too large");
   if (tiles <= 0) return 0;
-  if (bm == 256) {
-    dim3 grid((unsigned)tiles), block(512);
-    if (bn == 128) hipLaunchKernelGGL((igemm_split_kernel<128, DGRAD>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((igemm_split_kernel<64, DGRAD>), grid, block, 0, st, p);
-  } else {
-    dim3 grid((unsigned)tiles), block(256);
-    if (bn == 128) hipLaunchKernelGGL((igemm_split_small_kernel<128, DGRAD>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((igemm_split_small_kernel<64, DGRAD>), grid, block, 0, st, p);
-  }
+  dim3 grid((unsigned)tiles), block(256);
+  if (bn == 128) hipLaunchKernelGGL((igemm_split16_kernel<128, DGRAD>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL((igemm_split16_kernel<64, DGRAD>), grid, block, 0, st, p);
   return check_launch(DGRAD ? "conv_dgrad_split" : "conv_fprop_split");
 }
 
@@ -798,10 +632,9 @@ int mvg_weights_prep_batch(const void *items_dev, int n, int mode, void *stream)
 int mvg_conv_stats_partials_split(const mvg_conv_desc *d, int32_t *rows_per_partial) {
   if (validate_split(d)) return -1;
   const long long rows = (long long)d->n * d->ho * d->wo;
-  if (rows_per_partial) *rows_per_partial = 64;               // one wave tile of rows, whichever kernel runs
-  // the 256-row kernel writes 4 partials per tile (the last tile's may lie beyond the rows: count 0), the 128-row
-  // kernel 2: size for the larger count, bn_finalize ignores partials that start beyond the rows
-  return ceil_div(rows, SP_BM) * 4;
+  if (rows_per_partial) *rows_per_partial = 64;               // one wave tile of rows
+  // two partials per 128-row tile (the last tile's second one may lie beyond the rows: count 0, ignored by bn_finalize)
+  return ceil_div(rows, SP_BM) * 2;
 }
 
 struct SplitAffine {       // inference forward: y = acc * scale + shift (+ residual) [relu], result fp32 or s3
@@ -862,7 +695,7 @@ static int fprop_split_impl(const mvg_conv_desc *d, const void *x_s3, const void
                        4.0 * d->groups * (double)p.rows_per_group * d->cout;
   const bool lin = d->r == 1 && d->s == 1 && d->h == 1 && d->w == 1;
   ProfScope ps(lin ? MVG_K_LINEAR_FPROP : MVG_K_CONV_FPROP, (hipStream_t)stream, flops, bytes);
-  p.stats_partials = ceil_div(p.rows_per_group, SP_BM) * 4;    // = mvg_conv_stats_partials_split, whichever kernel runs
+  p.stats_partials = ceil_div(p.rows_per_group, SP_BM) * 2;    // = mvg_conv_stats_partials_split
   p.ncls = 1;
   class_from_params(p.cls[0], p);
   return launch_igemm_split<false>(p, (hipStream_t)stream);
@@ -1008,11 +841,7 @@ int mvg_conv_dgrad_split(const mvg_conv_desc *d, const void *dy_s3, const void *
 int mvg_conv_dgrad_bn_partials_split(const mvg_conv_desc *d) {
   if (validate_split(d)) return -1;
   if (d->stride != 1) return 0;                         // parity-class launches scatter their rows: not fused
-  IgemmParams q;
-  memset(&q, 0, sizeof(q));
-  q.ncls = 1;
-  q.cls[0].ktotal = d->r * d->s * d->cout;
-  return ceil_div((long long)d->n * d->h * d->w, split_bm(q));
+  return ceil_div((long long)d->n * d->h * d->w, SP_BM);
 }
 
 int mvg_conv_dgrad_split_bnreduce(const mvg_conv_desc *d, const void *dy_s3, const void *w_crsk_s3, float *dx, const float *addend,

@@ -7,14 +7,16 @@
 //   gpurun_out/kloop_probe [M C N taps reps]
 //
 // Variants (selected by name on the command line or all):
-//   small1     the shipped igemm_split_small_kernel loop: 128 x 128 x 32, 4 waves, ONE stage, 3 workgroups / CU,
+//   small1     round 2's igemm_split_small_kernel loop: 128 x 128 x 32, 4 waves, ONE stage, 3 workgroups / CU,
 //              piece-major LDS image, one DMA wave-instruction = 16 rows x 4 x 16 B of one piece (48-byte stride)
 //   small1s    the same loop with SPAN DMA: a wave-instruction covers 64 consecutive 16-byte slots of [row][13 slots]
 //              (12 data slots = the row's 192 contiguous bytes of all three pieces, one pad slot; 208-byte rows are
 //              conflict-free for ds_read_b128)
-//   big2       the shipped igemm_split_kernel loop: 256 x 128 x 32, 8 waves, two stages, 1 workgroup / CU
+//   big2       round 2's igemm_split_kernel loop: 256 x 128 x 32, 8 waves, two stages, 1 workgroup / CU
 //   big2s      ... with SPAN DMA
-//   big2si     ... SPAN DMA issued in between the MFMA groups (sched_group_barrier), counted vmcnt
+//   big2si     ... SPAN DMA issued in between the MFMA groups
+//   sw32_* / sw16_*   UNPADDED swizzled span image (the layout igemm_split16_kernel ships), 32x32x16 / 16x16x32 MFMAs
+//   *_nodma / *_nomfma   floors: only the first K-step's DMA / one of the six products
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -23,6 +25,7 @@
 #include <math.h>
 
 #include <string>
+#include <type_traits>
 #include <vector>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -365,6 +368,166 @@ __global__ __launch_bounds__(NW * 64, WPC) void k_span(P p) {
   store_acc<TM, TN>(p, acc, mtile * BM + wm * WTM, ntile * BN + wn * WTN, lane);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// swizzled span image, NO padding: rows of 192 B = 12 slots, slot of (chunk cc, piece pc) in row R =
+// 4 pc + (cc ^ g(R)); g(R) = (R >> 2) & 3 for the 32x32x16 fragments, (-(R >> 2)) & 3 for the 16x16x32 ones (both
+// conflict-free for ds_read_b128: see DESIGN.md).  SHAPE16: v_mfma_f32_16x16x32_bf16 instead of 32x32x16.
+// ------------------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int BM, int BN, int NW, int STAGES, int WPC, bool SHAPE16, bool NODMA>
+__global__ __launch_bounds__(NW * 64, WPC) void k_sw(P p) {
+  constexpr int WGN = 2, WGM = NW / 2;
+  constexpr int WTM = BM / WGM, WTN = BN / WGN;
+  constexpr int ROWB = 192, ROWS = BM + BN, STAGE_B = ROWS * ROWB;
+  constexpr int NQ = ROWS * 12 / 64, QPW = (NQ + NW - 1) / NW;
+  static_assert((BM * 12) % 64 == 0, "an instruction must not straddle A and B");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[STAGES * STAGE_B];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int ntile = wg % p.ntiles, mtile = wg / p.ntiles;
+  auto gsw = [](int R) { return SHAPE16 ? ((-(R >> 2)) & 3) : ((R >> 2) & 3); };
+  unsigned q_base[QPW];
+#pragma unroll
+  for (int i = 0; i < QPW; ++i) {
+    const int Q = wave + NW * i;
+    const int s = Q * 64 + lane;
+    const int row = s / 12, j = s - row * 12;
+    const int pc = j >> 2, cc = (j & 3) ^ gsw(row);
+    const bool isb = row >= BM;
+    bool ok = Q < NQ;
+    unsigned base;
+    if (!isb) {
+      const int m = mtile * BM + row;
+      ok = ok && m < p.M;
+      base = (unsigned)(m + p.pad_rows) * (unsigned)p.C * 6u + 16u * (cc * 3 + pc);
+    } else {
+      const int n = ntile * BN + (row - BM);
+      ok = ok && n < p.N;
+      base = (unsigned)n * (unsigned)(p.taps * p.C) * 6u + 16u * (cc * 3 + pc);
+    }
+    q_base[i] = pred_off(base, ok);
+  }
+  const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(p.a, p.a_bytes), rs_b = make_rsrc(p.b, p.b_bytes);
+  const int cblks = p.C / 32;
+  unsigned d_a = 0, d_b = 0;
+  auto step_delta = [&](int kt) {
+    const int tap = __builtin_amdgcn_readfirstlane(kt / cblks), cb = __builtin_amdgcn_readfirstlane(kt - tap * cblks);
+    d_a = (unsigned)((p.toff[tap] * p.C + cb * 32) * 6);
+    d_b = (unsigned)((tap * p.C + cb * 32) * 6);
+  };
+  auto dma_all = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < QPW; ++i) {
+      const int Q = wave + NW * i;
+      if (Q < NQ) {
+        if (Q * 64 >= BM * 12)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_vp)(smem + buf * STAGE_B + Q * 1024), 16, (int)(q_base[i] + d_b), 0, 0, 0);
+        else
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_vp)(smem + buf * STAGE_B + Q * 1024), 16, (int)(q_base[i] + d_a), 0, 0, 0);
+      }
+    }
+  };
+  constexpr int TM = SHAPE16 ? WTM / 16 : WTM / 32, TN = SHAPE16 ? WTN / 16 : WTN / 32;
+  typedef typename std::conditional<SHAPE16, f32x4, f32x16>::type acc_t;
+  acc_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < (SHAPE16 ? 4 : 16); ++e) acc[i][j][e] = 0.f;
+  // fragment addresses
+  int a_off[TM], b_off[TN], a_g[TM], b_g[TN];
+  const int lr = SHAPE16 ? (lane & 15) : (lane & 31);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int R = wm * WTM + i * (SHAPE16 ? 16 : 32) + lr;
+    a_off[i] = R * ROWB;
+    a_g[i] = gsw(R);
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int R = wn * WTN + j * (SHAPE16 ? 16 : 32) + lr;
+    b_off[j] = (BM + R) * ROWB;
+    b_g[j] = gsw(R + BM);
+  }
+  auto compute = [&](int buf) {
+    const unsigned char *S = smem + buf * STAGE_B;
+    if constexpr (SHAPE16) {
+      const int cc = lane >> 4;
+      bf16x8 av[3][TM], bv[3][TN];
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) av[pc][i] = *reinterpret_cast<const bf16x8 *>(S + a_off[i] + (4 * pc + (cc ^ a_g[i])) * 16);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bv[pc][j] = *reinterpret_cast<const bf16x8 *>(S + b_off[j] + (4 * pc + (cc ^ b_g[j])) * 16);
+      }
+#define ONE16(PA, PB)                                                                              \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)    \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[PA][i], bv[PB][j], acc[i][j], 0, 0, 0);
+      ONE16(0, 2) ONE16(2, 0) ONE16(1, 1) ONE16(0, 1) ONE16(1, 0) ONE16(0, 0)
+    } else {
+      const int lh = lane >> 5;
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg) {
+        bf16x8 av[3][TM], bv[3][TN];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) av[pc][i] = *reinterpret_cast<const bf16x8 *>(S + a_off[i] + (4 * pc + ((2 * kg + lh) ^ a_g[i])) * 16);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bv[pc][j] = *reinterpret_cast<const bf16x8 *>(S + b_off[j] + (4 * pc + ((2 * kg + lh) ^ b_g[j])) * 16);
+        }
+        SPLIT_PRODUCTS(av, bv, acc)
+      }
+    }
+  };
+  const int KT = p.KT;
+  if (STAGES == 1) {
+    for (int kt = 0; kt < KT; ++kt) {
+      if (!NODMA || kt == 0) {
+        step_delta(kt);
+        dma_all(0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      compute(0);
+      __syncthreads();
+    }
+  } else {
+    step_delta(0);
+    dma_all(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < KT && !NODMA) {
+        step_delta(kt + 1);
+        dma_all(cur ^ 1);
+      }
+      compute(cur);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  }
+  if constexpr (SHAPE16) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = mtile * BM + wm * WTM + i * 16 + (lane >> 4) * 4 + e, cc = ntile * BN + wn * WTN + j * 16 + (lane & 15);
+          if (r < p.M && cc < p.N) p.c[(long long)r * p.N + cc] = acc[i][j][e];
+        }
+  } else {
+    store_acc<TM, TN>(p, acc, mtile * BM + wm * WTM, ntile * BN + wn * WTN, lane);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 static unsigned short f2bf(float x) {
   unsigned u;
@@ -436,6 +599,14 @@ int main(int argc, char **argv) {
       {"small1s", k_span<128, 128, 4, 1, 3, 0, false, false>, 128, 128, 256, 0},
       {"small1s_nodma", k_span<128, 128, 4, 1, 3, 0, true, false>, 128, 128, 256, 0},
       {"small1s_nomfma", k_span<128, 128, 4, 1, 3, 0, false, true>, 128, 128, 256, 0},
+      {"sw32_small1", k_sw<128, 128, 4, 1, 3, false, false>, 128, 128, 256, 0},
+      {"sw16_small1", k_sw<128, 128, 4, 1, 3, true, false>, 128, 128, 256, 0},
+      {"sw32_small1_nodma", k_sw<128, 128, 4, 1, 3, false, true>, 128, 128, 256, 0},
+      {"sw16_small1_nodma", k_sw<128, 128, 4, 1, 3, true, true>, 128, 128, 256, 0},
+      {"sw32_big2", k_sw<256, 128, 8, 2, 1, false, false>, 256, 128, 512, 0},
+      {"sw16_big2", k_sw<256, 128, 8, 2, 1, true, false>, 256, 128, 512, 0},
+      {"sw32_big2_nodma", k_sw<256, 128, 8, 2, 1, false, true>, 256, 128, 512, 0},
+      {"sw16_big2_nodma", k_sw<256, 128, 8, 2, 1, true, true>, 256, 128, 512, 0},
       {"big2", k_piece<256, 128, 8, 2, 1>, 256, 128, 512, 0},
       {"big2s", k_span<256, 128, 8, 2, 1, 0, false, false>, 256, 128, 512, 0},
       {"big2si", k_span<256, 128, 8, 2, 1, 1, false, false>, 256, 128, 512, 0},
@@ -449,7 +620,19 @@ int main(int argc, char **argv) {
   const double flops = 2.0 * M * N * (double)taps * C;
   printf("M %d C %d N %d taps %d (K %d)  %.1f GFLOP per launch\n", M, C, N, taps, taps * C, flops / 1e9);
   for (auto &v : vs) {
-    if (only && !strstr(only, v.name)) continue;
+    if (only) {                      // comma-separated substrings of variant names
+      bool hit = false;
+      std::string o(only);
+      size_t pos = 0;
+      while (pos <= o.size()) {
+        size_t e = o.find(',', pos);
+        if (e == std::string::npos) e = o.size();
+        const std::string tok = o.substr(pos, e - pos);
+        if (!tok.empty() && strstr(v.name, tok.c_str())) hit = true;
+        pos = e + 1;
+      }
+      if (!hit) continue;
+    }
     p.mtiles = (M + v.bm - 1) / v.bm; p.ntiles = (N + v.bn - 1) / v.bn;
     const int grid = p.mtiles * p.ntiles;
     CHECK(hipMemset(dc, 0, (size_t)M * N * 4));

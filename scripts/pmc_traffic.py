@@ -14,8 +14,8 @@ import sys
 
 
 CONV_KERNELS = ("igemm_kernel", "wgrad_kernel", "igemm_fixup_kernel", "wgrad_reduce_kernel", "dgrad_empty_class_kernel",
-                "igemm_split_kernel", "igemm_split_small_kernel", "wgrad_split_kernel", "dgrad_empty_class_split_kernel")
-MAIN_KERNELS = ("igemm_kernel<", "wgrad_kernel<", "igemm_split_kernel<", "igemm_split_small_kernel<", "wgrad_split_kernel<")
+                "igemm_split16_kernel", "wgrad_split_kernel", "dgrad_empty_class_split_kernel")
+MAIN_KERNELS = ("igemm_kernel<", "wgrad_kernel<", "igemm_split16_kernel<", "wgrad_split_kernel<")
 
 
 def load(d, counter):

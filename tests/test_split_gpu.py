@@ -42,7 +42,7 @@ CONV_CASES = [
     (2, 3, 14, 256, 256, 3, 1, 1), (1, 5, 28, 128, 128, 3, 2, 1), (3, 2, 14, 1024, 256, 1, 1, 0), (2, 4, 28, 256, 512, 1, 2, 0),
     (2, 3, 56, 64, 64, 3, 1, 1), (1, 2, 56, 64, 256, 1, 1, 0), (2, 7, 7, 512, 2048, 1, 1, 0), (1, 1, 9, 32, 64, 3, 1, 1),
     (2, 1, 5, 64, 32, 3, 2, 1),        # odd map, stride 2: ragged parity classes, a class with a single tap
-    (1, 3, 1, 64, 128, 1, 1, 0),       # 1x1 map: 3 rows in a 256-row tile
+    (1, 3, 1, 64, 128, 1, 1, 0),       # 1x1 map: 3 rows in a 128-row tile
     (4, 9, 15, 96, 160, 1, 1, 0),      # channel counts that are multiples of 32 but not powers of two (1x1 only)
     # few tiles, long K (less than one resident round of workgroups)
     (2, 16, 14, 256, 256, 3, 1, 1), (2, 16, 14, 1024, 256, 1, 1, 0), (2, 16, 28, 256, 256, 3, 2, 1), (3, 20, 7, 512, 64, 3, 1, 1),
