@@ -9,13 +9,19 @@
  *
  * Conventions
  *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless named host_*;
- *   - all activations are NHWC fp32, images ordered [group][n][h][w][c]; a "group" is one
- *     view's batch: BatchNorm statistics are reduced per group because the reference runs the
- *     backbone once per view (rot_mv.py:196-197);
+ *   - activations are NHWC, images ordered [group][n][h][w][c]; a "group" is one view's batch:
+ *     BatchNorm statistics are reduced per group because the reference runs the backbone once
+ *     per view (rot_mv.py:196-197).  Storage is fp32 by default; the *_split entry points read
+ *     their operands in "s3" (every fp32 value as three bf16 pieces: 8-channel chunks, the three
+ *     pieces of a chunk adjacent, 6 bytes per element - section "split-operand kernels") and the
+ *     *_bf16 entry points keep activations and activation gradients in bf16 (config C5);
  *   - conv weights are KRSC fp32 ([cout][r][s][cin]) = the physical layout of a PyTorch
  *     [O,I,H,W] tensor in torch.channels_last; linear weights are [out][in] (PyTorch native);
  *   - the caller owns every buffer, including workspaces; the library never allocates device
- *     memory and never synchronises (except mvg_prof_collect);
+ *     memory and never synchronises (except mvg_prof_collect).  Kernel sequences that want
+ *     scratch of their own (stream-K pieces, two-level statistics) take it from the workspace
+ *     the caller registered for the stream with mvg_set_scratch, and run their scratch-free
+ *     form when there is none;
  *   - every launch goes to the caller's hipStream_t (passed as void*; NULL = default stream);
  *   - return 0 on success, non-zero on error; mvg_last_error() gives the message. No exceptions
  *     cross the boundary.
@@ -30,13 +36,20 @@
 extern "C" {
 #endif
 
-#define MVG_ABI_VERSION 6
+#define MVG_ABI_VERSION 7
 
 /* ---------------------------------------------------------------- library */
 int mvg_abi_version(void);
 const char *mvg_last_error(void);
 /* number of CUs of the current device (used by the host to size split-K). */
 int mvg_device_cus(void);
+/* Register (ptr != NULL) or drop (ptr == NULL) the caller-owned workspace that launches on `stream` of the
+ * current device may use as scratch; 16-byte aligned, valid until replaced or dropped.  Uses are ordered by the
+ * stream, so one workspace per stream suffices.  mvg_scratch_bytes(): a size that covers every entry point on
+ * the current device.  Without a workspace (or with a smaller one) the affected launches run their
+ * scratch-free forms: correct, a few percent slower on the stem / fusion-block GEMMs. */
+int mvg_set_scratch(void *ptr, size_t bytes, void *stream);
+size_t mvg_scratch_bytes(void);
 /* A HIP stream of the device's LOWEST priority (hipStreamNonBlocking) for work that should only fill
  * what the caller's stream leaves idle - the backward-weight kernels, which are off the critical
  * path of backward.  NULL on failure.  The stream lives until process exit. */
@@ -105,20 +118,6 @@ int mvg_conv_stats_partials(const mvg_conv_desc *d, int32_t *out_rows_per_partia
  *   addend (same shape as dx, may alias dx): added after masking (residual / fan-in accumulation). */
 int mvg_conv_dgrad(const mvg_conv_desc *d, const float *dy, const float *wgt, float *dx,
                    const float *mask, const float *addend, void *stream);
-
-/* mvg_conv_dgrad fused with mvg_bn_bwd_reduce of the conv+BatchNorm unit whose OUTPUT gradient this launch
- * produces (the unit feeding the conv: resnet.py:80-96,128-148 under autograd): the epilogue masks dx by that
- * unit's ReLU (bn_act > 0, or fma(bn_y, relu_scale, relu_shift) > 0, or none), stores the masked gradient and
- * adds up s1 = sum(dx), s2 = sum(dx * xhat) per wave; a second, tiny launch merges the partials in a fixed
- * order (fp64) into s1, s2 [groups][cin] and dgamma / dbeta [cin].  The separate reduce pass over (g, act, y)
- * disappears; mvg_bn_bwd_apply then runs on (dx, bn_y) without a mask.  Stride-1 convs only:
- * mvg_conv_dgrad_bn_partials() returns P (partials: [groups][P][2][cin] floats) or 0 when not fusable. */
-int mvg_conv_dgrad_bn_partials(const mvg_conv_desc *d);
-int mvg_conv_dgrad_bnreduce(const mvg_conv_desc *d, const float *dy, const float *wgt, float *dx,
-                            const float *addend, const float *bn_y, const float *bn_act, const float *bn_mean,
-                            const float *bn_invstd, const float *relu_scale, const float *relu_shift,
-                            float *partials, float *s1, float *s2, float *dgamma, float *dbeta, int accumulate,
-                            void *stream);
 
 /* dw[cout][r][s][cin] (+)= sum over all groups/images/pixels of dy (x) x.  Split over the pixel
  * axis into `splits` slabs in `workspace` (splits * cout*r*s*cin floats, ignored when

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "librotmvgaze_hip.so")
 
 K_FAMILIES = 18
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class ConvDesc(C.Structure):
@@ -45,6 +45,8 @@ SIGNATURES = {
     "mvg_abi_version": (_I, []),
     "mvg_last_error": (C.c_char_p, []),
     "mvg_device_cus": (_I, []),
+    "mvg_set_scratch": (_I, [_P, C.c_size_t, _P]),
+    "mvg_scratch_bytes": (C.c_size_t, []),
     "mvg_set_reserved_cus": (_I, [_I]),
     "mvg_stream_create_low_priority": (_P, []),
     "mvg_prof_enable": (_I, [_I]),
@@ -55,8 +57,6 @@ SIGNATURES = {
     "mvg_conv_fprop_affine": (_I, [_D, _P, _P, _P, _P, _P, _P, _I, _P]),
     "mvg_conv_stats_partials": (_I, [_D, C.POINTER(C.c_int32)]),
     "mvg_conv_dgrad": (_I, [_D, _P, _P, _P, _P, _P, _P]),
-    "mvg_conv_dgrad_bn_partials": (_I, [_D]),
-    "mvg_conv_dgrad_bnreduce": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "mvg_conv_wgrad": (_I, [_D, _P, _P, _P, _P, _I, _I, _P]),
     "mvg_conv_wgrad_splits": (_I, [_D]),
     "mvg_linear_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _I, _I, _P]),

@@ -63,8 +63,8 @@ class Backbone:
         # side stream, where their MFMA work overlaps the HBM-bound BatchNorm-backward passes and the
         # stream-K fix-ups of the main stream.  grad_streams lists every stream that writes gradients
         # besides the caller's (the data-parallel reducer waits on them too).
-        self.overlap_wgrad = os.environ.get("MVG_WGRAD_OVERLAP", "1") != "0"
-        self.overlap_head = os.environ.get("MVG_HEAD_OVERLAP", "1") != "0"      # the fusion block's weight gradients too (+1.6 %)
+        self.overlap_wgrad = True
+        self.overlap_head = True      # the fusion block's weight gradients too (+1.6 %)
         self.wgrad_low_priority = True      # data-parallel runs use an ordinary stream: gradients must not finish last
         self.grad_streams: List[torch.cuda.Stream] = []
         self._wg_stream: Optional[torch.cuda.Stream] = None
@@ -72,15 +72,9 @@ class Backbone:
         # storage type of activations / activation gradients / conv operands: fp32 = the parity path (1e-4 vs
         # the reference); bf16 = BASELINE config C5's "bf16 MFMA path" (fp32 master weights, statistics, gradients)
         self.act_dtype = torch.float32
-        # BatchNorm-backward reduce pass fused into the epilogue of the backward-data launch that produces the
-        # unit's output gradient (fp32 path, stride-1 producers): MVG_BN_FUSE=1 switches it on.  Default OFF:
-        # measured at C3 the fused launches cost more than the pass they replace (backward-data 41.7 -> 50.6 ms,
-        # reduce pass 13.4 -> 7.2 ms: the stream-K workgroups reach their epilogues together, so the extra dword
-        # loads of y / act are not hidden under other workgroups' MFMAs)
-        self.fuse_bn_reduce = os.environ.get("MVG_BN_FUSE", "0") == "1"
         # residual units record their ReLU mask as bits in the forward apply pass; the backward reduce pass reads
-        # those (1/16 of the activation's bytes) instead of the activation.  MVG_BN_BITS=0: read the activation.
-        self.relu_bits = os.environ.get("MVG_BN_BITS", "1") != "0"
+        # those (1/16 of the activation's bytes) instead of the activation (attribute False: read the activation).
+        self.relu_bits = True
         # fp32 training steps on the split-operand kernels (conv_split.hip): every conv but the 3-channel stem reads its
         # operands as three bf16 pieces per fp32 value and runs six bf16 MFMAs per product - fp32-accurate (the 1e-4
         # parity path), 1.2-1.7x the fp32-MFMA kernels.  MVG_SPLIT=0: the fp32-MFMA kernels everywhere.
@@ -89,14 +83,15 @@ class Backbone:
         # output gradient (stride-1 launches: 44 of ResNet-50's 53 units): the staged epilogue already holds 8 channels
         # of a row per lane, reads y (and the mask bits) with 16-byte accesses, stores the masked gradient and leaves
         # one partial per row tile.  C3: backward-data 27.3 -> 31.1 ms, reduce passes 10.8 -> 5.4 ms, 1 000 -> 1 034
-        # samples/s.  MVG_BN_FUSE_SPLIT=0: separate reduce passes.
-        self.fuse_bn_split = os.environ.get("MVG_BN_FUSE_SPLIT", "1") != "0"
-        self.split_eval = os.environ.get("MVG_SPLIT_EVAL", "1") != "0"      # inference forward on the split kernels too
+        # samples/s.  (attribute False: separate reduce passes - the tests compare the two.)
+        self.fuse_bn_split = True
+        self.split_eval = True      # inference forward on the split kernels too
         self._wk_cache: Dict[str, tuple] = {}     # inference: conv name -> (data_ptr, version, s3 weights)
-        # training: one launch per step makes every conv's bf16 / s3 weight copies (MVG_BATCH_WEIGHT_PREP=0: one per conv)
-        self.batch_weight_prep = os.environ.get("MVG_BATCH_WEIGHT_PREP", "1") != "0"
+        # training: one launch per step makes every conv's bf16 / s3 weight copies
+        self.batch_weight_prep = True
         self._wprep: Optional[Dict[str, tuple]] = None
         self._wprep_state = None
+        self._wprep_versions = None
         self._split_now = self.split          # per forward call: off when a view's largest s3 tensor would exceed 2 GiB
 
     @property
@@ -143,7 +138,18 @@ class Backbone:
             self._wprep_state = (key, out, table, len(rows), mode)
         _, out, table, n, mode = self._wprep_state
         ops.weights_prep_batch(table, n, mode)
+        # the copies live in persistent buffers that the next forward overwrites: remember which parameter versions
+        # they hold, so that the backward of an OLDER tape can tell (tapes keep pointers into these buffers)
+        self._wprep_versions = tuple(self.p[c.name + ".weight"]._version for c in self.spec.all_convs())
         return out
+
+    def invalidate_weight_cache(self):
+        """Forget the inference path's cached s3 copies of the conv weights.  The cache is keyed on each parameter's
+        (data_ptr, version counter); writes that bypass the counter - ``p.data.copy_()`` / ``p.data.mul_()`` (EMA,
+        clipping) or writes to ``model.param_arena()`` - must be followed by this call (or by
+        ``torch.autograd.graph.increment_version(p)``), otherwise ``torch.no_grad()`` inference keeps using the old
+        weights.  ``model.train()`` and every training forward clear it too."""
+        self._wk_cache.clear()
 
     def bn_count_buffers(self) -> List[Tensor]:
         return [self.p[c.bn + ".num_batches_tracked"] for c in self.spec.all_convs()]
@@ -314,9 +320,13 @@ class Backbone:
         biggest_view_elems = B * ((H + 3) // 4) * ((W + 3) // 4) * self.spec.blocks[0].convs[-1].cout
         self._split_now = self.split and 6 * biggest_view_elems * self._guard_scale < 0x7FFFFFF0
         self._wprep = None
+        if training:
+            self._wk_cache.clear()               # the weights are about to change: drop the inference copies
         if self.batch_weight_prep and (self.bf16 or (self._split_now and training)):
             self._wprep = self._prepare_weights(dev)
         tape: Optional[dict] = {"units": [], "blocks": [], "V": V, "B": B} if keep_tape else None
+        if keep_tape and self._wprep is not None:
+            tape["wprep_versions"] = self._wprep_versions
         ulist = tape["units"] if keep_tape else None
         if training:
             torch._foreach_add_(self.bn_count_buffers(), V)       # num_batches_tracked += 1 per view call
@@ -464,7 +474,7 @@ class Backbone:
                sink: Optional[GradSink] = None):
         """dx = backward-data of unit u (+ addend).  fuse_for = the unit whose OUTPUT gradient dx is, when dx
         is final with this launch: its ReLU mask is applied and its BatchNorm-backward sums (s1, s2, dgamma,
-        dbeta) are produced by the same launch (mvg_conv_dgrad_bnreduce) instead of a pass over (g, act, y)."""
+        dbeta) are produced by the same launch (mvg_conv_dgrad_split_bnreduce; split kernels only) instead of a pass over (g, act, y)."""
         if u.split:
             U = fuse_for
             if U is not None and U.split and self.fuse_bn_split and u.desc.stride == 1:
@@ -480,17 +490,6 @@ class Backbone:
                 return
             ops.conv_dgrad_split(u.desc, dy, u.w, dx, addend)
             return
-        if fuse_for is not None and self.fuse_bn_reduce and not self.bf16 and u.desc.stride == 1:
-            U, c = fuse_for, fuse_for.spec
-            gp, bp = self.p[c.bn + ".weight"], self.p[c.bn + ".bias"]
-            acc = sink.accumulate(gp)
-            assert acc == sink.accumulate(bp)
-            s12 = torch.empty(2, dx.shape[0], c.cout, dtype=torch.float32, device=dx.device)
-            act = U.out if (U.relu and U.relu_affine is None) else None
-            ops.conv_dgrad_bnreduce(u.desc, dy, u.w, dx, addend, U.y, act, U.mean, U.invstd, U.relu_affine, s12[0], s12[1],
-                                    sink.view(gp), sink.view(bp), acc)
-            U.fused_s12 = s12
-            return
         ops.conv_dgrad(u.desc, dy, u.w, dx, None, addend)
 
     def backward(self, tape: dict, dfeat: Tensor, sink: GradSink, need_dimg: bool = False):
@@ -504,6 +503,11 @@ class Backbone:
         Hc, Wc = tape["final_hw"]
         if need_dimg and self.bf16:
             raise NotImplementedError("d(loss)/d(img) is not produced by the bf16 path")
+        if tape.get("wprep_versions") is not None and tape["wprep_versions"] != getattr(self, "_wprep_versions", None):
+            raise RuntimeError("backward of a tape whose bf16 / s3 weight copies were overwritten by a later forward with "
+                               "DIFFERENT weights (forward, optimizer step, forward, then backward of the first call): "
+                               "backward-data would run with the new weights.  Run backward before the weights change "
+                               "(PyTorch raises its version-counter error in the same situation)")
         g = torch.empty(V, B, Hc, Wc, self.fc_dim, dtype=self.act_dtype, device=dfeat.device)
         ops.avgpool_bwd(dfeat.contiguous(), g, V * B, Hc * Wc, self.fc_dim)
         P = self.p

@@ -25,6 +25,9 @@ int compute_cus() {
   return cus > 8 ? cus : 8;
 }
 
+// Workspaces the CALLER registered per (device, stream) with mvg_set_scratch: the library never allocates device
+// memory.  A kernel sequence that wants scratch and finds none (or too little) takes its scratch-free form
+// (plain launches instead of stream-K, a one-level bn_finalize).
 struct Scratch {
   int dev;
   hipStream_t st;
@@ -32,34 +35,14 @@ struct Scratch {
   size_t floats;
 };
 static std::mutex g_scratch_mu;
-static Scratch g_scratch[16];
+static Scratch g_scratch[32];
 float *stream_scratch(hipStream_t st, size_t floats) {
   std::lock_guard<std::mutex> lk(g_scratch_mu);
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  Scratch *slot = nullptr;
   for (auto &e : g_scratch)
-    if (e.ptr && e.st == st && e.dev == dev) slot = &e;
-  if (!slot)
-    for (auto &e : g_scratch)
-      if (!e.ptr) {
-        slot = &e;
-        break;
-      }
-  if (!slot) return nullptr;
-  if (slot->ptr && slot->floats >= floats) return slot->ptr;
-  if (slot->ptr) (void)hipFree(slot->ptr);       // waits for work that may still use it
-  slot->ptr = nullptr;
-  const size_t want = floats + floats / 4;
-  if (hipMalloc((void **)&slot->ptr, want * sizeof(float)) != hipSuccess) {
-    (void)hipGetLastError();
-    slot->ptr = nullptr;
-    return nullptr;
-  }
-  slot->dev = dev;
-  slot->st = st;
-  slot->floats = want;
-  return slot->ptr;
+    if (e.ptr && e.st == st && e.dev == dev) return e.floats >= floats ? e.ptr : nullptr;
+  return nullptr;
 }
 
 struct ProfRec {
@@ -133,6 +116,41 @@ int mvg_set_reserved_cus(int n) {
   MVG_REQUIRE(n >= 0 && n < 4096, "reserved CUs must be >= 0");
   mvg::g_reserved_cus = n;
   return 0;
+}
+
+int mvg_set_scratch(void *ptr, size_t bytes, void *stream) {
+  std::lock_guard<std::mutex> lk(mvg::g_scratch_mu);
+  int dev = 0;
+  MVG_REQUIRE(hipGetDevice(&dev) == hipSuccess, "set_scratch: no current device");
+  MVG_REQUIRE(((uintptr_t)ptr & 15) == 0, "set_scratch: the workspace must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  mvg::Scratch *slot = nullptr;
+  for (auto &e : mvg::g_scratch)
+    if (e.ptr && e.st == st && e.dev == dev) slot = &e;
+  if (!slot && ptr)
+    for (auto &e : mvg::g_scratch)
+      if (!e.ptr) {
+        slot = &e;
+        break;
+      }
+  if (!ptr) {                           // unregister
+    if (slot) slot->ptr = nullptr;
+    return 0;
+  }
+  MVG_REQUIRE(slot != nullptr, "set_scratch: more than 32 (device, stream) workspaces registered");
+  slot->dev = dev;
+  slot->st = st;
+  slot->ptr = (float *)ptr;
+  slot->floats = bytes / sizeof(float);
+  return 0;
+}
+
+size_t mvg_scratch_bytes(void) {
+  // the largest user: stream-K pieces of the fp32-MFMA kernels, 2 slots of a 128 x 128 fp32 tile per persistent
+  // workgroup, at most four workgroups per CU
+  int cus = mvg_device_cus();
+  if (cus <= 0) cus = 256;
+  return (size_t)cus * 4 * 2 * 128 * 128 * sizeof(float);
 }
 
 int mvg_device_cus(void) {

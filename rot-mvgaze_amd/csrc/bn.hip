@@ -811,13 +811,9 @@ static int bwd_chunks(int groups, long long rows, int c) {
   const int colblocks = ceil_div(c4n, cw);
   // one resident round: the kernel's registers and LDS admit three workgroups per CU; measured at C3's shapes
   // (scripts/bn_bench.py): 256 / 384 / 512 / 768 / 1024 / 2048 / 4096 workgroups -> 13.7 / 11.2 / 9.7 / 9.4 / 10.7 /
-  // 10.2 / 10.5 ms per step (1024 = a full round plus a third of one).  MVG_BN_REDUCE_WGS overrides.
-  static int total = -1;
-  if (total < 0) {
-    const char *e = getenv("MVG_BN_REDUCE_WGS");
-    total = e ? atoi(e) : 3 * compute_cus();
-    if (total < 64) total = 64;
-  }
+  // 10.2 / 10.5 ms per step (1024 = a full round plus a third of one)
+  int total = 3 * compute_cus();
+  if (total < 64) total = 64;
   long long want = total / ((long long)groups * colblocks);
   if (want < 1) want = 1;
   long long maxc = (rows + 63) / 64;

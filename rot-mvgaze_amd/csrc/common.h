@@ -15,9 +15,10 @@ bool prof_on();
 void prof_begin(int family, hipStream_t s, double flops, double bytes);
 void prof_end(int family, hipStream_t s);
 
-// Library-owned device scratch, one grow-only buffer per (device, stream).  Uses on a stream are
-// ordered by the stream, so every kernel sequence that finishes with its scratch before the next
-// launch on that stream may share it (stream-K pieces, bn_finalize slices).  nullptr = no memory.
+// The workspace the caller registered for this (device, stream) with mvg_set_scratch, if it holds `floats`
+// floats; nullptr otherwise (the caller of this function then takes its scratch-free form).  Uses on a stream are
+// ordered by the stream, so every kernel sequence that finishes with its scratch before the next launch on that
+// stream may share it (stream-K pieces, bn_finalize slices).  The library allocates nothing.
 float *stream_scratch(hipStream_t st, size_t floats);
 // device CUs minus mvg_set_reserved_cus(): what stream-K grids, wgrad splits and split-K plan for
 int compute_cus();

@@ -687,16 +687,6 @@ static int validate_bf16(const mvg_conv_desc *d) {
   return 0;
 }
 
-// MVG_BF16_DMA=0: the register-staged kernel for every shape (A/B switch)
-static bool bf16_dma_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char *e = getenv("MVG_BF16_DMA");
-    v = (e && !strcmp(e, "0")) ? 0 : 1;
-  }
-  return v == 1;
-}
-
 template <bool DGRAD>
 static int launch_igemm_bf16(IgemmParams &p, hipStream_t st, bool f32io = false) {
   const int bn = p.ncols >= 128 ? 128 : 64;
@@ -727,28 +717,15 @@ static int launch_igemm_bf16(IgemmParams &p, hipStream_t st, bool f32io = false)
       if (fasta) hipLaunchKernelGGL((igemm_bf16_kernel<64, DGRAD, true, true>), grid, block, 0, st, p);
       else hipLaunchKernelGGL((igemm_bf16_kernel<64, DGRAD, false, true>), grid, block, 0, st, p);
     }
-  } else if (fasta && bf16_dma_enabled()) {
-    int kmax = 0;
-    for (int i = 0; i < p.ncls; ++i) kmax = p.cls[i].ktotal > kmax ? p.cls[i].ktotal : kmax;
-    // GEMM K below this runs the one-stage, four-workgroups-per-CU form: measured faster at every ResNet-50 shape
-    // (C5: fprop 10.4 -> 8.4 ms, dgrad 9.5 -> 7.5 ms), so the default is "always"; MVG_BF16_ONE_STAGE_K=0 restores
-    // the two-stage form everywhere (A/B switch)
-    static int one_stage_k = -1;
-    if (one_stage_k < 0) {
-      const char *e = getenv("MVG_BF16_ONE_STAGE_K");
-      one_stage_k = e ? atoi(e) : 0x7FFFFFFF;
-    }
-    if (kmax < one_stage_k) {
-      if (bn == 128) hipLaunchKernelGGL((igemm_bf16_dma_kernel<128, DGRAD, 1>), grid, block, 0, st, p);
-      else hipLaunchKernelGGL((igemm_bf16_dma_kernel<64, DGRAD, 1>), grid, block, 0, st, p);
-    } else if (bn == 128) hipLaunchKernelGGL((igemm_bf16_dma_kernel<128, DGRAD>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((igemm_bf16_dma_kernel<64, DGRAD>), grid, block, 0, st, p);
-  } else if (bn == 128) {
-    if (fasta) hipLaunchKernelGGL((igemm_bf16_kernel<128, DGRAD, true>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((igemm_bf16_kernel<128, DGRAD, false>), grid, block, 0, st, p);
+  } else if (fasta) {
+    // uniform-tap shapes: the LDS-DMA kernel in its one-stage, four-workgroups-per-CU form (measured faster than the
+    // two-stage form at every ResNet-50 shape: C5 fprop 10.4 -> 8.4 ms, dgrad 9.5 -> 7.5 ms)
+    if (bn == 128) hipLaunchKernelGGL((igemm_bf16_dma_kernel<128, DGRAD, 1>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((igemm_bf16_dma_kernel<64, DGRAD, 1>), grid, block, 0, st, p);
+  } else if (bn == 128) {                   // the stem (4-channel taps): register-staged loader
+    hipLaunchKernelGGL((igemm_bf16_kernel<128, DGRAD, false>), grid, block, 0, st, p);
   } else {
-    if (fasta) hipLaunchKernelGGL((igemm_bf16_kernel<64, DGRAD, true>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((igemm_bf16_kernel<64, DGRAD, false>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((igemm_bf16_kernel<64, DGRAD, false>), grid, block, 0, st, p);
   }
   return check_launch(DGRAD ? "conv_dgrad_bf16" : "conv_fprop_bf16");
 }

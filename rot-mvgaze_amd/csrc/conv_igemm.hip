@@ -110,9 +110,6 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams &p, const Igemm
     float *out_t = p.out + tile_off;
     const float *add_t = p.addend ? p.addend + tile_off : nullptr;
     const float *mask_t = p.mask ? p.mask + tile_off : nullptr;
-    const bool bnf = DGRAD && p.bn_part != nullptr;                      // BatchNorm-backward reduce fused (see IgemmParams)
-    const float *bny_t = bnf ? p.bn_y + tile_off : nullptr;
-    const float *bna_t = (bnf && p.bn_act) ? p.bn_act + tile_off : nullptr;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = ntile * BN + wn * WTN + j * 32 + li;
@@ -121,15 +118,6 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams &p, const Igemm
       if (!DGRAD && p.bias) bias = p.bias[col];
       if (!DGRAD && p.scale) scl = p.scale[col];
       float csum = 0.f;
-      float bmu = 0.f, bis = 0.f, brs = 0.f, brh = 0.f, bs1 = 0.f, bs2 = 0.f;
-      if (bnf) {
-        bmu = p.bn_mean[(long long)g * p.ncols + col];
-        bis = p.bn_invstd[(long long)g * p.ncols + col];
-        if (p.bn_rscale) {
-          brs = p.bn_rscale[(long long)g * p.ncols + col];
-          brh = p.bn_rshift[(long long)g * p.ncols + col];
-        }
-      }
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -139,13 +127,6 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams &p, const Igemm
           if (DGRAD) {
             if (mask_t) v = (mask_t[off] > 0.f) ? v : 0.f;
             if (add_t) v += add_t[off];
-            if (bnf) {
-              const float yv = bny_t[off];
-              if (bna_t) v = (bna_t[off] > 0.f) ? v : 0.f;
-              else if (p.bn_rscale) v = (__builtin_fmaf(yv, brs, brh) > 0.f) ? v : 0.f;
-              bs1 += v;
-              bs2 += v * ((yv - bmu) * bis);
-            }
           } else {
             v = v * scl + bias;
             if (add_t) v += add_t[off];
@@ -153,17 +134,6 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams &p, const Igemm
             csum += v;
           }
           out_t[off] = v;
-        }
-      }
-      if (bnf) {
-        bs1 += __shfl_xor(bs1, 32, 64);
-        bs2 += __shfl_xor(bs2, 32, 64);
-        if (lh == 0) {
-          const long long P = (long long)c.mtiles_per_group * WGM;
-          const long long pi = (long long)mtile * WGM + wm;
-          float *st = p.bn_part + (((long long)g * P + pi) * 2) * p.ncols;
-          st[col] = bs1;
-          st[p.ncols + col] = bs2;
         }
       }
       if (!DGRAD && p.stats) {
@@ -197,16 +167,6 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams &p, const Igemm
     if (!DGRAD && p.bias && cok) bias = p.bias[col];
     if (!DGRAD && p.scale && cok) scl = p.scale[col];        // inference: BatchNorm folded into the conv
     float csum = 0.f;
-    const bool bnf = DGRAD && p.bn_part != nullptr;
-    float bmu = 0.f, bis = 0.f, brs = 0.f, brh = 0.f, bs1 = 0.f, bs2 = 0.f;
-    if (bnf && cok) {
-      bmu = p.bn_mean[(long long)g * p.ncols + col];
-      bis = p.bn_invstd[(long long)g * p.ncols + col];
-      if (p.bn_rscale) {
-        brs = p.bn_rscale[(long long)g * p.ncols + col];
-        brh = p.bn_rshift[(long long)g * p.ncols + col];
-      }
-    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -228,13 +188,6 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams &p, const Igemm
           if (DGRAD) {
             if (p.mask) v = (p.mask[off] > 0.f) ? v : 0.f;
             if (p.addend) v += p.addend[off];
-            if (bnf) {
-              const float yv = p.bn_y[off];
-              if (p.bn_act) v = (p.bn_act[off] > 0.f) ? v : 0.f;
-              else if (p.bn_rscale) v = (__builtin_fmaf(yv, brs, brh) > 0.f) ? v : 0.f;
-              bs1 += v;
-              bs2 += v * ((yv - bmu) * bis);
-            }
           } else {
             v = v * scl + bias;
             if (p.addend) v += p.addend[off];                  // inference: residual branch
@@ -243,17 +196,6 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams &p, const Igemm
           }
           p.out[off] = v;
         }
-      }
-    }
-    if (bnf) {
-      bs1 += __shfl_xor(bs1, 32, 64);
-      bs2 += __shfl_xor(bs2, 32, 64);
-      if (lh == 0 && cok) {
-        const long long P = (long long)c.mtiles_per_group * WGM;
-        const long long pi = (long long)mtile * WGM + wm;
-        float *st = p.bn_part + (((long long)g * P + pi) * 2) * p.ncols;
-        st[col] = bs1;
-        st[p.ncols + col] = bs2;
       }
     }
     if (!DGRAD && p.stats) {
@@ -1079,24 +1021,8 @@ struct TileChoice {
 };
 
 // K depth of one pipeline step: 32 for the 128x128 fprop tile (half the barriers per MFMA, twice the
-// LDS; +3-4 % on the 128..512-channel layers), 16 elsewhere.  MVG_BK32=0 / 2: off / also dgrad.
-static int tile_bk(int bm, int bn, bool dgrad) {
-  static int bk32 = -1;
-  if (bk32 < 0) {
-    const char *e = getenv("MVG_BK32");
-    bk32 = e ? atoi(e) : 1;
-  }
-  return (bm == 128 && bn == 128 && (dgrad ? bk32 >= 2 : bk32 >= 1)) ? 32 : 16;
-}
-
-static int g_streamk = -1;
-static bool streamk_enabled() {
-  if (g_streamk < 0) {
-    const char *e = getenv("MVG_STREAMK");
-    g_streamk = (e && !strcmp(e, "0")) ? 0 : 1;
-  }
-  return g_streamk == 1;
-}
+// LDS; +3-4 % on the 128..512-channel layers), 16 elsewhere (measured: 32 for dgrad -2.7 %).
+static int tile_bk(int bm, int bn, bool dgrad) { return (bm == 128 && bn == 128 && !dgrad) ? 32 : 16; }
 
 // ---- stream-K planning ---------------------------------------------------------------------
 template <int BM, int BN, int BK, int WGM, int WGN, bool DGRAD, bool FASTA = false, int AMODE = 0>
@@ -1129,7 +1055,7 @@ static int tile_occupancy(int bm, int bn, bool dgrad) {
 // with n resident workgroups runs at min(1, n * solo) of its matrix rate; the fix-up moves each
 // piece twice at ~4 TB/s (128-wide tiles) / ~2.5 TB/s (64-wide: more, smaller pieces).
 static int plan_streamk(long long tiles, int KT, int bm, int bn, int occ, int bk = 16) {
-  if (!streamk_enabled() || tiles <= 0 || bm != 128 || bn < 64) return 0;
+  if (tiles <= 0 || bm != 128 || bn < 64) return 0;
   const int cus = compute_cus();
   const long long S = (long long)occ * cus;
   if (tiles * KT < 8 * S) return 0;                       // < 8 K-steps per workgroup: overheads dominate
@@ -1229,12 +1155,7 @@ static int launch_igemm(IgemmParams &p, TileChoice t, hipStream_t st) {
   MVG_REQUIRE(p.splits == 1 || p.ncls == 1, "conv: split-K with several classes");
   if (tiles <= 0) return 0;
   // uniform-tap loader: every class has whole K-steps inside one tap and at most 32 taps
-  static int fasta_env = -1;
-  if (fasta_env < 0) {
-    const char *e = getenv("MVG_FASTA");
-    fasta_env = (e && !strcmp(e, "0")) ? 0 : 1;
-  }
-  bool fasta = fasta_env == 1;
+  bool fasta = true;
   for (int i = 0; i < p.ncls; ++i) {
     const IgemmClass &c = p.cls[i];
     fasta = fasta && c.ntaps >= 1 && c.ntaps <= 32 && c.ktotal % bk == 0 && p.src_c % bk == 0;
@@ -1392,27 +1313,12 @@ static int fprop_impl(const mvg_conv_desc *d, const float *x, const float *wgt, 
   return launch_igemm<false>(p, t, (hipStream_t)stream);
 }
 
-struct BnFuse {            // see IgemmParams::bn_part
-  const float *y, *act, *mean, *invstd, *rscale, *rshift;
-  float *part;
-};
-
 static int dgrad_impl(const mvg_conv_desc *d, const float *dy, const float *wgt, float *dx, const float *mask,
-                      const float *addend, float *ws, size_t ws_floats, void *stream, const BnFuse *bnf = nullptr) {
+                      const float *addend, float *ws, size_t ws_floats, void *stream) {
   if (validate(d)) return 2;
   MVG_REQUIRE(d->cout % 4 == 0, "dgrad: cout %% 4 != 0 (%d)", d->cout);
-  MVG_REQUIRE(!bnf || (d->stride == 1 && ws == nullptr), "dgrad: the BatchNorm-backward fusion needs a stride-1, unsplit launch");
   IgemmParams p;
   memset(&p, 0, sizeof(p));
-  if (bnf) {
-    p.bn_y = bnf->y;
-    p.bn_act = bnf->act;
-    p.bn_mean = bnf->mean;
-    p.bn_invstd = bnf->invstd;
-    p.bn_rscale = bnf->rscale;
-    p.bn_rshift = bnf->rshift;
-    p.bn_part = bnf->part;
-  }
   p.a = dy;
   p.b = wgt;
   p.out = dx;
@@ -1545,30 +1451,6 @@ int mvg_conv_dgrad(const mvg_conv_desc *d, const float *dy, const float *wgt, fl
   return dgrad_impl(d, dy, wgt, dx, mask, addend, nullptr, 0, stream);
 }
 
-int mvg_conv_dgrad_bn_partials(const mvg_conv_desc *d) {
-  if (validate(d)) return -1;
-  if (d->stride != 1) return 0;                         // parity-class launches scatter their rows: not fused
-  const long long rows = (long long)d->n * d->h * d->w;
-  const int ktotal = d->r * d->s * d->cout;
-  const TileChoice t = choose_tile_multi(&rows, &ktotal, 1, d->groups, d->cin, true);
-  return ceil_div(rows, t.bm) * (t.bm / wave_rows(t));
-}
-
-int mvg_conv_dgrad_bnreduce(const mvg_conv_desc *d, const float *dy, const float *wgt, float *dx, const float *addend,
-                            const float *bn_y, const float *bn_act, const float *bn_mean, const float *bn_invstd,
-                            const float *relu_scale, const float *relu_shift, float *partials, float *s1, float *s2,
-                            float *dgamma, float *dbeta, int accumulate, void *stream) {
-  MVG_REQUIRE(bn_y && bn_mean && bn_invstd && partials && s1 && s2, "dgrad_bnreduce: null argument");
-  MVG_REQUIRE(!(bn_act && relu_scale) && ((relu_scale == nullptr) == (relu_shift == nullptr)),
-              "dgrad_bnreduce: give the ReLU mask either as bn_act or as (relu_scale, relu_shift)");
-  const int P = mvg_conv_dgrad_bn_partials(d);
-  MVG_REQUIRE(P > 0, "dgrad_bnreduce: this shape cannot be fused (stride %d)", d ? d->stride : -1);
-  const BnFuse f = {bn_y, bn_act, bn_mean, bn_invstd, relu_scale, relu_shift, partials};
-  if (dgrad_impl(d, dy, wgt, dx, nullptr, addend, nullptr, 0, stream, &f)) return 1;
-  ProfScope ps(MVG_K_BN_BWD_REDUCE, (hipStream_t)stream, 0.0, 8.0 * d->groups * (double)P * d->cin);
-  return bn_bwd_finalize_launch(partials, d->groups, P, d->cin, s1, s2, dgamma, dbeta, accumulate, (hipStream_t)stream);
-}
-
 int mvg_conv_fprop_affine(const mvg_conv_desc *d, const float *x, const float *wgt, float *out, const float *scale,
                           const float *shift, const float *residual, int relu, void *stream) {
   MVG_REQUIRE(scale && shift, "fprop_affine: scale and shift are required");
@@ -1636,14 +1518,8 @@ int mvg_conv_wgrad_splits(const mvg_conv_desc *d) {
   const int cus = compute_cus();
   // one resident round: tiles x splits <= CUs x workgroups-per-CU (rounding the split count UP puts a
   // handful of workgroups into a second round that costs as much as the first)
-  static int wpc_env = -1;
-  if (wpc_env < 0) {
-    const char *e = getenv("MVG_WGRAD_WPC");
-    wpc_env = e ? atoi(e) : 0;
-  }
   int wpc = wgrad_occupancy(t);
   if (wpc > 4) wpc = 4;
-  if (wpc_env > 0) wpc = wpc_env;
   long long want = ((long long)wpc * cus) / tiles;
   long long maxs = pixels / 256;                           // at least 256 pixels (16 K-steps) per split
   if (maxs < 1) maxs = 1;
@@ -1712,12 +1588,7 @@ static int wgrad_impl(const mvg_conv_desc *d, const float *x, const float *dy, f
     dim3 grid(p.mtiles * p.ntiles * splits), block(256);
     // incremental pixel stepping: needs >= 32 pixels per image (one image wrap per step at most), 24-bit
     // factors in the offset multiplies and 32-bit x offsets
-    static int incr_env = -1;
-    if (incr_env < 0) {
-      const char *e = getenv("MVG_WGRAD_INCR");
-      incr_env = (e && !strcmp(e, "0")) ? 0 : 1;
-    }
-    const bool incr = incr_env == 1 && (long long)d->ho * d->wo >= 32 && d->ho < (1 << 20) && d->wo < (1 << 20) &&
+    const bool incr = (long long)d->ho * d->wo >= 32 && d->ho < (1 << 20) && d->wo < (1 << 20) &&
                       (long long)d->stride * d->w * d->cin * 4 < (1 << 24);
 #define MVG_WGRAD_LAUNCH(BM_, BN_, WGM_, WGN_)                                                              \
   do {                                                                                                      \

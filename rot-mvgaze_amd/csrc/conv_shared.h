@@ -125,16 +125,16 @@ struct IgemmParams {
   int b_row_len;             // bf16 kernels: elements per row of the (k-contiguous) weight operand
   int stats_partials;        // bf16_epilogue: partials per group of `stats` as the caller allocated it (0: mtiles * wave rows)
   // Backward-data fused with the BatchNorm-backward REDUCE pass of the unit whose output gradient this
-  // launch produces (fp32 kernels, stride-1 launches): the epilogue masks the gradient by that unit's ReLU
-  // (bn_act > 0, or fma(bn_y, bn_rscale, bn_rshift) > 0, or no mask), stores the masked gradient and adds up,
+  // launch produces (split kernels, stride-1 launches): the epilogue masks the gradient by that unit's ReLU
+  // (bn_bits, or fma(bn_y, bn_rscale, bn_rshift) > 0, or no mask), stores the masked gradient and adds up,
   // per wave and column, s1 = sum(dz) and s2 = sum(dz * xhat), xhat = (bn_y - bn_mean) * bn_invstd, into
   // bn_part [groups][P][2][ncols] (P = row partials per group, like the forward statistics).
-  const float *bn_y, *bn_act, *bn_mean, *bn_invstd, *bn_rscale, *bn_rshift;
+  const float *bn_y, *bn_mean, *bn_invstd, *bn_rscale, *bn_rshift;
   float *bn_part;
   // split kernels, inference forward (BatchNorm folded: y = acc * scale + bias (+ residual) [relu]): the residual
   // and / or the result in s3 (the next conv's operand format) instead of fp32
   int addend_s3, out_s3;
-  const unsigned char *bn_bits;   // split kernels: the unit's ReLU mask as bits (one byte per 4 channels, mvg_bn_apply_split) instead of bn_act
+  const unsigned char *bn_bits;   // split kernels: the unit's ReLU mask as bits (one byte per 4 channels, mvg_bn_apply_split) 
   // Cross-view fusion (igemm_kernel AMODE = 1, Linear forward): the A operand is never materialised - row m of
   //   X = [ img_feat[rc_row_img[m]] (rc_cf floats) | rc_rel[m] (3x3) @ feat[rc_row_src[m]] (3 x rc_nvec, axis-major) ]
   // (rot_mv.py:44-50,234-239) is generated by the loader: the image part is a plain row load (p.a = img_feat),
@@ -254,12 +254,7 @@ static void class_from_params(IgemmClass &c, const IgemmParams &p) {
   c.ohw_div = p.ohw_div;
   c.ow_div = p.ow_div;
   c.KT = p.ktotal > 0 ? ceil_div(p.ktotal, 16) : 1;
-  static int korder_env = -1;
-  if (korder_env < 0) {
-    const char *e = getenv("MVG_KORDER");
-    korder_env = (e && !strcmp(e, "0")) ? 0 : 1;
-  }
-  c.korder = (korder_env && p.ntaps > 1 && p.src_c % 32 == 0) ? 1 : 0;
+  c.korder = (p.ntaps > 1 && p.src_c % 32 == 0) ? 1 : 0;
   c.per_div = make_fastdiv((unsigned)(p.ntaps > 0 ? 2 * p.ntaps : 1));      // for BK = 16; launch_igemm resets it
 }
 

@@ -118,6 +118,8 @@ class GradAllReducer:
             self.buckets.append([start, cur])
             self.last_param_bucket[id(entries[-1][0])] = len(self.buckets) - 1
         self._param_end = {id(p): off + n for (p, off, n) in entries}
+        self._entries = entries
+        self._published = set()
         self._next = 0
         self._done_upto = 0
         if arena.is_cuda and self._side is None:
@@ -151,6 +153,7 @@ class GradAllReducer:
     def _on_ready(self, params):
         self._build()
         for p in params:
+            self._published.add(id(p))
             self._done_upto = max(self._done_upto, self._param_end[id(p)])
         while self._next < len(self.buckets) and self.buckets[self._next][1] <= self._done_upto:
             self._launch(self._next)
@@ -158,10 +161,22 @@ class GradAllReducer:
 
     def _on_done(self):
         self._build()
-        while self._next < len(self.buckets):         # anything left (should be nothing)
-            self._launch(self._next)
+        # Buckets that were not complete when backward ended: a backward that never reached part of the model (no
+        # gradient flows into the image features, say) leaves those slices of the arena holding the PREVIOUS step's
+        # gradients.  A bucket none of whose parameters was published this backward is skipped (every rank skips the
+        # same ones: the model is the same everywhere); in a partly published bucket the stale slices are zeroed first,
+        # so that nothing stale is averaged into gradients that are still attached from an earlier step.
+        while self._next < len(self.buckets):
+            s, e = self.buckets[self._next]
+            inside = [(p, off, n) for (p, off, n) in self._entries if s <= off < e]
+            if any(id(p) in self._published for (p, _, _) in inside):
+                for (p, off, n) in inside:
+                    if id(p) not in self._published:
+                        self.arena[off:off + n].zero_()
+                self._launch(self._next)
             self._next += 1
         if self.arena.is_cuda and self.active:
             torch.cuda.current_stream().wait_stream(self._side)
+        self._published = set()
         self._next = 0
         self._done_upto = 0

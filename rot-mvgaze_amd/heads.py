@@ -242,8 +242,7 @@ class FusionHead:
         self.ibn = [params[f"_img_fusers.{i}._batchnorm.running_mean"] for i in range(num_iter)] \
             if variant.share_feature else None
         # MVG_FUSED_INPUT=0: materialise the fuser / head inputs with rotcat kernels instead (A/B switch)
-        import os as _os
-        self.fused_input = _os.environ.get("MVG_FUSED_INPUT", "1") != "0"
+        self.fused_input = True
         self.mixed = False                        # bf16 path: Linear products on the bf16 matrix cores (set by the model per call)
         self.kin = self.fusers[0].in_width            # row length of the fuser input (zero-padded)
         self.hin = self.heads[0].in_width

@@ -296,6 +296,20 @@ class MultiViewGaze(nn.Module):
         """(flat fp32 gradient buffer, [(param, offset, numel)] in grad-ready order)."""
         return self._grad_arena, [(p, self._grad_offsets[id(p)], p.numel()) for p in self._grad_order]
 
+    def invalidate_weight_cache(self) -> None:
+        """``torch.no_grad()`` inference keeps s3 copies of the conv weights between calls, keyed on every parameter's
+        version counter.  The counter misses writes through ``p.data`` (``p.data.copy_`` / ``mul_``: EMA, clipping) and
+        writes to ``param_arena()``: call this after such a write (or ``torch.autograd.graph.increment_version(p)``).
+        ``load_state_dict``, the fused Adam, the data-parallel broadcast, ``train()`` and training forwards are covered."""
+        bb = getattr(self, "_backbone", None)
+        if bb is not None:
+            bb.invalidate_weight_cache()
+
+    def train(self, mode: bool = True):
+        if mode:                                   # weights are about to change; eval() keeps the cache (it is what uses it)
+            self.invalidate_weight_cache()
+        return super().train(mode)
+
     def param_arena(self) -> Tensor:
         """Flat fp32 buffer holding every trainable parameter at the offsets of ``grad_arena``."""
         return self._param_arena

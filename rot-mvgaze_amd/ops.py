@@ -22,8 +22,29 @@ def _p(t: Optional[Tensor]):
     return C.c_void_p(t.data_ptr())
 
 
+_workspaces = {}      # (device index, stream handle) -> the uint8 tensor registered with mvg_set_scratch
+
+
 def _s():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """The current HIP stream as the library's `void *stream`.  The first launch on a (device, stream) allocates that
+    stream's scratch workspace from PyTorch's caching allocator and registers it (mvg_set_scratch): the library
+    itself never allocates device memory ("caller owns every buffer incl. workspace")."""
+    st = torch.cuda.current_stream()
+    key = (st.device_index, st.cuda_stream)
+    if key not in _workspaces:
+        with torch.cuda.device(st.device_index):
+            ws = torch.empty(int(lib().mvg_scratch_bytes()), dtype=torch.uint8, device=torch.device("cuda", st.device_index))
+            check(lib().mvg_set_scratch(C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(st.cuda_stream)), "set_scratch")
+        _workspaces[key] = ws
+    return C.c_void_p(st.cuda_stream)
+
+
+def release_workspaces():
+    """Drop every registered scratch workspace (the library forgets the pointers before PyTorch frees them)."""
+    for (dev, handle), ws in list(_workspaces.items()):
+        with torch.cuda.device(dev):
+            check(lib().mvg_set_scratch(None, 0, C.c_void_p(handle)), "set_scratch")
+    _workspaces.clear()
 
 
 def _f32c(t: Tensor) -> Tensor:
@@ -59,26 +80,6 @@ def conv_fprop_affine(d: ConvDesc, x: Tensor, w: Tensor, out: Tensor, scale: Ten
 def conv_dgrad(d: ConvDesc, dy: Tensor, w: Tensor, dx: Tensor, mask: Optional[Tensor] = None,
                addend: Optional[Tensor] = None):
     check(_fn("mvg_conv_dgrad", dy)(C.byref(d), _p(dy), _p(w), _p(dx), _p(mask), _p(addend), _s()), "conv_dgrad")
-
-
-def conv_dgrad_bn_partials(d: ConvDesc) -> int:
-    """Row partials per group of conv_dgrad_bnreduce for this shape; 0 = not fusable (stride 2)."""
-    n = lib().mvg_conv_dgrad_bn_partials(C.byref(d))
-    if n < 0:
-        check(1, "conv_dgrad_bn_partials")
-    return n
-
-
-def conv_dgrad_bnreduce(d: ConvDesc, dy, w, dx, addend, bn_y, bn_act, bn_mean, bn_invstd, relu_affine, s1, s2, dgamma, dbeta,
-                        accumulate: bool):
-    """dx = dgrad(dy) (+ addend), masked by the ReLU of the unit whose output gradient dx is, and that unit's
-    BatchNorm-backward sums (s1, s2, dgamma, dbeta) from the same launch."""
-    P = conv_dgrad_bn_partials(d)
-    part = torch.empty(d.groups * P * 2 * d.cin, dtype=torch.float32, device=dy.device)
-    rs, rh = relu_affine if relu_affine is not None else (None, None)
-    check(lib().mvg_conv_dgrad_bnreduce(C.byref(d), _p(dy), _p(w), _p(dx), _p(addend), _p(bn_y), _p(bn_act), _p(bn_mean),
-                                        _p(bn_invstd), _p(rs), _p(rh), _p(part), _p(s1), _p(s2), _p(dgamma), _p(dbeta),
-                                        int(accumulate), _s()), "conv_dgrad_bnreduce")
 
 
 def cast_weights_bf16(d: ConvDesc, w: Tensor, cin_src: int, need_transposed: bool = True):

@@ -152,4 +152,20 @@ def test_bucket_boundaries_follow_grad_ready_order():
     m._on_grads_ready(m.params[3:4])
     assert fired == [0, 1]
     m._on_backward_done()
-    assert fired == [0, 1, 2]
+    assert fired == [0, 1]                        # bucket 2 holds only param 4, which this backward never published: skipped
+    # a backward that stops after the first two parameters (nothing flows further down: model.py's dfeat-is-None
+    # branch): buckets 1 and 2 hold the previous step's gradients and must not be averaged into anything
+    arena, entries = m.grad_arena()
+    arena.fill_(7.0)
+    del fired[:]
+    m._on_grads_ready(m.params[:2])
+    assert fired == [0]
+    m._on_backward_done()
+    assert fired == [0]
+    # ... and one that stops in the middle of bucket 1: the published half is reduced, the stale half zeroed first
+    del fired[:]
+    m._on_grads_ready(m.params[:3])
+    m._on_backward_done()
+    assert fired == [0, 1]
+    (p3, off3, n3) = entries[3]
+    assert float(arena[off3:off3 + n3].abs().max()) == 0.0 and float(arena[off3 - 1]) == 7.0     # the unpublished half was zeroed

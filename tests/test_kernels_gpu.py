@@ -124,52 +124,6 @@ def test_conv_fprop_dgrad_wgrad(case):
     close(dw, 2 * dw_ref, what="wgrad accumulate")
 
 
-FUSED_DGRAD_CASES = [
-    (2, 3, 14, 14, 64, 128, 3, 1, 1), (2, 8, 56, 56, 64, 256, 1, 1, 0), (1, 16, 28, 28, 128, 128, 3, 1, 1),
-    (1, 30, 14, 14, 256, 256, 3, 1, 1),   # ragged last M tile under stream-K
-    (2, 2, 7, 7, 512, 512, 3, 1, 1), (1, 3, 9, 9, 32, 32, 3, 1, 1), (2, 16, 56, 56, 64, 64, 3, 1, 1),
-    (1, 5, 14, 14, 128, 64, 1, 1, 0),
-]
-
-
-@pytest.mark.parametrize("mask", ["act", "affine", "none"])
-@pytest.mark.parametrize("case", FUSED_DGRAD_CASES)
-def test_conv_dgrad_fused_with_bn_backward_reduce(case, mask):
-    """mvg_conv_dgrad_bnreduce == mvg_conv_dgrad followed by mvg_bn_bwd_reduce (masked gradient written in
-    place) of the unit whose output gradient the launch produces: identical masked gradient, sums to 1e-5."""
-    from rot_mvgaze_amd import ops
-    from rot_mvgaze_amd._lib import ConvDesc
-    G, N, H, W, Cin, Cout, k, st, pad = case
-    d = ConvDesc.make(G, N, H, W, Cin, Cout, k, st, pad)
-    assert ops.conv_dgrad_bn_partials(d) > 0
-    assert ops.conv_dgrad_bn_partials(ConvDesc.make(G, N, H, W, Cin, Cout, 1, 2, 0)) == 0       # stride 2: not fusable
-    rows = N * H * W
-    gy = rnd((G, N, d.ho, d.wo, Cout), 1, "gy").to(dev())
-    w = rnd((Cout, k, k, Cin), 2, "w", 1.0 / np.sqrt(Cin * k * k)).to(dev())
-    add, yu, act = (rnd((G, N, H, W, Cin), 3 + i, "t").to(dev()) for i in range(3))
-    mean, invstd = (rnd((G, Cin), 6, "m") * 0.2).to(dev()), (rnd((G, Cin), 7, "i") * 0.1 + 1).to(dev())
-    scale, shift = (rnd((G, Cin), 8, "s") * 0.2 + 1).to(dev()), (rnd((G, Cin), 9, "h") * 0.3).to(dev())
-    a = act if mask == "act" else None
-    ra = (scale, shift) if mask == "affine" else None
-    outs = []
-    for fused in (False, True):
-        dx = add.clone()
-        s1, s2 = torch.full((G, Cin), float("nan"), device=dev()), torch.full((G, Cin), float("nan"), device=dev())
-        dg, db = torch.ones(Cin, device=dev()), torch.ones(Cin, device=dev())
-        if fused:
-            ops.conv_dgrad_bnreduce(d, gy, w, dx, dx, yu, a, mean, invstd, ra, s1, s2, dg, db, True)
-        else:
-            ops.conv_dgrad(d, gy, w, dx, None, dx)
-            ops.bn_bwd_reduce(dx, a, yu, mean, invstd, G, rows, Cin, s1, s2, dg, db, True, ra, dz_out=dx)
-        outs.append((dx, s1, s2, dg, db))
-    (dx0, s10, s20, dg0, db0), (dx1, s11, s21, dg1, db1) = outs
-    assert torch.equal(dx1, dx0), "masked gradient"
-    close(s11, s10, 2e-5, "s1")
-    close(s21, s20, 2e-5, "s2")
-    close(dg1, dg0, 2e-5, "dgamma (accumulated)")
-    close(db1, db0, 2e-5, "dbeta (accumulated)")
-
-
 @pytest.mark.parametrize("rows,fin,fout,relu", [(128, 2048, 2048, True), (6, 512, 1536, False), (70, 3584, 512, True),
                                                 (33, 1536, 1536, False), (1536, 3584, 3584, True), (3000, 2048, 1536, False)])
 def test_linear_via_conv(rows, fin, fout, relu):

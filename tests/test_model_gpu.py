@@ -540,27 +540,8 @@ def test_gradient_arena_slices_are_16_byte_aligned():
 
 
 @pytest.mark.parametrize("depth", [18, 50])
-def test_fused_bn_backward_reduce_switch_gives_the_same_step(depth):
-    """MVG_BN_FUSE=1 (backward-data launches deliver the BatchNorm-backward sums of the unit they feed; off by
-    default because it measured slower) computes the same step: identical forward, gradients to summation-order noise."""
-    grads = []
-    for fuse in (False, True):
-        m = build(depth)
-        m.ensure_layout()
-        m._backbone.split = False           # the fusion is a feature of the fp32-MFMA backward-data kernel
-        m._backbone.fuse_bn_reduce = fuse
-        d = m(inputs(4, 96, seed=3))
-        loss = metrics()(d)
-        loss.backward()
-        grads.append((loss.item(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}))
-    assert grads[0][0] == grads[1][0]
-    for k, g in grads[0][1].items():
-        rel_close(grads[1][1][k], g.cpu().numpy(), 2e-4, "fused vs separate reduce: " + k)
-
-
-@pytest.mark.parametrize("depth", [18, 50])
 def test_split_path_fused_bn_backward_reduce_switch_gives_the_same_step(depth):
-    """MVG_BN_FUSE_SPLIT: the split backward-data launches deliver the BatchNorm-backward sums of the unit they feed.
+    """Backbone.fuse_bn_split: the split backward-data launches deliver the BatchNorm-backward sums of the unit they feed.
     Same forward, same masks, gradients to summation-order noise."""
     grads = []
     for fuse in (False, True):
@@ -579,7 +560,7 @@ def test_split_path_fused_bn_backward_reduce_switch_gives_the_same_step(depth):
 
 @pytest.mark.parametrize("depth,dtype", [(18, torch.float32), (50, torch.float32), (50, torch.bfloat16)])
 def test_relu_mask_bits_give_the_same_step_as_reading_the_activation(depth, dtype):
-    """Residual units hand their ReLU mask to the backward as bits (MVG_BN_BITS, default on): the same mask the
+    """Residual units hand their ReLU mask to the backward as bits (Backbone.relu_bits, default on): the same mask the
     activation gives, so every gradient is bit-identical to the run that reads the activation."""
     grads = []
     for bits in (False, True):
@@ -1022,6 +1003,77 @@ def test_inference_weight_cache_follows_parameter_updates():
     with torch.no_grad():
         next(p for n, p in m.named_parameters() if n.endswith("layer1.0.conv1.weight")).mul_(1.5)
     assert not torch.equal(infer(), p1)
+
+
+def test_inference_weight_cache_misses_writes_through_data_until_invalidated():
+    """The documented limit of that cache: it is keyed on the parameters' version counters, which a write through
+    ``p.data`` does not move.  ``model.invalidate_weight_cache()`` (or ``train()``) is the remedy."""
+    m = build(18)
+    x = inputs(3, 64, seed=4)
+    m.eval()
+
+    def infer():
+        with torch.no_grad():
+            return m(dict(x))["iter_2"]["pred_gaze_1"].clone()
+    p0 = infer()
+    w = next(p for n, p in m.named_parameters() if n.endswith("layer1.0.conv1.weight"))
+    w.data.mul_(1.5)                                 # bypasses the version counter
+    assert torch.equal(infer(), p0), "expected the stale cached copy here - if this fails the cache key got stronger: update the docs"
+    m.invalidate_weight_cache()
+    p1 = infer()
+    assert not torch.equal(p1, p0)
+    w.data.mul_(1.5)
+    m.train()                                        # entering train mode drops the copies as well
+    m.eval()
+    assert not torch.equal(infer(), p1)
+
+
+def test_backward_of_a_tape_whose_weight_copies_were_overwritten_raises():
+    """Tapes point into the persistent buffers that hold a step's s3 / bf16 weight copies.  forward A, weights change,
+    forward B, backward A would run backward-data of A with B's weights: it raises instead (like PyTorch's
+    version-counter check).  Without a weight change in between the older tape is still good."""
+    m = build(18)
+    xa, xb = inputs(2, 64, seed=1), inputs(2, 64, seed=2)
+    da = m(dict(xa))
+    db = m(dict(xb))                                 # same weights: rewrites the copies with identical values
+    metrics()(db).backward()
+    metrics()(da).backward()                         # fine
+    da = m(dict(xa))
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith("conv1.weight"):
+                p.mul_(1.0001)                       # an optimizer step (bumps the version counters)
+    db = m(dict(xb))
+    with pytest.raises(RuntimeError, match="DIFFERENT weights"):
+        metrics()(da).backward()
+
+
+def test_scratch_workspace_is_registered_by_the_caller_not_allocated_by_the_library():
+    """the caller owns every buffer incl. workspace.  The first launch on a stream registers a torch-owned
+    workspace (mvg_set_scratch); without one the stream-K / two-level launches run their scratch-free forms and
+    give the same results to summation order."""
+    from rot_mvgaze_amd import ops
+    from rot_mvgaze_amd._lib import ConvDesc, lib
+    st = torch.cuda.current_stream()
+    d = ConvDesc.make(2, 8, 112, 112, 4, 64, 7, 2, 3)
+    x = torch.randn(2, 8, 112, 112, 4, device=dev())
+    w = torch.randn(64, 7, 7, 4, device=dev()) * 0.05
+    y1 = torch.empty(2, 8, 56, 56, 64, device=dev())
+    ops.conv_fprop(d, x, w, y1)
+    key = (st.device_index, st.cuda_stream)
+    assert key in ops._workspaces and ops._workspaces[key].numel() == lib().mvg_scratch_bytes() > 0
+    assert torch.cuda.memory_allocated() >= ops._workspaces[key].numel()      # visible to PyTorch's accounting
+    ops.release_workspaces()
+    assert key not in ops._workspaces
+    import ctypes as C
+    raw = ops._s
+    try:
+        ops._s = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)     # launches with NO workspace registered
+        y2 = torch.empty_like(y1)
+        ops.conv_fprop(d, x, w, y2)
+    finally:
+        ops._s = raw
+    rel_close(y2, y1.cpu().numpy(), 1e-5, "stem conv without a scratch workspace")
 
 
 def test_view_swap_symmetry_eval():
