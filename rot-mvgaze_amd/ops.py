@@ -22,20 +22,31 @@ def _p(t: Optional[Tensor]):
     return C.c_void_p(t.data_ptr())
 
 
-_workspaces = {}      # (device index, stream handle) -> the uint8 tensor registered with mvg_set_scratch
+_workspaces = {}      # (device index, stream handle) -> the uint8 tensor registered with mvg_set_scratch (insertion = LRU order)
+_MAX_WORKSPACES = 8
 
 
-def _s():
-    """The current HIP stream as the library's `void *stream`.  The first launch on a (device, stream) allocates that
-    stream's scratch workspace from PyTorch's caching allocator and registers it (mvg_set_scratch): the library
-    itself never allocates device memory ("caller owns every buffer incl. workspace")."""
+def _s(scratch: bool = False):
+    """The current HIP stream as the library's `void *stream`.  scratch=True (the entry points that can use scratch:
+    fp32 conv / Linear fprop and dgrad - stream-K pieces - and bn_finalize): the first such launch on a
+    (device, stream) allocates that stream's workspace from PyTorch's caching allocator and registers it
+    (mvg_set_scratch) - the library itself never allocates device memory ("caller owns every buffer
+    incl. workspace").  At most _MAX_WORKSPACES stay registered; the least recently used one is dropped (uses are
+    stream-ordered and the tensor was allocated on that stream, so queued kernels are safe)."""
     st = torch.cuda.current_stream()
-    key = (st.device_index, st.cuda_stream)
-    if key not in _workspaces:
-        with torch.cuda.device(st.device_index):
-            ws = torch.empty(int(lib().mvg_scratch_bytes()), dtype=torch.uint8, device=torch.device("cuda", st.device_index))
-            check(lib().mvg_set_scratch(C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(st.cuda_stream)), "set_scratch")
-        _workspaces[key] = ws
+    if scratch:
+        key = (st.device_index, st.cuda_stream)
+        ws = _workspaces.pop(key, None)
+        if ws is None:
+            while len(_workspaces) >= _MAX_WORKSPACES:
+                (odev, ohandle), _old = next(iter(_workspaces.items()))
+                with torch.cuda.device(odev):
+                    check(lib().mvg_set_scratch(None, 0, C.c_void_p(ohandle)), "set_scratch")
+                del _workspaces[(odev, ohandle)]
+            with torch.cuda.device(st.device_index):
+                ws = torch.empty(int(lib().mvg_scratch_bytes()), dtype=torch.uint8, device=torch.device("cuda", st.device_index))
+                check(lib().mvg_set_scratch(C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(st.cuda_stream)), "set_scratch")
+        _workspaces[key] = ws                      # (re)insert as most recently used
     return C.c_void_p(st.cuda_stream)
 
 
@@ -68,18 +79,18 @@ def conv_stats_partials(d: ConvDesc, bf16: bool = False):
 
 def conv_fprop(d: ConvDesc, x: Tensor, w: Tensor, y: Tensor, bias: Optional[Tensor] = None, relu: bool = False,
                stats: Optional[Tensor] = None):
-    check(_fn("mvg_conv_fprop", x)(C.byref(d), _p(x), _p(w), _p(y), _p(bias), int(relu), _p(stats), _s()), "conv_fprop")
+    check(_fn("mvg_conv_fprop", x)(C.byref(d), _p(x), _p(w), _p(y), _p(bias), int(relu), _p(stats), _s(True)), "conv_fprop")
 
 
 def conv_fprop_affine(d: ConvDesc, x: Tensor, w: Tensor, out: Tensor, scale: Tensor, shift: Tensor,
                       residual: Optional[Tensor], relu: bool):
     check(lib().mvg_conv_fprop_affine(C.byref(d), _p(x), _p(w), _p(out), _p(scale), _p(shift), _p(residual), int(relu),
-                                      _s()), "conv_fprop_affine")
+                                      _s(True)), "conv_fprop_affine")
 
 
 def conv_dgrad(d: ConvDesc, dy: Tensor, w: Tensor, dx: Tensor, mask: Optional[Tensor] = None,
                addend: Optional[Tensor] = None):
-    check(_fn("mvg_conv_dgrad", dy)(C.byref(d), _p(dy), _p(w), _p(dx), _p(mask), _p(addend), _s()), "conv_dgrad")
+    check(_fn("mvg_conv_dgrad", dy)(C.byref(d), _p(dy), _p(w), _p(dx), _p(mask), _p(addend), _s(True)), "conv_dgrad")
 
 
 def cast_weights_bf16(d: ConvDesc, w: Tensor, cin_src: int, need_transposed: bool = True):
@@ -116,7 +127,7 @@ def fuser_fprop(img_feat, feat, rel, row_img, row_src, w, bias, relu, y, rows, c
     the GEMM's operand loader (mvg_fuser_fprop) - no X tensor."""
     ws, n = _linear_ws(img_feat, rows, cf + 3 * nvec, fout)
     check(lib().mvg_fuser_fprop(_p(img_feat), _p(feat), _p(rel), _p(row_img), _p(row_src), _p(w), _p(bias), int(relu), _p(y), rows,
-                                cf, nvec, fout, img_feat.numel() // cf, feat.numel() // (3 * nvec), _p(ws), n, _s()), "fuser_fprop")
+                                cf, nvec, fout, img_feat.numel() // cf, feat.numel() // (3 * nvec), _p(ws), n, _s(True)), "fuser_fprop")
 
 
 def fuser_wgrad(img_feat, feat, rel, row_img, row_src, dy, dw, db, rows, cf, nvec, fout, accumulate=False):
@@ -276,14 +287,14 @@ def _linear_ws(x: Tensor, rows: int, fin: int, fout: int):
 
 def linear_fprop(x: Tensor, w: Tensor, bias: Optional[Tensor], relu: bool, y: Tensor, rows: int, fin: int, fout: int):
     ws, n = _linear_ws(x, rows, fin, fout)
-    check(lib().mvg_linear_fprop(_p(x), _p(w), _p(bias), int(relu), _p(y), rows, fin, fout, _p(ws), n, _s()),
+    check(lib().mvg_linear_fprop(_p(x), _p(w), _p(bias), int(relu), _p(y), rows, fin, fout, _p(ws), n, _s(True)),
           "linear_fprop")
 
 
 def linear_dgrad(dy: Tensor, w: Tensor, mask: Optional[Tensor], addend: Optional[Tensor], dx: Tensor, rows: int,
                  fin: int, fout: int):
     ws, n = _linear_ws(dy, rows, fin, fout)
-    check(lib().mvg_linear_dgrad(_p(dy), _p(w), _p(mask), _p(addend), _p(dx), rows, fin, fout, _p(ws), n, _s()),
+    check(lib().mvg_linear_dgrad(_p(dy), _p(w), _p(mask), _p(addend), _p(dx), rows, fin, fout, _p(ws), n, _s(True)),
           "linear_dgrad")
 
 
@@ -292,7 +303,7 @@ def bn_finalize(stats, groups, partials, rows_per_partial, rows_per_group, c, ga
                 momentum, eps, mean, invstd, scale, shift):
     check(lib().mvg_bn_finalize(_p(stats), groups, partials, rows_per_partial, rows_per_group, c, _p(gamma), _p(beta),
                                 _p(running_mean), _p(running_var), momentum, eps, _p(mean), _p(invstd), _p(scale),
-                                _p(shift), _s()), "bn_finalize")
+                                _p(shift), _s(True)), "bn_finalize")
 
 
 def bn_eval_affine(groups, c, gamma, beta, running_mean, running_var, eps, scale, shift):

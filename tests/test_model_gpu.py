@@ -1068,7 +1068,7 @@ def test_scratch_workspace_is_registered_by_the_caller_not_allocated_by_the_libr
     import ctypes as C
     raw = ops._s
     try:
-        ops._s = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)     # launches with NO workspace registered
+        ops._s = lambda scratch=False: C.c_void_p(torch.cuda.current_stream().cuda_stream)     # NO workspace registered
         y2 = torch.empty_like(y1)
         ops.conv_fprop(d, x, w, y2)
     finally:
