@@ -323,6 +323,7 @@ def main():
         marks[i].record()
         loss = step()
     marks[args.steps].record()
+    host_ms = (time.perf_counter() - t0) / max(args.steps, 1) * 1e3      # host time to QUEUE a step (no synchronisation inside)
     fence()
     elapsed = time.perf_counter() - t0
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
@@ -432,6 +433,8 @@ def main():
                       "multi-view samples/sec (inference forward), BxVx3x224x224",
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "ms_per_step_median_events": round(median_ms, 3) if median_ms else None,
+            "ms_per_step_events_min_max": [round(step_ms[0], 3), round(step_ms[-1], 3)] if step_ms else None,
+            "host_ms_per_step_queueing": round(host_ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
             "config": {"workload": desc, "backbone": f"ResNet-{depth}", "views": V, "batch_per_gpu": B,

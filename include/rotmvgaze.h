@@ -12,8 +12,9 @@
  *   - activations are NHWC, images ordered [group][n][h][w][c]; a "group" is one view's batch:
  *     BatchNorm statistics are reduced per group because the reference runs the backbone once
  *     per view (rot_mv.py:196-197).  Storage is fp32 by default; the *_split entry points read
- *     their operands in "s3" (every fp32 value as three bf16 pieces: 8-channel chunks, the three
- *     pieces of a chunk adjacent, 6 bytes per element - section "split-operand kernels") and the
+ *     their operands in "sp" (every fp32 value as two fp16 pieces and a per-tensor power-of-two
+ *     scale: 8-channel chunks, the two pieces of a chunk adjacent, 4 bytes per element - section
+ *     "split operands") and the
  *     *_bf16 entry points keep activations and activation gradients in bf16 (config C5);
  *   - conv weights are KRSC fp32 ([cout][r][s][cin]) = the physical layout of a PyTorch
  *     [O,I,H,W] tensor in torch.channels_last; linear weights are [out][in] (PyTorch native);
@@ -36,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MVG_ABI_VERSION 7
+#define MVG_ABI_VERSION 8
 
 /* ---------------------------------------------------------------- library */
 int mvg_abi_version(void);
@@ -438,61 +439,80 @@ int mvg_avgpool_bwd_bf16(const float *dy, uint16_t *dx, int n, int hw, int c, vo
 /* fp32 NCHW images (rot_mv.py:188-189) -> bf16 NHWC with the channels zero-padded to 8 */
 int mvg_nchw_to_nhwc8_bf16(const float *src, uint16_t *dst, int n, int c, int h, int w, void *stream);
 
-/* ---- "split" operands: fp32-accurate convolutions on the bf16 matrix cores (csrc/conv_split.hip) ----------------
- * An fp32 tensor in "s3" format holds every value as the exact sum of three bf16 pieces; channels go in chunks
- * of 8 with the three pieces of a chunk adjacent (6 bytes per element; n elements = 6 n bytes).  Six bf16 MFMAs
- * per 16 k reproduce the fp32 product to fp32 rounding (conv_split.hip header), so these entries serve the same
- * 1e-4 parity path as mvg_conv_fprop / _dgrad / _wgrad (resnet.py:31-47: F.conv2d forward and its autograd
- * backward) - outputs (y, dx, dw) are plain fp32.  Shapes: cin, cout multiples of 32, r*s <= 32 (everything in
- * the backbone but the 3-channel stem). */
-int mvg_split_f32(const float *x, void *out_s3, int64_t n, void *stream);           /* n % 8 == 0 */
-int mvg_merge_s3(const void *x_s3, float *out, int64_t n, void *stream);            /* exact inverse */
-/* fp32 KRSC weights -> s3 KRSC (fprop) and, when w_crsk_s3 != NULL, the s3 transposed copy CRSK (dgrad) */
-int mvg_split_weights(const mvg_conv_desc *d, const float *w, void *w_krsc_s3, void *w_crsk_s3, void *stream);
-/* All weight copies of a training step in one launch.  items_dev: n records in DEVICE memory of
- *   { const float *w (fp32 KRSC); void *wk; void *wt (NULL: no transposed copy); int32 cout, rs, cin, cin_pad; }  (40 bytes)
- * mode 1: wk / wt = the s3 KRSC / CRSK copies of mvg_split_weights (cin_pad unused); mode 0: the bf16 KRSC (cin
- * zero-padded to cin_pad) / CRSK copies of mvg_cast_weights_bf16. */
+/* ---- "split" operands: fp32-accurate convolutions on the fp16 matrix cores (csrc/conv_split.hip) ----------------
+ * An fp32 tensor in "sp" format holds every value v - times a per-tensor power-of-two scale 2^k chosen by its producer -
+ * as TWO fp16 pieces, h1 = fp16(v 2^k), h2 = fp16(v 2^k - h1): |v - (h1 + h2) 2^-k| <= 2^-24 |v|, half a unit in the last
+ * place of the fp32 value.  Channels go in chunks of 8 with the two pieces of a chunk adjacent (4 bytes per element).
+ * Three fp16 MFMAs per 32 k (h1 g1 + h1 g2 + h2 g1, fp32 accumulation) reproduce the fp32 product to fp32-accumulation
+ * accuracy (conv_split.hip header; tests/test_split_gpu.py holds every kernel to 2e-6 against fp64 and to the
+ * fp32-MFMA kernel's own error), so these entries serve the same 1e-4 parity path as mvg_conv_fprop / _dgrad / _wgrad
+ * (resnet.py:31-47: F.conv2d forward and its autograd backward) - outputs (y, dx, dw) are plain fp32.
+ * Scales travel as DEVICE scalars "sinv" = 2^-k next to their tensor (NULL = 1): activations are stored unscaled,
+ * gradients dy get theirs from mvg_bn_bwd_apply_split, weight copies from the weight prep; a consumer multiplies its
+ * accumulators by the sinv of both operands.  Shapes: cin, cout multiples of 32, r*s <= 32 (everything in the
+ * backbone but the 3-channel stem). */
+int mvg_split_f32(const float *x, void *out_sp, int64_t n, float scale, void *stream);        /* n % 8 == 0; out = sp(x * scale) */
+int mvg_merge_sp(const void *x_sp, float *out, int64_t n, float inv_scale, void *stream);     /* out = (h1 + h2) * inv_scale */
+/* fp32 KRSC weights -> sp KRSC (fprop) and, when w_crsk_sp != NULL, the sp transposed copy CRSK (dgrad), both scaled by the
+ * 2^k that puts max |w| just below 2^15.  stat2: two device floats, receive {max |w| (bits), 2^-k}: pass stat2 + 1 as the
+ * w_sinv of the consumers.  items_dev: 64 bytes of device memory (staging of the one-record table). */
+int mvg_split_weights(const mvg_conv_desc *d, const float *w, void *w_krsc_sp, void *w_crsk_sp, float *stat2, void *items_dev,
+                      void *stream);
+/* All weight copies of a training step in two launches (max |w| per conv, then the copies).  items_dev: n records in
+ * DEVICE memory of
+ *   { const float *w (fp32 KRSC); void *wk; void *wt (NULL: no transposed copy); int32 cout, rs, cin, cin_pad;
+ *     float *stat (mode 1: two device floats per conv, stat[0] CLEARED by the caller, receive {max |w| bits, 2^-k}); }  (48 bytes)
+ * mode 1: wk / wt = the sp KRSC / CRSK copies of mvg_split_weights (cin_pad unused); mode 0: the bf16 KRSC (cin
+ * zero-padded to cin_pad) / CRSK copies of mvg_cast_weights_bf16 (stat unused). */
 int mvg_weights_prep_batch(const void *items_dev, int n, int mode, void *stream);
 /* partial-statistics geometry of mvg_conv_fprop_split (like mvg_conv_stats_partials) */
 int mvg_conv_stats_partials_split(const mvg_conv_desc *d, int32_t *rows_per_partial);
-int mvg_conv_fprop_split(const mvg_conv_desc *d, const void *x_s3, const void *w_s3, float *y, float *stats, void *stream);
+int mvg_conv_fprop_split(const mvg_conv_desc *d, const void *x_sp, const float *x_sinv, const void *w_sp, const float *w_sinv,
+                         float *y, float *stats, void *stream);
 /* inference forward with BatchNorm folded into the epilogue (like mvg_conv_fprop_affine): out = relu?(conv * scale +
- * shift (+ residual)); residual fp32 or s3 (residual_s3), the result fp32 or s3 (out_s3) - in s3 the next conv reads
- * it directly (resnet.py:60-75,113-133 in eval mode) */
-int mvg_conv_fprop_split_affine(const mvg_conv_desc *d, const void *x_s3, const void *w_s3, void *out, int out_s3,
-                                const float *scale, const float *shift, const void *residual, int residual_s3, int relu,
-                                void *stream);
-int mvg_conv_dgrad_split(const mvg_conv_desc *d, const void *dy_s3, const void *w_crsk_s3, float *dx, const float *addend,
-                         void *stream);
+ * shift (+ residual)); residual fp32 or sp (residual_s3; unscaled), the result fp32 or sp (out_s3; unscaled) - in sp the
+ * next conv reads it directly (resnet.py:60-75,113-133 in eval mode) */
+int mvg_conv_fprop_split_affine(const mvg_conv_desc *d, const void *x_sp, const float *x_sinv, const void *w_sp, const float *w_sinv,
+                                void *out, int out_s3, const float *scale, const float *shift, const void *residual,
+                                int residual_s3, int relu, void *stream);
+int mvg_conv_dgrad_split(const mvg_conv_desc *d, const void *dy_sp, const float *dy_sinv, const void *w_crsk_sp,
+                         const float *w_sinv, float *dx, const float *addend, void *stream);
 /* The BatchNorm passes on the split path: the conv output y and every gradient g stay fp32; what the next conv
- * reads is written in s3 - the normalised activation (mvg_bn_apply_split, residual = the previous block's s3 output
+ * reads is written in sp - the normalised activation (mvg_bn_apply_split, residual = the previous block's sp output
  * when residual_s3 != 0, else the raw fp32 downsample output with its res_scale / res_shift), the stem's pooled map
  * (mvg_bn_relu_maxpool_fwd_split) and dy (mvg_bn_bwd_apply_split: g already masked, or the mask from relu_scale /
- * relu_shift).  relu_bits as in mvg_bn_apply_bits (1 byte per 4 channels).  mvg_avgpool_fwd_split pools an s3 map. */
+ * relu_shift).  relu_bits as in mvg_bn_apply_bits (1 byte per 4 channels).  mvg_avgpool_fwd_split pools an sp map.
+ * dy is stored times 2^k, k from the bound  max |gamma invstd| * M * (2 + sqrt(rows_per_group)) >= |dy|, M = max |masked
+ * gradient| = *absmax (float bits; left there by mvg_bn_bwd_reduce_split or mvg_conv_dgrad_split_bnreduce, which
+ * atomicMax into it: clear it before); *dy_sinv receives 2^-k for mvg_conv_dgrad_split / _wgrad_split. */
 int mvg_bn_apply_split(const float *y, const float *scale, const float *shift, const void *residual, int residual_s3,
                        const float *res_scale, const float *res_shift, int relu, void *out_s3, uint8_t *relu_bits,
                        int groups, int64_t rows_per_group, int c, void *stream);
+int mvg_bn_bwd_reduce_split(const float *g, const uint8_t *relu_bits, const float *y, const float *mean, const float *invstd,
+                            const float *relu_scale, const float *relu_shift, int groups, int64_t rows_per_group, int c,
+                            float *s1, float *s2, float *dgamma, float *dbeta, int accumulate, float *workspace,
+                            float *dz_out, uint32_t *absmax, void *stream);
 int mvg_bn_bwd_apply_split(const float *g, const float *y, const float *mean, const float *invstd, const float *gamma,
                            const float *s1, const float *s2, const float *relu_scale, const float *relu_shift,
-                           int groups, int64_t rows_per_group, int c, void *dy_s3, void *stream);
+                           int groups, int64_t rows_per_group, int c, void *dy_s3, const uint32_t *absmax, float *dy_sinv,
+                           void *stream);
 int mvg_bn_relu_maxpool_fwd_split(const float *y, const float *scale, const float *shift, void *pooled_s3,
                                   uint8_t *argmax, int groups, int n_per_group, int h, int w, int c, int ho, int wo,
                                   void *stream);
 int mvg_avgpool_fwd_split(const void *x_s3, float *y, int n, int hw, int c, void *stream);
 /* mvg_conv_dgrad_split fused with the BatchNorm-backward reduce pass of the unit whose output gradient dx is (stride-1
  * launches): dx is stored masked by that unit's ReLU (bn_bits from mvg_bn_apply_split, or fma(bn_y, relu_scale,
- * relu_shift) > 0, or no mask) and s1 / s2 / dgamma / dbeta come out of the same launch + a finalize (like
- * mvg_conv_dgrad_bnreduce).  partials: groups * mvg_conv_dgrad_bn_partials_split(d) * 2 * cin floats. */
+ * relu_shift) > 0, or no mask) and s1 / s2 / dgamma / dbeta come out of the same launch + a finalize; max |dx| goes to
+ * *absmax (may be NULL).  partials: groups * mvg_conv_dgrad_bn_partials_split(d) * 2 * cin floats. */
 int mvg_conv_dgrad_bn_partials_split(const mvg_conv_desc *d);
-int mvg_conv_dgrad_split_bnreduce(const mvg_conv_desc *d, const void *dy_s3, const void *w_crsk_s3, float *dx,
-                                  const float *addend, const float *bn_y, const uint8_t *bn_bits, const float *bn_mean,
-                                  const float *bn_invstd, const float *relu_scale, const float *relu_shift,
+int mvg_conv_dgrad_split_bnreduce(const mvg_conv_desc *d, const void *dy_sp, const float *dy_sinv, const void *w_crsk_sp,
+                                  const float *w_sinv, float *dx, const float *addend, const float *bn_y, const uint8_t *bn_bits,
+                                  const float *bn_mean, const float *bn_invstd, const float *relu_scale, const float *relu_shift,
                                   float *partials, float *s1, float *s2, float *dgamma, float *dbeta, int accumulate,
-                                  void *stream);
+                                  uint32_t *absmax, void *stream);
 int mvg_conv_wgrad_splits_split(const mvg_conv_desc *d);   /* pixel-split count; workspace = splits * cout*r*s*cin floats */
-int mvg_conv_wgrad_split(const mvg_conv_desc *d, const void *x_s3, const void *dy_s3, float *dw, float *workspace, int splits,
-                         int accumulate, void *stream);
+int mvg_conv_wgrad_split(const mvg_conv_desc *d, const void *x_sp, const void *dy_sp, const float *dy_sinv, float *dw,
+                         float *workspace, int splits, int accumulate, void *stream);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "librotmvgaze_hip.so")
 
 K_FAMILIES = 18
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class ConvDesc(C.Structure):
@@ -69,22 +69,23 @@ SIGNATURES = {
     "mvg_bn_eval_affine": (_I, [_I, _I, _P, _P, _P, _P, _F, _P, _P, _P]),
     "mvg_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _I, _I64, _I, _P]),
     "mvg_bn_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
-    "mvg_split_f32": (_I, [_P, _P, _I64, _P]),
-    "mvg_merge_s3": (_I, [_P, _P, _I64, _P]),
-    "mvg_split_weights": (_I, [_D, _P, _P, _P, _P]),
+    "mvg_split_f32": (_I, [_P, _P, _I64, _F, _P]),
+    "mvg_merge_sp": (_I, [_P, _P, _I64, _F, _P]),
+    "mvg_split_weights": (_I, [_D, _P, _P, _P, _P, _P, _P]),
     "mvg_weights_prep_batch": (_I, [_P, _I, _I, _P]),
     "mvg_conv_stats_partials_split": (_I, [_D, C.POINTER(C.c_int32)]),
-    "mvg_conv_fprop_split": (_I, [_D, _P, _P, _P, _P, _P]),
-    "mvg_conv_fprop_split_affine": (_I, [_D, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P]),
-    "mvg_conv_dgrad_split": (_I, [_D, _P, _P, _P, _P, _P]),
+    "mvg_conv_fprop_split": (_I, [_D, _P, _P, _P, _P, _P, _P, _P]),
+    "mvg_conv_fprop_split_affine": (_I, [_D, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P]),
+    "mvg_conv_dgrad_split": (_I, [_D, _P, _P, _P, _P, _P, _P, _P]),
     "mvg_bn_apply_split": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _I, _I64, _I, _P]),
-    "mvg_bn_bwd_apply_split": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _P, _P]),
+    "mvg_bn_bwd_apply_split": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _P, _P, _P, _P]),
+    "mvg_bn_bwd_reduce_split": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
     "mvg_bn_relu_maxpool_fwd_split": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mvg_avgpool_fwd_split": (_I, [_P, _P, _I, _I, _I, _P]),
     "mvg_conv_dgrad_bn_partials_split": (_I, [_D]),
-    "mvg_conv_dgrad_split_bnreduce": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "mvg_conv_dgrad_split_bnreduce": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "mvg_conv_wgrad_splits_split": (_I, [_D]),
-    "mvg_conv_wgrad_split": (_I, [_D, _P, _P, _P, _P, _I, _I, _P]),
+    "mvg_conv_wgrad_split": (_I, [_D, _P, _P, _P, _P, _P, _I, _I, _P]),
     "mvg_bn_apply_bits": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _P]),
     "mvg_bn_bwd_reduce_bits": (_I, [_P, _P, _P, _P, _P, _I, _I64, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
     "mvg_bn_apply_bits_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _P]),

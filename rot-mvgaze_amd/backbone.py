@@ -44,12 +44,13 @@ class GradSink:
 class _Unit:
     """Saved state of one conv + BN (+ReLU) (+residual) for the backward pass."""
     __slots__ = ("spec", "desc", "x_in", "y", "out", "mean", "invstd", "relu", "rows", "w", "trained", "pool",
-                 "relu_affine", "fused_s12", "relu_bits", "split")
+                 "relu_affine", "fused_s12", "relu_bits", "split", "absmax")
 
     def __init__(self):
-        self.split = False        # conv operands (x_in, out, dy, w) in s3, split-operand kernels (conv_split.hip)
+        self.split = False        # conv operands (x_in, out, dy, w) in sp (two fp16 pieces), split-operand kernels (conv_split.hip)
         self.relu_bits = None     # residual units: the ReLU mask as one byte per 16-byte access (ops.bn_apply_bits)
         self.fused_s12 = None     # BatchNorm-backward sums delivered by the backward-data launch that produced this unit's gradient
+        self.absmax = None        # split path, backward: 1-element int32 view, max |masked gradient| of this unit as float bits
 
 
 class Backbone:
@@ -119,13 +120,15 @@ class Backbone:
         key = (mode, str(dev), tuple(self.p[c.name + ".weight"].data_ptr() for c in convs))
         if self._wprep_state is None or self._wprep_state[0] != key:
             out, rows = {}, []
-            for c in convs:
+            wstat = torch.zeros(len(convs), 2, dtype=torch.float32, device=dev)      # per conv {max |w| bits, 2^-k} (split path)
+            for ci, c in enumerate(convs):
                 wsrc = self.p[c.name + ".weight"]
                 assert wsrc.is_contiguous(memory_format=torch.channels_last) or (c.k == 1 and wsrc.is_contiguous())
                 rs = c.k * c.k
                 if mode == 1:
-                    wk = torch.empty(c.cout, rs * c.cin // 8, 3, 8, dtype=torch.bfloat16, device=dev)
-                    wt = torch.empty(c.cin, rs * c.cout // 8, 3, 8, dtype=torch.bfloat16, device=dev)
+                    wk = ops.sp_empty(c.cout, rs * c.cin, device=dev)
+                    wt = ops.sp_empty(c.cin, rs * c.cout, device=dev)
+                    wk.sinv = wt.sinv = wstat[ci, 1:2]
                     cin_pad = c.cin
                 else:
                     cin_pad = 8 if c.cin == 3 else c.cin
@@ -133,10 +136,12 @@ class Backbone:
                     wt = None if c.cin == 3 else torch.empty(cin_pad, c.k, c.k, c.cout, dtype=torch.bfloat16, device=dev)
                 out[c.name] = (wk, wt)
                 rows.append([wsrc.data_ptr(), wk.data_ptr(), wt.data_ptr() if wt is not None else 0, c.cout | (rs << 32),
-                             c.cin | (cin_pad << 32)])
+                             c.cin | (cin_pad << 32), wstat[ci].data_ptr()])
             table = torch.tensor(rows, dtype=torch.int64).to(dev)            # once per placement (a host-to-device copy)
-            self._wprep_state = (key, out, table, len(rows), mode)
-        _, out, table, n, mode = self._wprep_state
+            self._wprep_state = (key, out, table, len(rows), mode, wstat)
+        _, out, table, n, mode, wstat = self._wprep_state
+        if mode == 1:
+            wstat.zero_()                                  # the max |w| slots are atomicMax targets
         ops.weights_prep_batch(table, n, mode)
         # the copies live in persistent buffers that the next forward overwrites: remember which parameter versions
         # they hold, so that the backward of an OLDER tape can tell (tapes keep pointers into these buffers)
@@ -219,7 +224,7 @@ class Backbone:
                 else:
                     wk, _ = ops.split_weights(d, wsrc, need_transposed=False)
                     self._wk_cache[c.name] = (wsrc.data_ptr(), wsrc._version, wk)
-                out = ops.s3_empty(G, N, d.ho, d.wo, c.cout, device=dev) if relu else y
+                out = ops.sp_empty(G, N, d.ho, d.wo, c.cout, device=dev) if relu else y
                 ops.conv_fprop_split_affine(d, x, wk, out, scale[0], shift[0], residual, relu)
                 return out
             ops.conv_fprop_affine(d, x, w, y, scale[0], shift[0], residual, relu)
@@ -247,13 +252,13 @@ class Backbone:
             hp, wp_ = (d.ho + 2 - 3) // 2 + 1, (d.wo + 2 - 3) // 2 + 1
             argmax = torch.empty(G, N, hp, wp_, c.cout, dtype=torch.uint8, device=dev)
             if sp_out:
-                out = ops.s3_empty(G, N, hp, wp_, c.cout, device=dev)
+                out = ops.sp_empty(G, N, hp, wp_, c.cout, device=dev)
                 ops.bn_relu_maxpool_fwd_split(y, scale, shift, out, argmax, G, N, d.ho, d.wo, c.cout, hp, wp_)
             else:
                 out = torch.empty(G, N, hp, wp_, c.cout, dtype=self.act_dtype, device=dev)
                 ops.bn_relu_maxpool_fwd(y, scale, shift, out, argmax, G, N, d.ho, d.wo, c.cout, hp, wp_)
         elif sp_out:
-            out = ops.s3_empty(G, N, d.ho, d.wo, c.cout, device=dev)
+            out = ops.sp_empty(G, N, d.ho, d.wo, c.cout, device=dev)
             bits = ops.bn_apply_split(y, scale, shift, residual, relu, out, G, rows, c.cout, residual_affine,
                                       want_bits=keep and relu and residual is not None)
         else:
@@ -314,11 +319,11 @@ class Backbone:
             else:
                 assert im.dtype == torch.float32
                 ops.nchw_to_nhwc4(im.detach().contiguous(), x0[v], B, 3, H, W)
-        # The split kernels address one view of an s3 tensor (6 bytes per element) with 32-bit offsets: the largest one
+        # The split kernels address one view of an sp tensor (4 bytes per element) with 32-bit offsets: the largest one
         # (layer1's output: (H/4) x (W/4) x 64 or 256 channels per image) must stay below 2 GiB, or this call runs on the
-        # fp32-MFMA kernels (4 bytes per element: B < 668 instead of B < 445 per view at 224 x 224 with ResNet-50)
+        # fp32-MFMA kernels (64-bit row offsets there; B < 668 per view at 224 x 224 with ResNet-50)
         biggest_view_elems = B * ((H + 3) // 4) * ((W + 3) // 4) * self.spec.blocks[0].convs[-1].cout
-        self._split_now = self.split and 6 * biggest_view_elems * self._guard_scale < 0x7FFFFFF0
+        self._split_now = self.split and 4 * biggest_view_elems * self._guard_scale < 0x7FFFFFF0
         self._wprep = None
         if training:
             self._wk_cache.clear()               # the weights are about to change: drop the inference copies
@@ -360,7 +365,7 @@ class Backbone:
             x = out
             Hc, Wc = out.shape[2], out.shape[3]
         feat = torch.empty(V, B, self.fc_dim, dtype=torch.float32, device=dev)
-        if x.dtype == torch.bfloat16 and not self.bf16:             # s3 activation of the split path
+        if x.dtype == torch.float16:                                # sp activation of the split path
             ops.avgpool_fwd_split(x, feat, V * B, Hc * Wc, self.fc_dim)
         else:
             ops.avgpool_fwd(x, feat, V * B, Hc * Wc, self.fc_dim)
@@ -378,8 +383,8 @@ class Backbone:
         if u.fused_s12 is not None and u.split:
             # split path, fused: g arrived masked and the sums came with it; dy goes out in s3
             s12, u.fused_s12 = u.fused_s12, None
-            dy = ops.s3_empty(*u.y.shape, device=g.device)
-            ops.bn_bwd_apply_split(g, u.y, u.mean, u.invstd, gp.detach(), s12[0], s12[1], G, u.rows, c.cout, dy, None)
+            dy = ops.sp_empty(*u.y.shape, device=g.device)
+            ops.bn_bwd_apply_split(g, u.y, u.mean, u.invstd, gp.detach(), s12[0], s12[1], G, u.rows, c.cout, dy, None, u.absmax)
             return dy, (g if need_dz else None)
         if u.fused_s12 is not None:
             # g arrived masked by this unit's ReLU and its sums (incl. dgamma / dbeta) came with it
@@ -396,14 +401,14 @@ class Backbone:
             # split path: g and y are fp32, dy goes to the conv kernels in s3; residual units carry their mask as bits
             assert not (u.relu and ra is None) or u.relu_bits is not None
             if u.relu_bits is not None:
-                ops.bn_bwd_reduce_bits(g, u.relu_bits, u.y, u.mean, u.invstd, G, u.rows, c.cout, s12[0], s12[1], sink.view(gp),
-                                       sink.view(bp), acc, dz_out=g)
+                ops.bn_bwd_reduce_split(g, u.relu_bits, u.y, u.mean, u.invstd, G, u.rows, c.cout, s12[0], s12[1], sink.view(gp),
+                                        sink.view(bp), acc, u.absmax, None, dz_out=g)
             else:
-                ops.bn_bwd_reduce(g, None, u.y, u.mean, u.invstd, G, u.rows, c.cout, s12[0], s12[1], sink.view(gp), sink.view(bp),
-                                  acc, ra)
-            dy = ops.s3_empty(*u.y.shape, device=g.device)
+                ops.bn_bwd_reduce_split(g, None, u.y, u.mean, u.invstd, G, u.rows, c.cout, s12[0], s12[1], sink.view(gp),
+                                        sink.view(bp), acc, u.absmax, ra)
+            dy = ops.sp_empty(*u.y.shape, device=g.device)
             ops.bn_bwd_apply_split(g, u.y, u.mean, u.invstd, gp.detach(), s12[0], s12[1], G, u.rows, c.cout, dy,
-                                   None if u.relu_bits is not None else ra)
+                                   None if u.relu_bits is not None else ra, u.absmax)
             return dy, (g if need_dz else None)
         if need_dz:
             # the reduce pass writes the masked gradient dz over g: the apply pass then reads (dz, y) only - no
@@ -444,13 +449,15 @@ class Backbone:
             side.wait_stream(torch.cuda.current_stream())         # dy (and everything before it) is ready
             with torch.cuda.stream(side):
                 self._wgrad(u, dy, sink)
+            if getattr(dy, "sinv", None) is not None:
+                dy.sinv.record_stream(side)
             dy.record_stream(side)                                # the allocator must not recycle these while
             u.x_in.record_stream(side)                            # the side stream still reads them
         else:
             self._wgrad(u, dy, sink)
         dx = None
         if need_dx:
-            dx = torch.empty(ops.s3_shape(u.x_in), dtype=torch.float32, device=dy.device) if u.split else torch.empty_like(u.x_in)
+            dx = torch.empty(ops.sp_shape(u.x_in), dtype=torch.float32, device=dy.device) if u.split else torch.empty_like(u.x_in)
             self._dgrad(u, dy, dx, addend, fuse_for, sink)
         return dx
 
@@ -485,7 +492,7 @@ class Backbone:
                 s12 = torch.empty(2, dx.shape[0], c.cout, dtype=torch.float32, device=dx.device)
                 ops.conv_dgrad_split_bnreduce(u.desc, dy, u.w, dx, addend, U.y, U.relu_bits, U.mean, U.invstd,
                                               None if U.relu_bits is not None else U.relu_affine, s12[0], s12[1], sink.view(gp),
-                                              sink.view(bp), acc)
+                                              sink.view(bp), acc, U.absmax)
                 U.fused_s12 = s12
                 return
             ops.conv_dgrad_split(u.desc, dy, u.w, dx, addend)
@@ -510,6 +517,11 @@ class Backbone:
                                "(PyTorch raises its version-counter error in the same situation)")
         g = torch.empty(V, B, Hc, Wc, self.fc_dim, dtype=self.act_dtype, device=dfeat.device)
         ops.avgpool_bwd(dfeat.contiguous(), g, V * B, Hc * Wc, self.fc_dim)
+        # split path: every unit's reduce pass leaves max |masked gradient| (float bits, atomicMax) in its slot; the apply
+        # pass turns it into the power-of-two scale of the unit's dy (one memset for all of them)
+        absmax = torch.zeros(len(units), dtype=torch.int32, device=dfeat.device)
+        for i, u_ in enumerate(units):
+            u_.absmax = absmax[i:i + 1]
         P = self.p
         blocks = tape["blocks"]
         for bi in range(len(blocks) - 1, -1, -1):

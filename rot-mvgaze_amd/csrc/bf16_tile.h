@@ -2,6 +2,7 @@
 // bf16 pieces): vector types, packing, and the LDS-staged tile epilogue.  Static / inline only (conv_shared.h).
 #pragma once
 #include "conv_shared.h"
+#include "elem.h"
 
 namespace mvg {
 
@@ -13,25 +14,6 @@ __device__ __forceinline__ float bf_hi(unsigned v) { return __uint_as_float(v & 
 __device__ __forceinline__ unsigned pack_bf2(float a, float b) {          // round-to-nearest-even, NaN-safe (plain casts)
   const __bf16 x = (__bf16)a, y = (__bf16)b;
   return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
-}
-
-// fp32 x[8] -> the three bf16 pieces of an s3 chunk (conv_split.hip's operand format; elem.h has the uint4 flavour)
-__device__ __forceinline__ void split3_store(const float (&x)[8], u32x4 &q1, u32x4 &q2, u32x4 &q3) {
-  unsigned a[8], b[8], c[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const __bf16 h1 = (__bf16)x[k];
-    float r = x[k] - (float)h1;
-    const __bf16 h2 = (__bf16)r;
-    r -= (float)h2;
-    const __bf16 h3 = (__bf16)r;
-    a[k] = __builtin_bit_cast(unsigned short, h1);
-    b[k] = __builtin_bit_cast(unsigned short, h2);
-    c[k] = __builtin_bit_cast(unsigned short, h3);
-  }
-  q1 = u32x4{a[0] | (a[1] << 16), a[2] | (a[3] << 16), a[4] | (a[5] << 16), a[6] | (a[7] << 16)};
-  q2 = u32x4{b[0] | (b[1] << 16), b[2] | (b[3] << 16), b[4] | (b[5] << 16), b[6] | (b[7] << 16)};
-  q3 = u32x4{c[0] | (c[1] << 16), c[2] | (c[3] << 16), c[4] | (c[5] << 16), c[6] | (c[7] << 16)};
 }
 
 // Epilogue shared by the bf16 GEMM kernels: BN partial statistics from the fp32 accumulators, then the tile goes
@@ -57,6 +39,8 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
   auto erow = [&](int e) { return ACC16 ? 4 * lh + e : (e & 3) + 8 * (e >> 2) + 4 * lh; };
   const int ohw = c.out_h * c.out_w;
   const long long row_base = (long long)mtile * BM + wm * WTM;
+  // split operands carry per-tensor power-of-two scales: exact to undo on the accumulators
+  const float osc = F32IO ? (p.a_sinv ? *p.a_sinv : 1.f) * (p.b_sinv ? *p.b_sinv : 1.f) : 1.f;
   if (!DGRAD && p.stats) {
     // per-wave partial over its WTM rows: column sum and sum of squares centred on the partial's own mean
     long long cnt_ll = c.rows_per_group - row_base;
@@ -90,8 +74,8 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
         const long long P = p.stats_partials ? p.stats_partials : (long long)c.mtiles_per_group * WGM;
         const long long pi = (long long)mtile * WGM + wm;
         float *st = p.stats + (((long long)g * P + pi) * 2) * p.ncols;
-        st[col] = csum;
-        st[p.ncols + col] = q;
+        st[col] = csum * osc;
+        st[p.ncols + col] = q * (osc * osc);
       }
     }
   }
@@ -131,6 +115,7 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
   // per workgroup through LDS, and written as one partial per (group, row tile) for bn_bwd_finalize.
   const bool bnf = DGRAD && F32IO && p.bn_part != nullptr;
   float bn_mu[8], bn_is[8], bn_ra[8], bn_rb[8], bn_s1[8], bn_s2[8];
+  float bn_mx = 0.f;                           // max |masked gradient| this thread stores (p.bn_absmax)
   const bool bn_aff = bnf && p.bn_rscale != nullptr;
   if (bnf) {
     const int col0 = ntile * BN + (tid % CV) * 8;
@@ -168,6 +153,10 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
     const float4 lo = *reinterpret_cast<const float4 *>(ot + rl * LDO + cv * 8);
     const float4 hi = *reinterpret_cast<const float4 *>(ot + rl * LDO + cv * 8 + 4);
     float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    if constexpr (F32IO) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) x[k] *= osc;
+    }
     if (!DGRAD && F32IO && p.scale) {          // inference: BatchNorm folded into a per-channel affine
       const float4 s0 = *reinterpret_cast<const float4 *>(p.scale + col), s1 = *reinterpret_cast<const float4 *>(p.scale + col + 4);
       x[0] *= s0.x; x[1] *= s0.y; x[2] *= s0.z; x[3] *= s0.w; x[4] *= s1.x; x[5] *= s1.y; x[6] *= s1.z; x[7] *= s1.w;
@@ -182,15 +171,12 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
     }
     if constexpr (F32IO) {
       if (!DGRAD && p.addend) {                // forward residual (fp32, or s3: the previous block's output), then ReLU
-        if (p.addend_s3) {
-          const u32x4 *q = reinterpret_cast<const u32x4 *>(p.addend) + (((long long)g * gelems + off + col) >> 3) * 3;
-          const u32x4 a = q[0], b = q[1], c3 = q[2];
-          const unsigned ua[4] = {a.x, a.y, a.z, a.w}, ub[4] = {b.x, b.y, b.z, b.w}, uc[4] = {c3.x, c3.y, c3.z, c3.w};
+        if (p.addend_s3) {                     // (an activation in sp storage: scale 1)
+          const uint4 *q = reinterpret_cast<const uint4 *>(p.addend) + (((long long)g * gelems + off + col) >> 3) * SP_NP;
+          float r[8];
+          merge2_chunk(q[0], q[1], r);
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            x[2 * k] += (bf_lo(ua[k]) + bf_lo(ub[k])) + bf_lo(uc[k]);
-            x[2 * k + 1] += (bf_hi(ua[k]) + bf_hi(ub[k])) + bf_hi(uc[k]);
-          }
+          for (int k = 0; k < 8; ++k) x[k] += r[k];
         } else {
           const float4 a0 = *reinterpret_cast<const float4 *>(add_f + off + col), a1 = *reinterpret_cast<const float4 *>(add_f + off + col + 4);
           x[0] += a0.x; x[1] += a0.y; x[2] += a0.z; x[3] += a0.w; x[4] += a1.x; x[5] += a1.y; x[6] += a1.z; x[7] += a1.w;
@@ -201,12 +187,11 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
         }
       }
       if (!DGRAD && p.out_s3) {                // the next conv's operand, written directly (one chunk per lane)
-        u32x4 q1, q2, q3;
-        split3_store(x, q1, q2, q3);
-        u32x4 *dst = reinterpret_cast<u32x4 *>(p.out) + (((long long)g * gelems + off + col) >> 3) * 3;
+        uint4 q1, q2;
+        split2_chunk(x, q1, q2);
+        uint4 *dst = reinterpret_cast<uint4 *>(p.out) + (((long long)g * gelems + off + col) >> 3) * SP_NP;
         dst[0] = q1;
         dst[1] = q2;
-        dst[2] = q3;
         continue;
       }
       if (DGRAD && mask_f) {
@@ -232,6 +217,7 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
         for (int k = 0; k < 8; ++k) {
           const bool on = bn_aff ? (__builtin_fmaf(yy[k], bn_ra[k], bn_rb[k]) > 0.f) : (((bits >> k) & 1u) != 0u);
           x[k] = on ? x[k] : 0.f;
+          bn_mx = fmaxf(bn_mx, fabsf(x[k]));
           bn_s1[k] += x[k];
           bn_s2[k] += x[k] * ((yy[k] - bn_mu[k]) * bn_is[k]);
         }
@@ -284,6 +270,11 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
       float t = 0.f;
       for (int r = 0; r < RL; ++r) t += red[(which * RL + r) * BN + cc];       // fixed order
       p.bn_part[(((long long)g * c.mtiles_per_group + mtile) * 2 + which) * p.ncols + colr] = t;
+    }
+    if (p.bn_absmax) {                         // a maximum does not depend on the order: one atomic per wave
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) bn_mx = fmaxf(bn_mx, __shfl_xor(bn_mx, o, 64));
+      if (lane == 0 && bn_mx > 0.f) atomicMax(p.bn_absmax, __float_as_uint(bn_mx));
     }
   }
 }

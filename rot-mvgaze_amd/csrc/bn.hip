@@ -264,7 +264,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *g, const T 
                                                             const float *__restrict__ mshift, long long rows,
                                                             long long rows_per_chunk, int c, int cwn, int cw,
                                                             float *__restrict__ partial, int chunks, T *dz_out,
-                                                            const unsigned char *__restrict__ relu_bits) {
+                                                            const unsigned char *__restrict__ relu_bits,
+                                                            unsigned *__restrict__ absmax) {
   typedef Elem<T> E;
   constexpr int W = E::W;                 // float4 groups per 16-byte access; a "column" below is one such access
   __shared__ float4 sh[2][256][W];
@@ -274,6 +275,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *g, const T 
   const int cq = blockIdx.y * cw + cl;
   const bool cok = cq < cwn;
   float4 s1[W], s2[W];
+  float mx = 0.f;                      // max |masked gradient| (absmax: the bound mvg_bn_bwd_apply_split scales dy by)
 #pragma unroll
   for (int w = 0; w < W; ++w) s1[w] = s2[w] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (cok) {
@@ -320,6 +322,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *g, const T 
           d[w].z = __builtin_fmaf(v[w].z, ma[w].z, mb[w].z) > 0.f ? d[w].z : 0.f;
           d[w].w = __builtin_fmaf(v[w].w, ma[w].w, mb[w].w) > 0.f ? d[w].w : 0.f;
         }
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(d[w].x), fabsf(d[w].y))), fmaxf(fabsf(d[w].z), fabsf(d[w].w)));
         a1[w].x += d[w].x;
         a1[w].y += d[w].y;
         a1[w].z += d[w].z;
@@ -356,6 +359,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *g, const T 
         s2[w].x += t2[0][w].x; s2[w].y += t2[0][w].y; s2[w].z += t2[0][w].z; s2[w].w += t2[0][w].w;
       }
     }
+  }
+  if (absmax) {                        // a maximum does not depend on the order: one atomic per wave
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(absmax, __float_as_uint(mx));
   }
 #pragma unroll
   for (int w = 0; w < W; ++w) {
@@ -498,10 +506,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
   }
 }
 
-// ---- split path: the passes that write s3, one 8-channel chunk per lane -------------------------------
-// (fp32 tensors as two float4 per lane, the s3 tensor as the chunk's three 16-byte pieces; the generic kernels
-// with Elem<s3_t> move 4 channels per lane as three 8-byte accesses and reach 4.2-4.5 TB/s where the fp32 forms
-// reach 5.1-5.3.)  A lane's channel chunk is fixed whenever the grid stride is a multiple of the chunks per row
+// ---- split path: the passes that write sp (elem.h), one 8-channel chunk per lane -------------------------------
+// (fp32 tensors as two float4 per lane, the sp tensor as the chunk's two 16-byte pieces; the generic kernels
+// with Elem<sp_t> move 4 channels per lane as 8-byte accesses and are slower.)  A lane's channel chunk is fixed whenever the grid stride is a multiple of the chunks per row
 // (every ResNet shape): the per-channel factors are loaded once, outside the row loop.
 struct F8 {
   float v[8];
@@ -510,32 +517,25 @@ __device__ __forceinline__ F8 ld8(const float *p, long long chunk) {
   const float4 a = reinterpret_cast<const float4 *>(p)[2 * chunk], b = reinterpret_cast<const float4 *>(p)[2 * chunk + 1];
   return F8{{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
 }
-__device__ __forceinline__ F8 ld8_s3(const s3_t *p, long long chunk) {
-  const uint4 *q = reinterpret_cast<const uint4 *>(p) + 3 * chunk;
-  const uint4 a = q[0], b = q[1], c = q[2];
-  const unsigned ua[4] = {a.x, a.y, a.z, a.w}, ub[4] = {b.x, b.y, b.z, b.w}, uc[4] = {c.x, c.y, c.z, c.w};
+__device__ __forceinline__ F8 ld8_sp(const sp_t *p, long long chunk) {
+  const uint4 *q = reinterpret_cast<const uint4 *>(p) + SP_NP * chunk;
   F8 r;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    r.v[2 * k] = (bf16_lo(ua[k]) + bf16_lo(ub[k])) + bf16_lo(uc[k]);
-    r.v[2 * k + 1] = (bf16_hi(ua[k]) + bf16_hi(ub[k])) + bf16_hi(uc[k]);
-  }
+  merge2_chunk(q[0], q[1], r.v);
   return r;
 }
-__device__ __forceinline__ void st8_s3(s3_t *p, long long chunk, const F8 &x) {
-  uint4 q1, q2, q3;
-  split3_chunk(x.v, q1, q2, q3);
-  uint4 *q = reinterpret_cast<uint4 *>(p) + 3 * chunk;
+__device__ __forceinline__ void st8_sp(sp_t *p, long long chunk, const F8 &x) {
+  uint4 q1, q2;
+  split2_chunk(x.v, q1, q2);
+  uint4 *q = reinterpret_cast<uint4 *>(p) + SP_NP * chunk;
   q[0] = q1;
   q[1] = q2;
-  q[2] = q3;
 }
 
 template <bool RES_S3>
 __global__ __launch_bounds__(256) void bn_apply_s3_kernel(const float *__restrict__ y, const float *__restrict__ scale,
                                                           const float *__restrict__ shift, const void *__restrict__ residual,
                                                           const float *__restrict__ res_scale,
-                                                          const float *__restrict__ res_shift, int relu, s3_t *__restrict__ out,
+                                                          const float *__restrict__ res_shift, int relu, sp_t *__restrict__ out,
                                                           long long n8_per_group, int c8n, int c,
                                                           unsigned short *__restrict__ relu_bits) {
   const int g = blockIdx.y;
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(256) void bn_apply_s3_kernel(const float *__restric
     }
     const F8 v = ld8(y, base + i);
     F8 r, o;
-    if (residual) r = RES_S3 ? ld8_s3(reinterpret_cast<const s3_t *>(residual), base + i) : ld8(reinterpret_cast<const float *>(residual), base + i);
+    if (residual) r = RES_S3 ? ld8_sp(reinterpret_cast<const sp_t *>(residual), base + i) : ld8(reinterpret_cast<const float *>(residual), base + i);
     unsigned m = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(256) void bn_apply_s3_kernel(const float *__restric
       o.v[k] = x;
       m |= (x > 0.f ? 1u : 0u) << (k + (k >= 4 ? 4 : 0));    // two bytes, low nibbles: one byte per 4 channels (bn_bwd_reduce_bits)
     }
-    st8_s3(out, base + i, o);
+    st8_sp(out, base + i, o);
     if (relu_bits) relu_bits[base + i] = (unsigned short)m;
     cq += step;
     if (cq >= c8n) cq -= c8n;
@@ -583,7 +583,25 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_s3_kernel(const float *__res
                                                               const float *__restrict__ gamma, const float *__restrict__ s1,
                                                               const float *__restrict__ s2, const float *__restrict__ mscale,
                                                               const float *__restrict__ mshift, long long n8_per_group,
-                                                              float inv_rows, int c8n, int c, s3_t *__restrict__ dy) {
+                                                              float inv_rows, int c8n, int c, sp_t *__restrict__ dy,
+                                                              const unsigned *__restrict__ absmax, int groups, float sqrt_rows,
+                                                              float *__restrict__ dy_sinv) {
+  // dy is stored times 2^k, k from a bound on |dy| (elem.h: sp_scale_for):
+  //   |dy| = |gamma invstd| |dz - s1/n - xhat s2/n| <= max_c |gamma invstd| * M * (2 + sqrt(n)),  M = max |dz| (absmax),
+  // because |s1/n| <= M, |s2/n| = |mean(dz xhat)| <= M mean|xhat| <= M, and a z-score of n samples is at most
+  // sqrt(n - 1).  Typical values sit a factor ~sqrt(n) below the bound: well inside the 2^29 range sp keeps exact.
+  __shared__ float sh_gi[4];
+  {
+    float gi = 0.f;
+    for (int i = threadIdx.x; i < groups * c; i += 256) gi = fmaxf(gi, fabsf(gamma[i % c] * invstd[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) gi = fmaxf(gi, __shfl_xor(gi, o, 64));
+    if ((threadIdx.x & 63) == 0) sh_gi[threadIdx.x >> 6] = gi;
+    __syncthreads();
+  }
+  const float gimax = fmaxf(fmaxf(sh_gi[0], sh_gi[1]), fmaxf(sh_gi[2], sh_gi[3]));
+  const float dsc = sp_scale_for(gimax * __uint_as_float(*absmax) * (2.f + sqrt_rows));
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *dy_sinv = 1.f / dsc;
   const int grp = blockIdx.y;
   const long long base = (long long)grp * n8_per_group;
   const long long stride = (long long)gridDim.x * 256;
@@ -610,9 +628,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_s3_kernel(const float *__res
     for (int k = 0; k < 8; ++k) {
       float dd = d.v[k];
       if (mscale) dd = __builtin_fmaf(v.v[k], ma.v[k], mb.v[k]) > 0.f ? dd : 0.f;
-      o.v[k] = ga.v[k] * is.v[k] * (dd - sa.v[k] * inv_rows - (v.v[k] - mu.v[k]) * is.v[k] * (sb.v[k] * inv_rows));
+      o.v[k] = (ga.v[k] * is.v[k] * (dd - sa.v[k] * inv_rows - (v.v[k] - mu.v[k]) * is.v[k] * (sb.v[k] * inv_rows))) * dsc;
     }
-    st8_s3(dy, base + i, o);
+    st8_sp(dy, base + i, o);
     cq += step;
     if (cq >= c8n) cq -= c8n;
   }
@@ -900,7 +918,7 @@ template <typename T>
 static int bn_bwd_reduce_impl(const T *g, const T *act, const T *y, const float *mean, const float *invstd,
                               const float *relu_scale, const float *relu_shift, int groups, int64_t rows_per_group, int c,
                               float *s1, float *s2, float *dgamma, float *dbeta, int accumulate, float *workspace, T *dz_out,
-                              void *stream, const uint8_t *relu_bits = nullptr) {
+                              void *stream, const uint8_t *relu_bits = nullptr, uint32_t *absmax = nullptr) {
   MVG_REQUIRE(!(act && relu_scale) && !(relu_bits && (act || relu_scale)),
               "bn_bwd_reduce: give the ReLU mask ONE way: act, (relu_scale, relu_shift) or relu_bits");
   MVG_REQUIRE((relu_scale == nullptr) == (relu_shift == nullptr), "bn_bwd_reduce: relu_scale and relu_shift go together");
@@ -916,7 +934,7 @@ static int bn_bwd_reduce_impl(const T *g, const T *act, const T *y, const float 
   const long long rpc = (rows_per_group + chunks - 1) / chunks;
   ProfScope ps(MVG_K_BN_BWD_REDUCE, st, 0.0, Elem<T>::kBytes * groups * (double)rows_per_group * c * ((act ? 3 : 2) + (dz_out ? 1 : 0)));
   hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(chunks, ceil_div(c4n, cw), groups), dim3(256), 0, st, g, act, y, mean, invstd,
-                     relu_scale, relu_shift, (long long)rows_per_group, rpc, c, c4n, cw, workspace, chunks, dz_out, relu_bits);
+                     relu_scale, relu_shift, (long long)rows_per_group, rpc, c, c4n, cw, workspace, chunks, dz_out, relu_bits, absmax);
   if (check_launch("bn_bwd_reduce")) return 1;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(c, 16)), dim3(1024), 0, st, workspace, groups, chunks, c, s1, s2,
                      dgamma, dbeta, accumulate);
@@ -1069,7 +1087,18 @@ MVG_BN_FACES(_bf16, uint16_t)
     return bn_bwd_reduce_impl<T>(g, nullptr, y, mean, invstd, nullptr, nullptr, groups, rows_per_group, c, s1, s2, dgamma,   \
                                  dbeta, accumulate, workspace, dz_out, stream, relu_bits);                                   \
   }
-// ---- split path (conv_split.hip): conv outputs and gradients fp32, conv INPUTS (activations, dy) in s3 ----------
+// ---- split path (conv_split.hip): conv outputs and gradients fp32, conv INPUTS (activations, dy) in sp ----------
+// the reduce pass of a unit whose dy goes out in sp: mvg_bn_bwd_reduce / _bits (mask from relu_bits, or from relu_scale /
+// relu_shift, or none) that also leaves max |masked gradient| in *absmax (float bits, atomicMax: clear it first)
+int mvg_bn_bwd_reduce_split(const float *g, const uint8_t *relu_bits, const float *y, const float *mean, const float *invstd,
+                            const float *relu_scale, const float *relu_shift, int groups, int64_t rows_per_group, int c, float *s1,
+                            float *s2, float *dgamma, float *dbeta, int accumulate, float *workspace, float *dz_out,
+                            uint32_t *absmax, void *stream) {
+  MVG_REQUIRE(absmax != nullptr, "bn_bwd_reduce_split: absmax is required");
+  return bn_bwd_reduce_impl<float>(g, nullptr, y, mean, invstd, relu_scale, relu_shift, groups, rows_per_group, c, s1, s2, dgamma,
+                                   dbeta, accumulate, workspace, dz_out, stream, relu_bits, absmax);
+}
+
 int mvg_bn_apply_split(const float *y, const float *scale, const float *shift, const void *residual, int residual_s3,
                        const float *res_scale, const float *res_shift, int relu, void *out_s3, uint8_t *relu_bits, int groups,
                        int64_t rows_per_group, int c, void *stream) {
@@ -1079,34 +1108,36 @@ int mvg_bn_apply_split(const float *y, const float *scale, const float *shift, c
               "bn_apply_split: res_scale / res_shift go together and need a residual");
   hipStream_t st = (hipStream_t)stream;
   const long long n8 = rows_per_group * (c / 8);
-  ProfScope ps(MVG_K_BN_APPLY, st, 0.0, 8.0 * groups * (double)n8 * (4.0 + 6.0 + (residual ? (residual_s3 ? 6.0 : 4.0) : 0.0)));
+  ProfScope ps(MVG_K_BN_APPLY, st, 0.0, 8.0 * groups * (double)n8 * (4.0 + SP_BYTES + (residual ? (residual_s3 ? (double)SP_BYTES : 4.0) : 0.0)));
   const dim3 grid(grid_for(n8), groups), block(256);
   if (residual && residual_s3)
     hipLaunchKernelGGL(bn_apply_s3_kernel<true>, grid, block, 0, st, y, scale, shift, residual, res_scale, res_shift, relu,
-                       (s3_t *)out_s3, n8, c / 8, c, (unsigned short *)relu_bits);
+                       (sp_t *)out_s3, n8, c / 8, c, (unsigned short *)relu_bits);
   else
     hipLaunchKernelGGL(bn_apply_s3_kernel<false>, grid, block, 0, st, y, scale, shift, residual, res_scale, res_shift, relu,
-                       (s3_t *)out_s3, n8, c / 8, c, (unsigned short *)relu_bits);
+                       (sp_t *)out_s3, n8, c / 8, c, (unsigned short *)relu_bits);
   return check_launch("bn_apply_split");
 }
 
 int mvg_bn_bwd_apply_split(const float *g, const float *y, const float *mean, const float *invstd, const float *gamma,
                            const float *s1, const float *s2, const float *relu_scale, const float *relu_shift, int groups,
-                           int64_t rows_per_group, int c, void *dy_s3, void *stream) {
+                           int64_t rows_per_group, int c, void *dy_s3, const uint32_t *absmax, float *dy_sinv, void *stream) {
   MVG_REQUIRE(c % 8 == 0, "bn_bwd_apply_split: c %% 8 != 0");
+  MVG_REQUIRE(absmax && dy_sinv, "bn_bwd_apply_split: absmax (max |masked gradient| from the reduce pass) and dy_sinv are required");
   MVG_REQUIRE((relu_scale == nullptr) == (relu_shift == nullptr), "bn_bwd_apply_split: relu_scale and relu_shift go together");
   hipStream_t st = (hipStream_t)stream;
   const long long n8 = rows_per_group * (c / 8);
-  ProfScope ps(MVG_K_BN_BWD_APPLY, st, 0.0, 8.0 * groups * (double)n8 * 14.0);
+  ProfScope ps(MVG_K_BN_BWD_APPLY, st, 0.0, 8.0 * groups * (double)n8 * (8.0 + SP_BYTES));
   hipLaunchKernelGGL(bn_bwd_apply_s3_kernel, dim3(grid_for(n8), groups), dim3(256), 0, st, g, y, mean, invstd, gamma, s1, s2,
-                     relu_scale, relu_shift, n8, 1.0f / (float)rows_per_group, c / 8, c, (s3_t *)dy_s3);
+                     relu_scale, relu_shift, n8, 1.0f / (float)rows_per_group, c / 8, c, (sp_t *)dy_s3, absmax, groups,
+                     sqrtf((float)rows_per_group), dy_sinv);
   return check_launch("bn_bwd_apply_split");
 }
 
 int mvg_bn_relu_maxpool_fwd_split(const float *y, const float *scale, const float *shift, void *pooled_s3, uint8_t *argmax,
                                   int groups, int n_per_group, int h, int w, int c, int ho, int wo, void *stream) {
   MVG_REQUIRE(c % 8 == 0, "bn_relu_maxpool_fwd_split: c %% 8 != 0");
-  return bn_relu_maxpool_fwd_impl<float, s3_t>(y, scale, shift, (s3_t *)pooled_s3, argmax, groups, n_per_group, h, w, c, ho, wo,
+  return bn_relu_maxpool_fwd_impl<float, sp_t>(y, scale, shift, (sp_t *)pooled_s3, argmax, groups, n_per_group, h, w, c, ho, wo,
                                                stream);
 }
 

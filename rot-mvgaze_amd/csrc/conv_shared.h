@@ -134,6 +134,10 @@ struct IgemmParams {
   // split kernels, inference forward (BatchNorm folded: y = acc * scale + bias (+ residual) [relu]): the residual
   // and / or the result in s3 (the next conv's operand format) instead of fp32
   int addend_s3, out_s3;
+  // split kernels: the operands hold (value * 2^k) for a per-tensor k (elem.h: sp_t); the epilogue multiplies the
+  // accumulators by *a_sinv * *b_sinv (device scalars, each 2^-k of its operand; null = 1)
+  const float *a_sinv, *b_sinv;
+  unsigned *bn_absmax;            // fused BatchNorm-backward reduce: max |masked gradient| as float bits (atomicMax), or null
   const unsigned char *bn_bits;   // split kernels: the unit's ReLU mask as bits (one byte per 4 channels, mvg_bn_apply_split) 
   // Cross-view fusion (igemm_kernel AMODE = 1, Linear forward): the A operand is never materialised - row m of
   //   X = [ img_feat[rc_row_img[m]] (rc_cf floats) | rc_rel[m] (3x3) @ feat[rc_row_src[m]] (3 x rc_nvec, axis-major) ]
@@ -173,6 +177,7 @@ struct WgradParams {
   int rc_cf, rc_nvec;
   long long rc_img_bytes, rc_feat_bytes;
   FastDiv ohw_div, wo_div, cin_div, s_div;
+  const float *dy_sinv;           // split kernels: 2^-k of the dy operand's per-tensor scale (device scalar, null = 1)
 };
 
 // Sum of the per-split slabs.  A workgroup covers 256/lanes float4 columns; `lanes` threads per column

@@ -1,18 +1,23 @@
-// fp32-accurate convolution / linear kernels on the gfx950 bf16 matrix cores ("split" operands).
+// fp32-accurate convolution / linear kernels on the gfx950 fp16 matrix cores ("split" operands).
 //
-// An fp32 value is the exact sum of three bf16 pieces, a = a1 + a2 + a3 (a1 = bf16(a), a2 = bf16(a - a1),
-// a3 = bf16(a - a1 - a2): 3 x 8 significand bits, same exponent range as fp32).  A product of two pieces is exact
-// in fp32, so
-//     a * b  =  a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a2 b2 + a3 b1)  + O(2^-24 |a b|)
-// six bf16 MFMAs (v_mfma_f32_32x32x16_bf16, fp32 accumulation) per 16 k reproduce the fp32 product to fp32
-// rounding: measured against fp64 on 2048 x 256..4608 GEMMs the result is as close as (or closer than) the fp32
-// MFMA kernel's (rel. L2 0.7-3.4e-7 vs 1.5-4.1e-7).  Six bf16 MFMAs of 16 k cost 6 x 32 cycles,
-// the eight fp32 MFMAs (32x32x2) they replace 8 x 64: the matrix pipe needs 2.7x less time per fp32-accurate
-// product.  This is the 1e-4 parity path's arithmetic, NOT the reduced-precision bf16 path of conv_bf16.hip.
+// An fp32 value a is held as TWO fp16 pieces, a1 = fp16(a), a2 = fp16(a - a1) (round to nearest; a - a1 is exact):
+// |a - a1 - a2| <= 2^-24 |a|, HALF a unit in the last place of the fp32 value itself, provided the value sits inside
+// fp16's exponent range - which a per-tensor power-of-two scale arranges (exact to apply and to undo; elem.h: sp_t).
+// A product of two pieces is exact in fp32, so
+//     a * b  =  a1 b1 + (a1 b2 + a2 b1)  + O(2^-22 |a b|)
+// THREE fp16 MFMAs (v_mfma_f32_16x16x32_f16, fp32 accumulation) per 32 k.  Measured against fp64 (DESIGN.md 4a,
+// profiles/r03_split_accuracy.txt): the result is as close as the fp32-MFMA kernel's, whose own k-ordered fp32
+// accumulation error (1.5-4e-7 relative L2) is larger than what the operand rounding (6e-8) and the dropped a2 b2
+// term (4e-8) contribute.  Round 2 used three bf16 pieces and six products ("s3", exact operands, 6 bytes per
+// element): this format moves 4 bytes per element and half the MFMA work.
+// This is the 1e-4 parity path's arithmetic, NOT the reduced-precision bf16 path of conv_bf16.hip.
 //
-// Operand format "s3" (written by the producers: bn.hip's apply passes, split_weights below): channels in chunks
-// of 8, the three pieces of a chunk adjacent - element (row, c, piece) at ushort offset
-//     ((row * C/8 + c/8) * 3 + piece) * 8 + c % 8            (48 contiguous bytes per 8 channels, 6 bytes/element)
+// Operand format "sp" (written by the producers: bn.hip's apply passes, the weight prep below): channels in chunks
+// of 8, the two pieces of a chunk adjacent - element (row, c, piece) at ushort offset
+//     ((row * C/8 + c/8) * 2 + piece) * 8 + c % 8            (32 contiguous bytes per 8 channels, 4 bytes/element)
+// Scales: activations are stored unscaled (BatchNorm keeps them O(1); fp16 reaches 65504); every gradient tensor dy
+// and every weight copy carries a device scalar 2^-k written by its producer (bn_bwd_apply: from a bound on |dy|;
+// the weight prep: from max |w|), which the consumer's epilogue multiplies back in.
 //
 // Kernels: igemm_split16_kernel (fprop and dgrad, uniform-tap shapes with channels % 32 == 0; below) and
 // wgrad_split_kernel.  fp32 output through the LDS-staged epilogue of bf16_tile.h (BN statistics partials, addend;
@@ -22,94 +27,72 @@
 
 namespace mvg {
 
-// acc[i][j] += the six piece products of fragments av[piece][i], bv[piece][j]; product-major (consecutive MFMAs go
-// to different accumulators), smallest terms first: (a1 b3, a3 b1, a2 b2), (a1 b2, a2 b1), a1 b1
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// acc[i][j] += the three piece products of fragments av[piece][i], bv[piece][j] (32x32x16 tiles: wgrad); smallest
+// terms first: (a1 b2, a2 b1), a1 b1
 #define SPLIT_ONE(PA, PB, av, bv, acc)                                                                         \
   _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)                \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[PA][i], bv[PB][j], acc[i][j], 0, 0, 0);
-#define SPLIT_PRODUCTS(av, bv, acc)                                                                            \
-  SPLIT_ONE(0, 2, av, bv, acc) SPLIT_ONE(2, 0, av, bv, acc) SPLIT_ONE(1, 1, av, bv, acc) SPLIT_ONE(0, 1, av, bv, acc) \
-  SPLIT_ONE(1, 0, av, bv, acc) SPLIT_ONE(0, 0, av, bv, acc)
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[PA][i], bv[PB][j], acc[i][j], 0, 0, 0);
+#define SPLIT_PRODUCTS(av, bv, acc) SPLIT_ONE(0, 1, av, bv, acc) SPLIT_ONE(1, 0, av, bv, acc) SPLIT_ONE(0, 0, av, bv, acc)
 
 constexpr int SP_BM = 128, SP_BK = 32;
 
-// fp32 [n8 * 8] -> s3 (layout plumbing for tests and for tensors no kernel writes in s3 directly)
-__global__ __launch_bounds__(256) void split_f32_kernel(const float4 *__restrict__ x, uint4 *__restrict__ out, long long n8) {
+// fp32 [n8 * 8] * scale -> sp (layout plumbing for tests and for tensors no kernel writes in sp directly)
+__global__ __launch_bounds__(256) void split_f32_kernel(const float4 *__restrict__ x, uint4 *__restrict__ out, long long n8, float scale) {
   const long long stride = (long long)gridDim.x * 256;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += stride) {
     const float4 lo = x[2 * i], hi = x[2 * i + 1];
-    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    uint4 q1, q2, q3;
-    split3_chunk(v, q1, q2, q3);
-    out[3 * i] = q1;
-    out[3 * i + 1] = q2;
-    out[3 * i + 2] = q3;
+    const float v[8] = {lo.x * scale, lo.y * scale, lo.z * scale, lo.w * scale, hi.x * scale, hi.y * scale, hi.z * scale, hi.w * scale};
+    uint4 q1, q2;
+    split2_chunk(v, q1, q2);
+    out[2 * i] = q1;
+    out[2 * i + 1] = q2;
   }
 }
 
-// s3 -> fp32 (exact: the three pieces sum without rounding)
-__global__ __launch_bounds__(256) void merge_s3_kernel(const uint4 *__restrict__ x, float4 *__restrict__ out, long long n8) {
+// sp -> fp32: (piece 1 + piece 2) * inv_scale
+__global__ __launch_bounds__(256) void merge_sp_kernel(const uint4 *__restrict__ x, float4 *__restrict__ out, long long n8, float inv_scale) {
   const long long stride = (long long)gridDim.x * 256;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += stride) {
-    const uint4 q1 = x[3 * i], q2 = x[3 * i + 1], q3 = x[3 * i + 2];
-    const unsigned a[4] = {q1.x, q1.y, q1.z, q1.w}, b[4] = {q2.x, q2.y, q2.z, q2.w}, c[4] = {q3.x, q3.y, q3.z, q3.w};
     float v[8];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      v[2 * k] = (bf_lo(a[k]) + bf_lo(b[k])) + bf_lo(c[k]);
-      v[2 * k + 1] = (bf_hi(a[k]) + bf_hi(b[k])) + bf_hi(c[k]);
-    }
-    out[2 * i] = make_float4(v[0], v[1], v[2], v[3]);
-    out[2 * i + 1] = make_float4(v[4], v[5], v[6], v[7]);
+    merge2_chunk(x[2 * i], x[2 * i + 1], v);
+    out[2 * i] = make_float4(v[0] * inv_scale, v[1] * inv_scale, v[2] * inv_scale, v[3] * inv_scale);
+    out[2 * i + 1] = make_float4(v[4] * inv_scale, v[5] * inv_scale, v[6] * inv_scale, v[7] * inv_scale);
   }
 }
 
-// fp32 KRSC weights -> s3 KRSC ([cout][rs*cin]) and, optionally, the s3 transposed copy the backward-data kernel
-// reads (CRSK: [cin][rs*cout]).  One thread per (row, tap, 8-channel chunk) of each output.
-__global__ __launch_bounds__(256) void split_weights_kernel(const float *__restrict__ w, uint4 *__restrict__ wk, uint4 *__restrict__ wt,
-                                                            int cout, int rs, int cin) {
-  const int c8n = cin / 8, o8n = cout / 8;
-  const long long nk = (long long)cout * rs * c8n, nt = wt ? (long long)cin * rs * o8n : 0;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nk + nt; i += (long long)gridDim.x * 256) {
-    float v[8];
-    uint4 *dst;
-    if (i < nk) {
-      const float4 *src = reinterpret_cast<const float4 *>(w + i * 8);          // (o, tap, c8) is the KRSC order itself
-      const float4 lo = src[0], hi = src[1];
-      v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-      dst = wk + 3 * i;
-    } else {
-      const long long j = i - nk;
-      const int o8 = (int)(j % o8n);
-      const long long t = j / o8n;
-      const int tap = (int)(t % rs), c = (int)(t / rs);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = w[((long long)(o8 * 8 + k) * rs + tap) * cin + c];
-      dst = wt + 3 * j;
-    }
-    uint4 q1, q2, q3;
-    split3_chunk(v, q1, q2, q3);
-    dst[0] = q1;
-    dst[1] = q2;
-    dst[2] = q3;
-  }
-}
-
-// Every conv's weight copies of one training step in ONE launch (grid.y = conv): the per-conv launches were
-// latency-bound (53-72 launches of a few microseconds of work each: 0.7 ms per step on the split path, 1.4 ms on
-// the bf16 path).  mode 1: fp32 KRSC -> s3 KRSC (+ s3 CRSK); mode 0: -> bf16 KRSC (cin zero-padded to cin_pad)
-// (+ bf16 CRSK), the layouts of split_weights_kernel / conv_bf16.hip's cast_weights_bf16_kernel.
+// Every conv's weight copies of one training step in TWO launches (grid.y = conv): (1) max |w| per conv, (2) the
+// copies.  mode 1: fp32 KRSC -> sp KRSC (+ sp CRSK), both scaled by 2^k with max |w| * 2^k just below 2^15, and
+// wstat[conv] = {max |w| bits, 2^-k} for the consumers' epilogues; mode 0: -> bf16 KRSC (cin zero-padded to cin_pad)
+// (+ bf16 CRSK), conv_bf16.hip's layouts (no scale).
 struct WPrepItem {
   const float *w;
   void *wk, *wt;
   int cout, rs, cin, cin_pad;
+  float *stat;               // mode 1: [2] device floats {max |w| as uint bits (zero before the absmax launch), 2^-k}
 };
+
+__global__ __launch_bounds__(256) void weights_absmax_kernel(const WPrepItem *__restrict__ items) {
+  const WPrepItem it = items[blockIdx.y];
+  const long long n4 = (long long)it.cout * it.rs * it.cin / 4;
+  float m = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4 *>(it.w)[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned *>(it.stat), __float_as_uint(m));
+}
 
 __global__ __launch_bounds__(256) void weights_prep_batch_kernel(const WPrepItem *__restrict__ items, int mode) {
   const WPrepItem it = items[blockIdx.y];
   const float *__restrict__ w = it.w;
   const int cout = it.cout, rs = it.rs, cin = it.cin;
   if (mode == 1) {
+    const float scale = sp_scale_for(__uint_as_float(*reinterpret_cast<const unsigned *>(it.stat)));
+    if (blockIdx.x == 0 && threadIdx.x == 0) it.stat[1] = 1.f / scale;
     uint4 *wk = reinterpret_cast<uint4 *>(it.wk), *wt = reinterpret_cast<uint4 *>(it.wt);
     const int c8n = cin / 8, o8n = cout / 8;
     const long long nk = (long long)cout * rs * c8n, nt = wt ? (long long)cin * rs * o8n : 0;
@@ -117,10 +100,10 @@ __global__ __launch_bounds__(256) void weights_prep_batch_kernel(const WPrepItem
       float v[8];
       uint4 *dst;
       if (i < nk) {
-        const float4 *src = reinterpret_cast<const float4 *>(w + i * 8);
+        const float4 *src = reinterpret_cast<const float4 *>(w + i * 8);          // (o, tap, c8) is the KRSC order itself
         const float4 lo = src[0], hi = src[1];
         v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-        dst = wk + 3 * i;
+        dst = wk + SP_NP * i;
       } else {
         const long long j = i - nk;
         const int o8 = (int)(j % o8n);
@@ -128,13 +111,14 @@ __global__ __launch_bounds__(256) void weights_prep_batch_kernel(const WPrepItem
         const int tap = (int)(t % rs), c = (int)(t / rs);
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = w[((long long)(o8 * 8 + k) * rs + tap) * cin + c];
-        dst = wt + 3 * j;
+        dst = wt + SP_NP * j;
       }
-      uint4 q1, q2, q3;
-      split3_chunk(v, q1, q2, q3);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] *= scale;
+      uint4 q1, q2;
+      split2_chunk(v, q1, q2);
       dst[0] = q1;
       dst[1] = q2;
-      dst[2] = q3;
     }
     return;
   }
@@ -154,40 +138,46 @@ __global__ __launch_bounds__(256) void weights_prep_batch_kernel(const WPrepItem
 }
 
 // ------------------------------------------------------------------------------------------
-// igemm_split16_kernel: the 128 x BN x 32 tile on v_mfma_f32_16x16x32_bf16 with a "span" loader.
+// igemm_split16_kernel: 128 x BN x 32 tile, 4 waves as 2 x 2 (wave tile 64 x BN/2), v_mfma_f32_16x16x32_f16, a
+// "span" LDS-DMA loader, ONE stage of (128 + BN) x 128 bytes (32 KB) and three (backward-data) or four (forward)
+// workgroups per CU, which cover each other's DMA waits and epilogues.
 //
-// Measured in scripts/kloop_probe.hip (a GEMM sandbox with this tile and a 3x3 conv's operand reuse; MI355X,
-// profiles/r03_kloop_probe.txt) against round 2's kernel (32x32x16 MFMAs, piece-major image), same sync structure (one
-// stage of 48 KB, three workgroups per CU, which cover each other's DMA waits and epilogues):
-//   * loader: +8..19 %.  One LDS-DMA wave-instruction used to fetch, for 16 rows, the four 16-byte chunks of ONE
-//     piece - 64 segments of 16 bytes at a 48-byte stride, three instructions re-touching the same 128-byte lines.
-//     Now an instruction covers 64 CONSECUTIVE 16-byte slots of a row-major LDS image whose rows are the 192
-//     contiguous bytes a row contributes to a K-step (4 chunks x 3 pieces): 5 1/3 rows x 192 contiguous bytes.
-//     The LDS image has no padding (stage = (128 + BN) x 192 bytes, as before): the slot of (chunk cc, piece pc) in
-//     row R is 4 pc + (cc ^ g(R)), g(R) = (-(R >> 2)) & 3, filled by permuting the SOURCE address inside the row's
-//     span (the DMA destination is linear in the lane).  A ds_read_b128 of a fragment is conflict-free for the
-//     16x16x32 operand map (lane: row l & 15, chunk l >> 4) and for the 32x32x16 one (brute-force check in DESIGN.md).
-//   * MFMA shape: +9..10 % on top.  16x16x32 and 32x32x16 need the same cycles per flop and the same LDS reads per
-//     K-step (a 64 x 64 wave tile: 8 fragments per piece either way), but an MFMA-dense loop is clock-limited by
-//     power on this chip and holds a higher clock on the 16x16x32 shape (MI355X_MICROARCH.md, DVFS give-back 7).
-// Row -> address: every lane needs the base offset and tap-validity mask of SIX rows (one per A instruction it
-// issues) instead of two; thread r computes row r's once and the lanes pick theirs up through LDS.
+// What scripts/kloop_probe.hip measured (a GEMM sandbox with this tile and a 3x3 conv's operand reuse; MI355X,
+// profiles/r03_kloop_probe*.txt), step by step from round 2's kernel (three bf16 pieces, 32x32x16 MFMAs,
+// piece-major LDS image) at K = 2304 / 1024:
+//   * span loader: 175 -> 196, 138 -> 164 TF/s.  One LDS-DMA wave-instruction used to fetch, for 16 rows, the four
+//     16-byte chunks of ONE piece - 64 segments of 16 bytes at a 48-byte stride, the pieces' instructions re-touching
+//     the same 128-byte lines.  Now an instruction covers 64 CONSECUTIVE 16-byte slots of a row-major LDS image whose
+//     rows are the contiguous bytes a row contributes to a K-step (4 chunks x 2 pieces = 128 bytes): 8 whole rows.
+//     No padding: the slot of (chunk cc, piece pc) in row R is (2 cc + pc) ^ h(R), h(R) = ((R >> 1) & 1) |
+//     (((R >> 2) & 1) << 2), filled by permuting the SOURCE address inside the row's span (the DMA destination is
+//     linear in the lane); a ds_read_b128 of a 16x16x32 fragment (lane: row l & 15, chunk l >> 4) is conflict-free
+//     (brute-force check: DESIGN.md 4a).
+//   * 16x16x32 instead of 32x32x16 MFMAs: 196 -> 214, 164 -> 177.  Same cycles per flop and the same LDS reads per
+//     K-step, but an MFMA-dense loop is clock-limited by power on this chip and holds a higher clock on this shape
+//     (MI355X_MICROARCH.md, DVFS give-back 7).
+//   * two fp16 pieces and three products instead of three bf16 pieces and six: 214 -> 366, 177 -> 291.
+// Row -> address: every lane needs the base offset and tap-validity mask of FOUR rows (one per A instruction it
+// issues); thread r computes row r's once and the lanes pick theirs up through LDS.
 // ------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define SPLIT16_ONE(PA, PB)                                                                       \
   _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)   \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[PA][i], bv[PB][j], acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[PA][i], bv[PB][j], acc[i][j], 0, 0, 0);
+
+__device__ __forceinline__ int sp_row_swz(int R) { return ((R >> 1) & 1) | (((R >> 2) & 1) << 2); }
 
 template <int BN, bool DGRAD>
-__global__ __launch_bounds__(256, 3) void igemm_split16_kernel(IgemmParams p) {
+__global__ __launch_bounds__(256, DGRAD ? 3 : 4) void igemm_split16_kernel(IgemmParams p) {
   constexpr int BM = 128, WGM = 2, WGN = 2, NW = 4;
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 16, TN = WTN / 16;
-  constexpr int ROWB = 192, ROWS = BM + BN, STAGE_B = ROWS * ROWB;
-  constexpr int NQ = ROWS * 12 / 64;                          // DMA wave-instructions per stage (48 / 36)
-  constexpr int QA = BM * 12 / 64;                            // ... of which the first 24 fill the A rows
-  constexpr int A_PER = QA / NW, B_PER = (NQ - QA) / NW;      // per wave: 6 and 6 / 3
+  constexpr int SLOTS = 4 * SP_NP;                            // 16-byte slots per LDS row (8)
+  constexpr int ROWB = 16 * SLOTS, ROWS = BM + BN, STAGE_B = ROWS * ROWB;
+  constexpr int NQ = ROWS * SLOTS / 64;                       // DMA wave-instructions per stage (32 / 24)
+  constexpr int QA = BM * SLOTS / 64;                         // ... of which the first 16 fill the A rows
+  constexpr int A_PER = QA / NW, B_PER = (NQ - QA) / NW;      // per wave: 4 and 4 / 2
   static_assert(QA % NW == 0 && (NQ - QA) % NW == 0, "whole instructions per wave");
   constexpr int LDO = BN + 4;
   constexpr int EPI_B = (BM / 2) * LDO * 4 + BM * 4;
@@ -222,7 +212,7 @@ __global__ __launch_bounds__(256, 3) void igemm_split16_kernel(IgemmParams p) {
     const int oy = (int)fdiv((unsigned)rem, c.ow_div), ox = rem - oy * c.out_w;
     const int y0 = DGRAD ? oy + c.cls_cy : oy * p.stride - p.pad;
     const int x0 = DGRAD ? ox + c.cls_cx : ox * p.stride - p.pad;
-    const unsigned base = (unsigned)(img * p.src_img_stride * 6) + (unsigned)((y0 * p.src_w + x0) * p.src_c) * 6u;
+    const unsigned base = (unsigned)(img * p.src_img_stride * SP_BYTES) + (unsigned)((y0 * p.src_w + x0) * p.src_c) * (unsigned)SP_BYTES;
     unsigned msk = 0;
     for (int t = 0; t < c.ntaps; ++t) {
       const int fr = (int)fdiv((unsigned)t, c.tap_ns_div), fs = t - fr * c.tap_ns;
@@ -233,27 +223,26 @@ __global__ __launch_bounds__(256, 3) void igemm_split16_kernel(IgemmParams p) {
     rowinfo[tid] = make_uint2(base, ok ? msk : 0u);
   }
   __syncthreads();
-  // ---- the instructions this wave issues: Q = wave + 4 i; lane -> linear slot 64 Q + lane -> (row, slot in row)
+  // ---- the instructions this wave issues: Q = wave + 4 i; lane -> linear slot 64 Q + lane -> (row, slot in row);
+  // the slot holds source slot j = slot ^ h(row) of the row's 128-byte span (j = 2 cc + pc: the memory order)
   unsigned a_base[A_PER], a_vmask[A_PER], b_base[B_PER];
 #pragma unroll
   for (int i = 0; i < A_PER; ++i) {
     const int sl = (wave + NW * i) * 64 + lane;
-    const int row = sl / 12, j = sl - row * 12;
-    const int pc = j >> 2, cc = (j & 3) ^ ((-(row >> 2)) & 3);
+    const int row = sl / SLOTS, j = (sl % SLOTS) ^ sp_row_swz(row);
     const uint2 ri = rowinfo[row];
-    a_base[i] = ri.x + 16u * (unsigned)(cc * 3 + pc);
+    a_base[i] = ri.x + 16u * (unsigned)j;
     a_vmask[i] = ri.y;
   }
 #pragma unroll
   for (int i = 0; i < B_PER; ++i) {
-    const int sl = (wave + NW * (A_PER + i)) * 64 + lane - BM * 12;
-    const int row = sl / 12, j = sl - row * 12;                  // (BM >> 2) & 3 == 0: the swizzle of stage row BM + row is g(row)
-    const int pc = j >> 2, cc = (j & 3) ^ ((-(row >> 2)) & 3);
+    const int sl = (wave + NW * (A_PER + i)) * 64 + lane - BM * SLOTS;
+    const int row = sl / SLOTS, j = (sl % SLOTS) ^ sp_row_swz(row);        // h(BM + row) == h(row): BM is a multiple of 8
     const int n = ntile * BN + row;
-    b_base[i] = pred_off(((unsigned)n * (unsigned)p.b_row_len) * 6u + 16u * (unsigned)(cc * 3 + pc), n < p.ncols);
+    b_base[i] = pred_off(((unsigned)n * (unsigned)p.b_row_len) * (unsigned)SP_BYTES + 16u * (unsigned)j, n < p.ncols);
   }
   const __amdgpu_buffer_rsrc_t rs_a =
-      make_rsrc(reinterpret_cast<const char *>(p.a) + (long long)g * p.imgs_per_group * p.src_img_stride * 6, p.a_group_bytes);
+      make_rsrc(reinterpret_cast<const char *>(p.a) + (long long)g * p.imgs_per_group * p.src_img_stride * SP_BYTES, p.a_group_bytes);
   const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(p.b, p.b_bytes);
   typedef __attribute__((address_space(3))) void *lds_vp;
 
@@ -268,11 +257,11 @@ __global__ __launch_bounds__(256, 3) void igemm_split16_kernel(IgemmParams p) {
     const int chb = ks - (tap_u << p.src_c_shift);
     const int fru = (int)fdiv((unsigned)tap_u, c.tap_ns_div), fsu = tap_u - fru * c.tap_ns;
     const int disp = (fru * p.src_w + fsu) * p.src_c;
-    const unsigned sdelta = (unsigned)(((DGRAD ? -disp : disp) + chb) * 6);
-    unsigned kb = (unsigned)ks * 6u;
+    const unsigned sdelta = (unsigned)(((DGRAD ? -disp : disp) + chb) * SP_BYTES);
+    unsigned kb = (unsigned)ks * (unsigned)SP_BYTES;
     if (DGRAD) {
       const int btap = (c.tap_r0 + p.tap_step * fru) * p.s + c.tap_s0 + p.tap_step * fsu;
-      kb = (unsigned)(btap * p.src_c + chb) * 6u;
+      kb = (unsigned)(btap * p.src_c + chb) * (unsigned)SP_BYTES;
     }
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
@@ -292,18 +281,20 @@ __global__ __launch_bounds__(256, 3) void igemm_split16_kernel(IgemmParams p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
 
-  // fragment addresses: lane -> row (l & 15) of a 16-row tile, chunk cc = l >> 4 -> slot 4 pc + (cc ^ g(row))
+  // fragment addresses: lane -> row (l & 15) of a 16-row tile, chunk cc = l >> 4, piece pc -> slot (2 cc + pc) ^ h(row)
   const int cc_l = lane >> 4;
-  int a_off[TM], b_off[TN];
+  int a_off[TM][SP_NP], b_off[TN][SP_NP];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int R = wm * WTM + i * 16 + (lane & 15);
-    a_off[i] = R * ROWB + ((cc_l ^ ((-(R >> 2)) & 3)) << 4);
+#pragma unroll
+    for (int pc = 0; pc < SP_NP; ++pc) a_off[i][pc] = R * ROWB + (((2 * cc_l + pc) ^ sp_row_swz(R)) << 4);
   }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int R = wn * WTN + j * 16 + (lane & 15);
-    b_off[j] = (BM + R) * ROWB + ((cc_l ^ ((-(R >> 2)) & 3)) << 4);
+#pragma unroll
+    for (int pc = 0; pc < SP_NP; ++pc) b_off[j][pc] = (BM + R) * ROWB + (((2 * cc_l + pc) ^ sp_row_swz(R)) << 4);
   }
 
   for (int kt = 0; kt < KT; ++kt) {
@@ -311,16 +302,16 @@ __global__ __launch_bounds__(256, 3) void igemm_split16_kernel(IgemmParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     {
-      bf16x8 av[3][TM], bv[3][TN];
+      f16x8 av[SP_NP][TM], bv[SP_NP][TN];
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc) {
+      for (int pc = 0; pc < SP_NP; ++pc) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) av[pc][i] = *reinterpret_cast<const bf16x8 *>(smem + a_off[i] + pc * 64);
+        for (int i = 0; i < TM; ++i) av[pc][i] = *reinterpret_cast<const f16x8 *>(smem + a_off[i][pc]);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bv[pc][j] = *reinterpret_cast<const bf16x8 *>(smem + b_off[j] + pc * 64);
+        for (int j = 0; j < TN; ++j) bv[pc][j] = *reinterpret_cast<const f16x8 *>(smem + b_off[j][pc]);
       }
-      // smallest terms first: (a1 b3, a3 b1, a2 b2), (a1 b2, a2 b1), a1 b1
-      SPLIT16_ONE(0, 2) SPLIT16_ONE(2, 0) SPLIT16_ONE(1, 1) SPLIT16_ONE(0, 1) SPLIT16_ONE(1, 0) SPLIT16_ONE(0, 0)
+      // smallest terms first: (a1 b2, a2 b1), a1 b1
+      SPLIT16_ONE(0, 1) SPLIT16_ONE(1, 0) SPLIT16_ONE(0, 0)
     }
     __syncthreads();                                         // everyone is done reading before the next DMA lands
   }
@@ -328,11 +319,11 @@ __global__ __launch_bounds__(256, 3) void igemm_split16_kernel(IgemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// wgrad: dw[o][tap][c] = sum over pixels of dy[pix][o] * x[pix at tap][c] with both operands in s3.  Like the bf16
+// wgrad: dw[o][tap][c] = sum over pixels of dy[pix][o] * x[pix at tap][c] with both operands in sp.  Like the bf16
 // kernel (conv_bf16.hip): M = cout, N = (tap, c), K = pixels split into slabs; the LDS images stay pixel-major
-// [piece][k][m] (rows padded by 32 elements) and the fragments come from ds_read_b64_tr_b16.  A K-step is 16
-// pixels: 30 KB per stage, two stages, two workgroups per CU; a thread's three piece vectors of one 8-channel chunk
-// are 48 contiguous bytes in memory.
+// [piece][k][m] (rows padded by 32 elements) and the fragments come from ds_read_b64_tr_b16 (v_mfma_f32_32x32x16_f16,
+// three products per 16 pixels).  A K-step is 16 pixels: 20 KB per stage, two stages; a thread's two piece vectors of
+// one 8-channel chunk are 32 contiguous bytes in memory.  The result is multiplied by dy's 2^-k (p.dy_sinv).
 // ------------------------------------------------------------------------------------------
 template <int BM, int BN, bool INCR>
 __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradParams p) {
@@ -345,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradParams p) {
   constexpr int A_CPT = MV / A_TPR > 0 ? MV / A_TPR : 1;   // chunks per thread
   constexpr int B_CPT = NVB / A_TPR > 0 ? NVB / A_TPR : 1;
   constexpr int A_ELEMS = BK * LDA, B_ELEMS = BK * LDB;    // one piece
-  constexpr int STAGE = 3 * (A_ELEMS + B_ELEMS);
+  constexpr int STAGE = SP_NP * (A_ELEMS + B_ELEMS);
   __shared__ __attribute__((aligned(16))) unsigned short smem[2 * STAGE];
 
   const int tid = threadIdx.x;
@@ -367,9 +358,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradParams p) {
 
   const char *dy = reinterpret_cast<const char *>(p.dy);
   const char *x = reinterpret_cast<const char *>(p.x);
-  const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(dy + m_begin * p.cout * 6, 6ll * m_count * p.cout);
+  const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(dy + m_begin * p.cout * SP_BYTES, (long long)SP_BYTES * m_count * p.cout);
   const long long x_img_elems = (long long)p.h * p.w * p.cin;
-  const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(x + img0 * x_img_elems * 6, p.x_bytes - 6ll * img0 * x_img_elems);
+  const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(x + img0 * x_img_elems * SP_BYTES, p.x_bytes - (long long)SP_BYTES * img0 * x_img_elems);
   // both loaders: pixel row i_row = tid / 16, chunk lane i_v0 = tid % 16 (+ 16 per extra chunk)
   const int i_row = tid / A_TPR, i_v0 = tid % A_TPR;
   unsigned a_off[A_CPT];
@@ -379,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradParams p) {
     const int cv = i_v0 + j * A_TPR;
     const int col = mtile * BM + cv * 8;
     a_on[j] = cv < MV;
-    a_off[j] = (a_on[j] && col < p.cout) ? (unsigned)(i_row * p.cout + col) * 6u : 0x80000000u;
+    a_off[j] = (a_on[j] && col < p.cout) ? (unsigned)(i_row * p.cout + col) * (unsigned)SP_BYTES : 0x80000000u;
   }
   int i_dy[B_CPT], i_dx[B_CPT];
   unsigned i_tconst[B_CPT];
@@ -395,10 +386,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradParams p) {
     const int fr = (int)fdiv((unsigned)tap, p.s_div), fs = tap - fr * p.s;
     i_dy[j] = fr - p.pad;
     i_dx[j] = fs - p.pad;
-    i_tconst[j] = (unsigned)((i_dy[j] * p.w + i_dx[j]) * p.cin + cc) * 6u;
+    i_tconst[j] = (unsigned)((i_dy[j] * p.w + i_dx[j]) * p.cin + cc) * (unsigned)SP_BYTES;
   }
-  const unsigned row_bytes = (unsigned)(p.stride * p.w * p.cin) * 6u, col_bytes = (unsigned)(p.stride * p.cin) * 6u;
-  const unsigned img_bytes = (unsigned)x_img_elems * 6u;
+  const unsigned row_bytes = (unsigned)(p.stride * p.w * p.cin) * (unsigned)SP_BYTES, col_bytes = (unsigned)(p.stride * p.cin) * (unsigned)SP_BYTES;
+  const unsigned img_bytes = (unsigned)x_img_elems * (unsigned)SP_BYTES;
   int s_oy = 0, s_ox = 0;
   unsigned s_imgoff = 0;
   if (INCR) {
@@ -410,14 +401,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradParams p) {
     s_ox = (int)(rem - oy * (unsigned)p.wo);
     s_imgoff = img * img_bytes;
   }
-  u32x4 a_reg[A_CPT][3], b_reg[B_CPT][3];
+  u32x4 a_reg[A_CPT][SP_NP], b_reg[B_CPT][SP_NP];
   auto load_tiles = [&](int kt) {
 #pragma unroll
     for (int j = 0; j < A_CPT; ++j) {
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc)             // rows >= m_count: beyond the descriptor = zeros
+      for (int pc = 0; pc < SP_NP; ++pc)             // rows >= m_count: beyond the descriptor = zeros
         a_reg[j][pc] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_off[j] + 16u * pc, 0, 0);
-      a_off[j] += (unsigned)(BK * p.cout) * 6u;
+      a_off[j] += (unsigned)(BK * p.cout) * (unsigned)SP_BYTES;
     }
     const bool mok = kt * BK + i_row < m_count;
     int oy, ox;
@@ -441,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradParams p) {
     for (int j = 0; j < B_CPT; ++j) {
       const bool ok = mok & i_cok[j] & ((unsigned)(iy0 + i_dy[j]) < (unsigned)p.h) & ((unsigned)(ix0 + i_dx[j]) < (unsigned)p.w);
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc)
+      for (int pc = 0; pc < SP_NP; ++pc)
         b_reg[j][pc] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, pred_off(pixoff + i_tconst[j] + 16u * pc, ok), 0, 0);
     }
     if constexpr (INCR) {
@@ -458,19 +449,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradParams p) {
   };
   auto store_tiles = [&](int buf) {
     unsigned short *As = smem + buf * STAGE;
-    unsigned short *Bs = As + 3 * A_ELEMS;
+    unsigned short *Bs = As + SP_NP * A_ELEMS;
 #pragma unroll
     for (int j = 0; j < A_CPT; ++j)
       if (a_on[j]) {
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc)
+        for (int pc = 0; pc < SP_NP; ++pc)
           *reinterpret_cast<u32x4 *>(As + pc * A_ELEMS + i_row * LDA + (i_v0 + j * A_TPR) * 8) = a_reg[j][pc];
       }
 #pragma unroll
     for (int j = 0; j < B_CPT; ++j)
       if (b_on[j]) {
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc)
+        for (int pc = 0; pc < SP_NP; ++pc)
           *reinterpret_cast<u32x4 *>(Bs + pc * B_ELEMS + i_row * LDB + (i_v0 + j * A_TPR) * 8) = b_reg[j][pc];
       }
   };
@@ -493,20 +484,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradParams p) {
     store_tiles(cur ^ 1);
     load_tiles(kt + 2);
     const unsigned short *As = smem + cur * STAGE;
-    const unsigned short *Bs = As + 3 * A_ELEMS;
-    bf16x8 av[3][TM], bv[3][TN];
+    const unsigned short *Bs = As + SP_NP * A_ELEMS;
+    f16x8 av[SP_NP][TM], bv[SP_NP][TN];
 #pragma unroll
-    for (int pc = 0; pc < 3; ++pc) {
+    for (int pc = 0; pc < SP_NP; ++pc) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) av[pc][i] = tr_frag(As + pc * A_ELEMS, LDA, 0, wm * WTM + i * 32, lane);
+      for (int i = 0; i < TM; ++i) av[pc][i] = __builtin_bit_cast(f16x8, tr_frag(As + pc * A_ELEMS, LDA, 0, wm * WTM + i * 32, lane));
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bv[pc][j] = tr_frag(Bs + pc * B_ELEMS, LDB, 0, wn * WTN + j * 32, lane);
+      for (int j = 0; j < TN; ++j) bv[pc][j] = __builtin_bit_cast(f16x8, tr_frag(Bs + pc * B_ELEMS, LDB, 0, wn * WTN + j * 32, lane));
     }
     SPLIT_PRODUCTS(av, bv, acc)
     __syncthreads();
   }
 
   float *out = p.out + (long long)split * p.cout * p.ncols;
+  const float osc = p.dy_sinv ? *p.dy_sinv : 1.f;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -517,7 +509,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradParams p) {
         const int row = mtile * BM + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
         if (row < p.cout && col < p.ncols) {
           const long long off = (long long)row * p.ncols + col;
-          float v = acc[i][j][e];
+          float v = acc[i][j][e] * osc;
           if (p.accumulate) v += out[off];
           out[off] = v;
         }
@@ -586,45 +578,63 @@ using namespace mvg;
 
 extern "C" {
 
-int mvg_split_f32(const float *x, void *out_s3, int64_t n, void *stream) {
-  MVG_REQUIRE(x && out_s3 && n >= 0 && n % 8 == 0, "split_f32: null argument or n %% 8 != 0");
+int mvg_split_f32(const float *x, void *out_sp, int64_t n, float scale, void *stream) {
+  MVG_REQUIRE(x && out_sp && n >= 0 && n % 8 == 0, "split_f32: null argument or n %% 8 != 0");
+  MVG_REQUIRE(scale > 0.f, "split_f32: scale must be positive (a power of two keeps the round trip exact)");
   if (n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  ProfScope ps(MVG_K_LAYOUT, st, 0.0, 10.0 * (double)n);
+  ProfScope ps(MVG_K_LAYOUT, st, 0.0, (4.0 + SP_BYTES) * (double)n);
   long long blocks = (n / 8 + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(split_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float4 *)x, (uint4 *)out_s3, (long long)(n / 8));
+  hipLaunchKernelGGL(split_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float4 *)x, (uint4 *)out_sp, (long long)(n / 8), scale);
   return check_launch("split_f32");
 }
 
-int mvg_merge_s3(const void *x_s3, float *out, int64_t n, void *stream) {
-  MVG_REQUIRE(x_s3 && out && n >= 0 && n % 8 == 0, "merge_s3: null argument or n %% 8 != 0");
+int mvg_merge_sp(const void *x_sp, float *out, int64_t n, float inv_scale, void *stream) {
+  MVG_REQUIRE(x_sp && out && n >= 0 && n % 8 == 0, "merge_sp: null argument or n %% 8 != 0");
   if (n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  ProfScope ps(MVG_K_LAYOUT, st, 0.0, 10.0 * (double)n);
+  ProfScope ps(MVG_K_LAYOUT, st, 0.0, (4.0 + SP_BYTES) * (double)n);
   long long blocks = (n / 8 + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(merge_s3_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const uint4 *)x_s3, (float4 *)out, (long long)(n / 8));
-  return check_launch("merge_s3");
+  hipLaunchKernelGGL(merge_sp_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const uint4 *)x_sp, (float4 *)out, (long long)(n / 8), inv_scale);
+  return check_launch("merge_sp");
 }
 
-int mvg_split_weights(const mvg_conv_desc *d, const float *w, void *w_krsc_s3, void *w_crsk_s3, void *stream) {
-  MVG_REQUIRE(d && w && w_krsc_s3, "split_weights: null argument");
+int mvg_split_weights(const mvg_conv_desc *d, const float *w, void *w_krsc_sp, void *w_crsk_sp, float *stat2, void *items_dev,
+                      void *stream) {
+  // one conv through the batched kernels: items_dev = 64 bytes of device memory for the one-record table, stat2 =
+  // two device floats that receive {max |w| bits, 2^-k} (the consumer's b_sinv = stat2 + 1)
+  MVG_REQUIRE(d && w && w_krsc_sp && stat2 && items_dev, "split_weights: null argument");
   if (validate_split(d)) return 2;
   hipStream_t st = (hipStream_t)stream;
-  const long long total = (long long)d->cout * d->r * d->s * d->cin;
-  ProfScope ps(MVG_K_LAYOUT, st, 0.0, (w_crsk_s3 ? 20.0 : 10.0) * (double)total);
-  long long blocks = ((w_crsk_s3 ? 2 : 1) * total / 8 + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, st, w, (uint4 *)w_krsc_s3, (uint4 *)w_crsk_s3, d->cout,
-                     d->r * d->s, d->cin);
-  return check_launch("split_weights");
+  WPrepItem it;
+  memset(&it, 0, sizeof(it));
+  it.w = w;
+  it.wk = w_krsc_sp;
+  it.wt = w_crsk_sp;
+  it.cout = d->cout;
+  it.rs = d->r * d->s;
+  it.cin = d->cin;
+  it.cin_pad = d->cin;
+  it.stat = stat2;
+  static_assert(sizeof(WPrepItem) <= 64, "WPrepItem grew: update the callers' table record size");
+  if (hipMemsetAsync(stat2, 0, 2 * sizeof(float), st) != hipSuccess || hipMemcpyAsync(items_dev, &it, sizeof(it), hipMemcpyHostToDevice, st) != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("split_weights: staging the table record failed");
+    return 1;
+  }
+  return mvg_weights_prep_batch(items_dev, 1, 1, stream);
 }
 
 int mvg_weights_prep_batch(const void *items_dev, int n, int mode, void *stream) {
   MVG_REQUIRE(items_dev != nullptr && n > 0 && (mode == 0 || mode == 1), "weights_prep_batch: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps(MVG_K_LAYOUT, st, 0.0, 0.0);
+  if (mode == 1) {           // max |w| per conv first (the records' stat[0] must be zero: the caller clears them)
+    hipLaunchKernelGGL(weights_absmax_kernel, dim3(16, (unsigned)n), dim3(256), 0, st, (const WPrepItem *)items_dev);
+    if (check_launch("weights_absmax")) return 1;
+  }
   hipLaunchKernelGGL(weights_prep_batch_kernel, dim3(64, (unsigned)n), dim3(256), 0, st, (const WPrepItem *)items_dev, mode);
   return check_launch("weights_prep_batch");
 }
@@ -643,13 +653,15 @@ struct SplitAffine {       // inference forward: y = acc * scale + shift (+ resi
   int residual_s3, relu, out_s3;
 };
 
-static int fprop_split_impl(const mvg_conv_desc *d, const void *x_s3, const void *w_s3, void *y, float *stats, void *stream,
-                            const SplitAffine *aff) {
+static int fprop_split_impl(const mvg_conv_desc *d, const void *x_sp, const float *x_sinv, const void *w_sp, const float *w_sinv,
+                            void *y, float *stats, void *stream, const SplitAffine *aff) {
   if (validate_split(d)) return 2;
   IgemmParams p;
   memset(&p, 0, sizeof(p));
-  p.a = (const float *)x_s3;
-  p.b = (const float *)w_s3;
+  p.a = (const float *)x_sp;
+  p.b = (const float *)w_sp;
+  p.a_sinv = x_sinv;
+  p.b_sinv = w_sinv;
   p.out = (float *)y;
   p.stats = stats;
   if (aff) {
@@ -683,15 +695,15 @@ static int fprop_split_impl(const mvg_conv_desc *d, const void *x_s3, const void
   p.tap_ns = d->s;
   p.tap_step = 1;
   p.cls_step = 1;
-  p.a_group_bytes = 6ll * d->n * p.src_img_stride;
-  p.b_bytes = 6ll * d->cout * p.ktotal;
+  p.a_group_bytes = (long long)SP_BYTES * d->n * p.src_img_stride;
+  p.b_bytes = (long long)SP_BYTES * d->cout * p.ktotal;
   MVG_REQUIRE(p.a_group_bytes < 0x7FFFFFF0ll && p.b_bytes < 0x7FFFFFF0ll, "split conv: a group / the weights exceed 2 GiB");
   MVG_REQUIRE(p.rows_per_group * (long long)d->cout < (1ll << 31), "split conv: a group of the output exceeds 2^31 elements");
   p.tap_ns_div = make_fastdiv((unsigned)p.tap_ns);
   p.ohw_div = make_fastdiv((unsigned)(p.out_h * p.out_w));
   p.ow_div = make_fastdiv((unsigned)p.out_w);
   const double flops = 2.0 * d->groups * (double)p.rows_per_group * d->cout * d->r * d->s * d->cin;
-  const double bytes = 6.0 * (d->groups * (double)d->n * d->h * d->w * d->cin + (double)d->cout * d->r * d->s * d->cin) +
+  const double bytes = (double)SP_BYTES * (d->groups * (double)d->n * d->h * d->w * d->cin + (double)d->cout * d->r * d->s * d->cin) +
                        4.0 * d->groups * (double)p.rows_per_group * d->cout;
   const bool lin = d->r == 1 && d->s == 1 && d->h == 1 && d->w == 1;
   ProfScope ps(lin ? MVG_K_LINEAR_FPROP : MVG_K_CONV_FPROP, (hipStream_t)stream, flops, bytes);
@@ -701,16 +713,17 @@ static int fprop_split_impl(const mvg_conv_desc *d, const void *x_s3, const void
   return launch_igemm_split<false>(p, (hipStream_t)stream);
 }
 
-int mvg_conv_fprop_split(const mvg_conv_desc *d, const void *x_s3, const void *w_s3, float *y, float *stats, void *stream) {
-  return fprop_split_impl(d, x_s3, w_s3, y, stats, stream, nullptr);
+int mvg_conv_fprop_split(const mvg_conv_desc *d, const void *x_sp, const float *x_sinv, const void *w_sp, const float *w_sinv, float *y,
+                         float *stats, void *stream) {
+  return fprop_split_impl(d, x_sp, x_sinv, w_sp, w_sinv, y, stats, stream, nullptr);
 }
 
-int mvg_conv_fprop_split_affine(const mvg_conv_desc *d, const void *x_s3, const void *w_s3, void *out, int out_s3,
-                                const float *scale, const float *shift, const void *residual, int residual_s3, int relu,
-                                void *stream) {
+int mvg_conv_fprop_split_affine(const mvg_conv_desc *d, const void *x_sp, const float *x_sinv, const void *w_sp, const float *w_sinv,
+                                void *out, int out_s3, const float *scale, const float *shift, const void *residual, int residual_s3,
+                                int relu, void *stream) {
   MVG_REQUIRE(scale && shift && out, "fprop_split_affine: scale, shift and out are required");
   const SplitAffine a = {scale, shift, residual, residual_s3, relu, out_s3};
-  return fprop_split_impl(d, x_s3, w_s3, out, nullptr, stream, &a);
+  return fprop_split_impl(d, x_sp, x_sinv, w_sp, w_sinv, out, nullptr, stream, &a);
 }
 
 struct SplitBnFuse {       // fused BatchNorm-backward reduce of the unit whose output gradient dx is (IgemmParams::bn_*)
@@ -718,15 +731,18 @@ struct SplitBnFuse {       // fused BatchNorm-backward reduce of the unit whose 
   const uint8_t *bits;
   const float *mean, *invstd, *rscale, *rshift;
   float *part;
+  unsigned *absmax;
 };
 
-static int dgrad_split_impl(const mvg_conv_desc *d, const void *dy_s3, const void *w_crsk_s3, float *dx, const float *addend,
-                            void *stream, const SplitBnFuse *bnf) {
+static int dgrad_split_impl(const mvg_conv_desc *d, const void *dy_sp, const float *dy_sinv, const void *w_crsk_sp, const float *w_sinv,
+                            float *dx, const float *addend, void *stream, const SplitBnFuse *bnf) {
   if (validate_split(d)) return 2;
   IgemmParams p;
   memset(&p, 0, sizeof(p));
-  p.a = (const float *)dy_s3;
-  p.b = (const float *)w_crsk_s3;
+  p.a = (const float *)dy_sp;
+  p.b = (const float *)w_crsk_sp;
+  p.a_sinv = dy_sinv;
+  p.b_sinv = w_sinv;
   p.out = dx;
   p.addend = addend;
   if (bnf) {
@@ -737,6 +753,7 @@ static int dgrad_split_impl(const mvg_conv_desc *d, const void *dy_s3, const voi
     p.bn_rscale = bnf->rscale;
     p.bn_rshift = bnf->rshift;
     p.bn_part = bnf->part;
+    p.bn_absmax = bnf->absmax;
   }
   p.groups = d->groups;
   p.out_h = d->h;
@@ -758,12 +775,12 @@ static int dgrad_split_impl(const mvg_conv_desc *d, const void *dy_s3, const voi
   p.imgs_per_group = d->n;
   p.full_h = d->h;
   p.full_w = d->w;
-  p.a_group_bytes = 6ll * d->n * p.src_img_stride;
-  p.b_bytes = 6ll * d->cin * p.b_row_len;
+  p.a_group_bytes = (long long)SP_BYTES * d->n * p.src_img_stride;
+  p.b_bytes = (long long)SP_BYTES * d->cin * p.b_row_len;
   MVG_REQUIRE(p.a_group_bytes < 0x7FFFFFF0ll && p.b_bytes < 0x7FFFFFF0ll, "split conv: a group / the weights exceed 2 GiB");
   MVG_REQUIRE((long long)d->n * d->h * d->w * d->cin < (1ll << 31), "split conv: a group of dx exceeds 2^31 elements");
   const double flops = 2.0 * d->groups * (double)d->n * d->ho * d->wo * d->cout * d->r * d->s * d->cin;
-  const double bytes = 6.0 * (d->groups * (double)d->n * d->ho * d->wo * d->cout + (double)d->cout * d->r * d->s * d->cin) +
+  const double bytes = (double)SP_BYTES * (d->groups * (double)d->n * d->ho * d->wo * d->cout + (double)d->cout * d->r * d->s * d->cin) +
                        4.0 * d->groups * (double)d->n * d->h * d->w * d->cin;
   const bool lin = d->r == 1 && d->s == 1 && d->h == 1 && d->w == 1;
   ProfScope ps(lin ? MVG_K_LINEAR_DGRAD : MVG_K_CONV_DGRAD, (hipStream_t)stream, flops, bytes);
@@ -832,9 +849,9 @@ static int dgrad_split_impl(const mvg_conv_desc *d, const void *dy_s3, const voi
   return launch_igemm_split<true>(m, (hipStream_t)stream);
 }
 
-int mvg_conv_dgrad_split(const mvg_conv_desc *d, const void *dy_s3, const void *w_crsk_s3, float *dx, const float *addend,
-                         void *stream) {
-  return dgrad_split_impl(d, dy_s3, w_crsk_s3, dx, addend, stream, nullptr);
+int mvg_conv_dgrad_split(const mvg_conv_desc *d, const void *dy_sp, const float *dy_sinv, const void *w_crsk_sp, const float *w_sinv,
+                         float *dx, const float *addend, void *stream) {
+  return dgrad_split_impl(d, dy_sp, dy_sinv, w_crsk_sp, w_sinv, dx, addend, stream, nullptr);
 }
 
 // row tiles per group of the backward-data launch = partials per group of the fused reduce (0: not fusable)
@@ -844,17 +861,18 @@ int mvg_conv_dgrad_bn_partials_split(const mvg_conv_desc *d) {
   return ceil_div((long long)d->n * d->h * d->w, SP_BM);
 }
 
-int mvg_conv_dgrad_split_bnreduce(const mvg_conv_desc *d, const void *dy_s3, const void *w_crsk_s3, float *dx, const float *addend,
-                                  const float *bn_y, const uint8_t *bn_bits, const float *bn_mean, const float *bn_invstd,
-                                  const float *relu_scale, const float *relu_shift, float *partials, float *s1, float *s2,
-                                  float *dgamma, float *dbeta, int accumulate, void *stream) {
+int mvg_conv_dgrad_split_bnreduce(const mvg_conv_desc *d, const void *dy_sp, const float *dy_sinv, const void *w_crsk_sp,
+                                  const float *w_sinv, float *dx, const float *addend, const float *bn_y, const uint8_t *bn_bits,
+                                  const float *bn_mean, const float *bn_invstd, const float *relu_scale, const float *relu_shift,
+                                  float *partials, float *s1, float *s2, float *dgamma, float *dbeta, int accumulate,
+                                  uint32_t *absmax, void *stream) {
   MVG_REQUIRE(bn_y && bn_mean && bn_invstd && partials && s1 && s2, "dgrad_split_bnreduce: null argument");
   MVG_REQUIRE(!(bn_bits && relu_scale) && ((relu_scale == nullptr) == (relu_shift == nullptr)),
               "dgrad_split_bnreduce: give the ReLU mask either as bits or as (relu_scale, relu_shift)");
   const int P = mvg_conv_dgrad_bn_partials_split(d);
   MVG_REQUIRE(P > 0, "dgrad_split_bnreduce: this shape cannot be fused (stride %d)", d ? d->stride : -1);
-  const SplitBnFuse f = {bn_y, bn_bits, bn_mean, bn_invstd, relu_scale, relu_shift, partials};
-  if (dgrad_split_impl(d, dy_s3, w_crsk_s3, dx, addend, stream, &f)) return 1;
+  const SplitBnFuse f = {bn_y, bn_bits, bn_mean, bn_invstd, relu_scale, relu_shift, partials, absmax};
+  if (dgrad_split_impl(d, dy_sp, dy_sinv, w_crsk_sp, w_sinv, dx, addend, stream, &f)) return 1;
   ProfScope ps(MVG_K_BN_BWD_REDUCE, (hipStream_t)stream, 0.0, 8.0 * d->groups * (double)P * d->cin);
   return bn_bwd_finalize_launch(partials, d->groups, P, d->cin, s1, s2, dgamma, dbeta, accumulate, (hipStream_t)stream);
 }
@@ -882,15 +900,16 @@ int mvg_conv_wgrad_splits_split(const mvg_conv_desc *d) {
   return (int)want;
 }
 
-int mvg_conv_wgrad_split(const mvg_conv_desc *d, const void *x_s3, const void *dy_s3, float *dw, float *workspace, int splits,
-                         int accumulate, void *stream) {
+int mvg_conv_wgrad_split(const mvg_conv_desc *d, const void *x_sp, const void *dy_sp, const float *dy_sinv, float *dw, float *workspace,
+                         int splits, int accumulate, void *stream) {
   if (validate_split(d)) return 2;
   MVG_REQUIRE(splits >= 1, "wgrad_split: splits < 1");
   MVG_REQUIRE(splits == 1 || workspace != nullptr, "wgrad_split: workspace required for splits > 1");
   WgradParams p;
   memset(&p, 0, sizeof(p));
-  p.x = (const float *)x_s3;
-  p.dy = (const float *)dy_s3;
+  p.x = (const float *)x_sp;
+  p.dy = (const float *)dy_sp;
+  p.dy_sinv = dy_sinv;
   p.h = d->h;
   p.w = d->w;
   p.cin = d->cin;
@@ -904,13 +923,13 @@ int mvg_conv_wgrad_split(const mvg_conv_desc *d, const void *x_s3, const void *d
   p.ncols = d->r * d->s * d->cin;
   p.pixels = (long long)d->groups * d->n * d->ho * d->wo;
   p.pixels_per_split = ((p.pixels + splits - 1) / splits + 15) / 16 * 16;
-  p.x_bytes = 6ll * d->groups * d->n * d->h * d->w * d->cin;
+  p.x_bytes = (long long)SP_BYTES * d->groups * d->n * d->h * d->w * d->cin;
   p.ohw_div = make_fastdiv((unsigned)(d->ho * d->wo));
   p.wo_div = make_fastdiv((unsigned)d->wo);
   p.cin_div = make_fastdiv((unsigned)d->cin);
   p.s_div = make_fastdiv((unsigned)d->s);
-  MVG_REQUIRE(p.pixels_per_split * d->cout * 6 < 0x7FFFFFF0ll, "wgrad_split: split too large for 32-bit offsets");
-  MVG_REQUIRE(6ll * (p.pixels_per_split / (d->ho * d->wo) + 2) * d->h * d->w * d->cin < 0x7FFFFFF0ll,
+  MVG_REQUIRE(p.pixels_per_split * d->cout * SP_BYTES < 0x7FFFFFF0ll, "wgrad_split: split too large for 32-bit offsets");
+  MVG_REQUIRE((long long)SP_BYTES * (p.pixels_per_split / (d->ho * d->wo) + 2) * d->h * d->w * d->cin < 0x7FFFFFF0ll,
               "wgrad_split: split too large for 32-bit offsets");
   int bm, bn;
   wgrad_split_tile(d, bm, bn);
@@ -922,7 +941,7 @@ int mvg_conv_wgrad_split(const mvg_conv_desc *d, const void *x_s3, const void *d
   const bool lin = d->r == 1 && d->s == 1 && d->h == 1 && d->w == 1;
   {
     const double flops = 2.0 * (double)p.pixels * d->cout * d->r * d->s * d->cin;
-    const double bytes = 6.0 * ((double)d->groups * d->n * d->h * d->w * d->cin + (double)p.pixels * d->cout) +
+    const double bytes = (double)SP_BYTES * ((double)d->groups * d->n * d->h * d->w * d->cin + (double)p.pixels * d->cout) +
                          4.0 * (double)d->cout * d->r * d->s * d->cin;
     ProfScope ps(lin ? MVG_K_LINEAR_WGRAD : MVG_K_CONV_WGRAD, st, flops, bytes);
     MVG_REQUIRE((long long)p.mtiles * p.ntiles * splits < (1LL << 31), "wgrad_split: grid too large");

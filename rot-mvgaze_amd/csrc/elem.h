@@ -54,60 +54,79 @@ struct Elem<bf16_t> {
   static __device__ __forceinline__ float ld1(const bf16_t *p, long long i) { return __uint_as_float((unsigned)p[i] << 16); }
 };
 
-// "s3" storage (conv_split.hip): an fp32 value as the exact sum of three bf16 pieces; channels in chunks of 8 with
-// the three pieces of a chunk adjacent (48 bytes).  The streaming passes address 4-channel groups like fp32: group
-// i4 is half (i4 & 1) of chunk (i4 >> 1), i.e. three 8-byte accesses 16 bytes apart.
-struct s3_t {
+// "sp" storage (conv_split.hip's operand format): an fp32 value v - times a per-tensor power-of-two scale chosen by
+// the producer, so that the pieces stay inside fp16's range - as TWO fp16 pieces, h1 = fp16(v), h2 = fp16(v - h1)
+// (round to nearest even; v - h1 is exact in fp32).  |v - h1 - h2| <= 2^-24 |v| whenever h2 is a normal fp16 number:
+// half a unit in the last place of the fp32 value itself.  Channels in chunks of 8 with the two pieces of a chunk
+// adjacent (32 bytes, 4 bytes per element).  The streaming passes address 4-channel groups like fp32: group i4 is
+// half (i4 & 1) of chunk (i4 >> 1), i.e. two 8-byte accesses 16 bytes apart.
+struct sp_t {
   unsigned short v;
 };
+constexpr int SP_NP = 2;            // pieces per value
+constexpr int SP_BYTES = 2 * SP_NP; // bytes per element
 
-__device__ __forceinline__ void split3(float v, unsigned short &p1, unsigned short &p2, unsigned short &p3) {
-  const __bf16 h1 = (__bf16)v;
-  float r = v - (float)h1;
-  const __bf16 h2 = (__bf16)r;
-  r -= (float)h2;
-  const __bf16 h3 = (__bf16)r;
+__device__ __forceinline__ void split2(float v, unsigned short &p1, unsigned short &p2) {
+  const _Float16 h1 = (_Float16)v;
+  const _Float16 h2 = (_Float16)(v - (float)h1);
   p1 = __builtin_bit_cast(unsigned short, h1);
   p2 = __builtin_bit_cast(unsigned short, h2);
-  p3 = __builtin_bit_cast(unsigned short, h3);
 }
+__device__ __forceinline__ float h_lo(unsigned v) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(v & 0xFFFFu)); }
+__device__ __forceinline__ float h_hi(unsigned v) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(v >> 16)); }
 
-// 8 consecutive fp32 values -> the chunk's three 16-byte piece vectors
-__device__ __forceinline__ void split3_chunk(const float (&v)[8], uint4 &q1, uint4 &q2, uint4 &q3) {
-  unsigned short a[8], b[8], c[8];
+// 8 consecutive fp32 values -> the chunk's two 16-byte piece vectors
+__device__ __forceinline__ void split2_chunk(const float (&v)[8], uint4 &q1, uint4 &q2) {
+  unsigned short a[8], b[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) split3(v[k], a[k], b[k], c[k]);
+  for (int k = 0; k < 8; ++k) split2(v[k], a[k], b[k]);
   q1 = make_uint4((unsigned)a[0] | ((unsigned)a[1] << 16), (unsigned)a[2] | ((unsigned)a[3] << 16), (unsigned)a[4] | ((unsigned)a[5] << 16),
              (unsigned)a[6] | ((unsigned)a[7] << 16));
   q2 = make_uint4((unsigned)b[0] | ((unsigned)b[1] << 16), (unsigned)b[2] | ((unsigned)b[3] << 16), (unsigned)b[4] | ((unsigned)b[5] << 16),
              (unsigned)b[6] | ((unsigned)b[7] << 16));
-  q3 = make_uint4((unsigned)c[0] | ((unsigned)c[1] << 16), (unsigned)c[2] | ((unsigned)c[3] << 16), (unsigned)c[4] | ((unsigned)c[5] << 16),
-             (unsigned)c[6] | ((unsigned)c[7] << 16));
+}
+// ... and back (the sum of the two pieces: exact in fp32)
+__device__ __forceinline__ void merge2_chunk(const uint4 &q1, const uint4 &q2, float (&v)[8]) {
+  const unsigned a[4] = {q1.x, q1.y, q1.z, q1.w}, b[4] = {q2.x, q2.y, q2.z, q2.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    v[2 * k] = h_lo(a[k]) + h_lo(b[k]);
+    v[2 * k + 1] = h_hi(a[k]) + h_hi(b[k]);
+  }
+}
+
+// The power-of-two scale that maps `bound` (>= every |value| of the tensor) just below 2^15: fp16 then keeps 11 bits
+// for values down to 2^-29 of the bound, and the second piece stays a normal number for values down to 2^-18 of it.
+__device__ __forceinline__ float sp_scale_for(float bound) {
+  if (!(bound > 0.f) || !(bound < 3.0e38f)) return 1.f;
+  int e;
+  (void)frexpf(bound, &e);                      // bound = m * 2^e, m in [0.5, 1)
+  int k = 15 - e;
+  k = k > 100 ? 100 : (k < -100 ? -100 : k);
+  return ldexpf(1.f, k);
 }
 
 template <>
-struct Elem<s3_t> {
-  static constexpr double kBytes = 6.0;
+struct Elem<sp_t> {
+  static constexpr double kBytes = (double)SP_BYTES;
   static constexpr int W = 1;
-  static __device__ __forceinline__ float4 ld4(const s3_t *p, long long i4) {
-    const uint2 *q = reinterpret_cast<const uint2 *>(p) + (i4 >> 1) * 6 + (i4 & 1);
-    const uint2 a = q[0], b = q[2], c = q[4];
-    return make_float4((bf16_lo(a.x) + bf16_lo(b.x)) + bf16_lo(c.x), (bf16_hi(a.x) + bf16_hi(b.x)) + bf16_hi(c.x),
-                       (bf16_lo(a.y) + bf16_lo(b.y)) + bf16_lo(c.y), (bf16_hi(a.y) + bf16_hi(b.y)) + bf16_hi(c.y));
+  static __device__ __forceinline__ float4 ld4(const sp_t *p, long long i4) {
+    const uint2 *q = reinterpret_cast<const uint2 *>(p) + (i4 >> 1) * 4 + (i4 & 1);
+    const uint2 a = q[0], b = q[2];
+    return make_float4(h_lo(a.x) + h_lo(b.x), h_hi(a.x) + h_hi(b.x), h_lo(a.y) + h_lo(b.y), h_hi(a.y) + h_hi(b.y));
   }
-  static __device__ __forceinline__ void st4(s3_t *p, long long i4, float4 v) {
-    unsigned short a[4], b[4], c[4];
-    split3(v.x, a[0], b[0], c[0]);
-    split3(v.y, a[1], b[1], c[1]);
-    split3(v.z, a[2], b[2], c[2]);
-    split3(v.w, a[3], b[3], c[3]);
-    uint2 *q = reinterpret_cast<uint2 *>(p) + (i4 >> 1) * 6 + (i4 & 1);
+  static __device__ __forceinline__ void st4(sp_t *p, long long i4, float4 v) {
+    unsigned short a[4], b[4];
+    split2(v.x, a[0], b[0]);
+    split2(v.y, a[1], b[1]);
+    split2(v.z, a[2], b[2]);
+    split2(v.w, a[3], b[3]);
+    uint2 *q = reinterpret_cast<uint2 *>(p) + (i4 >> 1) * 4 + (i4 & 1);
     q[0] = make_uint2((unsigned)a[0] | ((unsigned)a[1] << 16), (unsigned)a[2] | ((unsigned)a[3] << 16));
     q[2] = make_uint2((unsigned)b[0] | ((unsigned)b[1] << 16), (unsigned)b[2] | ((unsigned)b[3] << 16));
-    q[4] = make_uint2((unsigned)c[0] | ((unsigned)c[1] << 16), (unsigned)c[2] | ((unsigned)c[3] << 16));
   }
-  static __device__ __forceinline__ void ldw(const s3_t *p, long long iw, float4 (&v)[1]) { v[0] = ld4(p, iw); }
-  static __device__ __forceinline__ void stw(s3_t *p, long long iw, const float4 (&v)[1]) { st4(p, iw, v[0]); }
+  static __device__ __forceinline__ void ldw(const sp_t *p, long long iw, float4 (&v)[1]) { v[0] = ld4(p, iw); }
+  static __device__ __forceinline__ void stw(sp_t *p, long long iw, const float4 (&v)[1]) { st4(p, iw, v[0]); }
 };
 
 }  // namespace mvg

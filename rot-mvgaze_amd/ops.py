@@ -18,7 +18,7 @@ Tensor = torch.Tensor
 def _p(t: Optional[Tensor]):
     if t is None:
         return None
-    assert t.is_cuda and t.dtype in (torch.float32, torch.int32, torch.uint8, torch.int16, torch.bfloat16), (t.device, t.dtype)
+    assert t.is_cuda and t.dtype in (torch.float32, torch.int32, torch.uint8, torch.int16, torch.bfloat16, torch.float16), (t.device, t.dtype)
     return C.c_void_p(t.data_ptr())
 
 
@@ -142,35 +142,65 @@ def fuser_wgrad(img_feat, feat, rel, row_img, row_src, dy, dw, db, rows, cf, nve
           "fuser_wgrad")
 
 
-# ---- "split" operands: fp32 values as three bf16 pieces, fp32-accurate products on the bf16 matrix cores
-def split_f32(x: Tensor) -> Tensor:
-    """fp32 [..., C] (C % 8 == 0) -> s3 tensor [..., C/8, 3, 8] bf16 (the three pieces sum to x exactly)."""
+# ---- "split" operands: fp32 values as two fp16 pieces (+ a per-tensor power-of-two scale), fp32-accurate products on
+# the fp16 matrix cores.  An sp tensor is a float16 tensor [..., C/8, 2, 8]; its scale travels as the attribute
+# ``sinv`` - a 1-element fp32 DEVICE tensor holding 2^-k, or absent / None for unscaled tensors (activations).
+def _sinv(t: Optional[Tensor]):
+    return _p(getattr(t, "sinv", None)) if t is not None else None
+
+
+def sp_empty(*shape, device) -> Tensor:
+    """An uninitialised sp tensor for fp32 shape [..., C] (C % 8 == 0): float16 [..., C/8, 2, 8]."""
+    assert shape[-1] % 8 == 0
+    return torch.empty(*shape[:-1], shape[-1] // 8, 2, 8, dtype=torch.float16, device=device)
+
+
+def sp_shape(x_sp: Tensor):
+    return tuple(x_sp.shape[:-3]) + (x_sp.shape[-3] * 8,)
+
+
+def is_sp(t: Optional[Tensor]) -> bool:
+    return t is not None and t.dtype == torch.float16
+
+
+def split_f32(x: Tensor, scale: float = 1.0) -> Tensor:
+    """fp32 [..., C] (C % 8 == 0) -> sp tensor of x * scale (scale: a power of two that puts max |x| * scale below 65504)."""
     assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] % 8 == 0
-    out = torch.empty(*x.shape[:-1], x.shape[-1] // 8, 3, 8, dtype=torch.bfloat16, device=x.device)
-    check(lib().mvg_split_f32(_p(x), _p(out), x.numel(), _s()), "split_f32")
+    out = sp_empty(*x.shape, device=x.device)
+    check(lib().mvg_split_f32(_p(x), _p(out), x.numel(), float(scale), _s()), "split_f32")
+    out.sinv = None if scale == 1.0 else torch.full((1,), 1.0 / scale, dtype=torch.float32, device=x.device)
     return out
 
 
-def merge_s3(x: Tensor) -> Tensor:
-    assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.shape[-2:] == (3, 8)
-    out = torch.empty(*x.shape[:-3], x.shape[-3] * 8, dtype=torch.float32, device=x.device)
-    check(lib().mvg_merge_s3(_p(x), _p(out), out.numel(), _s()), "merge_s3")
+def merge_sp(x: Tensor) -> Tensor:
+    """sp -> fp32 (the sum of the pieces times the tensor's 2^-k; test plumbing: reads sinv on the host)."""
+    assert is_sp(x) and x.is_contiguous() and x.shape[-1] == 8 and x.shape[-2] == 2
+    out = torch.empty(sp_shape(x), dtype=torch.float32, device=x.device)
+    sinv = getattr(x, "sinv", None)
+    check(lib().mvg_merge_sp(_p(x), _p(out), out.numel(), float(sinv.item()) if sinv is not None else 1.0, _s()), "merge_sp")
     return out
+
+
+_items_scratch = {}
 
 
 def split_weights(d: ConvDesc, w: Tensor, need_transposed: bool = True):
-    """fp32 KRSC weights -> (s3 KRSC, s3 CRSK or None)."""
+    """fp32 KRSC weights -> (sp KRSC, sp CRSK or None), both carrying ``sinv`` (2^-k from max |w|)."""
+    assert w.dtype == torch.float32 and w.is_cuda
     rs = d.r * d.s
-    wk = torch.empty(d.cout, rs * d.cin // 8, 3, 8, dtype=torch.bfloat16, device=w.device)
-    wt = torch.empty(d.cin, rs * d.cout // 8, 3, 8, dtype=torch.bfloat16, device=w.device) if need_transposed else None
-    check(lib().mvg_split_weights(C.byref(d), _p(w), _p(wk), _p(wt), _s()), "split_weights")
+    wk = sp_empty(d.cout, rs * d.cin, device=w.device)
+    wt = sp_empty(d.cin, rs * d.cout, device=w.device) if need_transposed else None
+    stat = torch.empty(2, dtype=torch.float32, device=w.device)
+    items = torch.empty(64, dtype=torch.uint8, device=w.device)
+    check(lib().mvg_split_weights(C.byref(d), _p(w), _p(wk), _p(wt), _p(stat), _p(items), _s()), "split_weights")
+    wk.sinv = stat[1:2]
+    if wt is not None:
+        wt.sinv = stat[1:2]
     return wk, wt
 
 
-def weights_prep_batch(items: Tensor, n: int, mode: int):
-    """items: int64 device tensor [n, 5] = (w ptr, wk ptr, wt ptr or 0, cout | rs << 32, cin | cin_pad << 32)."""
-    assert items.is_cuda and items.dtype == torch.int64 and items.is_contiguous() and items.shape == (n, 5)
-    check(lib().mvg_weights_prep_batch(C.c_void_p(items.data_ptr()), n, mode, _s()), "weights_prep_batch")
+def weights_prep_batch(table: Tensor, n: int, mode: int):
+    check(lib().mvg_weights_prep_batch(_p(table), n, mode, _s()), "weights_prep_batch")
 
 
 def conv_stats_partials_split(d: ConvDesc):
@@ -181,21 +211,21 @@ def conv_stats_partials_split(d: ConvDesc):
     return n, rpp.value
 
 
-def conv_fprop_split(d: ConvDesc, x_s3: Tensor, w_s3: Tensor, y: Tensor, stats: Optional[Tensor] = None):
-    check(lib().mvg_conv_fprop_split(C.byref(d), _p(x_s3), _p(w_s3), _p(y), _p(stats), _s()), "conv_fprop_split")
+def conv_fprop_split(d: ConvDesc, x_sp: Tensor, w_sp: Tensor, y: Tensor, stats: Optional[Tensor] = None):
+    check(lib().mvg_conv_fprop_split(C.byref(d), _p(x_sp), _sinv(x_sp), _p(w_sp), _sinv(w_sp), _p(y), _p(stats), _s()), "conv_fprop_split")
 
 
 def conv_fprop_split_affine(d: ConvDesc, x_s3: Tensor, w_s3: Tensor, out: Tensor, scale: Tensor, shift: Tensor,
                             residual: Optional[Tensor], relu: bool):
     """Inference forward on the split kernels, BatchNorm folded: out = relu?(conv * scale + shift (+ residual)).
-    out / residual: fp32 tensors or s3 tensors (bf16 [..., C/8, 3, 8])."""
-    check(lib().mvg_conv_fprop_split_affine(C.byref(d), _p(x_s3), _p(w_s3), _p(out), int(out.dtype == torch.bfloat16), _p(scale),
-                                            _p(shift), _p(residual), int(residual is not None and residual.dtype == torch.bfloat16),
-                                            int(relu), _s()), "conv_fprop_split_affine")
+    out / residual: fp32 tensors or (unscaled) sp tensors."""
+    check(lib().mvg_conv_fprop_split_affine(C.byref(d), _p(x_s3), _sinv(x_s3), _p(w_s3), _sinv(w_s3), _p(out), int(is_sp(out)), _p(scale),
+                                            _p(shift), _p(residual), int(is_sp(residual)), int(relu), _s()), "conv_fprop_split_affine")
 
 
-def conv_dgrad_split(d: ConvDesc, dy_s3: Tensor, wt_s3: Tensor, dx: Tensor, addend: Optional[Tensor] = None):
-    check(lib().mvg_conv_dgrad_split(C.byref(d), _p(dy_s3), _p(wt_s3), _p(dx), _p(addend), _s()), "conv_dgrad_split")
+def conv_dgrad_split(d: ConvDesc, dy_sp: Tensor, wt_sp: Tensor, dx: Tensor, addend: Optional[Tensor] = None):
+    check(lib().mvg_conv_dgrad_split(C.byref(d), _p(dy_sp), _sinv(dy_sp), _p(wt_sp), _sinv(wt_sp), _p(dx), _p(addend), _s()),
+          "conv_dgrad_split")
 
 
 def conv_dgrad_bn_partials_split(d: ConvDesc) -> int:
@@ -206,14 +236,15 @@ def conv_dgrad_bn_partials_split(d: ConvDesc) -> int:
 
 
 def conv_dgrad_split_bnreduce(d: ConvDesc, dy_s3, wt_s3, dx, addend, bn_y, bn_bits, bn_mean, bn_invstd, relu_affine, s1, s2, dgamma,
-                              dbeta, accumulate: bool):
-    """conv_dgrad_split + the BatchNorm-backward reduce pass of the unit whose output gradient dx is, in one launch."""
+                              dbeta, accumulate: bool, absmax: Optional[Tensor] = None):
+    """conv_dgrad_split + the BatchNorm-backward reduce pass of the unit whose output gradient dx is, in one launch.
+    absmax (1-element int32 tensor, cleared by the caller): receives max |dx| as float bits (bn_bwd_apply_split's bound)."""
     P = conv_dgrad_bn_partials_split(d)
     part = torch.empty(d.groups * P * 2 * d.cin, dtype=torch.float32, device=dx.device)
     rs, rh = relu_affine if relu_affine is not None else (None, None)
-    check(lib().mvg_conv_dgrad_split_bnreduce(C.byref(d), _p(dy_s3), _p(wt_s3), _p(dx), _p(addend), _p(bn_y), _p(bn_bits), _p(bn_mean),
-                                              _p(bn_invstd), _p(rs), _p(rh), _p(part), _p(s1), _p(s2), _p(dgamma), _p(dbeta),
-                                              int(accumulate), _s()), "conv_dgrad_split_bnreduce")
+    check(lib().mvg_conv_dgrad_split_bnreduce(C.byref(d), _p(dy_s3), _sinv(dy_s3), _p(wt_s3), _sinv(wt_s3), _p(dx), _p(addend), _p(bn_y),
+                                              _p(bn_bits), _p(bn_mean), _p(bn_invstd), _p(rs), _p(rh), _p(part), _p(s1), _p(s2),
+                                              _p(dgamma), _p(dbeta), int(accumulate), _p(absmax), _s()), "conv_dgrad_split_bnreduce")
 
 
 def conv_wgrad_split(d: ConvDesc, x_s3: Tensor, dy_s3: Tensor, dw: Tensor, accumulate: bool = False):
@@ -221,18 +252,9 @@ def conv_wgrad_split(d: ConvDesc, x_s3: Tensor, dy_s3: Tensor, dw: Tensor, accum
     if splits < 1:
         check(1, "conv_wgrad_splits_split")
     ws = torch.empty(splits * dw.numel(), dtype=torch.float32, device=dw.device) if splits > 1 else None
-    check(lib().mvg_conv_wgrad_split(C.byref(d), _p(x_s3), _p(dy_s3), _p(dw), _p(ws), splits, int(accumulate), _s()),
+    assert getattr(x_s3, "sinv", None) is None, "conv_wgrad_split: the activation operand is stored unscaled"
+    check(lib().mvg_conv_wgrad_split(C.byref(d), _p(x_s3), _p(dy_s3), _sinv(dy_s3), _p(dw), _p(ws), splits, int(accumulate), _s()),
           "conv_wgrad_split")
-
-
-def s3_empty(*shape, device) -> Tensor:
-    """An uninitialised s3 tensor for fp32 shape [..., C] (C % 8 == 0): bf16 [..., C/8, 3, 8]."""
-    assert shape[-1] % 8 == 0
-    return torch.empty(*shape[:-1], shape[-1] // 8, 3, 8, dtype=torch.bfloat16, device=device)
-
-
-def s3_shape(x_s3: Tensor):
-    return tuple(x_s3.shape[:-3]) + (x_s3.shape[-3] * 8,)
 
 
 def bn_apply_split(y, scale, shift, residual, relu, out_s3, groups, rows_per_group, c, residual_affine=None, want_bits=False):
@@ -240,16 +262,32 @@ def bn_apply_split(y, scale, shift, residual, relu, out_s3, groups, rows_per_gro
     downsample output with residual_affine = its (scale, shift).  want_bits: also return the ReLU mask bytes."""
     bits = torch.empty(groups * rows_per_group * c // 4, dtype=torch.uint8, device=y.device) if want_bits else None
     rs, rh = residual_affine if residual_affine is not None else (None, None)
-    res_s3 = residual is not None and residual.dtype == torch.bfloat16
+    res_s3 = is_sp(residual)
     check(lib().mvg_bn_apply_split(_p(y), _p(scale), _p(shift), _p(residual), int(res_s3), _p(rs), _p(rh), int(relu), _p(out_s3),
                                    _p(bits), groups, rows_per_group, c, _s()), "bn_apply_split")
     return bits
 
 
-def bn_bwd_apply_split(g, y, mean, invstd, gamma, s1, s2, groups, rows_per_group, c, dy_s3, relu_affine=None):
+def bn_bwd_reduce_split(g, relu_bits, y, mean, invstd, groups, rows_per_group, c, s1, s2, dgamma, dbeta, accumulate, absmax,
+                        relu_affine=None, dz_out=None):
+    """The backward reduce pass of a unit whose dy goes out in sp: s1, s2 (+ dgamma, dbeta) and max |masked gradient| (float
+    bits, atomicMax into the 1-element int32 tensor ``absmax``, which the caller cleared)."""
     rs, rh = relu_affine if relu_affine is not None else (None, None)
+    n = lib().mvg_bn_bwd_workspace_floats(groups, rows_per_group, c)
+    ws = torch.empty(n, dtype=torch.float32, device=g.device)
+    check(lib().mvg_bn_bwd_reduce_split(_p(g), _p(relu_bits), _p(y), _p(mean), _p(invstd), _p(rs), _p(rh), groups, rows_per_group, c,
+                                        _p(s1), _p(s2), _p(dgamma), _p(dbeta), int(accumulate), _p(ws), _p(dz_out), _p(absmax), _s()),
+          "bn_bwd_reduce_split")
+
+
+def bn_bwd_apply_split(g, y, mean, invstd, gamma, s1, s2, groups, rows_per_group, c, dy_s3, relu_affine=None, absmax=None):
+    """dy (sp) = BatchNorm backward of the masked gradient g, scaled by the 2^k that its bound - from ``absmax`` (max |masked
+    gradient| bits, left by the reduce pass) - allows; dy_s3.sinv receives 2^-k."""
+    rs, rh = relu_affine if relu_affine is not None else (None, None)
+    assert absmax is not None and absmax.dtype == torch.int32
+    dy_s3.sinv = torch.empty(1, dtype=torch.float32, device=g.device)
     check(lib().mvg_bn_bwd_apply_split(_p(g), _p(y), _p(mean), _p(invstd), _p(gamma), _p(s1), _p(s2), _p(rs), _p(rh), groups,
-                                       rows_per_group, c, _p(dy_s3), _s()), "bn_bwd_apply_split")
+                                       rows_per_group, c, _p(dy_s3), _p(absmax), _p(dy_s3.sinv), _s()), "bn_bwd_apply_split")
 
 
 def bn_relu_maxpool_fwd_split(y, scale, shift, pooled_s3, argmax, groups, n_per_group, h, w, c, ho, wo):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Achieved HBM rate of the BatchNorm streaming passes on the ResNet-50 tensor shapes of one workload
-(synthetic data).  Usage: bn_bench.py [N per view] [views] [f32|split]   (split: the passes that write s3)"""
+(synthetic data).  Usage: bn_bench.py [N per view] [views] [f32|split]   (split: the passes that write sp)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -20,7 +20,7 @@ def timeit(fn, iters=10):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / iters
 
-print(f"N={N} G={G} {'split (s3 outputs)' if split else 'fp32'}: pass, ms, GB/s (algorithmic bytes)")
+print(f"N={N} G={G} {'split (sp outputs)' if split else 'fp32'}: pass, ms, GB/s (algorithmic bytes)")
 tot = {}
 for hw, C, cnt_plain, cnt_res in [(56, 64, 7, 0), (56, 256, 0, 3), (28, 128, 8, 0), (28, 512, 0, 4), (14, 256, 12, 0), (14, 1024, 0, 6),
                                   (7, 512, 6, 0), (7, 2048, 0, 3)]:
@@ -36,13 +36,14 @@ for hw, C, cnt_plain, cnt_res in [(56, 64, 7, 0), (56, 256, 0, 3), (28, 128, 8, 
     res = cnt_res > 0
     cnt = cnt_plain + cnt_res
     if split:
-        out = ops.s3_empty(G, rows, C, device=dev)
+        out = ops.sp_empty(G, rows, C, device=dev)
         r = ops.split_f32(torch.randn(G, rows, C, device=dev)) if res else None
         t_apply = timeit(lambda: ops.bn_apply_split(y, scale, shift, r, True, out, G, rows, C, None, want_bits=res))
-        b_apply = n * (4 + 6 + (6.25 if res else 0))
-        dy = ops.s3_empty(G, rows, C, device=dev)
-        t_bapply = timeit(lambda: ops.bn_bwd_apply_split(g, y, mean, invstd, gamma, s1, s2, G, rows, C, dy, None if res else (scale, shift)))
-        b_bapply = n * 14
+        b_apply = n * (4 + 4 + (4.25 if res else 0))
+        dy = ops.sp_empty(G, rows, C, device=dev)
+        absmax = g.abs().max().reshape(1).view(torch.int32).clone()
+        t_bapply = timeit(lambda: ops.bn_bwd_apply_split(g, y, mean, invstd, gamma, s1, s2, G, rows, C, dy, None if res else (scale, shift), absmax))
+        b_bapply = n * 12
     else:
         out = torch.empty_like(y)
         r = torch.randn(G, rows, C, device=dev) if res else None

@@ -528,6 +528,114 @@ __global__ __launch_bounds__(NW * 64, WPC) void k_sw(P p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// TWO fp16 pieces per fp32 value (h1 = fp16(a), h2 = fp16(a - h1): |a - h1 - h2| <= 2^-24 |a|, half an fp32 ulp),
+// v_mfma_f32_16x16x32_f16, NPROD = 3 (h1 g1, h1 g2, h2 g1) or 4 products.  Rows of 128 B = 8 slots, slot of
+// (chunk cc, piece pc) in row R = (2 cc + pc) ^ h(R), h(R) = ((R >> 1) & 1) | (((R >> 2) & 1) << 2): conflict-free.
+// ------------------------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <int BM, int BN, int NW, int WPC, int NPROD, bool NODMA>
+__global__ __launch_bounds__(NW * 64, WPC) void k_h2(P p) {
+  constexpr int WGN = 2, WGM = NW / 2;
+  constexpr int WTM = BM / WGM, WTN = BN / WGN, TM = WTM / 16, TN = WTN / 16;
+  constexpr int ROWB = 128, ROWS = BM + BN, STAGE_B = ROWS * ROWB;
+  constexpr int NQ = ROWS * 8 / 64, QPW = (NQ + NW - 1) / NW;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[STAGE_B];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int ntile = wg % p.ntiles, mtile = wg / p.ntiles;
+  auto hsw = [](int R) { return ((R >> 1) & 1) | (((R >> 2) & 1) << 2); };
+  unsigned q_base[QPW];
+#pragma unroll
+  for (int i = 0; i < QPW; ++i) {
+    const int Q = wave + NW * i;
+    const int s = Q * 64 + lane;
+    const int row = s >> 3, j = (s & 7) ^ hsw(row);            // j = 2 cc + pc: the memory order of the row's 128-byte span
+    const bool isb = row >= BM;
+    bool ok = Q < NQ;
+    unsigned base;
+    if (!isb) {
+      const int m = mtile * BM + row;
+      ok = ok && m < p.M;
+      base = (unsigned)(m + p.pad_rows) * (unsigned)p.C * 4u + 16u * j;
+    } else {
+      const int n = ntile * BN + (row - BM);
+      ok = ok && n < p.N;
+      base = (unsigned)n * (unsigned)(p.taps * p.C) * 4u + 16u * j;
+    }
+    q_base[i] = pred_off(base, ok);
+  }
+  const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(p.a, p.a_bytes), rs_b = make_rsrc(p.b, p.b_bytes);
+  const int cblks = p.C / 32;
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+  const int cc = lane >> 4;
+  int a_off[TM][2], b_off[TN][2];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int R = wm * WTM + i * 16 + (lane & 15);
+#pragma unroll
+    for (int pc = 0; pc < 2; ++pc) a_off[i][pc] = R * ROWB + (((2 * cc + pc) ^ hsw(R)) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int R = BM + wn * WTN + j * 16 + (lane & 15);
+#pragma unroll
+    for (int pc = 0; pc < 2; ++pc) b_off[j][pc] = R * ROWB + (((2 * cc + pc) ^ hsw(R)) << 4);
+  }
+  const int KT = p.KT;
+  for (int kt = 0; kt < KT; ++kt) {
+    if (!NODMA || kt == 0) {
+      const int tap = __builtin_amdgcn_readfirstlane(kt / cblks), cb = __builtin_amdgcn_readfirstlane(kt - tap * cblks);
+      const unsigned d_a = (unsigned)((p.toff[tap] * p.C + cb * 32) * 4), d_b = (unsigned)((tap * p.C + cb * 32) * 4);
+#pragma unroll
+      for (int i = 0; i < QPW; ++i) {
+        const int Q = wave + NW * i;
+        if (Q < NQ) {
+          if (Q * 64 >= BM * 8)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_vp)(smem + Q * 1024), 16, (int)(q_base[i] + d_b), 0, 0, 0);
+          else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_vp)(smem + Q * 1024), 16, (int)(q_base[i] + d_a), 0, 0, 0);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    {
+      f16x8 av[2][TM], bv[2][TN];
+#pragma unroll
+      for (int pc = 0; pc < 2; ++pc) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) av[pc][i] = *reinterpret_cast<const f16x8 *>(smem + a_off[i][pc]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bv[pc][j] = *reinterpret_cast<const f16x8 *>(smem + b_off[j][pc]);
+      }
+#define ONEH(PA, PB)                                                                               \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)    \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[PA][i], bv[PB][j], acc[i][j], 0, 0, 0);
+      if (NPROD == 4) { ONEH(1, 1) }
+      ONEH(0, 1) ONEH(1, 0) ONEH(0, 0)
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = mtile * BM + wm * WTM + i * 16 + (lane >> 4) * 4 + e, ccol = ntile * BN + wn * WTN + j * 16 + (lane & 15);
+        if (r < p.M && ccol < p.N) p.c[(long long)r * p.N + ccol] = acc[i][j][e];
+      }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 static unsigned short f2bf(float x) {
   unsigned u;
@@ -559,11 +667,29 @@ static void to_s3(const std::vector<float> &x, long long rows, int C, std::vecto
     }
 }
 
+// fp32 [rows][C] -> s2h: 8-channel chunks, the two fp16 pieces of a chunk adjacent (4 bytes per element)
+static void to_s2h(const std::vector<float> &x, long long rows, int C, std::vector<unsigned short> &out) {
+  out.resize((size_t)rows * C * 2);
+  for (long long r = 0; r < rows; ++r)
+    for (int c = 0; c < C; ++c) {
+      const float v = x[(size_t)r * C + c];
+      const _Float16 h1 = (_Float16)v;
+      const _Float16 h2 = (_Float16)(v - (float)h1);
+      unsigned short u1, u2;
+      memcpy(&u1, &h1, 2);
+      memcpy(&u2, &h2, 2);
+      const size_t base = ((size_t)r * (C / 8) + c / 8) * 2 * 8 + c % 8;
+      out[base] = u1;
+      out[base + 8] = u2;
+    }
+}
+
 struct Variant {
   const char *name;
   void (*kern)(P);
   int bm, bn, threads;
   size_t lds;
+  int fmt = 0;            // 0: s3 operands, 1: s2h operands
 };
 
 int main(int argc, char **argv) {
@@ -593,6 +719,14 @@ int main(int argc, char **argv) {
   CHECK(hipMemcpy(da, sa.data(), p.a_bytes, hipMemcpyHostToDevice));
   CHECK(hipMemcpy(db, sb.data(), p.b_bytes, hipMemcpyHostToDevice));
   p.a = da; p.b = db; p.c = dc;
+  std::vector<unsigned short> ha2, hb2;
+  to_s2h(ha, arows, C, ha2);
+  to_s2h(hb, N, taps * C, hb2);
+  unsigned short *da2, *db2;
+  CHECK(hipMalloc(&da2, ha2.size() * 2)); CHECK(hipMalloc(&db2, hb2.size() * 2));
+  CHECK(hipMemcpy(da2, ha2.data(), ha2.size() * 2, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(db2, hb2.data(), hb2.size() * 2, hipMemcpyHostToDevice));
+  const long long a_bytes3 = p.a_bytes, b_bytes3 = p.b_bytes;
 
   std::vector<Variant> vs = {
       {"small1", k_piece<128, 128, 4, 1, 3>, 128, 128, 256, 0},
@@ -607,6 +741,10 @@ int main(int argc, char **argv) {
       {"sw16_big2", k_sw<256, 128, 8, 2, 1, true, false>, 256, 128, 512, 0},
       {"sw32_big2_nodma", k_sw<256, 128, 8, 2, 1, false, true>, 256, 128, 512, 0},
       {"sw16_big2_nodma", k_sw<256, 128, 8, 2, 1, true, true>, 256, 128, 512, 0},
+      {"h2_3prod_wpc3", k_h2<128, 128, 4, 3, 3, false>, 128, 128, 256, 0, 1},
+      {"h2_4prod_wpc3", k_h2<128, 128, 4, 3, 4, false>, 128, 128, 256, 0, 1},
+      {"h2_3prod_wpc4", k_h2<128, 128, 4, 4, 3, false>, 128, 128, 256, 0, 1},
+      {"h2_3prod_wpc3_nodma", k_h2<128, 128, 4, 3, 3, true>, 128, 128, 256, 0, 1},
       {"big2", k_piece<256, 128, 8, 2, 1>, 256, 128, 512, 0},
       {"big2s", k_span<256, 128, 8, 2, 1, 0, false, false>, 256, 128, 512, 0},
       {"big2si", k_span<256, 128, 8, 2, 1, 1, false, false>, 256, 128, 512, 0},
@@ -634,6 +772,8 @@ int main(int argc, char **argv) {
       if (!hit) continue;
     }
     p.mtiles = (M + v.bm - 1) / v.bm; p.ntiles = (N + v.bn - 1) / v.bn;
+    p.a = v.fmt ? da2 : da; p.b = v.fmt ? db2 : db;
+    p.a_bytes = v.fmt ? (long long)ha2.size() * 2 : a_bytes3; p.b_bytes = v.fmt ? (long long)hb2.size() * 2 : b_bytes3;
     const int grid = p.mtiles * p.ntiles;
     CHECK(hipMemset(dc, 0, (size_t)M * N * 4));
     hipLaunchKernelGGL(v.kern, dim3(grid), dim3(v.threads), 0, 0, p);
@@ -658,7 +798,7 @@ int main(int argc, char **argv) {
     float ms;
     CHECK(hipEventElapsedTime(&ms, e0, e1));
     ms /= reps;
-    const double stage_bytes = (double)(v.bm + v.bn) * 192.0;
+    const double stage_bytes = (double)(v.bm + v.bn) * (v.fmt ? 128.0 : 192.0);
     printf("%-16s grid %6d  %8.3f ms  %7.1f TF/s  ingest %6.2f TB/s  err %.2e (max |ref| %.1f)\n", v.name, grid, ms, flops / ms / 1e9,
            stage_bytes * p.KT * grid / ms / 1e9, maxerr / maxref, maxref);
     fflush(stdout);

@@ -243,9 +243,9 @@ def _captured_masks(m, V=2):
     def unit_mask(u, v):
         if u.out is not None:
             o = u.out[v].contiguous()
-            if o.dtype == torch.bfloat16:           # split path: the activation is stored as three bf16 pieces (exact sum)
+            if o.dtype == torch.float16:            # split path: the activation is stored as two fp16 pieces (sp)
                 from rot_mvgaze_amd import ops
-                o = ops.merge_s3(o)
+                o = ops.merge_sp(o)
             return o > 0
         # fused stem: the normalised map is not stored; the kernels use fma(y, scale, shift) > 0, whose
         # sign equals the sign of the exact value (evaluated here in fp64)
@@ -599,7 +599,7 @@ def test_split_and_fp32_mfma_kernels_give_the_same_step(depth, batch, hw):
 
 
 def test_split_kernels_step_aside_when_a_view_would_not_fit_32_bit_offsets(monkeypatch):
-    """One view of the largest s3 tensor (6 bytes per element) must stay below 2 GiB; beyond that the call runs on the
+    """One view of the largest sp tensor (4 bytes per element) must stay below 2 GiB; beyond that the call runs on the
     fp32-MFMA kernels.  Exercised by scaling the guard's size estimate, not by allocating 2 GiB."""
     import rot_mvgaze_amd.backbone as B
     m = build(18)
@@ -750,7 +750,7 @@ def test_benchmark_configuration_c4_share_full_size_against_oracle():
 
 def test_benchmark_configuration_c3_full_size_against_oracle():
     """C3 - the workload the headline number is quoted on - at FULL size: ResNet-50, V = 4, B = 128, 224 x 224
-    (512 images, 1536 fusion-block rows, bench.py's weights and inputs; s3 activations of 617 MB per view against
+    (512 images, 1536 fusion-block rows, bench.py's weights and inputs; sp activations of 411 MB per view against
     the 2 GiB guard of the split kernels, more than 2 GiB across views).  The HIP TRAINING forward against the CPU
     oracle's forward (batch statistics) on the same inputs: loss and EVERY pair's gaze predictions and fused
     features of every iteration within the north star's 1e-4 (rot_mv.py:187-269 per pair), and the split-operand
@@ -976,7 +976,7 @@ def test_training_step_does_not_synchronise_the_host():
 
 
 def test_inference_weight_cache_follows_parameter_updates():
-    """The inference path keeps s3 copies of the conv weights between calls; an optimizer step (torch's or the fused
+    """The inference path keeps sp copies of the conv weights between calls; an optimizer step (torch's or the fused
     one, which writes through raw pointers), load_state_dict or an in-place edit must invalidate them."""
     from rot_mvgaze_amd.optim import Adam
     m = build(18)
@@ -1029,7 +1029,7 @@ def test_inference_weight_cache_misses_writes_through_data_until_invalidated():
 
 
 def test_backward_of_a_tape_whose_weight_copies_were_overwritten_raises():
-    """Tapes point into the persistent buffers that hold a step's s3 / bf16 weight copies.  forward A, weights change,
+    """Tapes point into the persistent buffers that hold a step's sp / bf16 weight copies.  forward A, weights change,
     forward B, backward A would run backward-data of A with B's weights: it raises instead (like PyTorch's
     version-counter check).  Without a weight change in between the older tape is still good."""
     m = build(18)
