@@ -441,8 +441,8 @@ int mvg_nchw_to_nhwc8_bf16(const float *src, uint16_t *dst, int n, int c, int h,
 
 /* ---- "split" operands: fp32-accurate convolutions on the fp16 matrix cores (csrc/conv_split.hip) ----------------
  * An fp32 tensor in "sp" format holds every value v - times a per-tensor power-of-two scale 2^k chosen by its producer -
- * as TWO fp16 pieces, h1 = fp16(v 2^k), h2 = fp16(v 2^k - h1): |v - (h1 + h2) 2^-k| <= 2^-24 |v|, half a unit in the last
- * place of the fp32 value.  Channels go in chunks of 8 with the two pieces of a chunk adjacent (4 bytes per element).
+ * as TWO fp16 pieces, h1 = fp16(v 2^k), h2 = fp16(v 2^k - h1): |v - (h1 + h2) 2^-k| <= 2^-23 |v| (at most the last of the
+ * 24 significand bits is lost; three values in four are exact).  Channels go in chunks of 8 with the two pieces of a chunk adjacent (4 bytes per element).
  * Three fp16 MFMAs per 32 k (h1 g1 + h1 g2 + h2 g1, fp32 accumulation) reproduce the fp32 product to fp32-accumulation
  * accuracy (conv_split.hip header; tests/test_split_gpu.py holds every kernel to 2e-6 against fp64 and to the
  * fp32-MFMA kernel's own error), so these entries serve the same 1e-4 parity path as mvg_conv_fprop / _dgrad / _wgrad
@@ -482,19 +482,19 @@ int mvg_conv_dgrad_split(const mvg_conv_desc *d, const void *dy_sp, const float 
  * when residual_s3 != 0, else the raw fp32 downsample output with its res_scale / res_shift), the stem's pooled map
  * (mvg_bn_relu_maxpool_fwd_split) and dy (mvg_bn_bwd_apply_split: g already masked, or the mask from relu_scale /
  * relu_shift).  relu_bits as in mvg_bn_apply_bits (1 byte per 4 channels).  mvg_avgpool_fwd_split pools an sp map.
- * dy is stored times 2^k, k from the bound  max |gamma invstd| * M * (2 + sqrt(rows_per_group)) >= |dy|, M = max |masked
- * gradient| = *absmax (float bits; left there by mvg_bn_bwd_reduce_split or mvg_conv_dgrad_split_bnreduce, which
- * atomicMax into it: clear it before); *dy_sinv receives 2^-k for mvg_conv_dgrad_split / _wgrad_split. */
+ * dy is stored times 2^k, k from the bound  max over (group, channel) of |gamma invstd| (mx + |s1|/n + sqrt(n) |s2|/n) >= |dy|,
+ * mx [groups][c] = max |masked gradient| per (group, channel), left by mvg_bn_bwd_reduce_split or
+ * mvg_conv_dgrad_split_bnreduce; *dy_sinv receives 2^-k for mvg_conv_dgrad_split / _wgrad_split. */
 int mvg_bn_apply_split(const float *y, const float *scale, const float *shift, const void *residual, int residual_s3,
                        const float *res_scale, const float *res_shift, int relu, void *out_s3, uint8_t *relu_bits,
                        int groups, int64_t rows_per_group, int c, void *stream);
 int mvg_bn_bwd_reduce_split(const float *g, const uint8_t *relu_bits, const float *y, const float *mean, const float *invstd,
                             const float *relu_scale, const float *relu_shift, int groups, int64_t rows_per_group, int c,
                             float *s1, float *s2, float *dgamma, float *dbeta, int accumulate, float *workspace,
-                            float *dz_out, uint32_t *absmax, void *stream);
+                            float *dz_out, float *mx, void *stream);
 int mvg_bn_bwd_apply_split(const float *g, const float *y, const float *mean, const float *invstd, const float *gamma,
                            const float *s1, const float *s2, const float *relu_scale, const float *relu_shift,
-                           int groups, int64_t rows_per_group, int c, void *dy_s3, const uint32_t *absmax, float *dy_sinv,
+                           int groups, int64_t rows_per_group, int c, void *dy_s3, const float *mx, float *dy_sinv,
                            void *stream);
 int mvg_bn_relu_maxpool_fwd_split(const float *y, const float *scale, const float *shift, void *pooled_s3,
                                   uint8_t *argmax, int groups, int n_per_group, int h, int w, int c, int ho, int wo,
@@ -502,14 +502,14 @@ int mvg_bn_relu_maxpool_fwd_split(const float *y, const float *scale, const floa
 int mvg_avgpool_fwd_split(const void *x_s3, float *y, int n, int hw, int c, void *stream);
 /* mvg_conv_dgrad_split fused with the BatchNorm-backward reduce pass of the unit whose output gradient dx is (stride-1
  * launches): dx is stored masked by that unit's ReLU (bn_bits from mvg_bn_apply_split, or fma(bn_y, relu_scale,
- * relu_shift) > 0, or no mask) and s1 / s2 / dgamma / dbeta come out of the same launch + a finalize; max |dx| goes to
- * *absmax (may be NULL).  partials: groups * mvg_conv_dgrad_bn_partials_split(d) * 2 * cin floats. */
+ * relu_shift) > 0, or no mask) and s1 / s2 / dgamma / dbeta come out of the same launch + a finalize; mx [groups][cin] (may be
+ * NULL) receives max |dx| per (group, channel).  partials: groups * mvg_conv_dgrad_bn_partials_split(d) * 3 * cin floats. */
 int mvg_conv_dgrad_bn_partials_split(const mvg_conv_desc *d);
 int mvg_conv_dgrad_split_bnreduce(const mvg_conv_desc *d, const void *dy_sp, const float *dy_sinv, const void *w_crsk_sp,
                                   const float *w_sinv, float *dx, const float *addend, const float *bn_y, const uint8_t *bn_bits,
                                   const float *bn_mean, const float *bn_invstd, const float *relu_scale, const float *relu_shift,
                                   float *partials, float *s1, float *s2, float *dgamma, float *dbeta, int accumulate,
-                                  uint32_t *absmax, void *stream);
+                                  float *mx, void *stream);
 int mvg_conv_wgrad_splits_split(const mvg_conv_desc *d);   /* pixel-split count; workspace = splits * cout*r*s*cin floats */
 int mvg_conv_wgrad_split(const mvg_conv_desc *d, const void *x_sp, const void *dy_sp, const float *dy_sinv, float *dw,
                          float *workspace, int splits, int accumulate, void *stream);

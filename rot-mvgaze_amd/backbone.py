@@ -44,13 +44,12 @@ class GradSink:
 class _Unit:
     """Saved state of one conv + BN (+ReLU) (+residual) for the backward pass."""
     __slots__ = ("spec", "desc", "x_in", "y", "out", "mean", "invstd", "relu", "rows", "w", "trained", "pool",
-                 "relu_affine", "fused_s12", "relu_bits", "split", "absmax")
+                 "relu_affine", "fused_s12", "relu_bits", "split")
 
     def __init__(self):
         self.split = False        # conv operands (x_in, out, dy, w) in sp (two fp16 pieces), split-operand kernels (conv_split.hip)
         self.relu_bits = None     # residual units: the ReLU mask as one byte per 16-byte access (ops.bn_apply_bits)
         self.fused_s12 = None     # BatchNorm-backward sums delivered by the backward-data launch that produced this unit's gradient
-        self.absmax = None        # split path, backward: 1-element int32 view, max |masked gradient| of this unit as float bits
 
 
 class Backbone:
@@ -384,7 +383,7 @@ class Backbone:
             # split path, fused: g arrived masked and the sums came with it; dy goes out in s3
             s12, u.fused_s12 = u.fused_s12, None
             dy = ops.sp_empty(*u.y.shape, device=g.device)
-            ops.bn_bwd_apply_split(g, u.y, u.mean, u.invstd, gp.detach(), s12[0], s12[1], G, u.rows, c.cout, dy, None, u.absmax)
+            ops.bn_bwd_apply_split(g, u.y, u.mean, u.invstd, gp.detach(), s12[0], s12[1], G, u.rows, c.cout, dy, None, s12[2])
             return dy, (g if need_dz else None)
         if u.fused_s12 is not None:
             # g arrived masked by this unit's ReLU and its sums (incl. dgamma / dbeta) came with it
@@ -392,7 +391,7 @@ class Backbone:
             dy = torch.empty_like(g) if need_dz else g
             ops.bn_bwd_apply(g, None, u.y, u.mean, u.invstd, gp.detach(), s12[0], s12[1], G, u.rows, c.cout, dy, None, None)
             return dy, (g if need_dz else None)
-        s12 = torch.empty(2, G, c.cout, dtype=torch.float32, device=g.device)
+        s12 = torch.empty(3 if u.split else 2, G, c.cout, dtype=torch.float32, device=g.device)     # s1, s2 (, max |dz| per channel)
         ra = u.relu_affine
         act = u.out if (u.relu and ra is None) else None
         acc = sink.accumulate(gp)
@@ -402,13 +401,13 @@ class Backbone:
             assert not (u.relu and ra is None) or u.relu_bits is not None
             if u.relu_bits is not None:
                 ops.bn_bwd_reduce_split(g, u.relu_bits, u.y, u.mean, u.invstd, G, u.rows, c.cout, s12[0], s12[1], sink.view(gp),
-                                        sink.view(bp), acc, u.absmax, None, dz_out=g)
+                                        sink.view(bp), acc, s12[2], None, dz_out=g)
             else:
                 ops.bn_bwd_reduce_split(g, None, u.y, u.mean, u.invstd, G, u.rows, c.cout, s12[0], s12[1], sink.view(gp),
-                                        sink.view(bp), acc, u.absmax, ra)
+                                        sink.view(bp), acc, s12[2], ra)
             dy = ops.sp_empty(*u.y.shape, device=g.device)
             ops.bn_bwd_apply_split(g, u.y, u.mean, u.invstd, gp.detach(), s12[0], s12[1], G, u.rows, c.cout, dy,
-                                   None if u.relu_bits is not None else ra, u.absmax)
+                                   None if u.relu_bits is not None else ra, s12[2])
             return dy, (g if need_dz else None)
         if need_dz:
             # the reduce pass writes the masked gradient dz over g: the apply pass then reads (dz, y) only - no
@@ -489,10 +488,10 @@ class Backbone:
                 gp, bp = self.p[c.bn + ".weight"], self.p[c.bn + ".bias"]
                 acc = sink.accumulate(gp)
                 assert acc == sink.accumulate(bp)
-                s12 = torch.empty(2, dx.shape[0], c.cout, dtype=torch.float32, device=dx.device)
+                s12 = torch.empty(3, dx.shape[0], c.cout, dtype=torch.float32, device=dx.device)     # s1, s2, max |dz| per channel
                 ops.conv_dgrad_split_bnreduce(u.desc, dy, u.w, dx, addend, U.y, U.relu_bits, U.mean, U.invstd,
                                               None if U.relu_bits is not None else U.relu_affine, s12[0], s12[1], sink.view(gp),
-                                              sink.view(bp), acc, U.absmax)
+                                              sink.view(bp), acc, s12[2])
                 U.fused_s12 = s12
                 return
             ops.conv_dgrad_split(u.desc, dy, u.w, dx, addend)
@@ -517,11 +516,6 @@ class Backbone:
                                "(PyTorch raises its version-counter error in the same situation)")
         g = torch.empty(V, B, Hc, Wc, self.fc_dim, dtype=self.act_dtype, device=dfeat.device)
         ops.avgpool_bwd(dfeat.contiguous(), g, V * B, Hc * Wc, self.fc_dim)
-        # split path: every unit's reduce pass leaves max |masked gradient| (float bits, atomicMax) in its slot; the apply
-        # pass turns it into the power-of-two scale of the unit's dy (one memset for all of them)
-        absmax = torch.zeros(len(units), dtype=torch.int32, device=dfeat.device)
-        for i, u_ in enumerate(units):
-            u_.absmax = absmax[i:i + 1]
         P = self.p
         blocks = tape["blocks"]
         for bi in range(len(blocks) - 1, -1, -1):

@@ -114,8 +114,7 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
   // masked, and s1 = sum(dz), s2 = sum(dz * xhat) are added up per thread (its 8 channels are fixed: NT % CV == 0),
   // per workgroup through LDS, and written as one partial per (group, row tile) for bn_bwd_finalize.
   const bool bnf = DGRAD && F32IO && p.bn_part != nullptr;
-  float bn_mu[8], bn_is[8], bn_ra[8], bn_rb[8], bn_s1[8], bn_s2[8];
-  float bn_mx = 0.f;                           // max |masked gradient| this thread stores (p.bn_absmax)
+  float bn_mu[8], bn_is[8], bn_ra[8], bn_rb[8], bn_s1[8], bn_s2[8], bn_mx[8];    // bn_mx: max |masked gradient| per channel
   const bool bn_aff = bnf && p.bn_rscale != nullptr;
   if (bnf) {
     const int col0 = ntile * BN + (tid % CV) * 8;
@@ -126,7 +125,7 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
       bn_is[k] = ok ? p.bn_invstd[(long long)g * p.ncols + col0 + k] : 0.f;
       bn_ra[k] = (ok && bn_aff) ? p.bn_rscale[(long long)g * p.ncols + col0 + k] : 0.f;
       bn_rb[k] = (ok && bn_aff) ? p.bn_rshift[(long long)g * p.ncols + col0 + k] : 0.f;
-      bn_s1[k] = bn_s2[k] = 0.f;
+      bn_s1[k] = bn_s2[k] = bn_mx[k] = 0.f;
     }
   }
 #pragma unroll
@@ -217,7 +216,7 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
         for (int k = 0; k < 8; ++k) {
           const bool on = bn_aff ? (__builtin_fmaf(yy[k], bn_ra[k], bn_rb[k]) > 0.f) : (((bits >> k) & 1u) != 0u);
           x[k] = on ? x[k] : 0.f;
-          bn_mx = fmaxf(bn_mx, fabsf(x[k]));
+          bn_mx[k] = fmaxf(bn_mx[k], fabsf(x[k]));
           bn_s1[k] += x[k];
           bn_s2[k] += x[k] * ((yy[k] - bn_mu[k]) * bn_is[k]);
         }
@@ -255,26 +254,26 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
   if (bnf) {
     constexpr int RL = NT / CV;                // threads (row lanes) per 8-channel column group
     __syncthreads();                           // the staging tile has been read out
-    float *red = reinterpret_cast<float *>(smem);           // [2][RL][BN]
+    float *red = reinterpret_cast<float *>(smem);           // [3][RL][BN]
     const int cvt = tid % CV, rlt = tid / CV;
+    const int nred = p.bn_part_rows;                        // 2: (s1, s2); 3: (s1, s2, max |dz|)
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       red[(0 * RL + rlt) * BN + cvt * 8 + k] = bn_s1[k];
       red[(1 * RL + rlt) * BN + cvt * 8 + k] = bn_s2[k];
+      red[(2 * RL + rlt) * BN + cvt * 8 + k] = bn_mx[k];
     }
     __syncthreads();
-    for (int idx = tid; idx < 2 * BN; idx += NT) {
+    for (int idx = tid; idx < nred * BN; idx += NT) {
       const int which = idx / BN, cc = idx - which * BN;
       const int colr = ntile * BN + cc;
       if (colr >= p.ncols) continue;
       float t = 0.f;
-      for (int r = 0; r < RL; ++r) t += red[(which * RL + r) * BN + cc];       // fixed order
-      p.bn_part[(((long long)g * c.mtiles_per_group + mtile) * 2 + which) * p.ncols + colr] = t;
-    }
-    if (p.bn_absmax) {                         // a maximum does not depend on the order: one atomic per wave
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) bn_mx = fmaxf(bn_mx, __shfl_xor(bn_mx, o, 64));
-      if (lane == 0 && bn_mx > 0.f) atomicMax(p.bn_absmax, __float_as_uint(bn_mx));
+      if (which < 2)
+        for (int r = 0; r < RL; ++r) t += red[(which * RL + r) * BN + cc];       // fixed order
+      else
+        for (int r = 0; r < RL; ++r) t = fmaxf(t, red[(which * RL + r) * BN + cc]);
+      p.bn_part[(((long long)g * c.mtiles_per_group + mtile) * nred + which) * p.ncols + colr] = t;
     }
   }
 }

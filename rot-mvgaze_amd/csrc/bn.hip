@@ -265,19 +265,19 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *g, const T 
                                                             long long rows_per_chunk, int c, int cwn, int cw,
                                                             float *__restrict__ partial, int chunks, T *dz_out,
                                                             const unsigned char *__restrict__ relu_bits,
-                                                            unsigned *__restrict__ absmax) {
+                                                            int prows) {
+  // prows: rows per partial - 2 (s1, s2) or 3 (+ max |masked gradient| per channel: mvg_bn_bwd_apply_split's bound)
   typedef Elem<T> E;
   constexpr int W = E::W;                 // float4 groups per 16-byte access; a "column" below is one such access
-  __shared__ float4 sh[2][256][W];
+  __shared__ float4 sh[3][256][W];
   const int grp = blockIdx.z;
   const int rl = threadIdx.x / cw, cl = threadIdx.x % cw;
   const int nrl = 256 / cw;
   const int cq = blockIdx.y * cw + cl;
   const bool cok = cq < cwn;
-  float4 s1[W], s2[W];
-  float mx = 0.f;                      // max |masked gradient| (absmax: the bound mvg_bn_bwd_apply_split scales dy by)
+  float4 s1[W], s2[W], mx[W];
 #pragma unroll
-  for (int w = 0; w < W; ++w) s1[w] = s2[w] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int w = 0; w < W; ++w) s1[w] = s2[w] = mx[w] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (cok) {
     float4 mu[W], is[W], ma[W], mb[W];
 #pragma unroll
@@ -322,7 +322,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *g, const T 
           d[w].z = __builtin_fmaf(v[w].z, ma[w].z, mb[w].z) > 0.f ? d[w].z : 0.f;
           d[w].w = __builtin_fmaf(v[w].w, ma[w].w, mb[w].w) > 0.f ? d[w].w : 0.f;
         }
-        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(d[w].x), fabsf(d[w].y))), fmaxf(fabsf(d[w].z), fabsf(d[w].w)));
+        mx[w].x = fmaxf(mx[w].x, fabsf(d[w].x));
+        mx[w].y = fmaxf(mx[w].y, fabsf(d[w].y));
+        mx[w].z = fmaxf(mx[w].z, fabsf(d[w].z));
+        mx[w].w = fmaxf(mx[w].w, fabsf(d[w].w));
         a1[w].x += d[w].x;
         a1[w].y += d[w].y;
         a1[w].z += d[w].z;
@@ -360,31 +363,29 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *g, const T 
       }
     }
   }
-  if (absmax) {                        // a maximum does not depend on the order: one atomic per wave
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(absmax, __float_as_uint(mx));
-  }
 #pragma unroll
   for (int w = 0; w < W; ++w) {
     sh[0][threadIdx.x][w] = s1[w];
     sh[1][threadIdx.x][w] = s2[w];
+    sh[2][threadIdx.x][w] = mx[w];
   }
   __syncthreads();
   if (rl == 0 && cok) {
     for (int k = 1; k < nrl; ++k) {
 #pragma unroll
       for (int w = 0; w < W; ++w) {
-        const float4 a = sh[0][k * cw + cl][w], b = sh[1][k * cw + cl][w];
+        const float4 a = sh[0][k * cw + cl][w], b = sh[1][k * cw + cl][w], m = sh[2][k * cw + cl][w];
         s1[w].x += a.x; s1[w].y += a.y; s1[w].z += a.z; s1[w].w += a.w;
         s2[w].x += b.x; s2[w].y += b.y; s2[w].z += b.z; s2[w].w += b.w;
+        mx[w].x = fmaxf(mx[w].x, m.x); mx[w].y = fmaxf(mx[w].y, m.y); mx[w].z = fmaxf(mx[w].z, m.z); mx[w].w = fmaxf(mx[w].w, m.w);
       }
     }
-    float4 *p = reinterpret_cast<float4 *>(partial + (((long long)grp * chunks + blockIdx.x) * 2) * c);
+    float4 *p = reinterpret_cast<float4 *>(partial + (((long long)grp * chunks + blockIdx.x) * prows) * c);
 #pragma unroll
     for (int w = 0; w < W; ++w) {
       p[cq * W + w] = s1[w];
       p[c / 4 + cq * W + w] = s2[w];
+      if (prows == 3) p[2 * (c / 4) + cq * W + w] = mx[w];
     }
   }
 }
@@ -393,25 +394,30 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *g, const T 
 // that dgamma/dbeta are summed in a fixed order (reproducible).
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float *__restrict__ partial, int groups, int chunks,
                                                                int c, float *s1, float *s2, float *dgamma,
-                                                               float *dbeta, int accumulate) {
-  __shared__ double sh[2][64][16];
+                                                               float *dbeta, int accumulate, float *mx) {
+  // mx != null: the partials have three rows (s1, s2, max |dz|) and mx [groups][c] receives the maxima
+  __shared__ double sh[3][64][16];
+  const int prows = mx ? 3 : 2;
   const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
   const int ch = blockIdx.x * 16 + cl;
   double tg = 0.0, tb = 0.0;
   for (int g = 0; g < groups; ++g) {
-    double a = 0.0, b = 0.0;
+    double a = 0.0, b = 0.0, m = 0.0;
     if (ch < c)
       for (int k = pl; k < chunks; k += 64) {
-        a += partial[(((long long)g * chunks + k) * 2) * c + ch];
-        b += partial[(((long long)g * chunks + k) * 2 + 1) * c + ch];
+        a += partial[(((long long)g * chunks + k) * prows) * c + ch];
+        b += partial[(((long long)g * chunks + k) * prows + 1) * c + ch];
+        if (mx) m = fmax(m, (double)partial[(((long long)g * chunks + k) * prows + 2) * c + ch]);
       }
     sh[0][pl][cl] = a;
     sh[1][pl][cl] = b;
+    sh[2][pl][cl] = m;
     __syncthreads();
     for (int o = 32; o > 0; o >>= 1) {
       if (pl < o) {
         sh[0][pl][cl] += sh[0][pl + o][cl];
         sh[1][pl][cl] += sh[1][pl + o][cl];
+        sh[2][pl][cl] = fmax(sh[2][pl][cl], sh[2][pl + o][cl]);
       }
       __syncthreads();
     }
@@ -420,6 +426,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float *__re
       b = sh[1][0][cl];
       s1[(long long)g * c + ch] = (float)a;
       s2[(long long)g * c + ch] = (float)b;
+      if (mx) mx[(long long)g * c + ch] = (float)sh[2][0][cl];
       tb += a;
       tg += b;
     }
@@ -584,23 +591,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_s3_kernel(const float *__res
                                                               const float *__restrict__ s2, const float *__restrict__ mscale,
                                                               const float *__restrict__ mshift, long long n8_per_group,
                                                               float inv_rows, int c8n, int c, sp_t *__restrict__ dy,
-                                                              const unsigned *__restrict__ absmax, int groups, float sqrt_rows,
+                                                              const float *__restrict__ mx, int groups, float sqrt_rows,
                                                               float *__restrict__ dy_sinv) {
-  // dy is stored times 2^k, k from a bound on |dy| (elem.h: sp_scale_for):
-  //   |dy| = |gamma invstd| |dz - s1/n - xhat s2/n| <= max_c |gamma invstd| * M * (2 + sqrt(n)),  M = max |dz| (absmax),
-  // because |s1/n| <= M, |s2/n| = |mean(dz xhat)| <= M mean|xhat| <= M, and a z-score of n samples is at most
-  // sqrt(n - 1).  Typical values sit a factor ~sqrt(n) below the bound: well inside the 2^29 range sp keeps exact.
-  __shared__ float sh_gi[4];
+  // dy is stored times 2^k, k from a bound on |dy| (elem.h: sp_scale_for), per (group, channel) and then the maximum:
+  //   |dy| = |gamma invstd| |dz - s1/n - xhat s2/n| <= |gamma invstd| (max |dz| + |s1|/n + sqrt(n) |s2|/n)
+  // (a z-score of n samples is at most sqrt(n - 1)); max |dz| per channel comes from the reduce pass (mx), so a dead or
+  // low-variance channel - huge invstd, zero gradient - does not inflate the bound.  Measured: the bound sits 2^3..2^8
+  // above the largest |dy|, typical values keep the format's full accuracy (scaled magnitude >= 2^-2).
+  __shared__ float sh_b[4];
   {
-    float gi = 0.f;
-    for (int i = threadIdx.x; i < groups * c; i += 256) gi = fmaxf(gi, fabsf(gamma[i % c] * invstd[i]));
+    float bd = 0.f;
+    for (int i = threadIdx.x; i < groups * c; i += 256)
+      bd = fmaxf(bd, fabsf(gamma[i % c] * invstd[i]) * (mx[i] + fabsf(s1[i]) * inv_rows + sqrt_rows * fabsf(s2[i]) * inv_rows));
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) gi = fmaxf(gi, __shfl_xor(gi, o, 64));
-    if ((threadIdx.x & 63) == 0) sh_gi[threadIdx.x >> 6] = gi;
+    for (int o = 32; o > 0; o >>= 1) bd = fmaxf(bd, __shfl_xor(bd, o, 64));
+    if ((threadIdx.x & 63) == 0) sh_b[threadIdx.x >> 6] = bd;
     __syncthreads();
   }
-  const float gimax = fmaxf(fmaxf(sh_gi[0], sh_gi[1]), fmaxf(sh_gi[2], sh_gi[3]));
-  const float dsc = sp_scale_for(gimax * __uint_as_float(*absmax) * (2.f + sqrt_rows));
+  const float dsc = sp_scale_for(fmaxf(fmaxf(sh_b[0], sh_b[1]), fmaxf(sh_b[2], sh_b[3])));
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *dy_sinv = 1.f / dsc;
   const int grp = blockIdx.y;
   const long long base = (long long)grp * n8_per_group;
@@ -847,9 +855,9 @@ static int grid_for(long long n4) {
 }
 
 int bn_bwd_finalize_launch(const float *partial, int groups, int chunks, int c, float *s1, float *s2, float *dgamma,
-                           float *dbeta, int accumulate, hipStream_t st) {
+                           float *dbeta, int accumulate, hipStream_t st, float *mx) {
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(c, 16)), dim3(1024), 0, st, partial, groups, chunks, c, s1, s2,
-                     dgamma, dbeta, accumulate);
+                     dgamma, dbeta, accumulate, mx);
   return check_launch("bn_bwd_finalize");
 }
 
@@ -918,7 +926,7 @@ template <typename T>
 static int bn_bwd_reduce_impl(const T *g, const T *act, const T *y, const float *mean, const float *invstd,
                               const float *relu_scale, const float *relu_shift, int groups, int64_t rows_per_group, int c,
                               float *s1, float *s2, float *dgamma, float *dbeta, int accumulate, float *workspace, T *dz_out,
-                              void *stream, const uint8_t *relu_bits = nullptr, uint32_t *absmax = nullptr) {
+                              void *stream, const uint8_t *relu_bits = nullptr, float *mx = nullptr) {
   MVG_REQUIRE(!(act && relu_scale) && !(relu_bits && (act || relu_scale)),
               "bn_bwd_reduce: give the ReLU mask ONE way: act, (relu_scale, relu_shift) or relu_bits");
   MVG_REQUIRE((relu_scale == nullptr) == (relu_shift == nullptr), "bn_bwd_reduce: relu_scale and relu_shift go together");
@@ -934,10 +942,10 @@ static int bn_bwd_reduce_impl(const T *g, const T *act, const T *y, const float 
   const long long rpc = (rows_per_group + chunks - 1) / chunks;
   ProfScope ps(MVG_K_BN_BWD_REDUCE, st, 0.0, Elem<T>::kBytes * groups * (double)rows_per_group * c * ((act ? 3 : 2) + (dz_out ? 1 : 0)));
   hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(chunks, ceil_div(c4n, cw), groups), dim3(256), 0, st, g, act, y, mean, invstd,
-                     relu_scale, relu_shift, (long long)rows_per_group, rpc, c, c4n, cw, workspace, chunks, dz_out, relu_bits, absmax);
+                     relu_scale, relu_shift, (long long)rows_per_group, rpc, c, c4n, cw, workspace, chunks, dz_out, relu_bits, mx ? 3 : 2);
   if (check_launch("bn_bwd_reduce")) return 1;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(c, 16)), dim3(1024), 0, st, workspace, groups, chunks, c, s1, s2,
-                     dgamma, dbeta, accumulate);
+                     dgamma, dbeta, accumulate, mx);
   return check_launch("bn_bwd_finalize");
 }
 
@@ -999,7 +1007,7 @@ static int bn_relu_maxpool_bwd_reduce_impl(const T *g_pooled, const uint8_t *arg
                      chunks);
   if (check_launch("bn_relu_maxpool_bwd_reduce")) return 1;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(c, 16)), dim3(1024), 0, st, workspace, groups, chunks, c, s1, s2,
-                     dgamma, dbeta, accumulate);
+                     dgamma, dbeta, accumulate, (float *)nullptr);
   return check_launch("bn_bwd_finalize");
 }
 
@@ -1022,7 +1030,7 @@ static int bn_relu_maxpool_bwd_apply_impl(const T *g_pooled, const uint8_t *argm
 extern "C" {
 
 size_t mvg_bn_bwd_workspace_floats(int groups, int64_t rows_per_group, int c) {
-  return (size_t)groups * bwd_chunks(groups, rows_per_group, c) * 2 * c;
+  return (size_t)groups * bwd_chunks(groups, rows_per_group, c) * 3 * c;      // (s1, s2, and - mvg_bn_bwd_reduce_split - max |dz|)
 }
 
 #define MVG_BN_FACES(SUFFIX, T)                                                                                              \
@@ -1089,14 +1097,14 @@ MVG_BN_FACES(_bf16, uint16_t)
   }
 // ---- split path (conv_split.hip): conv outputs and gradients fp32, conv INPUTS (activations, dy) in sp ----------
 // the reduce pass of a unit whose dy goes out in sp: mvg_bn_bwd_reduce / _bits (mask from relu_bits, or from relu_scale /
-// relu_shift, or none) that also leaves max |masked gradient| in *absmax (float bits, atomicMax: clear it first)
+// relu_shift, or none) that also leaves max |masked gradient| per (group, channel) in mx [groups][c]
 int mvg_bn_bwd_reduce_split(const float *g, const uint8_t *relu_bits, const float *y, const float *mean, const float *invstd,
                             const float *relu_scale, const float *relu_shift, int groups, int64_t rows_per_group, int c, float *s1,
                             float *s2, float *dgamma, float *dbeta, int accumulate, float *workspace, float *dz_out,
-                            uint32_t *absmax, void *stream) {
-  MVG_REQUIRE(absmax != nullptr, "bn_bwd_reduce_split: absmax is required");
+                            float *mx, void *stream) {
+  MVG_REQUIRE(mx != nullptr, "bn_bwd_reduce_split: mx is required");
   return bn_bwd_reduce_impl<float>(g, nullptr, y, mean, invstd, relu_scale, relu_shift, groups, rows_per_group, c, s1, s2, dgamma,
-                                   dbeta, accumulate, workspace, dz_out, stream, relu_bits, absmax);
+                                   dbeta, accumulate, workspace, dz_out, stream, relu_bits, mx);
 }
 
 int mvg_bn_apply_split(const float *y, const float *scale, const float *shift, const void *residual, int residual_s3,
@@ -1121,15 +1129,15 @@ int mvg_bn_apply_split(const float *y, const float *scale, const float *shift, c
 
 int mvg_bn_bwd_apply_split(const float *g, const float *y, const float *mean, const float *invstd, const float *gamma,
                            const float *s1, const float *s2, const float *relu_scale, const float *relu_shift, int groups,
-                           int64_t rows_per_group, int c, void *dy_s3, const uint32_t *absmax, float *dy_sinv, void *stream) {
+                           int64_t rows_per_group, int c, void *dy_s3, const float *mx, float *dy_sinv, void *stream) {
   MVG_REQUIRE(c % 8 == 0, "bn_bwd_apply_split: c %% 8 != 0");
-  MVG_REQUIRE(absmax && dy_sinv, "bn_bwd_apply_split: absmax (max |masked gradient| from the reduce pass) and dy_sinv are required");
+  MVG_REQUIRE(mx && dy_sinv, "bn_bwd_apply_split: mx (max |masked gradient| per (group, channel) from the reduce pass) and dy_sinv are required");
   MVG_REQUIRE((relu_scale == nullptr) == (relu_shift == nullptr), "bn_bwd_apply_split: relu_scale and relu_shift go together");
   hipStream_t st = (hipStream_t)stream;
   const long long n8 = rows_per_group * (c / 8);
   ProfScope ps(MVG_K_BN_BWD_APPLY, st, 0.0, 8.0 * groups * (double)n8 * (8.0 + SP_BYTES));
   hipLaunchKernelGGL(bn_bwd_apply_s3_kernel, dim3(grid_for(n8), groups), dim3(256), 0, st, g, y, mean, invstd, gamma, s1, s2,
-                     relu_scale, relu_shift, n8, 1.0f / (float)rows_per_group, c / 8, c, (sp_t *)dy_s3, absmax, groups,
+                     relu_scale, relu_shift, n8, 1.0f / (float)rows_per_group, c / 8, c, (sp_t *)dy_s3, mx, groups,
                      sqrtf((float)rows_per_group), dy_sinv);
   return check_launch("bn_bwd_apply_split");
 }

@@ -25,8 +25,9 @@ int compute_cus();
 
 // bn.hip: merge [groups][chunks][2][c] partial sums (s1, s2) of a BatchNorm backward in fp64, in a fixed order;
 // dgamma / dbeta (+)= the sums over the groups.  Host launcher shared with the fused backward-data path.
+// mx != nullptr: the partials carry a third row, max |dz| per channel, merged into mx [groups][c].
 int bn_bwd_finalize_launch(const float *partial, int groups, int chunks, int c, float *s1, float *s2, float *dgamma,
-                           float *dbeta, int accumulate, hipStream_t st);
+                           float *dbeta, int accumulate, hipStream_t st, float *mx = nullptr);
 
 struct ProfScope {
   int fam;

@@ -128,7 +128,7 @@ struct IgemmParams {
   // launch produces (split kernels, stride-1 launches): the epilogue masks the gradient by that unit's ReLU
   // (bn_bits, or fma(bn_y, bn_rscale, bn_rshift) > 0, or no mask), stores the masked gradient and adds up,
   // per wave and column, s1 = sum(dz) and s2 = sum(dz * xhat), xhat = (bn_y - bn_mean) * bn_invstd, into
-  // bn_part [groups][P][2][ncols] (P = row partials per group, like the forward statistics).
+  // bn_part [groups][P][bn_part_rows][ncols] (P = row partials per group, like the forward statistics).
   const float *bn_y, *bn_mean, *bn_invstd, *bn_rscale, *bn_rshift;
   float *bn_part;
   // split kernels, inference forward (BatchNorm folded: y = acc * scale + bias (+ residual) [relu]): the residual
@@ -137,7 +137,7 @@ struct IgemmParams {
   // split kernels: the operands hold (value * 2^k) for a per-tensor k (elem.h: sp_t); the epilogue multiplies the
   // accumulators by *a_sinv * *b_sinv (device scalars, each 2^-k of its operand; null = 1)
   const float *a_sinv, *b_sinv;
-  unsigned *bn_absmax;            // fused BatchNorm-backward reduce: max |masked gradient| as float bits (atomicMax), or null
+  int bn_part_rows;               // fused BatchNorm-backward reduce: rows per partial in bn_part - 2 (s1, s2) or 3 (+ max |dz| per channel)
   const unsigned char *bn_bits;   // split kernels: the unit's ReLU mask as bits (one byte per 4 channels, mvg_bn_apply_split) 
   // Cross-view fusion (igemm_kernel AMODE = 1, Linear forward): the A operand is never materialised - row m of
   //   X = [ img_feat[rc_row_img[m]] (rc_cf floats) | rc_rel[m] (3x3) @ feat[rc_row_src[m]] (3 x rc_nvec, axis-major) ]

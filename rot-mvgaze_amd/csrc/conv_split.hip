@@ -1,8 +1,9 @@
 // fp32-accurate convolution / linear kernels on the gfx950 fp16 matrix cores ("split" operands).
 //
 // An fp32 value a is held as TWO fp16 pieces, a1 = fp16(a), a2 = fp16(a - a1) (round to nearest; a - a1 is exact):
-// |a - a1 - a2| <= 2^-24 |a|, HALF a unit in the last place of the fp32 value itself, provided the value sits inside
-// fp16's exponent range - which a per-tensor power-of-two scale arranges (exact to apply and to undo; elem.h: sp_t).
+// |a - a1 - a2| <= 2^-23 |a| - at most the last of the 24 significand bits is lost, three values in four are exact, rms
+// 0.74 * 2^-24 |a| - provided the value sits inside fp16's exponent range, which a per-tensor power-of-two scale
+// arranges (exact to apply and to undo; elem.h: sp_t).
 // A product of two pieces is exact in fp32, so
 //     a * b  =  a1 b1 + (a1 b2 + a2 b1)  + O(2^-22 |a b|)
 // THREE fp16 MFMAs (v_mfma_f32_16x16x32_f16, fp32 accumulation) per 32 k.  Measured against fp64 (DESIGN.md 4a,
@@ -731,7 +732,7 @@ struct SplitBnFuse {       // fused BatchNorm-backward reduce of the unit whose 
   const uint8_t *bits;
   const float *mean, *invstd, *rscale, *rshift;
   float *part;
-  unsigned *absmax;
+  int part_rows;
 };
 
 static int dgrad_split_impl(const mvg_conv_desc *d, const void *dy_sp, const float *dy_sinv, const void *w_crsk_sp, const float *w_sinv,
@@ -753,7 +754,7 @@ static int dgrad_split_impl(const mvg_conv_desc *d, const void *dy_sp, const flo
     p.bn_rscale = bnf->rscale;
     p.bn_rshift = bnf->rshift;
     p.bn_part = bnf->part;
-    p.bn_absmax = bnf->absmax;
+    p.bn_part_rows = bnf->part_rows;
   }
   p.groups = d->groups;
   p.out_h = d->h;
@@ -865,16 +866,16 @@ int mvg_conv_dgrad_split_bnreduce(const mvg_conv_desc *d, const void *dy_sp, con
                                   const float *w_sinv, float *dx, const float *addend, const float *bn_y, const uint8_t *bn_bits,
                                   const float *bn_mean, const float *bn_invstd, const float *relu_scale, const float *relu_shift,
                                   float *partials, float *s1, float *s2, float *dgamma, float *dbeta, int accumulate,
-                                  uint32_t *absmax, void *stream) {
+                                  float *mx, void *stream) {
   MVG_REQUIRE(bn_y && bn_mean && bn_invstd && partials && s1 && s2, "dgrad_split_bnreduce: null argument");
   MVG_REQUIRE(!(bn_bits && relu_scale) && ((relu_scale == nullptr) == (relu_shift == nullptr)),
               "dgrad_split_bnreduce: give the ReLU mask either as bits or as (relu_scale, relu_shift)");
   const int P = mvg_conv_dgrad_bn_partials_split(d);
   MVG_REQUIRE(P > 0, "dgrad_split_bnreduce: this shape cannot be fused (stride %d)", d ? d->stride : -1);
-  const SplitBnFuse f = {bn_y, bn_bits, bn_mean, bn_invstd, relu_scale, relu_shift, partials, absmax};
+  const SplitBnFuse f = {bn_y, bn_bits, bn_mean, bn_invstd, relu_scale, relu_shift, partials, mx ? 3 : 2};
   if (dgrad_split_impl(d, dy_sp, dy_sinv, w_crsk_sp, w_sinv, dx, addend, stream, &f)) return 1;
   ProfScope ps(MVG_K_BN_BWD_REDUCE, (hipStream_t)stream, 0.0, 8.0 * d->groups * (double)P * d->cin);
-  return bn_bwd_finalize_launch(partials, d->groups, P, d->cin, s1, s2, dgamma, dbeta, accumulate, (hipStream_t)stream);
+  return bn_bwd_finalize_launch(partials, d->groups, P, d->cin, s1, s2, dgamma, dbeta, accumulate, (hipStream_t)stream, mx);
 }
 
 static void wgrad_split_tile(const mvg_conv_desc *d, int &bm, int &bn) {

@@ -56,8 +56,9 @@ struct Elem<bf16_t> {
 
 // "sp" storage (conv_split.hip's operand format): an fp32 value v - times a per-tensor power-of-two scale chosen by
 // the producer, so that the pieces stay inside fp16's range - as TWO fp16 pieces, h1 = fp16(v), h2 = fp16(v - h1)
-// (round to nearest even; v - h1 is exact in fp32).  |v - h1 - h2| <= 2^-24 |v| whenever h2 is a normal fp16 number:
-// half a unit in the last place of the fp32 value itself.  Channels in chunks of 8 with the two pieces of a chunk
+// (round to nearest even; v - h1 is exact in fp32).  |v - h1 - h2| <= 2^-23 |v| whenever h2 is a normal fp16 number:
+// at most the LAST of the 24 significand bits is lost (the remainder v - h1 has up to 12 significant bits, fp16 keeps
+// 11), and three values in four are represented exactly; rms error 0.74 * 2^-24 |v|.  Channels in chunks of 8 with the two pieces of a chunk
 // adjacent (32 bytes, 4 bytes per element).  The streaming passes address 4-channel groups like fp32: group i4 is
 // half (i4 & 1) of chunk (i4 >> 1), i.e. two 8-byte accesses 16 bytes apart.
 struct sp_t {
@@ -95,8 +96,8 @@ __device__ __forceinline__ void merge2_chunk(const uint4 &q1, const uint4 &q2, f
   }
 }
 
-// The power-of-two scale that maps `bound` (>= every |value| of the tensor) just below 2^15: fp16 then keeps 11 bits
-// for values down to 2^-29 of the bound, and the second piece stays a normal number for values down to 2^-18 of it.
+// The power-of-two scale that maps `bound` (>= every |value| of the tensor) just below 2^15: values down to 2^-17 of the
+// bound then keep the 2^-23 relative accuracy; smaller ones are off by at most 2^-25 / scale = 2^-40 of the bound.
 __device__ __forceinline__ float sp_scale_for(float bound) {
   if (!(bound > 0.f) || !(bound < 3.0e38f)) return 1.f;
   int e;

@@ -200,7 +200,9 @@ def split_weights(d: ConvDesc, w: Tensor, need_transposed: bool = True):
 
 
 def weights_prep_batch(table: Tensor, n: int, mode: int):
-    check(lib().mvg_weights_prep_batch(_p(table), n, mode, _s()), "weights_prep_batch")
+    """table: [n, 6] int64 DEVICE tensor of (w, wk, wt, cout | rs << 32, cin | cin_pad << 32, stat) records (48 bytes each)."""
+    assert table.is_cuda and table.dtype == torch.int64 and table.is_contiguous() and table.shape == (n, 6)
+    check(lib().mvg_weights_prep_batch(C.c_void_p(table.data_ptr()), n, mode, _s()), "weights_prep_batch")
 
 
 def conv_stats_partials_split(d: ConvDesc):
@@ -236,15 +238,15 @@ def conv_dgrad_bn_partials_split(d: ConvDesc) -> int:
 
 
 def conv_dgrad_split_bnreduce(d: ConvDesc, dy_s3, wt_s3, dx, addend, bn_y, bn_bits, bn_mean, bn_invstd, relu_affine, s1, s2, dgamma,
-                              dbeta, accumulate: bool, absmax: Optional[Tensor] = None):
+                              dbeta, accumulate: bool, mx: Optional[Tensor] = None):
     """conv_dgrad_split + the BatchNorm-backward reduce pass of the unit whose output gradient dx is, in one launch.
-    absmax (1-element int32 tensor, cleared by the caller): receives max |dx| as float bits (bn_bwd_apply_split's bound)."""
+    mx [groups, cin]: receives max |dx| per (group, channel) (bn_bwd_apply_split's bound)."""
     P = conv_dgrad_bn_partials_split(d)
-    part = torch.empty(d.groups * P * 2 * d.cin, dtype=torch.float32, device=dx.device)
+    part = torch.empty(d.groups * P * 3 * d.cin, dtype=torch.float32, device=dx.device)
     rs, rh = relu_affine if relu_affine is not None else (None, None)
     check(lib().mvg_conv_dgrad_split_bnreduce(C.byref(d), _p(dy_s3), _sinv(dy_s3), _p(wt_s3), _sinv(wt_s3), _p(dx), _p(addend), _p(bn_y),
                                               _p(bn_bits), _p(bn_mean), _p(bn_invstd), _p(rs), _p(rh), _p(part), _p(s1), _p(s2),
-                                              _p(dgamma), _p(dbeta), int(accumulate), _p(absmax), _s()), "conv_dgrad_split_bnreduce")
+                                              _p(dgamma), _p(dbeta), int(accumulate), _p(mx), _s()), "conv_dgrad_split_bnreduce")
 
 
 def conv_wgrad_split(d: ConvDesc, x_s3: Tensor, dy_s3: Tensor, dw: Tensor, accumulate: bool = False):
@@ -268,26 +270,26 @@ def bn_apply_split(y, scale, shift, residual, relu, out_s3, groups, rows_per_gro
     return bits
 
 
-def bn_bwd_reduce_split(g, relu_bits, y, mean, invstd, groups, rows_per_group, c, s1, s2, dgamma, dbeta, accumulate, absmax,
+def bn_bwd_reduce_split(g, relu_bits, y, mean, invstd, groups, rows_per_group, c, s1, s2, dgamma, dbeta, accumulate, mx,
                         relu_affine=None, dz_out=None):
-    """The backward reduce pass of a unit whose dy goes out in sp: s1, s2 (+ dgamma, dbeta) and max |masked gradient| (float
-    bits, atomicMax into the 1-element int32 tensor ``absmax``, which the caller cleared)."""
+    """The backward reduce pass of a unit whose dy goes out in sp: s1, s2 (+ dgamma, dbeta) and mx [groups, c] = max |masked
+    gradient| per (group, channel)."""
     rs, rh = relu_affine if relu_affine is not None else (None, None)
     n = lib().mvg_bn_bwd_workspace_floats(groups, rows_per_group, c)
     ws = torch.empty(n, dtype=torch.float32, device=g.device)
     check(lib().mvg_bn_bwd_reduce_split(_p(g), _p(relu_bits), _p(y), _p(mean), _p(invstd), _p(rs), _p(rh), groups, rows_per_group, c,
-                                        _p(s1), _p(s2), _p(dgamma), _p(dbeta), int(accumulate), _p(ws), _p(dz_out), _p(absmax), _s()),
+                                        _p(s1), _p(s2), _p(dgamma), _p(dbeta), int(accumulate), _p(ws), _p(dz_out), _p(mx), _s()),
           "bn_bwd_reduce_split")
 
 
-def bn_bwd_apply_split(g, y, mean, invstd, gamma, s1, s2, groups, rows_per_group, c, dy_s3, relu_affine=None, absmax=None):
-    """dy (sp) = BatchNorm backward of the masked gradient g, scaled by the 2^k that its bound - from ``absmax`` (max |masked
-    gradient| bits, left by the reduce pass) - allows; dy_s3.sinv receives 2^-k."""
+def bn_bwd_apply_split(g, y, mean, invstd, gamma, s1, s2, groups, rows_per_group, c, dy_s3, relu_affine=None, mx=None):
+    """dy (sp) = BatchNorm backward of the masked gradient g, scaled by the 2^k that its bound - from ``mx`` [groups, c] (max
+    |masked gradient| per (group, channel), left by the reduce pass) - allows; dy_s3.sinv receives 2^-k."""
     rs, rh = relu_affine if relu_affine is not None else (None, None)
-    assert absmax is not None and absmax.dtype == torch.int32
+    assert mx is not None and mx.dtype == torch.float32 and mx.numel() == groups * c
     dy_s3.sinv = torch.empty(1, dtype=torch.float32, device=g.device)
     check(lib().mvg_bn_bwd_apply_split(_p(g), _p(y), _p(mean), _p(invstd), _p(gamma), _p(s1), _p(s2), _p(rs), _p(rh), groups,
-                                       rows_per_group, c, _p(dy_s3), _p(absmax), _p(dy_s3.sinv), _s()), "bn_bwd_apply_split")
+                                       rows_per_group, c, _p(dy_s3), _p(mx), _p(dy_s3.sinv), _s()), "bn_bwd_apply_split")
 
 
 def bn_relu_maxpool_fwd_split(y, scale, shift, pooled_s3, argmax, groups, n_per_group, h, w, c, ho, wo):

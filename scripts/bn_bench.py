@@ -41,8 +41,8 @@ for hw, C, cnt_plain, cnt_res in [(56, 64, 7, 0), (56, 256, 0, 3), (28, 128, 8, 
         t_apply = timeit(lambda: ops.bn_apply_split(y, scale, shift, r, True, out, G, rows, C, None, want_bits=res))
         b_apply = n * (4 + 4 + (4.25 if res else 0))
         dy = ops.sp_empty(G, rows, C, device=dev)
-        absmax = g.abs().max().reshape(1).view(torch.int32).clone()
-        t_bapply = timeit(lambda: ops.bn_bwd_apply_split(g, y, mean, invstd, gamma, s1, s2, G, rows, C, dy, None if res else (scale, shift), absmax))
+        mxc = g.abs().amax(dim=1).contiguous()
+        t_bapply = timeit(lambda: ops.bn_bwd_apply_split(g, y, mean, invstd, gamma, s1, s2, G, rows, C, dy, None if res else (scale, shift), mxc))
         b_bapply = n * 12
     else:
         out = torch.empty_like(y)

@@ -35,9 +35,20 @@ GTOL_L2_FLIPS = 1e-2
 GTOL_L2_FLIPS_DEEP = 3e-2
 
 
+# ResNet-50 on ONE sample (layer4's BatchNorm sees 9 values per channel at 96 px): the realisation of the flips decides -
+# over 8 input seeds the worst gradient's error is 1.6e-2 .. 6.3e-2 on the split kernels and 1.1e-2 .. 4.5e-2 on the
+# fp32-MFMA kernels (scripts/flip_spread.py -> profiles/r03_flip_spread_r50_b1_hw96.txt; round 2's 3e-2 held on the one
+# seed the test uses); loss and predictions stay at 1e-5.
+GTOL_L2_FLIPS_SINGLE = 8e-2
+
+
 def l2_bound(depth, batch, hw):
-    """1e-2 where layer4's BatchNorm sees >= 64 values per channel on ResNet-18; 3e-2 for ResNet-50 and tiny populations."""
-    return GTOL_L2_FLIPS if (depth == 18 and batch * max(hw // 32, 1) ** 2 >= 64) else GTOL_L2_FLIPS_DEEP
+    """1e-2 where layer4's BatchNorm sees >= 64 values per channel on ResNet-18; 3e-2 for ResNet-50 and tiny populations;
+    8e-2 for ResNet-50 with fewer than 16 values per channel there (a single small sample)."""
+    pop = batch * max(hw // 32, 1) ** 2
+    if depth == 50 and pop < 16:
+        return GTOL_L2_FLIPS_SINGLE
+    return GTOL_L2_FLIPS if (depth == 18 and pop >= 64) else GTOL_L2_FLIPS_DEEP
 # the reference's own 2-3-sample fixtures: measured <= 1.2e-2 (model_r50_b3_hw64, stem conv: 12-sample
 # BatchNorm in layer4, one flipped ReLU there reaches the stem through 50 layers); everything else <= 1e-5
 GTOL_L2_FIXTURE = 2e-2          # ResNet-18 fixtures (measured <= 1e-5); the ResNet-50 ones use GTOL_L2_FLIPS_DEEP (2.1e-2 on b2_hw224)
@@ -241,12 +252,18 @@ def _captured_masks(m, V=2):
     relu_units = [u for u in bt["units"] if u.relu]
 
     def unit_mask(u, v):
+        # the mask the BACKWARD kernels use - not "stored activation > 0": the split path stores activations as two fp16
+        # pieces, which flush a positive value below fp16's smallest subnormal (6e-8) to zero while its mask stays on
+        if getattr(u, "relu_bits", None) is not None:       # residual units: one byte per 4 channels, bit k = channel k on
+            G = u.y.shape[0]
+            bits = u.relu_bits.view(G, -1)[v]
+            on = ((bits[:, None] >> torch.arange(4, device=bits.device, dtype=torch.uint8)[None, :]) & 1).bool()
+            return on.reshape(u.y.shape[1:])
+        if getattr(u, "relu_affine", None) is not None and u.out is not None and u.out.dtype == torch.float16:
+            scale, shift = u.relu_affine            # fma(y, scale, shift) > 0: the sign of the exact value (fp64 here)
+            return (u.y[v].double() * scale[v].double() + shift[v].double()) > 0
         if u.out is not None:
-            o = u.out[v].contiguous()
-            if o.dtype == torch.float16:            # split path: the activation is stored as two fp16 pieces (sp)
-                from rot_mvgaze_amd import ops
-                o = ops.merge_sp(o)
-            return o > 0
+            return u.out[v].contiguous() > 0
         # fused stem: the normalised map is not stored; the kernels use fma(y, scale, shift) > 0, whose
         # sign equals the sign of the exact value (evaluated here in fp64)
         scale, shift = u.pool[1], u.pool[2]

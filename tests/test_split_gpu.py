@@ -1,9 +1,9 @@
 """Split-operand kernels (csrc/conv_split.hip): fp32 values held as two fp16 pieces and a per-tensor power-of-two scale
-("sp": |v - pieces| <= 2^-24 |v|, half an fp32 ulp), three fp16 MFMAs per product.  These kernels serve the fp32 model
+("sp": |v - pieces| <= 2^-23 |v|: at most the last significand bit is lost), three fp16 MFMAs per product.  These kernels serve the fp32 model
 (the 1e-4 parity path), so the bar is the fp32-MFMA kernels' own: errors against an fp64 torch reference of F.conv2d
 and its autograd backward (resnet.py:31-47) at fp32-rounding level (2e-6 relative L2 and never more than 3x the
 fp32-MFMA kernel's own error on the same inputs), and the BatchNorm passes that write sp equal to the fp32 passes they
-mirror to that half ulp."""
+mirror to that last bit."""
 import numpy as np
 import pytest
 import torch
@@ -23,18 +23,18 @@ def rel_l2(a, ref):
     return ((a.double() - ref).norm() / ref.norm()).item()
 
 
-SP_ULP = 2.0 ** -24            # |v - (h1 + h2) 2^-k| <= 2^-24 |v| while the second piece is a normal fp16 number
+SP_ULP = 2.0 ** -23            # |v - (h1 + h2) 2^-k| <= 2^-23 |v| while the second piece is a normal fp16 number
 
 
 def sp_close(got, want, what=""):
-    """got == want to the sp format's half fp32 ulp (relative), with an absolute floor of 2^-25 for values whose second
+    """got == want to the sp format's last bit (relative 2^-23), with an absolute floor of 2^-25 for values whose second
     piece is an fp16 subnormal (|v| < 2^-3 of an unscaled tensor)."""
     err = (got.double() - want.double()).abs()
     bound = want.double().abs() * SP_ULP * 1.0001 + 2.0 ** -25
     assert bool((err <= bound).all()), f"{what}: max excess {float((err - bound).max()):.3e}"
 
 
-def test_sp_round_trip_is_half_an_ulp():
+def test_sp_round_trip_loses_at_most_the_last_bit():
     from rot_mvgaze_amd import ops
     torch.manual_seed(1)
     x = torch.randn(3, 5, 7, 64, device=dev()) * torch.logspace(-2, 3, 64, device=dev())
@@ -42,9 +42,10 @@ def test_sp_round_trip_is_half_an_ulp():
     s = ops.split_f32(x)
     assert s.shape == (3, 5, 7, 8, 2, 8) and s.dtype == torch.float16 and getattr(s, "sinv", None) is None
     back = ops.merge_sp(s)
-    big = x.abs() >= 2.0 ** -3                     # second piece normal: the relative bound holds
+    big = x.abs() >= 2.0 ** -2                     # (below: the second piece turns subnormal, absolute error <= 2^-25)
     assert bool(((back - x).abs()[big] <= x.abs()[big] * SP_ULP).all())
     assert float((back - x).abs().max()) <= max(float(x.abs().max()) * SP_ULP, 2.0 ** -25)
+    assert float((back == x)[big].float().mean()) > 0.7     # three values in four come back exactly
     # the pieces are what the definition says: fp16(a), fp16(a - a1)
     a1 = x.to(torch.float16)
     a2 = (x - a1.float()).to(torch.float16)
@@ -56,7 +57,7 @@ def test_sp_round_trip_is_half_an_ulp():
         st = ops.split_f32(t, scale)
         assert st.sinv is not None and float(st.sinv) == 1.0 / scale
         bt = ops.merge_sp(st)
-        sel = t.abs() >= t.abs().max() * 2.0 ** -12
+        sel = t.abs() * scale >= 0.25
         assert bool(((bt - t).abs()[sel] <= t.abs()[sel] * SP_ULP).all())
 
 
@@ -65,15 +66,17 @@ def test_split_weights_carry_their_scale():
     from rot_mvgaze_amd._lib import ConvDesc
     torch.manual_seed(2)
     for mag in (1.0, 1e-3, 300.0):
-        d = ConvDesc.make(1, 1, 8, 8, 64, 96, 3, 1, 1)
-        w = torch.randn(96, 3, 3, 64, device=dev()) * mag
+        d = ConvDesc.make(1, 1, 8, 8, 64, 128, 3, 1, 1)
+        w = torch.randn(128, 3, 3, 64, device=dev()) * mag
         wk, wt = ops.split_weights(d, w, True)
         assert wk.sinv is wt.sinv or torch.equal(wk.sinv, wt.sinv)
         sinv = float(wk.sinv)
         k = np.log2(sinv)
         assert k == round(k) and 2.0 ** 14 <= float(w.abs().max()) / sinv < 2.0 ** 15        # max |w| 2^k just below 2^15
-        sp_close(ops.merge_sp(wk).view(96, 3, 3, 64), w, "KRSC copy")
-        sp_close(ops.merge_sp(wt).view(64, 3, 3, 96), w.permute(3, 1, 2, 0).contiguous(), "CRSK copy")
+        for got, want, what in ((ops.merge_sp(wk).view(128, 3, 3, 64), w, "KRSC copy"),
+                                (ops.merge_sp(wt).view(64, 3, 3, 128), w.permute(3, 1, 2, 0).contiguous(), "CRSK copy")):
+            err = (got.double() - want.double()).abs()
+            assert bool((err <= want.double().abs() * SP_ULP + 2.0 ** -25 * sinv).all()), what
 
 
 CONV_CASES = [
@@ -149,7 +152,7 @@ def test_split_conv_fprop_dgrad_wgrad(case):
 @pytest.mark.parametrize("G,N,H,C,res", [(2, 3, 9, 64, "s3"), (2, 2, 7, 2048, None), (3, 2, 28, 128, "raw"), (1, 4, 12, 256, "s3")])
 def test_batchnorm_passes_writing_sp_match_the_fp32_passes(G, N, H, C, res):
     """bn_apply_split / bn_bwd_apply_split / the stem's pooled map / avgpool over sp: the same numbers as the fp32
-    kernels to the format's half ulp; the ReLU mask bits identical; dy comes with a power-of-two scale that keeps its
+    kernels to the format's last bit; the ReLU mask bits identical; dy comes with a power-of-two scale that keeps its
     pieces finite for O(1) and for 1e-7-sized gradients alike."""
     from rot_mvgaze_amd import ops
     torch.manual_seed(G * 100 + C)
@@ -183,10 +186,10 @@ def test_batchnorm_passes_writing_sp_match_the_fp32_passes(G, N, H, C, res):
             s1m, s2m = s1 * gmag, s2 * gmag
             dy_want = torch.empty_like(gg)
             ops.bn_bwd_apply(gg, None, y, mean, invstd, gamma, s1m, s2m, G, rows, C, dy_want, None, ra)
-            # max |masked gradient|, as the reduce pass would leave it (here: of the unmasked g, an upper bound)
-            absmax = gg.abs().max().reshape(1).view(torch.int32).clone()
+            # max |masked gradient| per (group, channel), as the reduce pass would leave it (here: of the unmasked g, an upper bound)
+            mx = gg.abs().amax(dim=1).contiguous()
             dy = ops.sp_empty(G, rows, C, device=dev())
-            ops.bn_bwd_apply_split(gg, y, mean, invstd, gamma, s1m, s2m, G, rows, C, dy, ra, absmax)
+            ops.bn_bwd_apply_split(gg, y, mean, invstd, gamma, s1m, s2m, G, rows, C, dy, ra, mx)
             k = np.log2(float(dy.sinv))
             assert k == round(k)
             assert float(dy.float().abs().max()) < 65504.0                          # the bound kept every piece finite
@@ -245,16 +248,16 @@ def test_split_dgrad_fused_with_bn_backward_reduce(case, mask):
     s_ref = [torch.empty(G, cin, device=dev()) for _ in range(2)]
     dg_ref, db_ref = torch.full((cin,), 0.5, device=dev()), torch.full((cin,), -0.25, device=dev())
     g2 = dx_ref.view(G, rows, cin)
-    am_ref = torch.zeros(1, dtype=torch.int32, device=dev())
+    am_ref = torch.full((G, cin), float("nan"), device=dev())
     ops.bn_bwd_reduce_split(g2, bits, y, mean, invstd, G, rows, cin, s_ref[0], s_ref[1], dg_ref, db_ref, True, am_ref, ra, dz_out=g2)
     # fused
     dx = torch.empty_like(dx_ref)
     s = [torch.empty(G, cin, device=dev()) for _ in range(2)]
     dg, db = torch.full((cin,), 0.5, device=dev()), torch.full((cin,), -0.25, device=dev())
-    am = torch.zeros(1, dtype=torch.int32, device=dev())
+    am = torch.full((G, cin), float("nan"), device=dev())
     ops.conv_dgrad_split_bnreduce(d, gys, wt, dx, add, y, bits, mean, invstd, ra, s[0], s[1], dg, db, True, am)
     assert torch.equal(dx, dx_ref), "masked gradient"
-    assert torch.equal(am, am_ref) and float(am.view(torch.float32)) == float(dx.abs().max()), "max |masked gradient|"
+    assert torch.equal(am, am_ref) and torch.equal(am, dx.view(G, rows, cin).abs().amax(dim=1)), "max |masked gradient| per (group, channel)"
     for got, want, name in ((s[0], s_ref[0], "s1"), (s[1], s_ref[1], "s2"), (dg, dg_ref, "dgamma"), (db, db_ref, "dbeta")):
         err = (got - want).abs().max().item()
         assert err <= 2e-5 * max(want.abs().max().item(), 1.0) * (rows ** 0.5), f"{name}: {err:.3e}"
