@@ -38,7 +38,7 @@ WORKLOADS = {
     "c5fp32": (50, 8, 64, "C5 shapes in fp32: ResNet-50, V=8, B=64 per GPU (512 on 8 GPUs), 3x224x224, fwd+loss+bwd"),
 }
 BF16_WORKLOADS = {"c5"}
-PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (the 5 PF headline includes 2:1 sparsity)
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA (the 5 PF headline includes 2:1 sparsity)
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0
 
@@ -368,23 +368,25 @@ def main():
             with open(cands[-1]) as f:
                 tj = json.load(f)
             traffic, traffic_src = tj["traffic_bytes_per_launch"], os.path.relpath(cands[-1], ROOT)
-        # fp32 training steps run the split-operand kernels (conv_split.hip: six bf16 MFMAs per fp32-accurate product),
-        # so their matrix-pipe ceiling is the bf16 MFMA peak / 6 (fp32-equivalent FLOP/s); MVG_SPLIT=0: the fp32 MFMA
+        # fp32 training steps run the split-operand kernels (conv_split.hip: three fp16 MFMAs per fp32-accurate product),
+        # so their matrix-pipe ceiling is the fp16 MFMA peak / 3 (fp32-equivalent FLOP/s); MVG_SPLIT=0: the fp32 MFMA
         split = (not bf16) and bb is not None and getattr(bb, "split", False) and \
             (args.mode == "train" or getattr(bb, "split_eval", False))
-        peak = PEAK_BF16_MFMA_TFLOPS if bf16 else (PEAK_BF16_MFMA_TFLOPS / 6.0 if split else PEAK_FP32_MFMA_TFLOPS)
+        peak = PEAK_BF16_MFMA_TFLOPS if bf16 else (PEAK_BF16_MFMA_TFLOPS / 3.0 if split else PEAK_FP32_MFMA_TFLOPS)
         kernels = "bf16" if bf16 else ("split" if split else "fp32mfma")
         if traffic is not None and tj.get("kernels", "fp32mfma") != kernels:
             traffic, traffic_src = None, None           # the committed counters belong to another kernel family
         roofline = {"bound": "mfma",
                     "kernel": ("igemm_bf16_kernel/wgrad_bf16_kernel (bf16 MFMA implicit-GEMM conv: fprop+dgrad+wgrad)" if bf16 else
-                               "igemm_split16_kernel/wgrad_split_kernel (fp32-accurate implicit-GEMM conv on the bf16 MFMA, six MFMAs "
-                               "per product; the 3-channel stem on the fp32 MFMA: fprop+dgrad+wgrad)" if split else
+                               "igemm_split16_kernel/wgrad_split_kernel (fp32-accurate implicit-GEMM conv on the fp16 MFMA: operands as two fp16 "
+                               "pieces, three MFMAs per product; the 3-channel stem on the fp32 MFMA: fprop+dgrad+wgrad)" if split else
                                "igemm_kernel/wgrad_kernel (fp32 MFMA implicit-GEMM conv: fprop+dgrad+wgrad)"),
                     "peak_basis": ("dense bf16 MFMA 2500 TFLOP/s" if bf16 else
-                                   "dense bf16 MFMA 2500 TFLOP/s / 6 MFMAs per fp32-accurate product = 416.7 fp32-equivalent TFLOP/s"
+                                   "dense fp16 MFMA 2500 TFLOP/s / 3 MFMAs per fp32-accurate product = 833.3 fp32-equivalent TFLOP/s (round 2's six-bf16-MFMA "
+                                   "kernels: 416.7; the MFMA-dense loops of this chip hold 1.5-1.7 of 2.4 GHz under load: profiles/README.md)"
                                    if split else "dense fp32 MFMA (v_mfma_f32_32x32x2_f32) 157.3 TFLOP/s"),
                     "frac_of_fp32_mfma_peak": None if bf16 else round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "frac_of_round2_six_product_ceiling": round(achieved / (PEAK_BF16_MFMA_TFLOPS / 6.0), 4) if split else None,
                     "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic,
                     "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE*2 + WRITE_SIZE, separate passes)",
