@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256, DGRAD ? 3 : 4) void igemm_split16_kernel(Igemm
 // one 8-channel chunk are 32 contiguous bytes in memory.  The result is multiplied by dy's 2^-k (p.dy_sinv).
 // ------------------------------------------------------------------------------------------
 template <int BM, int BN, bool INCR>
-__global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradParams p) {
+__global__ __launch_bounds__(256, 3) void wgrad_split_kernel(WgradParams p) {
   constexpr int BK = 16, WGM = 2, WGN = 2;
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -892,7 +892,8 @@ int mvg_conv_wgrad_splits_split(const mvg_conv_desc *d) {
   const long long tiles = (long long)ceil_div(d->cout, bm) * ceil_div(ncols, bn);
   const long long pixels = (long long)d->groups * d->n * d->ho * d->wo;
   const int cus = compute_cus();
-  long long want = (2LL * cus) / tiles;                    // one resident round at two workgroups per CU
+  long long want = (3LL * cus) / tiles;                    // one resident round at three workgroups per CU (measured at C3:
+                                                           // 2 / 3 / 4 / 6 per CU -> 17.8 / 16.8 / 16.7 / 17.7 ms of wgrad per step)
   long long maxs = pixels / 256;                           // at least 256 pixels (16 K-steps) per split
   if (maxs < 1) maxs = 1;
   if (want > maxs) want = maxs;

@@ -1,25 +1,30 @@
 #!/usr/bin/env python3
-"""How accurate is an fp32 GEMM computed as six bf16 MFMA products of three-piece operands (conv_split.hip's
-arithmetic)?  Emulated with the bf16-product Linear kernel (fp32 in / fp32 out) on explicitly split operands and
-compared, against float64, with the fp32-MFMA kernel, with three products only, and with torch's fp32 matmul.
-Output committed as profiles/r02_split_accuracy.txt."""
-import sys, torch
+"""How accurate is an fp32 GEMM computed as THREE fp16 MFMA products of two-piece operands (conv_split.hip's arithmetic:
+a = a1 + a2, a1 = fp16(a), a2 = fp16(a - a1); a b ~ a1 b1 + a1 b2 + a2 b1)?  The split kernels themselves (a Linear =
+a 1x1 conv on a 1x1 map) against float64, next to the fp32-MFMA kernel, torch's fp32 matmul, and - emulated in fp64 -
+what each ingredient contributes: the operand rounding (at most the last bit), the dropped a2 b2 term, and the fp32
+accumulation.  Output committed as profiles/r03_split_accuracy.txt."""
 import os
+import sys
+import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rot_mvgaze_amd  # noqa
 from rot_mvgaze_amd import ops
+from rot_mvgaze_amd._lib import ConvDesc
 
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 
-def split3(t):
-    a1 = t.to(torch.bfloat16).float()
-    r = t - a1
-    a2 = r.to(torch.bfloat16).float()
-    r = r - a2
-    a3 = r.to(torch.bfloat16).float()
-    assert torch.equal(a1 + a2 + a3, t) or (a1 + a2 + a3 - t).abs().max() < 1e-30
-    return a1, a2, a3
+
+def pieces(t):
+    a1 = t.to(torch.float16).double()
+    a2 = (t.double() - a1).float().to(torch.float16).double()
+    return a1, a2
+
+
+def err(y, r):
+    return ((y.double() - r).norm() / r.norm()).item(), ((y.double() - r).abs().max() / r.abs().max()).item()
+
 
 for rows, fin, fout in [(2048, 256, 256), (2048, 2304, 256), (2048, 4608, 512), (4096, 1024, 256)]:
     x = torch.relu(torch.randn(rows, fin, device=dev))
@@ -27,22 +32,19 @@ for rows, fin, fout in [(2048, 256, 256), (2048, 2304, 256), (2048, 4608, 512), 
     ref = x.double() @ w.double().T
     y32 = torch.empty(rows, fout, device=dev)
     ops.linear_fprop(x, w, None, False, y32, rows, fin, fout)
-    xs, ws = split3(x), [p.to(torch.bfloat16).contiguous() for p in split3(w)]
-    def mm(i, j):
-        y = torch.empty(rows, fout, device=dev)
-        ops.linear_fprop_mixed(xs[i].contiguous(), ws[j], None, False, y, rows, fin, fout)
-        return y
-    y11 = mm(0, 0)
-    ref11 = xs[0].double() @ ws[0].double().T
-    small = mm(0, 2) + mm(2, 0) + mm(1, 1)
-    mid = mm(0, 1) + mm(1, 0)
-    y3 = y11 + mid
-    y6 = y11 + (mid + small)
-    def err(y, r):
-        return ((y.double() - r).norm() / r.norm()).item(), ((y.double() - r).abs().max() / r.abs().max()).item()
+    d = ConvDesc.make(1, rows, 1, 1, fin, fout, 1, 1, 0)
+    wk, _ = ops.split_weights(d, w.view(fout, 1, 1, fin).contiguous(), False)
+    ysp = torch.empty(1, rows, 1, 1, fout, device=dev)
+    ops.conv_fprop_split(d, ops.split_f32(x.view(1, rows, 1, 1, fin)), wk, ysp, None)
+    ysp = ysp.view(rows, fout)
+    # fp64 emulation of the ingredients (the weights through the same power-of-two scale as the kernel's copy)
+    sw = 1.0 / float(wk.sinv)
+    (a1, a2), (b1, b2) = pieces(x), pieces(w * sw)
+    exact2 = ((a1 + a2) @ (b1 + b2).T) / sw          # operands rounded to two pieces, everything else exact
+    three = (a1 @ b1.T + a1 @ b2.T + a2 @ b1.T) / sw    # ... and the a2 b2 term dropped
     print(f"rows {rows} fin {fin} fout {fout}")
-    print("   fp32 MFMA        rel L2 %.3e  max %.3e" % err(y32, ref))
-    print("   a1*b1 vs exact   rel L2 %.3e  max %.3e   (accumulation error of the bf16 MFMA)" % err(y11, ref11))
-    print("   3 products       rel L2 %.3e  max %.3e" % err(y3, ref))
-    print("   6 products       rel L2 %.3e  max %.3e" % err(y6, ref))
-    print("   torch fp32 mm    rel L2 %.3e  max %.3e" % err(x @ w.T, ref))
+    print("   split kernel (3 fp16 MFMAs)   rel L2 %.3e  max %.3e" % err(ysp, ref))
+    print("   fp32-MFMA kernel              rel L2 %.3e  max %.3e" % err(y32, ref))
+    print("   torch fp32 mm                 rel L2 %.3e  max %.3e" % err(x @ w.T, ref))
+    print("   fp64: two-piece operands      rel L2 %.3e  max %.3e   (operand rounding alone)" % err(exact2, ref))
+    print("   fp64: ... minus a2 b2         rel L2 %.3e  max %.3e   (operand rounding + dropped term, exact accumulation)" % err(three, ref))
