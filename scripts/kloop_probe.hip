@@ -636,6 +636,112 @@ __global__ __launch_bounds__(NW * 64, WPC) void k_h2(P p) {
       }
 }
 
+
+// two fp16 pieces, TWO stages per workgroup (2 x 32 KB): the next K-step's DMA is issued before this step's MFMAs
+template <int BM, int BN, int NW, int WPC, bool EARLY>
+__global__ __launch_bounds__(NW * 64, WPC) void k_h2x2(P p) {
+  constexpr int WGN = 2, WGM = NW / 2;
+  constexpr int WTM = BM / WGM, WTN = BN / WGN, TM = WTM / 16, TN = WTN / 16;
+  constexpr int ROWB = 128, ROWS = BM + BN, STAGE_B = ROWS * ROWB;
+  constexpr int NQ = ROWS * 8 / 64, QPW = (NQ + NW - 1) / NW;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_B];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int ntile = wg % p.ntiles, mtile = wg / p.ntiles;
+  auto hsw = [](int R) { return ((R >> 1) & 1) | (((R >> 2) & 1) << 2); };
+  unsigned q_base[QPW];
+#pragma unroll
+  for (int i = 0; i < QPW; ++i) {
+    const int Q = wave + NW * i;
+    const int s = Q * 64 + lane;
+    const int row = s >> 3, j = (s & 7) ^ hsw(row);
+    const bool isb = row >= BM;
+    bool ok = Q < NQ;
+    unsigned base;
+    if (!isb) {
+      const int m = mtile * BM + row;
+      ok = ok && m < p.M;
+      base = (unsigned)(m + p.pad_rows) * (unsigned)p.C * 4u + 16u * j;
+    } else {
+      const int n = ntile * BN + (row - BM);
+      ok = ok && n < p.N;
+      base = (unsigned)n * (unsigned)(p.taps * p.C) * 4u + 16u * j;
+    }
+    q_base[i] = pred_off(base, ok);
+  }
+  const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(p.a, p.a_bytes), rs_b = make_rsrc(p.b, p.b_bytes);
+  const int cblks = p.C / 32;
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+  const int cc = lane >> 4;
+  int a_off[TM][2], b_off[TN][2];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int R = wm * WTM + i * 16 + (lane & 15);
+#pragma unroll
+    for (int pc = 0; pc < 2; ++pc) a_off[i][pc] = R * ROWB + (((2 * cc + pc) ^ hsw(R)) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int R = BM + wn * WTN + j * 16 + (lane & 15);
+#pragma unroll
+    for (int pc = 0; pc < 2; ++pc) b_off[j][pc] = R * ROWB + (((2 * cc + pc) ^ hsw(R)) << 4);
+  }
+  auto issue = [&](int kt, int buf) {
+    const int tap = __builtin_amdgcn_readfirstlane(kt / cblks), cb = __builtin_amdgcn_readfirstlane(kt - tap * cblks);
+    const unsigned d_a = (unsigned)((p.toff[tap] * p.C + cb * 32) * 4), d_b = (unsigned)((tap * p.C + cb * 32) * 4);
+#pragma unroll
+    for (int i = 0; i < QPW; ++i) {
+      const int Q = wave + NW * i;
+      if (Q < NQ) {
+        if (Q * 64 >= BM * 8)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_vp)(smem + buf * STAGE_B + Q * 1024), 16, (int)(q_base[i] + d_b), 0, 0, 0);
+        else
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_vp)(smem + buf * STAGE_B + Q * 1024), 16, (int)(q_base[i] + d_a), 0, 0, 0);
+      }
+    }
+  };
+  auto compute = [&](int buf) {
+    const unsigned char *S = smem + buf * STAGE_B;
+    f16x8 av[2][TM], bv[2][TN];
+#pragma unroll
+    for (int pc = 0; pc < 2; ++pc) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av[pc][i] = *reinterpret_cast<const f16x8 *>(S + a_off[i][pc]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bv[pc][j] = *reinterpret_cast<const f16x8 *>(S + b_off[j][pc]);
+    }
+    ONEH(0, 1) ONEH(1, 0) ONEH(0, 0)
+  };
+  const int KT = p.KT;
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    if (EARLY && kt + 1 < KT) issue(kt + 1, cur ^ 1);
+    compute(cur);
+    if (!EARLY && kt + 1 < KT) issue(kt + 1, cur ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = mtile * BM + wm * WTM + i * 16 + (lane >> 4) * 4 + e, ccol = ntile * BN + wn * WTN + j * 16 + (lane & 15);
+        if (r < p.M && ccol < p.N) p.c[(long long)r * p.N + ccol] = acc[i][j][e];
+      }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 static unsigned short f2bf(float x) {
   unsigned u;
@@ -745,6 +851,9 @@ int main(int argc, char **argv) {
       {"h2_4prod_wpc3", k_h2<128, 128, 4, 3, 4, false>, 128, 128, 256, 0, 1},
       {"h2_3prod_wpc4", k_h2<128, 128, 4, 4, 3, false>, 128, 128, 256, 0, 1},
       {"h2_3prod_wpc3_nodma", k_h2<128, 128, 4, 3, 3, true>, 128, 128, 256, 0, 1},
+      {"h2x2_wpc2_early", k_h2x2<128, 128, 4, 2, true>, 128, 128, 256, 0, 1},
+      {"h2x2_wpc2_late", k_h2x2<128, 128, 4, 2, false>, 128, 128, 256, 0, 1},
+      {"h2x2_256x128_wpc1", k_h2x2<256, 128, 8, 1, true>, 256, 128, 512, 0, 1},
       {"big2", k_piece<256, 128, 8, 2, 1>, 256, 128, 512, 0},
       {"big2s", k_span<256, 128, 8, 2, 1, 0, false, false>, 256, 128, 512, 0},
       {"big2si", k_span<256, 128, 8, 2, 1, 1, false, false>, 256, 128, 512, 0},

@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Per-kernel summaries of rocprofv3 --pmc passes (counter_collection.csv).
+
+  pmc_summarize.py traffic <fetch_dir> <write_dir> <steps> <out.json>     whole training steps: HBM bytes per kernel and per step
+  pmc_summarize.py mfma <dir> <out.json>                                 SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA
+                                                                         SQ_ACTIVE_INST_VALU SQ_INSTS_VALU over scripts/conv_pass.py
+
+gfx950 corrections (MI355X_MICROARCH.md, HBM): FETCH_SIZE (KiB) counts 128-byte requests at 64 bytes, so read bytes =
+2 * FETCH_SIZE * 1024; WRITE_SIZE (KiB) is exact for 16-byte-per-lane streaming stores."""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+
+def rows(d):
+    files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+    assert files, d
+    for f in files:
+        yield from csv.DictReader(open(f))
+
+
+def short(name):
+    name = re.sub(r"\(.*$", "", name)
+    return name.replace("void ", "").replace("mvg::", "").strip()
+
+
+def traffic(fetch_dir, write_dir, steps, out):
+    rd, wr, calls = collections.Counter(), collections.Counter(), collections.Counter()
+    for r in rows(fetch_dir):
+        if r["Counter_Name"] == "FETCH_SIZE":
+            rd[short(r["Kernel_Name"])] += 2.0 * float(r["Counter_Value"]) * 1024.0
+            calls[short(r["Kernel_Name"])] += 1
+    for r in rows(write_dir):
+        if r["Counter_Name"] == "WRITE_SIZE":
+            wr[short(r["Kernel_Name"])] += float(r["Counter_Value"]) * 1024.0
+    ks = sorted(set(rd) | set(wr), key=lambda k: -(rd[k] + wr[k]))
+    per = {k: {"launches_per_step": calls[k] / steps, "read_GB_per_step": round(rd[k] / steps / 1e9, 3),
+               "write_GB_per_step": round(wr[k] / steps / 1e9, 3)} for k in ks if (rd[k] + wr[k]) / steps > 5e7}
+    tot_r, tot_w = sum(rd.values()) / steps, sum(wr.values()) / steps
+    json.dump({"steps": steps, "read_GB_per_step": round(tot_r / 1e9, 2), "write_GB_per_step": round(tot_w / 1e9, 2),
+               "total_GB_per_step": round((tot_r + tot_w) / 1e9, 2),
+               "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over bench.py --steps N --warmup 0 "
+                         "--no-overlap --no-roofline --no-cpu-baseline; read = 2*FETCH_SIZE*1024 (gfx950), write = WRITE_SIZE*1024; "
+                         "kernels below 0.05 GB per step omitted from the table",
+               "kernels": per}, open(out, "w"), indent=1)
+    print(f"total {(tot_r + tot_w) / 1e9:.1f} GB per step (read {tot_r / 1e9:.1f}, written {tot_w / 1e9:.1f})")
+
+
+def mfma(d, out):
+    acc = collections.defaultdict(collections.Counter)
+    launches = collections.Counter()
+    for r in rows(d):
+        k = short(r["Kernel_Name"])
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Counter_Name"] == "SQ_BUSY_CYCLES":
+            launches[k] += 1
+    res = {}
+
+    def summarise(name, c, n):
+        busy = c["SQ_BUSY_CYCLES"]
+        if busy <= 0 or c["SQ_INSTS_MFMA"] <= 0:
+            return
+        # SQ_BUSY_CYCLES is summed over the shader engines' SQs; SQ_VALU_MFMA_BUSY_CYCLES over SIMDs: normalise per
+        # SIMD (4 per CU) like round 2's table - fraction of the cycles in which a SIMD's matrix pipe is busy
+        res[name] = {"launches": n, "mfma_busy_frac": round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * busy), 4),
+                     "valu_insts_per_mfma": round(c["SQ_INSTS_VALU"] / c["SQ_INSTS_MFMA"], 2),
+                     "mfma_busy_cycles_per_mfma": round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / c["SQ_INSTS_MFMA"], 1),
+                     "raw": {k: c[k] for k in sorted(c)}}
+    tot = collections.Counter()
+    n = 0
+    for k, c in acc.items():
+        if "split" in k:
+            for kk, v in c.items():
+                tot[kk] += v
+            n += launches[k]
+    summarise("all split conv kernels", tot, n)
+    for k, c in sorted(acc.items(), key=lambda kv: -kv[1]["SQ_VALU_MFMA_BUSY_CYCLES"]):
+        summarise(k, c, launches[k])
+    json.dump({"kernels": res, "note": "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CYCLES) as reported by rocprofv3 on "
+               "gfx950 (check the normalisation against mfma_busy_cycles_per_mfma: 16 cycles per v_mfma_f32_16x16x32_f16, 32 per "
+               "32x32x16)"}, open(out, "w"), indent=1)
+    for k, v in list(res.items())[:8]:
+        print(k, v["mfma_busy_frac"], v["valu_insts_per_mfma"], v["mfma_busy_cycles_per_mfma"])
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "traffic":
+        traffic(sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5])
+    else:
+        mfma(sys.argv[2], sys.argv[3])
