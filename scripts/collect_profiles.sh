@@ -7,7 +7,7 @@ TAG=${1:-r03}
 O=gpurun_out
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
-python3 bench.py > $O/${TAG}_bench_c3.json 2> $O/${TAG}_bench.err || exit 1
+( time python3 bench.py > $O/${TAG}_bench_c3.json 2> $O/${TAG}_bench.err ) 2> $O/${TAG}_bench_c3_walltime.txt || exit 1; echo "c3 bench done"
 for w in c2 c4 c5 r50v2 c5fp32; do python3 bench.py --workload $w --no-cpu-baseline > $O/${TAG}_bench_$w.json 2>> $O/${TAG}_bench.err || exit 1; done
 python3 bench.py --mode eval --workload c2 --no-cpu-baseline > $O/${TAG}_bench_c2_eval.json 2>> $O/${TAG}_bench.err || exit 1
 python3 bench.py --mode eval --no-cpu-baseline > $O/${TAG}_bench_c3_eval.json 2>> $O/${TAG}_bench.err || exit 1
@@ -23,7 +23,7 @@ done
 python3 scripts/pmc_traffic.py /tmp/pmc_conv_FETCH_SIZE /tmp/pmc_conv_WRITE_SIZE c3 $O/${TAG}_pmc_traffic_c3.json split > /dev/null || exit 1
 python3 scripts/pmc_summarize.py traffic /tmp/pmc_step_FETCH_SIZE /tmp/pmc_step_WRITE_SIZE 2 $O/${TAG}_pmc_step_traffic_c3.json || exit 1
 echo "traffic done"
-rm -rf /tmp/pmc_mfma && rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --output-format csv -d /tmp/pmc_mfma -- python3 scripts/conv_pass.py 50 128 4 split > /dev/null 2>> $O/${TAG}_bench.err || exit 1
+rm -rf /tmp/pmc_mfma && rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --output-format csv -d /tmp/pmc_mfma -- python3 scripts/conv_pass.py 50 128 4 split > /dev/null 2>> $O/${TAG}_bench.err || exit 1
 python3 scripts/pmc_summarize.py mfma /tmp/pmc_mfma $O/${TAG}_pmc_mfma_util_c3.json || exit 1
 python3 scripts/conv_bench.py 50 128 4 10 split 2>&1 | grep -v amdgpu.ids > $O/${TAG}_conv_shapes_r50_c3_split.txt
 python3 scripts/bn_bench.py 128 4 split 2>&1 | grep -v amdgpu.ids > $O/${TAG}_bn_shapes_c3_split.txt

@@ -2,7 +2,7 @@
 """Per-kernel summaries of rocprofv3 --pmc passes (counter_collection.csv).
 
   pmc_summarize.py traffic <fetch_dir> <write_dir> <steps> <out.json>     whole training steps: HBM bytes per kernel and per step
-  pmc_summarize.py mfma <dir> <out.json>                                 SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA
+  pmc_summarize.py mfma <dir> <out.json>                                 GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA
                                                                          SQ_ACTIVE_INST_VALU SQ_INSTS_VALU over scripts/conv_pass.py
 
 gfx950 corrections (MI355X_MICROARCH.md, HBM): FETCH_SIZE (KiB) counts 128-byte requests at 64 bytes, so read bytes =
@@ -55,20 +55,21 @@ def mfma(d, out):
     for r in rows(d):
         k = short(r["Kernel_Name"])
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
-        if r["Counter_Name"] == "SQ_BUSY_CYCLES":
+        if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
             launches[k] += 1
     res = {}
 
     def summarise(name, c, n):
-        busy = c["SQ_BUSY_CYCLES"]
-        if busy <= 0 or c["SQ_INSTS_MFMA"] <= 0:
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs (MI355X_MICROARCH.md, DVFS give-back): cycles of the launch = / 8;
+        # SQ_VALU_MFMA_BUSY_CYCLES is summed over the chip's 1024 SIMDs (16 cycles per v_mfma_f32_16x16x32_f16, 32 per
+        # 32x32x16): fraction of the SIMD-cycles in which the matrix pipe is busy = busy / (1024 * cycles)
+        cyc = c["GRBM_GUI_ACTIVE"] / 8.0
+        if cyc <= 0 or c["SQ_INSTS_MFMA"] <= 0:
             return
-        # SQ_BUSY_CYCLES is summed over the shader engines' SQs; SQ_VALU_MFMA_BUSY_CYCLES over SIMDs: normalise per
-        # SIMD (4 per CU) like round 2's table - fraction of the cycles in which a SIMD's matrix pipe is busy
-        res[name] = {"launches": n, "mfma_busy_frac": round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * busy), 4),
+        res[name] = {"launches": n, "mfma_busy_frac": round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc), 4),
                      "valu_insts_per_mfma": round(c["SQ_INSTS_VALU"] / c["SQ_INSTS_MFMA"], 2),
                      "mfma_busy_cycles_per_mfma": round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / c["SQ_INSTS_MFMA"], 1),
-                     "raw": {k: c[k] for k in sorted(c)}}
+                     "gpu_Mcycles": round(cyc / 1e6, 3)}
     tot = collections.Counter()
     n = 0
     for k, c in acc.items():
@@ -79,9 +80,9 @@ def mfma(d, out):
     summarise("all split conv kernels", tot, n)
     for k, c in sorted(acc.items(), key=lambda kv: -kv[1]["SQ_VALU_MFMA_BUSY_CYCLES"]):
         summarise(k, c, launches[k])
-    json.dump({"kernels": res, "note": "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CYCLES) as reported by rocprofv3 on "
-               "gfx950 (check the normalisation against mfma_busy_cycles_per_mfma: 16 cycles per v_mfma_f32_16x16x32_f16, 32 per "
-               "32x32x16)"}, open(out, "w"), indent=1)
+    json.dump({"kernels": res, "note": "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs): the share of "
+               "SIMD-cycles with the matrix pipe busy, at whatever clock the chip held (the time-based roofline fraction in bench.py is "
+               "this figure times held clock / 2.4 GHz)"}, open(out, "w"), indent=1)
     for k, v in list(res.items())[:8]:
         print(k, v["mfma_busy_frac"], v["valu_insts_per_mfma"], v["mfma_busy_cycles_per_mfma"])
 
