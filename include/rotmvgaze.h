@@ -453,6 +453,13 @@ int mvg_nchw_to_nhwc8_bf16(const float *src, uint16_t *dst, int n, int c, int h,
  * backbone but the 3-channel stem). */
 int mvg_split_f32(const float *x, void *out_sp, int64_t n, float scale, void *stream);        /* n % 8 == 0; out = sp(x * scale) */
 int mvg_merge_sp(const void *x_sp, float *out, int64_t n, float inv_scale, void *stream);     /* out = (h1 + h2) * inv_scale */
+/* A gradient of the fusion block on its way into the split kernels (a Linear = a 1x1 conv on a 1x1 map, blocks.py:41-47):
+ * mvg_colsum_absmax: db[cols] (+)= column sums of g [rows][cols] (the bias gradient; db may be NULL), stat2 = {max |g| (bits),
+ * -}; workspace: mvg_colsum_workspace_floats(rows, cols) floats; fixed summation order.  mvg_split_f32_dev: out = sp(g * 2^k),
+ * k from stat2[0] (max |g| just below 2^15), stat2[1] = 2^-k (the dy_sinv of the consumers). */
+size_t mvg_colsum_workspace_floats(int rows, int cols);
+int mvg_colsum_absmax(const float *g, int rows, int cols, float *db, int accumulate, float *stat2, float *workspace, void *stream);
+int mvg_split_f32_dev(const float *x, void *out_sp, int64_t n, float *stat2, void *stream);
 /* fp32 KRSC weights -> sp KRSC (fprop) and, when w_crsk_sp != NULL, the sp transposed copy CRSK (dgrad), both scaled by the
  * 2^k that puts max |w| just below 2^15.  stat2: two device floats, receive {max |w| (bits), 2^-k}: pass stat2 + 1 as the
  * w_sinv of the consumers.  items_dev: 64 bytes of device memory (staging of the one-record table). */
@@ -464,7 +471,7 @@ int mvg_split_weights(const mvg_conv_desc *d, const float *w, void *w_krsc_sp, v
  *     float *stat (mode 1: two device floats per conv, stat[0] CLEARED by the caller, receive {max |w| bits, 2^-k}); }  (48 bytes)
  * mode 1: wk / wt = the sp KRSC / CRSK copies of mvg_split_weights (cin_pad unused); mode 0: the bf16 KRSC (cin
  * zero-padded to cin_pad) / CRSK copies of mvg_cast_weights_bf16 (stat unused). */
-int mvg_weights_prep_batch(const void *items_dev, int n, int mode, void *stream);
+int mvg_weights_prep_batch(const void *items_dev, int n, int mode, int blocks_per_item /* 0: 64 */, void *stream);
 /* partial-statistics geometry of mvg_conv_fprop_split (like mvg_conv_stats_partials) */
 int mvg_conv_stats_partials_split(const mvg_conv_desc *d, int32_t *rows_per_partial);
 int mvg_conv_fprop_split(const mvg_conv_desc *d, const void *x_sp, const float *x_sinv, const void *w_sp, const float *w_sinv,
@@ -475,8 +482,10 @@ int mvg_conv_fprop_split(const mvg_conv_desc *d, const void *x_sp, const float *
 int mvg_conv_fprop_split_affine(const mvg_conv_desc *d, const void *x_sp, const float *x_sinv, const void *w_sp, const float *w_sinv,
                                 void *out, int out_s3, const float *scale, const float *shift, const void *residual,
                                 int residual_s3, int relu, void *stream);
+/* relu_mask_sp (may be NULL; stride-1 launches): an sp tensor shaped like dx - dx is zeroed where it is <= 0 (the ReLU of a
+ * Linear's hidden layer, whose activation the forward wrote in sp) */
 int mvg_conv_dgrad_split(const mvg_conv_desc *d, const void *dy_sp, const float *dy_sinv, const void *w_crsk_sp,
-                         const float *w_sinv, float *dx, const float *addend, void *stream);
+                         const float *w_sinv, float *dx, const float *addend, const void *relu_mask_sp, void *stream);
 /* The BatchNorm passes on the split path: the conv output y and every gradient g stay fp32; what the next conv
  * reads is written in sp - the normalised activation (mvg_bn_apply_split, residual = the previous block's sp output
  * when residual_s3 != 0, else the raw fp32 downsample output with its res_scale / res_shift), the stem's pooled map

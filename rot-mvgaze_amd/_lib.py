@@ -72,11 +72,14 @@ SIGNATURES = {
     "mvg_split_f32": (_I, [_P, _P, _I64, _F, _P]),
     "mvg_merge_sp": (_I, [_P, _P, _I64, _F, _P]),
     "mvg_split_weights": (_I, [_D, _P, _P, _P, _P, _P, _P]),
-    "mvg_weights_prep_batch": (_I, [_P, _I, _I, _P]),
+    "mvg_weights_prep_batch": (_I, [_P, _I, _I, _I, _P]),
     "mvg_conv_stats_partials_split": (_I, [_D, C.POINTER(C.c_int32)]),
     "mvg_conv_fprop_split": (_I, [_D, _P, _P, _P, _P, _P, _P, _P]),
     "mvg_conv_fprop_split_affine": (_I, [_D, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P]),
-    "mvg_conv_dgrad_split": (_I, [_D, _P, _P, _P, _P, _P, _P, _P]),
+    "mvg_conv_dgrad_split": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mvg_colsum_workspace_floats": (C.c_size_t, [_I, _I]),
+    "mvg_colsum_absmax": (_I, [_P, _I, _I, _P, _I, _P, _P, _P]),
+    "mvg_split_f32_dev": (_I, [_P, _P, _I64, _P, _P]),
     "mvg_bn_apply_split": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _I, _I64, _I, _P]),
     "mvg_bn_bwd_apply_split": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _P, _P, _P, _P]),
     "mvg_bn_bwd_reduce_split": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P]),

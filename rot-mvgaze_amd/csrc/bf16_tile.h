@@ -194,8 +194,14 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
         continue;
       }
       if (DGRAD && mask_f) {
-        const float4 m0 = *reinterpret_cast<const float4 *>(mask_f + off + col), m1 = *reinterpret_cast<const float4 *>(mask_f + off + col + 4);
-        const float mm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+        float mm[8];
+        if (p.mask_s3) {                       // the producer's activation in sp storage (a Linear's hidden layer)
+          const uint4 *q = reinterpret_cast<const uint4 *>(p.mask) + (((long long)g * gelems + off + col) >> 3) * SP_NP;
+          merge2_chunk(q[0], q[1], mm);
+        } else {
+          const float4 m0 = *reinterpret_cast<const float4 *>(mask_f + off + col), m1 = *reinterpret_cast<const float4 *>(mask_f + off + col + 4);
+          mm[0] = m0.x; mm[1] = m0.y; mm[2] = m0.z; mm[3] = m0.w; mm[4] = m1.x; mm[5] = m1.y; mm[6] = m1.z; mm[7] = m1.w;
+        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) x[k] = mm[k] > 0.f ? x[k] : 0.f;
       }

@@ -133,7 +133,7 @@ struct IgemmParams {
   float *bn_part;
   // split kernels, inference forward (BatchNorm folded: y = acc * scale + bias (+ residual) [relu]): the residual
   // and / or the result in s3 (the next conv's operand format) instead of fp32
-  int addend_s3, out_s3;
+  int addend_s3, out_s3, mask_s3;
   // split kernels: the operands hold (value * 2^k) for a per-tensor k (elem.h: sp_t); the epilogue multiplies the
   // accumulators by *a_sinv * *b_sinv (device scalars, each 2^-k of its operand; null = 1)
   const float *a_sinv, *b_sinv;

@@ -63,6 +63,53 @@ __global__ __launch_bounds__(256) void merge_sp_kernel(const uint4 *__restrict__
   }
 }
 
+// fp32 [n8 * 8] -> sp with the scale taken from a device scalar: stat[0] = max |x| (float bits, e.g. from
+// colsum_absmax_kernel), stat[1] receives 2^-k.  (A gradient tensor of the fusion block on its way into the split kernels.)
+__global__ __launch_bounds__(256) void split_f32_dev_kernel(const float4 *__restrict__ x, uint4 *__restrict__ out, long long n8,
+                                                            float *__restrict__ stat) {
+  const float scale = sp_scale_for(__uint_as_float(*reinterpret_cast<const unsigned *>(stat)));
+  if (blockIdx.x == 0 && threadIdx.x == 0) stat[1] = 1.f / scale;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += stride) {
+    const float4 lo = x[2 * i], hi = x[2 * i + 1];
+    const float v[8] = {lo.x * scale, lo.y * scale, lo.z * scale, lo.w * scale, hi.x * scale, hi.y * scale, hi.z * scale, hi.w * scale};
+    uint4 q1, q2;
+    split2_chunk(v, q1, q2);
+    out[2 * i] = q1;
+    out[2 * i + 1] = q2;
+  }
+}
+
+// Column sums (a Linear's bias gradient) and max |g| of g [rows][cols] in one pass: grid (cols / 256, chunks); a thread
+// owns one column of one row chunk (coalesced across the block), partial sums go to part [chunks][cols] and
+// colsum_finish_kernel adds them in chunk order (deterministic); the maximum is order-independent (atomicMax).
+__global__ __launch_bounds__(256) void colsum_absmax_kernel(const float *__restrict__ g, int rows, int cols, int rows_per_chunk,
+                                                            float *__restrict__ part, unsigned *__restrict__ absmax) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int r0 = blockIdx.y * rows_per_chunk;
+  int r1 = r0 + rows_per_chunk;
+  if (r1 > rows) r1 = rows;
+  float s = 0.f, m = 0.f;
+  if (c < cols)
+    for (int r = r0; r < r1; ++r) {
+      const float v = g[(long long)r * cols + c];
+      s += v;
+      m = fmaxf(m, fabsf(v));
+    }
+  if (c < cols) part[(long long)blockIdx.y * cols + c] = s;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(absmax, __float_as_uint(m));
+}
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float *__restrict__ part, int cols, int chunks, float *__restrict__ db,
+                                                            int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float s = accumulate ? db[c] : 0.f;
+  for (int k = 0; k < chunks; ++k) s += part[(long long)k * cols + c];
+  db[c] = s;
+}
+
 // Every conv's weight copies of one training step in TWO launches (grid.y = conv): (1) max |w| per conv, (2) the
 // copies.  mode 1: fp32 KRSC -> sp KRSC (+ sp CRSK), both scaled by 2^k with max |w| * 2^k just below 2^15, and
 // wstat[conv] = {max |w| bits, 2^-k} for the consumers' epilogues; mode 0: -> bf16 KRSC (cin zero-padded to cin_pad)
@@ -88,6 +135,7 @@ __global__ __launch_bounds__(256) void weights_absmax_kernel(const WPrepItem *__
 }
 
 __global__ __launch_bounds__(256) void weights_prep_batch_kernel(const WPrepItem *__restrict__ items, int mode) {
+  __shared__ float tile[64][65];             // mode 1, 1x1 / Linear weights: the transposed copy goes through LDS
   const WPrepItem it = items[blockIdx.y];
   const float *__restrict__ w = it.w;
   const int cout = it.cout, rs = it.rs, cin = it.cin;
@@ -96,7 +144,11 @@ __global__ __launch_bounds__(256) void weights_prep_batch_kernel(const WPrepItem
     if (blockIdx.x == 0 && threadIdx.x == 0) it.stat[1] = 1.f / scale;
     uint4 *wk = reinterpret_cast<uint4 *>(it.wk), *wt = reinterpret_cast<uint4 *>(it.wt);
     const int c8n = cin / 8, o8n = cout / 8;
-    const long long nk = (long long)cout * rs * c8n, nt = wt ? (long long)cin * rs * o8n : 0;
+    // 1x1 weights with 64-divisible sides (the fusion block's 3584 x 3584 Linears: 51 MB each): the CRSK copy as a tiled
+    // transpose - rows read as float4, 8-output-channel chunks written 256 contiguous bytes per input channel.  (The
+    // gather below reads 8 floats at a stride of cin per chunk: fine for the backbone's convs, 1 ms per Linear.)
+    const bool tiled = wt != nullptr && rs == 1 && (cin % 64) == 0 && (cout % 64) == 0;
+    const long long nk = (long long)cout * rs * c8n, nt = (wt && !tiled) ? (long long)cin * rs * o8n : 0;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nk + nt; i += (long long)gridDim.x * 256) {
       float v[8];
       uint4 *dst;
@@ -120,6 +172,35 @@ __global__ __launch_bounds__(256) void weights_prep_batch_kernel(const WPrepItem
       split2_chunk(v, q1, q2);
       dst[0] = q1;
       dst[1] = q2;
+    }
+    if (tiled) {
+      const int tc = cin / 64, ntiles = (cout / 64) * tc;
+      for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int o0 = (t / tc) * 64, c0 = (t % tc) * 64;
+        __syncthreads();                                       // the previous tile has been read out
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+          const int r = (threadIdx.x >> 4) + 16 * ps, cq = threadIdx.x & 15;
+          const float4 x = *reinterpret_cast<const float4 *>(w + (long long)(o0 + r) * cin + c0 + 4 * cq);
+          tile[r][4 * cq] = x.x;
+          tile[r][4 * cq + 1] = x.y;
+          tile[r][4 * cq + 2] = x.z;
+          tile[r][4 * cq + 3] = x.w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int idx = threadIdx.x + 256 * q, cl = idx >> 3, o8 = idx & 7;
+          float v[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = tile[o8 * 8 + k][cl] * scale;
+          uint4 q1, q2;
+          split2_chunk(v, q1, q2);
+          uint4 *dst = wt + SP_NP * ((long long)(c0 + cl) * o8n + (o0 >> 3) + o8);
+          dst[0] = q1;
+          dst[1] = q2;
+        }
+      }
     }
     return;
   }
@@ -625,18 +706,58 @@ int mvg_split_weights(const mvg_conv_desc *d, const float *w, void *w_krsc_sp, v
     set_error("split_weights: staging the table record failed");
     return 1;
   }
-  return mvg_weights_prep_batch(items_dev, 1, 1, stream);
+  const long long n8 = (long long)d->cout * it.rs * d->cin / 8;
+  long long blocks = (n8 + 256 * 8 - 1) / (256 * 8);             // ~8 chunks per thread
+  return mvg_weights_prep_batch(items_dev, 1, 1, (int)(blocks < 16 ? 16 : (blocks > 2048 ? 2048 : blocks)), stream);
 }
 
-int mvg_weights_prep_batch(const void *items_dev, int n, int mode, void *stream) {
-  MVG_REQUIRE(items_dev != nullptr && n > 0 && (mode == 0 || mode == 1), "weights_prep_batch: bad arguments");
+int mvg_split_f32_dev(const float *x, void *out_sp, int64_t n, float *stat2, void *stream) {
+  MVG_REQUIRE(x && out_sp && stat2 && n >= 0 && n % 8 == 0, "split_f32_dev: null argument or n %% 8 != 0");
+  if (n == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(MVG_K_LAYOUT, st, 0.0, (4.0 + SP_BYTES) * (double)n);
+  long long blocks = (n / 8 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(split_f32_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float4 *)x, (uint4 *)out_sp, (long long)(n / 8),
+                     stat2);
+  return check_launch("split_f32_dev");
+}
+
+size_t mvg_colsum_workspace_floats(int rows, int cols) { return (size_t)ceil_div(rows, 32) * (size_t)cols; }
+
+int mvg_colsum_absmax(const float *g, int rows, int cols, float *db, int accumulate, float *stat2, float *workspace, void *stream) {
+  MVG_REQUIRE(g && stat2 && workspace && rows > 0 && cols > 0, "colsum_absmax: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(MVG_K_LAYOUT, st, 0.0, 4.0 * (double)rows * cols);
+  if (hipMemsetAsync(stat2, 0, 2 * sizeof(float), st) != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("colsum_absmax: clearing the statistics failed");
+    return 1;
+  }
+  const int rpc = 32, chunks = ceil_div(rows, rpc);
+  hipLaunchKernelGGL(colsum_absmax_kernel, dim3(ceil_div(cols, 256), chunks), dim3(256), 0, st, g, rows, cols, rpc, workspace,
+                     (unsigned *)stat2);
+  if (check_launch("colsum_absmax")) return 1;
+  if (db) {
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(ceil_div(cols, 256)), dim3(256), 0, st, workspace, cols, chunks, db, accumulate);
+    return check_launch("colsum_finish");
+  }
+  return 0;
+}
+
+int mvg_weights_prep_batch(const void *items_dev, int n, int mode, int blocks_per_item, void *stream) {
+  MVG_REQUIRE(items_dev != nullptr && n > 0 && (mode == 0 || mode == 1) && blocks_per_item >= 0 && blocks_per_item <= 4096,
+              "weights_prep_batch: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps(MVG_K_LAYOUT, st, 0.0, 0.0);
+  // workgroups per record: 64 suits the backbone's convs (53 records, <= 2.4 M weights each); the fusion block's Linears
+  // (9 records of up to 12.8 M weights) want a few hundred
+  const unsigned bx = blocks_per_item > 0 ? (unsigned)blocks_per_item : 64u;
   if (mode == 1) {           // max |w| per conv first (the records' stat[0] must be zero: the caller clears them)
-    hipLaunchKernelGGL(weights_absmax_kernel, dim3(16, (unsigned)n), dim3(256), 0, st, (const WPrepItem *)items_dev);
+    hipLaunchKernelGGL(weights_absmax_kernel, dim3(bx > 64 ? bx / 2 : 16, (unsigned)n), dim3(256), 0, st, (const WPrepItem *)items_dev);
     if (check_launch("weights_absmax")) return 1;
   }
-  hipLaunchKernelGGL(weights_prep_batch_kernel, dim3(64, (unsigned)n), dim3(256), 0, st, (const WPrepItem *)items_dev, mode);
+  hipLaunchKernelGGL(weights_prep_batch_kernel, dim3(bx, (unsigned)n), dim3(256), 0, st, (const WPrepItem *)items_dev, mode);
   return check_launch("weights_prep_batch");
 }
 
@@ -736,7 +857,7 @@ struct SplitBnFuse {       // fused BatchNorm-backward reduce of the unit whose 
 };
 
 static int dgrad_split_impl(const mvg_conv_desc *d, const void *dy_sp, const float *dy_sinv, const void *w_crsk_sp, const float *w_sinv,
-                            float *dx, const float *addend, void *stream, const SplitBnFuse *bnf) {
+                            float *dx, const float *addend, void *stream, const SplitBnFuse *bnf, const void *relu_mask_sp = nullptr) {
   if (validate_split(d)) return 2;
   IgemmParams p;
   memset(&p, 0, sizeof(p));
@@ -746,6 +867,8 @@ static int dgrad_split_impl(const mvg_conv_desc *d, const void *dy_sp, const flo
   p.b_sinv = w_sinv;
   p.out = dx;
   p.addend = addend;
+  p.mask = (const float *)relu_mask_sp;
+  p.mask_s3 = relu_mask_sp != nullptr;
   if (bnf) {
     p.bn_y = bnf->y;
     p.bn_bits = bnf->bits;
@@ -851,8 +974,9 @@ static int dgrad_split_impl(const mvg_conv_desc *d, const void *dy_sp, const flo
 }
 
 int mvg_conv_dgrad_split(const mvg_conv_desc *d, const void *dy_sp, const float *dy_sinv, const void *w_crsk_sp, const float *w_sinv,
-                         float *dx, const float *addend, void *stream) {
-  return dgrad_split_impl(d, dy_sp, dy_sinv, w_crsk_sp, w_sinv, dx, addend, stream, nullptr);
+                         float *dx, const float *addend, const void *relu_mask_sp, void *stream) {
+  MVG_REQUIRE(!relu_mask_sp || d->stride == 1, "dgrad_split: the sp ReLU mask is for stride-1 launches (Linear layers)");
+  return dgrad_split_impl(d, dy_sp, dy_sinv, w_crsk_sp, w_sinv, dx, addend, stream, nullptr, relu_mask_sp);
 }
 
 // row tiles per group of the backward-data launch = partials per group of the fused reduce (0: not fusable)

@@ -29,6 +29,7 @@ from .backbone import GradSink
 
 Tensor = torch.Tensor
 IBN_MOMENTUM, IBN_EPS = 0.05, 1e-4          # IntensityBatchNorm defaults, rot_mv.py:14
+SPLIT_MIN_ROWS = 1024                       # Linears with at least this many rows run on the split-operand kernels
 
 
 def directed_pairs(views: int) -> Tuple[List[int], List[int]]:
@@ -105,9 +106,19 @@ class _Mlp:
         # forward() makes once per step (w [fout][fin] and its transpose for backward-data)
         self.mixed = False
         self._wbf: List[Optional[tuple]] = [None] * n_layers
+        # fp32 model, many rows (C3: 1536, C5's shapes: 3584): the Linears run on the split-operand kernels (conv_split.hip:
+        # a Linear is a 1x1 conv on a 1x1 map) - operands as two fp16 pieces, three fp16 MFMAs per product, fp32-accurate
+        # like the backbone's convs, 2-3x the fp32-MFMA kernels' rate.  forward() makes the sp weight copies once per step.
+        self.split = False
+        self._wsp: List[Optional[tuple]] = [None] * n_layers
+        self._ones: Dict[int, Tensor] = {}
 
     def _use_mixed(self, l: int) -> bool:
         return self.mixed and not self.padded[l] and not (l == self.n - 1 and self.fout[l] <= 4)
+
+    def _use_split(self, l: int, rows: int) -> bool:
+        return (self.split and not self.mixed and rows >= SPLIT_MIN_ROWS and not self.padded[l] and self.fin[l] % 32 == 0
+                and self.fout[l] % 32 == 0)
 
     def parameters(self):
         out = []
@@ -140,6 +151,24 @@ class _Mlp:
         for l in range(self.n):
             w, b = self._weights(l)
             last = l == self.n - 1
+            if self._use_split(l, rows):
+                assert gen is None
+                fin, fout = self.fin[l], self.fout[l]
+                d = ConvDesc.make(1, rows, 1, 1, fin, fout, 1, 1, 0)
+                assert self._wsp[l] is not None          # made by FusionHead._prepare_split_weights at the start of the step
+                x_sp = cur if ops.is_sp(cur) else ops.split_f32(cur)
+                # the hidden activation goes out in sp when the next layer reads it there (and the backward takes its ReLU
+                # mask and its wgrad operand from the same tensor); fp32 otherwise (the 512 -> 2 head layer)
+                to_sp = (not last) and self._use_split(l + 1, rows)
+                y = ops.sp_empty(rows, fout, device=dev) if to_sp else \
+                    (out if (last and out is not None) else torch.empty(rows, fout, dtype=torch.float32, device=dev))
+                if fout not in self._ones or self._ones[fout].device != dev:
+                    self._ones[fout] = torch.ones(fout, dtype=torch.float32, device=dev)
+                ops.conv_fprop_split_affine(d, x_sp, self._wsp[l][0], y, self._ones[fout], b, None, not last)
+                if not last:
+                    hs.append(y)
+                cur = y
+                continue
             y = out if (last and out is not None) else torch.empty(rows, self.fout_p[l], dtype=torch.float32, device=dev)
             if self._use_mixed(l):
                 assert gen is None
@@ -168,6 +197,27 @@ class _Mlp:
             w, _ = self._weights(l) if self.padded[l] else (self.w[l].detach(), None)
             last = l == self.n - 1
             fin, fout = self.fin_p[l], self.fout_p[l]
+            if self._use_split(l, rows):
+                assert gen is None
+                aw, ab = wr.acc(self.w[l]), wr.acc(self.b[l])
+                assert aw == ab
+                d = ConvDesc.make(1, rows, 1, 1, fin, fout, 1, 1, 0)
+                # one pass over g: its column sums (the bias gradient), its maximum -> the scale of its sp copy
+                g_sp = ops.split_grad(g, rows, fout, sink.view(self.b[l]), ab)
+                inp_sp = inp if ops.is_sp(inp) else ops.split_f32(inp)
+
+                def wgrad(inp_sp=inp_sp, g_sp=g_sp, d=d, l=l, aw=aw):
+                    ops.conv_wgrad_split(d, inp_sp, g_sp, sink.view(self.w[l]), aw)
+                wr.off_path(wgrad, inp_sp, g_sp, g_sp.sinv)
+                wt = self._wsp[l][1]
+                if l == 0:
+                    dx = dx_out if dx_out is not None else torch.empty(rows, fin, dtype=torch.float32, device=dev)
+                    ops.conv_dgrad_split(d, g_sp, wt, dx, dx_addend)
+                    return dx
+                dh = torch.empty(rows, fin, dtype=torch.float32, device=dev)
+                ops.conv_dgrad_split(d, g_sp, wt, dh, None, inp_sp)              # (g @ W) * (h > 0)
+                g = dh
+                continue
             # ---- weight / bias gradients
             if self.padded[l]:
                 accs = (wr.acc(self.w[l]), wr.acc(self.b[l]))
@@ -221,6 +271,7 @@ class _Mlp:
                     ops.linear_dgrad(g, w, None, dx_addend, dx, rows, fin, fout)
                 return dx
             dh = torch.empty(rows, fin, dtype=torch.float32, device=dev)
+            assert not ops.is_sp(hs[l - 1])
             if mixed:
                 ops.linear_dgrad_mixed(g, self._wbf[l][1], hs[l - 1], None, dh, rows, fin, fout)
             else:
@@ -244,9 +295,41 @@ class FusionHead:
         # MVG_FUSED_INPUT=0: materialise the fuser / head inputs with rotcat kernels instead (A/B switch)
         self.fused_input = True
         self.mixed = False                        # bf16 path: Linear products on the bf16 matrix cores (set by the model per call)
+        self.split = True                         # fp32 path: Linears with >= SPLIT_MIN_ROWS rows on the split-operand kernels
         self.kin = self.fusers[0].in_width            # row length of the fuser input (zero-padded)
         self.hin = self.heads[0].in_width
         self._idx_cache: Dict[Tuple[int, str], dict] = {}
+        self._wprep_state = None
+        self._wsp_versions = None
+
+    def _prepare_split_weights(self, rows: int, dev):
+        """The sp copies (KRSC for fprop, CRSK for backward-data) of every fuser / head Linear that runs on the split
+        kernels this step, made by ONE batched launch pair (like Backbone._prepare_weights: persistent destination buffers and
+        a device-resident record table built once per parameter placement)."""
+        mods = [m for m in self.unique_modules()]
+        layers = [(m, l) for m in mods for l in range(m.n) if m._use_split(l, rows)]
+        key = (str(dev), tuple(m.w[l].data_ptr() for m, l in layers))
+        if self._wprep_state is None or self._wprep_state[0] != key:
+            wstat = torch.zeros(len(layers), 2, dtype=torch.float32, device=dev)
+            rows_t, bufs = [], []
+            for i, (m, l) in enumerate(layers):
+                fin, fout = m.fin[l], m.fout[l]
+                wk, wt = ops.sp_empty(fout, fin, device=dev), ops.sp_empty(fin, fout, device=dev)
+                wk.sinv = wt.sinv = wstat[i, 1:2]
+                bufs.append((m, l, wk, wt))
+                rows_t.append([m.w[l].data_ptr(), wk.data_ptr(), wt.data_ptr(), fout | (1 << 32), fin | (fin << 32), wstat[i].data_ptr()])
+            table = torch.tensor(rows_t, dtype=torch.int64).to(dev) if rows_t else None
+            self._wprep_state = (key, bufs, table, wstat)
+        _, bufs, table, wstat = self._wprep_state
+        for m in mods:
+            m._wsp = [None] * m.n
+        if table is None:
+            return
+        wstat.zero_()
+        ops.weights_prep_batch(table, len(bufs), 1, 256)
+        for m, l, wk, wt in bufs:
+            m._wsp[l] = (wk, wt)
+        self._wsp_versions = tuple(m.w[l]._version for m, l, _, _ in bufs)
 
     def unique_modules(self) -> List[_Mlp]:
         """Heads and fusers in grad-ready order (last iteration first), each module once."""
@@ -311,8 +394,15 @@ class FusionHead:
         dev = img_feat.device
         ix = self._indices(V, dev)
         D, I, NV = ix["D"], self.I, NUM_FEAT_VEC
+        # fp32 model, default variant, many rows: the fuser / head Linears on the split-operand kernels (their inputs
+        # are then materialised: the span loader of those kernels reads plain rows)
+        split_on = self.split and not self.mixed and not (self.v.share_feature or self.v.encode_rotmat) and D * B >= SPLIT_MIN_ROWS
         for m in [self.lifter] + self.fusers + self.heads:
             m.mixed = self.mixed
+            m.split = split_on
+        self.lifter.split = False                  # V * B rows: stays on the fp32-MFMA kernels
+        if split_on:
+            self._prepare_split_weights(D * B, dev)
         hl, lifted = self.lifter.forward(img_feat.reshape(V * B, cf))
         rel = torch.empty(D, B, 3, 3, dtype=torch.float32, device=dev)
         ops.relative_rotation(rot.detach().to(torch.float32).contiguous(), ix["vi"], ix["vj"], rel, B, V, D)
@@ -324,7 +414,7 @@ class FusionHead:
         # default / ignore_rotmat variants: rotate + concat run inside the first Linear's operand loader - the
         # fuser input X = [img_feat | R @ F] and the head input [img_feat | F] are never written (the other
         # variants have 9 extra columns / interleaved rows and keep the materialised form)
-        fused_in = self.fused_input and not (self.v.share_feature or self.v.encode_rotmat) and not self.mixed
+        fused_in = self.fused_input and not (self.v.share_feature or self.v.encode_rotmat) and not self.mixed and not split_on
         rt = self._row_tables(V, B, dev) if fused_in else None
         img2d = img_feat.reshape(V * B, cf)
         for it in range(I):
@@ -349,8 +439,8 @@ class FusionHead:
             if keep_tape:
                 saved.append((X, Hf, Xh, Hh, scales))
             src, src_idx = Fn, ix["partner"]             # view j's feature of the SAME pair, previous iteration
-        tape = {"img_feat": img_feat, "lifted": lifted, "hl": hl, "rel": rel, "saved": saved, "V": V, "B": B} \
-            if keep_tape else None
+        tape = {"img_feat": img_feat, "lifted": lifted, "hl": hl, "rel": rel, "saved": saved, "V": V, "B": B,
+                "wsp_versions": self._wsp_versions if split_on else None} if keep_tape else None
         return lifted.view(V, B, 3, NV), feats.view(I, D, B, 3, NV), preds.view(I, D, B, 2), tape
 
     # ---------------------------------------------------------------- backward
@@ -360,6 +450,10 @@ class FusionHead:
         go to ``sink`` and are published iteration I-1 ... 0 (shared weights: once, after iteration 0),
         then the lifter."""
         V, B, cf, v = tape["V"], tape["B"], self.cf, self.v
+        if tape.get("wsp_versions") is not None and tape["wsp_versions"] != self._wsp_versions:
+            raise RuntimeError("backward of a tape whose sp weight copies were overwritten by a later forward with DIFFERENT "
+                               "weights (forward, optimizer step, forward, then backward of the first call): run backward "
+                               "before the weights change")
         img_feat, rel = tape["img_feat"], tape["rel"]
         dev = img_feat.device
         ix = self._indices(V, dev)

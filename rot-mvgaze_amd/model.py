@@ -333,6 +333,7 @@ class MultiViewGaze(nn.Module):
             raise ValueError("compute_dtype must be torch.float32 or torch.bfloat16")
         self._backbone.act_dtype = self.compute_dtype
         self._head.mixed = self.compute_dtype == torch.bfloat16
+        self._head.split = self._backbone.split          # one switch (MVG_SPLIT) selects the kernel family everywhere
         self._sink.active = False
         self._grad_mode = torch.is_grad_enabled()
         img_feat = _BackboneFn.apply(self, self.training, len(imgs), *imgs, *self._backbone_params)

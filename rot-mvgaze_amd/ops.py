@@ -199,10 +199,10 @@ def split_weights(d: ConvDesc, w: Tensor, need_transposed: bool = True):
     return wk, wt
 
 
-def weights_prep_batch(table: Tensor, n: int, mode: int):
+def weights_prep_batch(table: Tensor, n: int, mode: int, blocks_per_item: int = 0):
     """table: [n, 6] int64 DEVICE tensor of (w, wk, wt, cout | rs << 32, cin | cin_pad << 32, stat) records (48 bytes each)."""
     assert table.is_cuda and table.dtype == torch.int64 and table.is_contiguous() and table.shape == (n, 6)
-    check(lib().mvg_weights_prep_batch(C.c_void_p(table.data_ptr()), n, mode, _s()), "weights_prep_batch")
+    check(lib().mvg_weights_prep_batch(C.c_void_p(table.data_ptr()), n, mode, blocks_per_item, _s()), "weights_prep_batch")
 
 
 def conv_stats_partials_split(d: ConvDesc):
@@ -225,9 +225,24 @@ def conv_fprop_split_affine(d: ConvDesc, x_s3: Tensor, w_s3: Tensor, out: Tensor
                                             _p(shift), _p(residual), int(is_sp(residual)), int(relu), _s()), "conv_fprop_split_affine")
 
 
-def conv_dgrad_split(d: ConvDesc, dy_sp: Tensor, wt_sp: Tensor, dx: Tensor, addend: Optional[Tensor] = None):
-    check(lib().mvg_conv_dgrad_split(C.byref(d), _p(dy_sp), _sinv(dy_sp), _p(wt_sp), _sinv(wt_sp), _p(dx), _p(addend), _s()),
-          "conv_dgrad_split")
+def conv_dgrad_split(d: ConvDesc, dy_sp: Tensor, wt_sp: Tensor, dx: Tensor, addend: Optional[Tensor] = None,
+                     relu_mask_sp: Optional[Tensor] = None):
+    assert relu_mask_sp is None or (is_sp(relu_mask_sp) and getattr(relu_mask_sp, "sinv", None) is None)
+    check(lib().mvg_conv_dgrad_split(C.byref(d), _p(dy_sp), _sinv(dy_sp), _p(wt_sp), _sinv(wt_sp), _p(dx), _p(addend), _p(relu_mask_sp),
+                                     _s()), "conv_dgrad_split")
+
+
+def split_grad(g: Tensor, rows: int, cols: int, db: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    """A gradient g [rows, cols] of the fusion block -> sp with its own power-of-two scale (from max |g|, found on the
+    device), and - in the same pass over g - db (+)= its column sums (the Linear's bias gradient)."""
+    assert g.dtype == torch.float32 and g.is_contiguous() and g.numel() == rows * cols and cols % 8 == 0
+    stat = torch.empty(2, dtype=torch.float32, device=g.device)
+    ws = torch.empty(lib().mvg_colsum_workspace_floats(rows, cols), dtype=torch.float32, device=g.device)
+    check(lib().mvg_colsum_absmax(_p(g), rows, cols, _p(db), int(accumulate), _p(stat), _p(ws), _s()), "colsum_absmax")
+    out = sp_empty(rows, cols, device=g.device)
+    check(lib().mvg_split_f32_dev(_p(g), _p(out), g.numel(), _p(stat), _s()), "split_f32_dev")
+    out.sinv = stat[1:2]
+    return out
 
 
 def conv_dgrad_bn_partials_split(d: ConvDesc) -> int:
