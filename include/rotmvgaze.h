@@ -391,6 +391,17 @@ int mvg_conv_stats_partials_bf16(const mvg_conv_desc *d, int32_t *out_rows_per_p
 /* like mvg_conv_dgrad; wgt_crsk = the transposed bf16 weights; mask/addend (bf16) like dx */
 int mvg_conv_dgrad_bf16(const mvg_conv_desc *d, const void *dy, const void *wgt_crsk, void *dx,
                         const void *mask, const void *addend, void *stream);
+/* mvg_conv_dgrad_bf16 fused with the BatchNorm-backward reduce pass of the unit whose output gradient dx is (the bf16
+ * form of mvg_conv_dgrad_split_bnreduce below; resnet.py:113-133 backward): dx is stored masked by that unit's ReLU
+ * (bn_bits from mvg_bn_apply_bits_bf16 - one byte per 8 channels -, or fma(bn_y, relu_scale, relu_shift) > 0, or no mask)
+ * and s1 / s2 / dgamma / dbeta - sums of the ROUNDED gradient, what mvg_bn_bwd_reduce_bf16 would read back - come
+ * out of the same launch + a finalize.  Stride 1 or 2; cin, cout multiples of 64; bn_y bf16 shaped like dx.
+ * partials: groups * mvg_conv_dgrad_bn_partials_bf16(d) * 2 * cin floats. */
+int mvg_conv_dgrad_bn_partials_bf16(const mvg_conv_desc *d);
+int mvg_conv_dgrad_bf16_bnreduce(const mvg_conv_desc *d, const void *dy, const void *wgt_crsk, void *dx, const void *addend,
+                                 const void *bn_y, const uint8_t *bn_bits, const float *bn_mean, const float *bn_invstd,
+                                 const float *relu_scale, const float *relu_shift, float *partials, float *s1, float *s2,
+                                 float *dgamma, float *dbeta, int accumulate, void *stream);
 /* like mvg_conv_wgrad / mvg_conv_wgrad_splits; x, dy bf16, dw (and the slabs in workspace) fp32 */
 int mvg_conv_wgrad_bf16(const mvg_conv_desc *d, const void *x, const void *dy, float *dw, float *workspace,
                         int splits, int accumulate, void *stream);
@@ -509,8 +520,8 @@ int mvg_bn_relu_maxpool_fwd_split(const float *y, const float *scale, const floa
                                   uint8_t *argmax, int groups, int n_per_group, int h, int w, int c, int ho, int wo,
                                   void *stream);
 int mvg_avgpool_fwd_split(const void *x_s3, float *y, int n, int hw, int c, void *stream);
-/* mvg_conv_dgrad_split fused with the BatchNorm-backward reduce pass of the unit whose output gradient dx is (stride-1
- * launches): dx is stored masked by that unit's ReLU (bn_bits from mvg_bn_apply_split, or fma(bn_y, relu_scale,
+/* mvg_conv_dgrad_split fused with the BatchNorm-backward reduce pass of the unit whose output gradient dx is (stride 1
+ * or 2: a stride-2 launch's parity classes - those a 1x1 filter never touches included - each bring their partials): dx is stored masked by that unit's ReLU (bn_bits from mvg_bn_apply_split, or fma(bn_y, relu_scale,
  * relu_shift) > 0, or no mask) and s1 / s2 / dgamma / dbeta come out of the same launch + a finalize; mx [groups][cin] (may be
  * NULL) receives max |dx| per (group, channel).  partials: groups * mvg_conv_dgrad_bn_partials_split(d) * 3 * cin floats. */
 int mvg_conv_dgrad_bn_partials_split(const mvg_conv_desc *d);

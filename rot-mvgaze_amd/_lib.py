@@ -130,6 +130,8 @@ SIGNATURES = {
     "mvg_conv_fprop_bf16": (_I, [_D, _P, _P, _P, _P, _I, _P, _P]),
     "mvg_conv_stats_partials_bf16": (_I, [_D, C.POINTER(C.c_int32)]),
     "mvg_conv_dgrad_bf16": (_I, [_D, _P, _P, _P, _P, _P, _P]),
+    "mvg_conv_dgrad_bn_partials_bf16": (_I, [_D]),
+    "mvg_conv_dgrad_bf16_bnreduce": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "mvg_conv_wgrad_bf16": (_I, [_D, _P, _P, _P, _P, _I, _I, _P]),
     "mvg_conv_wgrad_splits_bf16": (_I, [_D]),
     "mvg_linear_fprop_mixed": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _P]),

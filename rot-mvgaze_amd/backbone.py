@@ -76,14 +76,15 @@ class Backbone:
         # those (1/16 of the activation's bytes) instead of the activation (attribute False: read the activation).
         self.relu_bits = True
         # fp32 training steps on the split-operand kernels (conv_split.hip): every conv but the 3-channel stem reads its
-        # operands as three bf16 pieces per fp32 value and runs six bf16 MFMAs per product - fp32-accurate (the 1e-4
-        # parity path), 1.2-1.7x the fp32-MFMA kernels.  MVG_SPLIT=0: the fp32-MFMA kernels everywhere.
+        # operands as two fp16 pieces per fp32 value and runs three fp16 MFMAs per product - fp32-accurate (the 1e-4
+        # parity path).  MVG_SPLIT=0: the fp32-MFMA kernels everywhere.
         self.split = os.environ.get("MVG_SPLIT", "1") != "0"
-        # split path: the BatchNorm-backward reduce pass of a unit rides on the backward-data launch that produces its
-        # output gradient (stride-1 launches: 44 of ResNet-50's 53 units): the staged epilogue already holds 8 channels
-        # of a row per lane, reads y (and the mask bits) with 16-byte accesses, stores the masked gradient and leaves
-        # one partial per row tile.  C3: backward-data 27.3 -> 31.1 ms, reduce passes 10.8 -> 5.4 ms, 1 000 -> 1 034
-        # samples/s.  (attribute False: separate reduce passes - the tests compare the two.)
+        # split and bf16 paths: the BatchNorm-backward reduce pass of a unit rides on the backward-data launch that
+        # produces its output gradient (every unit but the stem and the last one): the staged epilogue already holds 8
+        # channels of a row per lane, reads y (and the mask bits) with 16-byte accesses, stores the masked gradient and
+        # leaves one partial per row tile; a stride-2 launch's parity classes each bring theirs, the classes a 1x1
+        # stride-2 filter never touches as epilogue-only tiles.  (attribute False: separate reduce passes - the tests
+        # compare the two.)
         self.fuse_bn_split = True
         self.split_eval = True      # inference forward on the split kernels too
         self._wk_cache: Dict[str, tuple] = {}     # inference: conv name -> (data_ptr, version, s3 weights)
@@ -480,10 +481,23 @@ class Backbone:
                sink: Optional[GradSink] = None):
         """dx = backward-data of unit u (+ addend).  fuse_for = the unit whose OUTPUT gradient dx is, when dx
         is final with this launch: its ReLU mask is applied and its BatchNorm-backward sums (s1, s2, dgamma,
-        dbeta) are produced by the same launch (mvg_conv_dgrad_split_bnreduce; split kernels only) instead of a pass over (g, act, y)."""
+        dbeta) are produced by the same launch (mvg_conv_dgrad_split_bnreduce / mvg_conv_dgrad_bf16_bnreduce; stride-2 launches
+        too: every parity class brings its partials) instead of a pass over (g, act, y)."""
+        U = fuse_for
+        if (self.bf16 and U is not None and self.fuse_bn_split and u.spec.cin != 3 and u.desc.cin % 64 == 0 and u.desc.cout % 64 == 0
+                and (not U.relu or U.relu_bits is not None or U.relu_affine is not None)):     # (relu_bits off: mask from the activation)
+            c = U.spec
+            gp, bp = self.p[c.bn + ".weight"], self.p[c.bn + ".bias"]
+            acc = sink.accumulate(gp)
+            assert acc == sink.accumulate(bp)
+            s12 = torch.empty(2, dx.shape[0], c.cout, dtype=torch.float32, device=dx.device)
+            ops.conv_dgrad_bf16_bnreduce(u.desc, dy, u.w, dx, addend, U.y, U.relu_bits, U.mean, U.invstd,
+                                         None if U.relu_bits is not None else U.relu_affine, s12[0], s12[1], sink.view(gp),
+                                         sink.view(bp), acc)
+            U.fused_s12 = s12
+            return
         if u.split:
-            U = fuse_for
-            if U is not None and U.split and self.fuse_bn_split and u.desc.stride == 1:
+            if U is not None and U.split and self.fuse_bn_split:
                 c = U.spec
                 gp, bp = self.p[c.bn + ".weight"], self.p[c.bn + ".bias"]
                 acc = sink.accumulate(gp)

@@ -16,6 +16,11 @@ __device__ __forceinline__ unsigned pack_bf2(float a, float b) {          // rou
   return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
 }
 
+__device__ __forceinline__ void ld8(const float *p, float (&v)[8]) {       // 8 floats, 16-byte aligned
+  const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
 // Epilogue shared by the bf16 GEMM kernels: BN partial statistics from the fp32 accumulators, then the tile goes
 // through LDS (fp32, the operand buffers are free after the K loop) so that global stores are 16-byte vectors along
 // the channel axis, with bias / ReLU / mask / addend applied in fp32 and ONE rounding to bf16 (F32IO: fp32 stores).
@@ -24,7 +29,14 @@ __device__ __forceinline__ unsigned pack_bf2(float a, float b) {          // rou
 // ACC16: the accumulators are 16 x 16 tiles of v_mfma_f32_16x16x32_bf16 (f32x4 acc[WTM / 16][WTN / 16]: column =
 // lane & 15, row = 4 * (lane >> 4) + e) instead of 32 x 32 tiles of v_mfma_f32_32x32x16_bf16 (f32x16 acc[WTM / 32][WTN / 32]:
 // column = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)).
-template <int BM, int BN, int WGM, bool DGRAD, bool F32IO, int PASSES = 1, bool ACC16 = false, class AccT>
+// BNF: the kernel carries the fused BatchNorm-backward reduce (IgemmParams::bn_*); its shared memory then holds
+// bf16_epilogue_bytes<...>() bytes: the staging tile, the row offsets and 4 * BN floats of per-channel constants.
+template <int BM, int BN, int PASSES, bool BNF>
+constexpr int bf16_epilogue_bytes() {
+  return (BM / PASSES) * (BN + 4) * 4 + BM * 4 + (BNF ? 4 * BN * 4 : 0);
+}
+
+template <int BM, int BN, int WGM, bool DGRAD, bool F32IO, int PASSES = 1, bool ACC16 = false, bool BNF = false, class AccT>
 __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmClass &c, AccT &acc,
                                               unsigned short *smem, int tid, int g, int mtile, int ntile) {
   constexpr int WGN = 2, NT = WGM * WGN * 64;
@@ -110,23 +122,28 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
   const float *mask_f = p.mask ? p.mask + (long long)g * gelems : nullptr;
   constexpr int CV = BN / 8;                 // 16-byte output vectors per tile row
   // Backward-data fused with the BatchNorm-backward REDUCE pass of the unit whose output gradient this launch produces
-  // (fp32 results, stride-1 launches; IgemmParams::bn_*): the gradient is masked by that unit's ReLU here, stored
-  // masked, and s1 = sum(dz), s2 = sum(dz * xhat) are added up per thread (its 8 channels are fixed: NT % CV == 0),
-  // per workgroup through LDS, and written as one partial per (group, row tile) for bn_bwd_finalize.
-  const bool bnf = DGRAD && F32IO && p.bn_part != nullptr;
-  float bn_mu[8], bn_is[8], bn_ra[8], bn_rb[8], bn_s1[8], bn_s2[8], bn_mx[8];    // bn_mx: max |masked gradient| per channel
+  // (IgemmParams::bn_*): the gradient is masked by that unit's ReLU here, stored masked, and s1 = sum(dz),
+  // s2 = sum(dz * xhat) are added up per thread (its 8 channels are fixed: NT % CV == 0), per workgroup through
+  // LDS, and written as one partial per (group, class, row tile) for bn_bwd_finalize.  bf16 storage: the sums are
+  // those of the ROUNDED gradient, the values the apply pass will read.
+  // The per-channel constants (mean, invstd, the ReLU's scale / shift) wait in LDS and are re-read in every iteration:
+  // 32 values a thread would otherwise hold next to the accumulators and the 24 running sums - the kernels keep four
+  // workgroups per CU (<= 128 VGPRs) with the reduce fused.
+  const bool bnf = BNF && DGRAD && p.bn_part != nullptr;
+  float bn_s1[8], bn_s2[8], bn_mx[8];          // bn_mx: max |masked gradient| per channel
   const bool bn_aff = bnf && p.bn_rscale != nullptr;
+  float *bnc = reinterpret_cast<float *>(smem) + (BM / PASSES) * LDO + BM;      // [4][BN]: mean, invstd, relu scale, relu shift
   if (bnf) {
-    const int col0 = ntile * BN + (tid % CV) * 8;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const bool ok = col0 + k < p.ncols;
-      bn_mu[k] = ok ? p.bn_mean[(long long)g * p.ncols + col0 + k] : 0.f;
-      bn_is[k] = ok ? p.bn_invstd[(long long)g * p.ncols + col0 + k] : 0.f;
-      bn_ra[k] = (ok && bn_aff) ? p.bn_rscale[(long long)g * p.ncols + col0 + k] : 0.f;
-      bn_rb[k] = (ok && bn_aff) ? p.bn_rshift[(long long)g * p.ncols + col0 + k] : 0.f;
-      bn_s1[k] = bn_s2[k] = bn_mx[k] = 0.f;
+    for (int cc = tid; cc < BN; cc += NT) {
+      const int colc = ntile * BN + cc;
+      const bool ok = colc < p.ncols;
+      bnc[cc] = ok ? p.bn_mean[(long long)g * p.ncols + colc] : 0.f;
+      bnc[BN + cc] = ok ? p.bn_invstd[(long long)g * p.ncols + colc] : 0.f;
+      bnc[2 * BN + cc] = (ok && bn_aff) ? p.bn_rscale[(long long)g * p.ncols + colc] : 0.f;
+      bnc[3 * BN + cc] = (ok && bn_aff) ? p.bn_rshift[(long long)g * p.ncols + colc] : 0.f;
     }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bn_s1[k] = bn_s2[k] = bn_mx[k] = 0.f;
   }
 #pragma unroll
   for (int ph = 0; ph < PASSES; ++ph) {
@@ -141,14 +158,15 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
           ot[((wm % (WGM / PASSES)) * WTM + i * TS + erow(e)) * LDO + wn * WTN + j * TS + li] = acc[i][j][e];
   }
   __syncthreads();
-#pragma unroll
-  for (int it = 0; it < PR * CV / NT; ++it) {
+  // (with the reduce fused the iterations run one at a time: unrolled, the compiler keeps four iterations' loads in
+  // flight on top of the accumulators and the running sums, and spills)
+  auto store_rows = [&](int it) {
     const int v = tid + it * NT;
     const int rl = v / CV, cv = v - rl * CV;
     const int r = ph * PR + rl;
     const int col = ntile * BN + cv * 8;
     const int off = rowoff[r];
-    if (off < 0 || col >= p.ncols) continue;
+    if (off < 0 || col >= p.ncols) return;
     const float4 lo = *reinterpret_cast<const float4 *>(ot + rl * LDO + cv * 8);
     const float4 hi = *reinterpret_cast<const float4 *>(ot + rl * LDO + cv * 8 + 4);
     float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
@@ -191,7 +209,7 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
         uint4 *dst = reinterpret_cast<uint4 *>(p.out) + (((long long)g * gelems + off + col) >> 3) * SP_NP;
         dst[0] = q1;
         dst[1] = q2;
-        continue;
+        return;
       }
       if (DGRAD && mask_f) {
         float mm[8];
@@ -218,10 +236,20 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
           const unsigned short two = *reinterpret_cast<const unsigned short *>(p.bn_bits + (((long long)g * gelems + off + col) >> 2));
           bits = (two & 0xFu) | ((two >> 4) & 0xF0u);
         }
+        asm volatile("" ::: "memory");              // re-read the constants here (not hoisted into 32 live registers)
+        if (bn_aff) {
+          float bn_ra[8], bn_rb[8];
+          ld8(bnc + 2 * BN + cv * 8, bn_ra);
+          ld8(bnc + 3 * BN + cv * 8, bn_rb);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) bits = (bits & ~(1u << k)) | ((__builtin_fmaf(yy[k], bn_ra[k], bn_rb[k]) > 0.f ? 1u : 0u) << k);
+        }
+        float bn_mu[8], bn_is[8];
+        ld8(bnc + cv * 8, bn_mu);
+        ld8(bnc + BN + cv * 8, bn_is);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          const bool on = bn_aff ? (__builtin_fmaf(yy[k], bn_ra[k], bn_rb[k]) > 0.f) : (((bits >> k) & 1u) != 0u);
-          x[k] = on ? x[k] : 0.f;
+          x[k] = ((bits >> k) & 1u) != 0u ? x[k] : 0.f;
           bn_mx[k] = fmaxf(bn_mx[k], fabsf(x[k]));
           bn_s1[k] += x[k];
           bn_s2[k] += x[k] * ((yy[k] - bn_mu[k]) * bn_is[k]);
@@ -229,7 +257,7 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
       }
       *reinterpret_cast<float4 *>(out_f + off + col) = make_float4(x[0], x[1], x[2], x[3]);
       *reinterpret_cast<float4 *>(out_f + off + col + 4) = make_float4(x[4], x[5], x[6], x[7]);
-      continue;
+      return;
     }
     if (mask_g) {
       const u32x4 m = *reinterpret_cast<const u32x4 *>(mask_g + off + col);
@@ -250,11 +278,51 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
       }
     }
     u32x4 o;
-    o.x = pack_bf2(x[0], x[1]);
-    o.y = pack_bf2(x[2], x[3]);
-    o.z = pack_bf2(x[4], x[5]);
-    o.w = pack_bf2(x[6], x[7]);
+    if (bnf) {
+      const u32x4 yv = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const unsigned short *>(p.bn_y) + (long long)g * gelems + off + col);
+      const unsigned yw[4] = {yv.x, yv.y, yv.z, yv.w};
+      unsigned bits = p.bn_bits ? (unsigned)p.bn_bits[((long long)g * gelems + off + col) >> 3] : 0xFFu;
+      asm volatile("" ::: "memory");                // re-read the constants here (not hoisted into 32 live registers)
+      if (bn_aff) {
+        float bn_ra[8], bn_rb[8];
+        ld8(bnc + 2 * BN + cv * 8, bn_ra);
+        ld8(bnc + 3 * BN + cv * 8, bn_rb);
+        bits = 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          bits |= (__builtin_fmaf(bf_lo(yw[k]), bn_ra[2 * k], bn_rb[2 * k]) > 0.f ? 1u : 0u) << (2 * k);
+          bits |= (__builtin_fmaf(bf_hi(yw[k]), bn_ra[2 * k + 1], bn_rb[2 * k + 1]) > 0.f ? 1u : 0u) << (2 * k + 1);
+        }
+      }
+      // the second sum stays UNCENTRED here - sum(dz * y); bn_bwd_finalize turns the totals into s2 = invstd * (sum(dz * y)
+      // - mean * s1) in fp64 - so that this kernel, whose accumulators leave it ~50 registers, needs no constants
+      unsigned ow[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float y0 = bf_lo(yw[k]), y1 = bf_hi(yw[k]);
+        const bool on0 = ((bits >> (2 * k)) & 1u) != 0u, on1 = ((bits >> (2 * k + 1)) & 1u) != 0u;
+        ow[k] = pack_bf2(on0 ? x[2 * k] : 0.f, on1 ? x[2 * k + 1] : 0.f);
+        const float d0 = bf_lo(ow[k]), d1 = bf_hi(ow[k]);
+        bn_s1[2 * k] += d0;
+        bn_s1[2 * k + 1] += d1;
+        bn_s2[2 * k] = __builtin_fmaf(d0, y0, bn_s2[2 * k]);
+        bn_s2[2 * k + 1] = __builtin_fmaf(d1, y1, bn_s2[2 * k + 1]);
+      }
+      o.x = ow[0]; o.y = ow[1]; o.z = ow[2]; o.w = ow[3];
+    } else {
+      o.x = pack_bf2(x[0], x[1]);
+      o.y = pack_bf2(x[2], x[3]);
+      o.z = pack_bf2(x[4], x[5]);
+      o.w = pack_bf2(x[6], x[7]);
+    }
     *reinterpret_cast<u32x4 *>(out_g + off + col) = o;
+  };
+  if constexpr (BNF) {
+#pragma unroll 1
+    for (int it = 0; it < PR * CV / NT; ++it) store_rows(it);
+  } else {
+#pragma unroll
+    for (int it = 0; it < PR * CV / NT; ++it) store_rows(it);
   }
   }  // passes
   if (bnf) {
@@ -267,7 +335,7 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
     for (int k = 0; k < 8; ++k) {
       red[(0 * RL + rlt) * BN + cvt * 8 + k] = bn_s1[k];
       red[(1 * RL + rlt) * BN + cvt * 8 + k] = bn_s2[k];
-      red[(2 * RL + rlt) * BN + cvt * 8 + k] = bn_mx[k];
+      if (F32IO) red[(2 * RL + rlt) * BN + cvt * 8 + k] = bn_mx[k];       // (bf16 storage: two rows, no maximum)
     }
     __syncthreads();
     for (int idx = tid; idx < nred * BN; idx += NT) {
@@ -279,7 +347,7 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
         for (int r = 0; r < RL; ++r) t += red[(which * RL + r) * BN + cc];       // fixed order
       else
         for (int r = 0; r < RL; ++r) t = fmaxf(t, red[(which * RL + r) * BN + cc]);
-      p.bn_part[(((long long)g * c.mtiles_per_group + mtile) * nred + which) * p.ncols + colr] = t;
+      p.bn_part[(((long long)g * p.bn_parts + c.part0 + mtile) * nred + which) * p.ncols + colr] = t;
     }
   }
 }

@@ -394,8 +394,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *g, const T 
 // layer at C3 has 4 x 3136 x 3 x 64 partials: with the groups looped inside ONE workgroup per 16 channels this kernel
 // took 30-136 us per call, 1.8 ms per step); bn_bwd_dgamma_kernel then adds the groups in order (reproducible).
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float *__restrict__ partial, int groups, int chunks,
-                                                               int c, float *s1, float *s2, float *mx) {
+                                                               int c, float *s1, float *s2, float *mx,
+                                                               const float *__restrict__ raw_mean, const float *__restrict__ raw_invstd) {
   // mx != null: the partials have three rows (s1, s2, max |dz|) and mx [groups][c] receives the maxima
+  // raw_mean != null: the second row holds the UNCENTRED sum(dz * y) (the bf16 backward-data epilogue keeps no
+  // per-channel constants in registers): s2 = invstd * (sum(dz * y) - mean * s1), evaluated on the fp64 totals
   __shared__ double sh[3][64][16];
   const int prows = mx ? 3 : 2;
   const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
@@ -422,7 +425,9 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float *__re
   }
   if (pl == 0 && ch < c) {
     s1[(long long)g * c + ch] = (float)sh[0][0][cl];
-    s2[(long long)g * c + ch] = (float)sh[1][0][cl];
+    double t2 = sh[1][0][cl];
+    if (raw_mean) t2 = (double)raw_invstd[(long long)g * c + ch] * (t2 - (double)raw_mean[(long long)g * c + ch] * sh[0][0][cl]);
+    s2[(long long)g * c + ch] = (float)t2;
     if (mx) mx[(long long)g * c + ch] = (float)sh[2][0][cl];
   }
 }
@@ -863,8 +868,9 @@ static int grid_for(long long n4) {
 }
 
 int bn_bwd_finalize_launch(const float *partial, int groups, int chunks, int c, float *s1, float *s2, float *dgamma,
-                           float *dbeta, int accumulate, hipStream_t st, float *mx) {
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(c, 16), groups), dim3(1024), 0, st, partial, groups, chunks, c, s1, s2, mx);
+                           float *dbeta, int accumulate, hipStream_t st, float *mx, const float *raw_mean, const float *raw_invstd) {
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(c, 16), groups), dim3(1024), 0, st, partial, groups, chunks, c, s1, s2, mx,
+                     raw_mean, raw_invstd);
   if (check_launch("bn_bwd_finalize")) return 1;
   if (dgamma || dbeta) {
     hipLaunchKernelGGL(bn_bwd_dgamma_kernel, dim3(ceil_div(c, 256)), dim3(256), 0, st, s1, s2, groups, c, dgamma, dbeta, accumulate);

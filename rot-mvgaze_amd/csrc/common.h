@@ -26,8 +26,10 @@ int compute_cus();
 // bn.hip: merge [groups][chunks][2][c] partial sums (s1, s2) of a BatchNorm backward in fp64, in a fixed order;
 // dgamma / dbeta (+)= the sums over the groups.  Host launcher shared with the fused backward-data path.
 // mx != nullptr: the partials carry a third row, max |dz| per channel, merged into mx [groups][c].
+// raw_mean / raw_invstd != nullptr: the partials' second row is the uncentred sum(dz * y); s2 = invstd * (it - mean * s1).
 int bn_bwd_finalize_launch(const float *partial, int groups, int chunks, int c, float *s1, float *s2, float *dgamma,
-                           float *dbeta, int accumulate, hipStream_t st, float *mx = nullptr);
+                           float *dbeta, int accumulate, hipStream_t st, float *mx = nullptr, const float *raw_mean = nullptr,
+                           const float *raw_invstd = nullptr);
 
 struct ProfScope {
   int fam;

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 4 : 2) void igemm_bf16_dma_kerne
   constexpr int LDO = BN + 4;
   constexpr int OP_ELEMS = STAGES * (A_ELEMS + B_ELEMS);      // ushort
   constexpr int EPI_PASSES = STAGES == 1 ? 2 : 1;
-  constexpr int EPI_ELEMS = ((BM / EPI_PASSES) * LDO * 4 + BM * 4) / 2;
+  constexpr int EPI_ELEMS = bf16_epilogue_bytes<BM, BN, EPI_PASSES, DGRAD>() / 2;
   constexpr int SMEM = OP_ELEMS > EPI_ELEMS ? OP_ELEMS : EPI_ELEMS;
   __shared__ __attribute__((aligned(16))) unsigned short smem[SMEM];
 
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 4 : 2) void igemm_bf16_dma_kerne
     if constexpr (STAGES == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the next K-step's DMA has landed
     __syncthreads();                                         // ... for every wave, and everyone is done reading `cur`
   }
-  bf16_epilogue<BF_BM, BN, 2, DGRAD, false, EPI_PASSES>(p, c, acc, smem, tid, g, mtile, ntile);
+  bf16_epilogue<BF_BM, BN, 2, DGRAD, false, EPI_PASSES, false, DGRAD>(p, c, acc, smem, tid, g, mtile, ntile);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -695,18 +695,23 @@ static int launch_igemm_bf16(IgemmParams &p, hipStream_t st, bool f32io = false)
   p.sk_tiles = 0;
   long long tiles = 0;
   bool fasta = true;
+  const bool bnf = DGRAD && p.bn_part != nullptr;
+  p.bn_parts = 0;
   for (int i = 0; i < p.ncls; ++i) {
     IgemmClass &c = p.cls[i];
     c.mtiles_per_group = ceil_div(c.rows_per_group, BF_BM);
-    c.KT = c.ktotal > 0 ? ceil_div(c.ktotal, BF_BK) : 1;
+    c.KT = c.ktotal > 0 ? ceil_div(c.ktotal, BF_BK) : (bnf ? 0 : 1);     // fused reduce: a class without taps is epilogue only
     c.korder = (c.ntaps > 1 && p.src_c % BF_BK == 0) ? 1 : 0;
     c.per_div = make_fastdiv((unsigned)(c.ntaps > 0 ? c.ntaps : 1));
     c.tile0 = (int)tiles;
     c.unit0 = 0;
+    c.part0 = p.bn_parts;
+    p.bn_parts += c.mtiles_per_group;
     tiles += (long long)p.groups * c.mtiles_per_group * p.ntiles;
-    fasta = fasta && c.ntaps >= 1 && c.ntaps <= 32 && c.ktotal % BF_BK == 0 && p.src_c % BF_BK == 0;
+    fasta = fasta && (c.ntaps >= 1 || bnf) && c.ntaps <= 32 && c.ktotal % BF_BK == 0 && p.src_c % BF_BK == 0;
   }
   MVG_REQUIRE(tiles < (1LL << 31), "bf16 conv: grid too large");
+  MVG_REQUIRE(!bnf || (fasta && !f32io), "bf16 dgrad with a fused BatchNorm reduce: bf16 operands, channel counts in multiples of 64");
   if (tiles <= 0) return 0;
   dim3 grid((unsigned)tiles), block(256);
   if (f32io) {
@@ -814,8 +819,15 @@ int mvg_conv_fprop_bf16(const mvg_conv_desc *d, const void *x, const void *wgt, 
   return fprop_bf16_impl(d, x, wgt, y, bias, relu, stats, stream, false);
 }
 
+struct Bf16BnFuse {        // fused BatchNorm-backward reduce of the unit whose output gradient dx is (IgemmParams::bn_*)
+  const void *y;           // bf16, like dx
+  const uint8_t *bits;     // one byte per 8 channels (mvg_bn_apply_bits_bf16)
+  const float *mean, *invstd, *rscale, *rshift;
+  float *part;
+};
+
 static int dgrad_bf16_impl(const mvg_conv_desc *d, const void *dy, const void *wgt_crsk, void *dx, const void *mask,
-                           const void *addend, void *stream, bool f32io) {
+                           const void *addend, void *stream, bool f32io, const Bf16BnFuse *bnf = nullptr) {
   if (validate_bf16(d)) return 2;
   const long long EA = f32io ? 4 : 2;
   MVG_REQUIRE(!f32io || d->stride == 1, "bf16 dgrad with fp32 operands: stride 1 only");
@@ -826,6 +838,16 @@ static int dgrad_bf16_impl(const mvg_conv_desc *d, const void *dy, const void *w
   p.out = (float *)dx;
   p.mask = (const float *)mask;
   p.addend = (const float *)addend;
+  if (bnf) {
+    p.bn_y = (const float *)bnf->y;
+    p.bn_bits = bnf->bits;
+    p.bn_mean = bnf->mean;
+    p.bn_invstd = bnf->invstd;
+    p.bn_rscale = bnf->rscale;
+    p.bn_rshift = bnf->rshift;
+    p.bn_part = bnf->part;
+    p.bn_part_rows = 2;
+  }
   p.groups = d->groups;
   p.out_h = d->h;
   p.out_w = d->w;
@@ -884,7 +906,7 @@ static int dgrad_bf16_impl(const mvg_conv_desc *d, const void *dy, const void *w
       q.cls_px = px;
       q.cls_cy = (py + d->pad - r0) / step;
       q.cls_cx = (px + d->pad - s0) / step;
-      if (q.ntaps == 0) {
+      if (q.ntaps == 0 && !bnf) {
         if (addend != dx || !addend) {                 // nothing to do when the caller accumulates in place
           const long long n = (long long)d->groups * d->n * sub_h * sub_w * (d->cin / 8);
           long long blocks = (n + 255) / 256;
@@ -923,6 +945,27 @@ static int dgrad_bf16_impl(const mvg_conv_desc *d, const void *dy, const void *w
 int mvg_conv_dgrad_bf16(const mvg_conv_desc *d, const void *dy, const void *wgt_crsk, void *dx, const void *mask,
                         const void *addend, void *stream) {
   return dgrad_bf16_impl(d, dy, wgt_crsk, dx, mask, addend, stream, false);
+}
+
+int mvg_conv_dgrad_bn_partials_bf16(const mvg_conv_desc *d) {
+  if (validate_bf16(d)) return -1;
+  return dgrad_bn_partials(d, BF_BM);
+}
+
+int mvg_conv_dgrad_bf16_bnreduce(const mvg_conv_desc *d, const void *dy, const void *wgt_crsk, void *dx, const void *addend,
+                                 const void *bn_y, const uint8_t *bn_bits, const float *bn_mean, const float *bn_invstd,
+                                 const float *relu_scale, const float *relu_shift, float *partials, float *s1, float *s2,
+                                 float *dgamma, float *dbeta, int accumulate, void *stream) {
+  MVG_REQUIRE(bn_y && bn_mean && bn_invstd && partials && s1 && s2, "dgrad_bf16_bnreduce: null argument");
+  MVG_REQUIRE(!(bn_bits && relu_scale) && ((relu_scale == nullptr) == (relu_shift == nullptr)),
+              "dgrad_bf16_bnreduce: give the ReLU mask either as bits or as (relu_scale, relu_shift)");
+  const int P = mvg_conv_dgrad_bn_partials_bf16(d);
+  MVG_REQUIRE(P > 0, "dgrad_bf16_bnreduce: bad descriptor");
+  const Bf16BnFuse f = {bn_y, bn_bits, bn_mean, bn_invstd, relu_scale, relu_shift, partials};
+  if (dgrad_bf16_impl(d, dy, wgt_crsk, dx, nullptr, addend, stream, false, &f)) return 1;
+  ProfScope ps(MVG_K_BN_BWD_REDUCE, (hipStream_t)stream, 0.0, 8.0 * d->groups * (double)P * d->cin);
+  return bn_bwd_finalize_launch(partials, d->groups, P, d->cin, s1, s2, dgamma, dbeta, accumulate, (hipStream_t)stream, nullptr, bn_mean,
+                                bn_invstd);
 }
 
 static mvg_conv_desc linear_desc_bf16(int rows, int fin, int fout) {

@@ -69,7 +69,9 @@ struct IgemmClass {
   FastDiv per_div;           // K-steps per 32-channel block: ntaps * 32 / BK
   long long unit0;           // first (tile, K-step) unit of this class in the launch's unit space
   int tile0;                 // first tile of this class
-  int KT;                    // K-steps per tile (>= 1: a class without taps runs one all-zero step)
+  int KT;                    // K-steps per tile (>= 1: a class without taps runs one all-zero step; split / bf16 kernels
+                             // with a fused BatchNorm reduce: 0 - such a class's tiles are epilogue only)
+  int part0;                 // fused BatchNorm-backward reduce: this class's first partial row inside a group (bn_part)
 };
 
 struct IgemmParams {
@@ -125,12 +127,16 @@ struct IgemmParams {
   int b_row_len;             // bf16 kernels: elements per row of the (k-contiguous) weight operand
   int stats_partials;        // bf16_epilogue: partials per group of `stats` as the caller allocated it (0: mtiles * wave rows)
   // Backward-data fused with the BatchNorm-backward REDUCE pass of the unit whose output gradient this
-  // launch produces (split kernels, stride-1 launches): the epilogue masks the gradient by that unit's ReLU
+  // launch produces (split and bf16 kernels): the epilogue masks the gradient by that unit's ReLU
   // (bn_bits, or fma(bn_y, bn_rscale, bn_rshift) > 0, or no mask), stores the masked gradient and adds up,
-  // per wave and column, s1 = sum(dz) and s2 = sum(dz * xhat), xhat = (bn_y - bn_mean) * bn_invstd, into
-  // bn_part [groups][P][bn_part_rows][ncols] (P = row partials per group, like the forward statistics).
+  // per workgroup and column, s1 = sum(dz) and s2 = sum(dz * xhat), xhat = (bn_y - bn_mean) * bn_invstd, into
+  // bn_part [groups][bn_parts][bn_part_rows][ncols] (bn_parts = row tiles per group over all classes: a stride-2
+  // launch's parity classes each own the range starting at IgemmClass::part0; a class without taps - a 1x1 stride-2
+  // filter touches one pixel in four - still runs its tiles, epilogue only, for the mask and the sums).
+  // bn_y has the storage type of `out` (fp32, or bf16 in the bf16 kernels).
   const float *bn_y, *bn_mean, *bn_invstd, *bn_rscale, *bn_rshift;
   float *bn_part;
+  int bn_parts;
   // split kernels, inference forward (BatchNorm folded: y = acc * scale + bias (+ residual) [relu]): the residual
   // and / or the result in s3 (the next conv's operand format) instead of fp32
   int addend_s3, out_s3, mask_s3;
@@ -138,7 +144,7 @@ struct IgemmParams {
   // accumulators by *a_sinv * *b_sinv (device scalars, each 2^-k of its operand; null = 1)
   const float *a_sinv, *b_sinv;
   int bn_part_rows;               // fused BatchNorm-backward reduce: rows per partial in bn_part - 2 (s1, s2) or 3 (+ max |dz| per channel)
-  const unsigned char *bn_bits;   // split kernels: the unit's ReLU mask as bits (one byte per 4 channels, mvg_bn_apply_split) 
+  const unsigned char *bn_bits;   // the unit's ReLU mask as bits: one byte per 4 channels (fp32: mvg_bn_apply_split) or per 8 (bf16: mvg_bn_apply_bits_bf16)
   // Cross-view fusion (igemm_kernel AMODE = 1, Linear forward): the A operand is never materialised - row m of
   //   X = [ img_feat[rc_row_img[m]] (rc_cf floats) | rc_rel[m] (3x3) @ feat[rc_row_src[m]] (3 x rc_nvec, axis-major) ]
   // (rot_mv.py:44-50,234-239) is generated by the loader: the image part is a plain row load (p.a = img_feat),
@@ -237,6 +243,18 @@ static int validate(const mvg_conv_desc *d) {
   MVG_REQUIRE((long long)d->n * d->ho * d->wo < (1LL << 31) && (long long)d->n * d->h * d->w < (1LL << 31),
               "conv: rows per group overflow int32");
   return 0;
+}
+
+// row tiles per group of the backward-data launch = partials per group of the fused reduce: a stride-2 launch has its
+// four parity classes' tiles (classes without taps included: their pixels are masked and summed too)
+[[maybe_unused]] static int dgrad_bn_partials(const mvg_conv_desc *d, int bm) {
+  int parts = 0;
+  for (int py = 0; py < d->stride; ++py)
+    for (int px = 0; px < d->stride; ++px) {
+      const int sub_h = (d->h - py + d->stride - 1) / d->stride, sub_w = (d->w - px + d->stride - 1) / d->stride;
+      if (sub_h > 0 && sub_w > 0) parts += ceil_div((long long)d->n * sub_h * sub_w, bm);
+    }
+  return parts;
 }
 
 // the class view of the top-level fields (single-class launches)

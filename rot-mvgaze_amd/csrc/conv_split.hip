@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256, DGRAD ? 3 : 4) void igemm_split16_kernel(Igemm
   constexpr int A_PER = QA / NW, B_PER = (NQ - QA) / NW;      // per wave: 4 and 4 / 2
   static_assert(QA % NW == 0 && (NQ - QA) % NW == 0, "whole instructions per wave");
   constexpr int LDO = BN + 4;
-  constexpr int EPI_B = (BM / 2) * LDO * 4 + BM * 4;
+  constexpr int EPI_B = bf16_epilogue_bytes<BM, BN, 2, DGRAD>();
   constexpr int INFO_OFF = STAGE_B > EPI_B ? STAGE_B : EPI_B;  // row table behind the stage / the epilogue tile
   constexpr int SMEM_B = INFO_OFF + BM * 8;
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_B];
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256, DGRAD ? 3 : 4) void igemm_split16_kernel(Igemm
     }
     __syncthreads();                                         // everyone is done reading before the next DMA lands
   }
-  bf16_epilogue<BM, BN, WGM, DGRAD, true, 2, true>(p, c, acc, reinterpret_cast<unsigned short *>(smem), tid, g, mtile, ntile);
+  bf16_epilogue<BM, BN, WGM, DGRAD, true, 2, true, DGRAD>(p, c, acc, reinterpret_cast<unsigned short *>(smem), tid, g, mtile, ntile);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -635,16 +635,19 @@ static int launch_igemm_split(IgemmParams &p, hipStream_t st) {
   p.splits = 1;
   p.sk_tiles = 0;
   long long tiles = 0;
+  p.bn_parts = 0;
   for (int i = 0; i < p.ncls; ++i) {
     IgemmClass &c = p.cls[i];
     c.mtiles_per_group = ceil_div(c.rows_per_group, bm);
-    c.KT = c.ktotal > 0 ? ceil_div(c.ktotal, SP_BK) : 1;
+    c.KT = ceil_div(c.ktotal, SP_BK);              // 0: a class without taps (fused reduce only) - its tiles are epilogue only
     c.korder = c.ntaps > 1 ? 1 : 0;
     c.per_div = make_fastdiv((unsigned)(c.ntaps > 0 ? c.ntaps : 1));
     c.tile0 = (int)tiles;
     c.unit0 = 0;
+    c.part0 = p.bn_parts;
+    p.bn_parts += c.mtiles_per_group;
     tiles += (long long)p.groups * c.mtiles_per_group * p.ntiles;
-    MVG_REQUIRE(c.ntaps >= 1 && c.ntaps <= 32 && c.ktotal % SP_BK == 0, "split conv: class shape not covered");
+    MVG_REQUIRE((c.ntaps >= 1 || (DGRAD && p.bn_part)) && c.ntaps <= 32 && c.ktotal % SP_BK == 0, "split conv: class shape not covered");
   }
   MVG_REQUIRE(tiles < (1LL << 31), "split conv: grid too large");
   if (tiles <= 0) return 0;
@@ -937,7 +940,7 @@ static int dgrad_split_impl(const mvg_conv_desc *d, const void *dy_sp, const flo
       q.cls_px = px;
       q.cls_cy = (py + d->pad - r0) / step;
       q.cls_cx = (px + d->pad - s0) / step;
-      if (q.ntaps == 0) {
+      if (q.ntaps == 0 && !bnf) {
         if (addend != dx || !addend) {                 // nothing to do when the caller accumulates in place
           const long long n = (long long)d->groups * d->n * sub_h * sub_w * (d->cin / 4);
           long long blocks = (n + 255) / 256;
@@ -979,11 +982,9 @@ int mvg_conv_dgrad_split(const mvg_conv_desc *d, const void *dy_sp, const float 
   return dgrad_split_impl(d, dy_sp, dy_sinv, w_crsk_sp, w_sinv, dx, addend, stream, nullptr, relu_mask_sp);
 }
 
-// row tiles per group of the backward-data launch = partials per group of the fused reduce (0: not fusable)
 int mvg_conv_dgrad_bn_partials_split(const mvg_conv_desc *d) {
   if (validate_split(d)) return -1;
-  if (d->stride != 1) return 0;                         // parity-class launches scatter their rows: not fused
-  return ceil_div((long long)d->n * d->h * d->w, SP_BM);
+  return dgrad_bn_partials(d, SP_BM);
 }
 
 int mvg_conv_dgrad_split_bnreduce(const mvg_conv_desc *d, const void *dy_sp, const float *dy_sinv, const void *w_crsk_sp,
@@ -995,7 +996,7 @@ int mvg_conv_dgrad_split_bnreduce(const mvg_conv_desc *d, const void *dy_sp, con
   MVG_REQUIRE(!(bn_bits && relu_scale) && ((relu_scale == nullptr) == (relu_shift == nullptr)),
               "dgrad_split_bnreduce: give the ReLU mask either as bits or as (relu_scale, relu_shift)");
   const int P = mvg_conv_dgrad_bn_partials_split(d);
-  MVG_REQUIRE(P > 0, "dgrad_split_bnreduce: this shape cannot be fused (stride %d)", d ? d->stride : -1);
+  MVG_REQUIRE(P > 0, "dgrad_split_bnreduce: bad descriptor");
   const SplitBnFuse f = {bn_y, bn_bits, bn_mean, bn_invstd, relu_scale, relu_shift, partials, mx ? 3 : 2};
   if (dgrad_split_impl(d, dy_sp, dy_sinv, w_crsk_sp, w_sinv, dx, addend, stream, &f)) return 1;
   ProfScope ps(MVG_K_BN_BWD_REDUCE, (hipStream_t)stream, 0.0, 8.0 * d->groups * (double)P * d->cin);

@@ -264,6 +264,19 @@ def conv_dgrad_split_bnreduce(d: ConvDesc, dy_s3, wt_s3, dx, addend, bn_y, bn_bi
                                               _p(dgamma), _p(dbeta), int(accumulate), _p(mx), _s()), "conv_dgrad_split_bnreduce")
 
 
+def conv_dgrad_bf16_bnreduce(d: ConvDesc, dy, wt, dx, addend, bn_y, bn_bits, bn_mean, bn_invstd, relu_affine, s1, s2, dgamma, dbeta,
+                             accumulate: bool):
+    """conv_dgrad (bf16 storage) + the BatchNorm-backward reduce pass of the unit whose output gradient dx is, in one launch."""
+    P = lib().mvg_conv_dgrad_bn_partials_bf16(C.byref(d))
+    if P < 1:
+        check(1, "conv_dgrad_bn_partials_bf16")
+    part = torch.empty(d.groups * P * 2 * d.cin, dtype=torch.float32, device=dx.device)
+    rs, rh = relu_affine if relu_affine is not None else (None, None)
+    check(lib().mvg_conv_dgrad_bf16_bnreduce(C.byref(d), _p(dy), _p(wt), _p(dx), _p(addend), _p(bn_y), _p(bn_bits), _p(bn_mean),
+                                             _p(bn_invstd), _p(rs), _p(rh), _p(part), _p(s1), _p(s2), _p(dgamma), _p(dbeta),
+                                             int(accumulate), _s()), "conv_dgrad_bf16_bnreduce")
+
+
 def conv_wgrad_split(d: ConvDesc, x_s3: Tensor, dy_s3: Tensor, dw: Tensor, accumulate: bool = False):
     splits = lib().mvg_conv_wgrad_splits_split(C.byref(d))
     if splits < 1:

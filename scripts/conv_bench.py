@@ -47,7 +47,7 @@ def timeit(fn):
 
 tot = {"fprop": [0, 0], "dgrad": [0, 0], "wgrad": [0, 0]}
 print(f"ResNet-{depth}  N={N} G={G}  {'bf16' if bf16 else ('fp32 values, split-operand kernels' if split else 'fp32')}")
-print(f"{'cin':>5} {'cout':>5} k s {'hw':>4} cnt | {'fprop ms':>9} {'TF':>6} | {'dgrad ms':>9} {'TF':>6} | {'wgrad ms':>9} {'TF':>6}")
+print(f"{'cin':>5} {'cout':>5} k s {'hw':>4} cnt | {'fprop ms':>9} {'TF':>6} | {'dgrad ms':>9} {'TF':>6} | {'wgrad ms':>9} {'TF':>6} | dgrad + fused BN reduce (mask bits) ms, GB/s of (dy, dx, y, bits)")
 for (cin, cout, k, st, pad, h), cnt in shapes.items():
     d = ConvDesc.make(G, N, h, h, cin, cout, k, st, pad)
     x = torch.randn(G, N, h, h, cin, device=dev).to(adt)
@@ -60,6 +60,10 @@ for (cin, cout, k, st, pad, h), cnt in shapes.items():
     dx = torch.empty_like(x)
     dw = torch.empty_like(w32)
     flops = 2.0 * G * N * d.ho * d.wo * cout * k * k * cin
+    tdf = float("nan")
+    rows = N * h * h
+    mean, invstd = torch.randn(G, cin, device=dev) * 0.1, torch.rand(G, cin, device=dev) + 0.5
+    s12, dgb = torch.empty(2, G, cin, device=dev), torch.zeros(2, cin, device=dev)
     if split and cin > 8:
         xs, gys = ops.split_f32(x), ops.split_f32(gy)
         wk, wts = ops.split_weights(d, w32, True)
@@ -68,15 +72,26 @@ for (cin, cout, k, st, pad, h), cnt in shapes.items():
         tf = timeit(lambda: ops.conv_fprop_split(d, xs, wk, y, stats_s))
         td = timeit(lambda: ops.conv_dgrad_split(d, gys, wts, dx))
         tw = timeit(lambda: ops.conv_wgrad_split(d, xs, gys, dw))
+        bits = torch.randint(0, 16, (G * rows * cin // 4,), dtype=torch.uint8, device=dev)
+        mx = torch.empty(G, cin, device=dev)
+        tdf = timeit(lambda: ops.conv_dgrad_split_bnreduce(d, gys, wts, dx, None, x, bits, mean, invstd, None, s12[0], s12[1], dgb[0], dgb[1], False, mx))
+        fbytes = 4.0 * (gy.numel() + 2 * x.numel()) + bits.numel()
     else:
         tf = timeit(lambda: ops.conv_fprop(d, x, w, y, None, False, stats))
         td = timeit(lambda: ops.conv_dgrad(d, gy, wt, dx)) if cin > 8 else float("nan")
         tw = timeit(lambda: ops.conv_wgrad(d, x, gy, dw))
-    print(f"{cin:5d} {cout:5d} {k} {st} {h:4d} {cnt:3d} | {tf*1e3:9.3f} {flops/tf/1e12:6.1f} | {td*1e3:9.3f} {flops/td/1e12:6.1f} | {tw*1e3:9.3f} {flops/tw/1e12:6.1f}")
+        if bf16 and cin % 64 == 0 and cout % 64 == 0:
+            bits = torch.randint(0, 256, (G * rows * cin // 8,), dtype=torch.uint8, device=dev)
+            tdf = timeit(lambda: ops.conv_dgrad_bf16_bnreduce(d, gy, wt, dx, None, x, bits, mean, invstd, None, s12[0], s12[1], dgb[0], dgb[1], False))
+            fbytes = 2.0 * (gy.numel() + 2 * x.numel()) + bits.numel()
+    fused = f" | {tdf*1e3:9.3f} {fbytes/tdf/1e9:7.0f}" if tdf == tdf else ""
+    print(f"{cin:5d} {cout:5d} {k} {st} {h:4d} {cnt:3d} | {tf*1e3:9.3f} {flops/tf/1e12:6.1f} | {td*1e3:9.3f} {flops/td/1e12:6.1f} | {tw*1e3:9.3f} {flops/tw/1e12:6.1f}{fused}")
+    if tdf == tdf:
+        tot.setdefault("dgrad+bn", [0, 0]); tot["dgrad+bn"][0] += tdf * cnt; tot["dgrad+bn"][1] += flops * cnt
     for name, t in (("fprop", tf), ("dgrad", td), ("wgrad", tw)):
         if t == t:
             tot[name][0] += t * cnt; tot[name][1] += flops * cnt
 for name, (t, f) in tot.items():
     print(f"{name}: {t*1e3:.2f} ms total, {f/t/1e12:.1f} TF/s")
-tt = sum(v[0] for v in tot.values()); ff = sum(v[1] for v in tot.values())
+tt = sum(v[0] for k, v in tot.items() if k != "dgrad+bn"); ff = sum(v[1] for k, v in tot.items() if k != "dgrad+bn")
 print(f"all: {tt*1e3:.2f} ms, {ff/tt/1e12:.1f} TF/s")

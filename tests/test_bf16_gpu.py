@@ -163,6 +163,55 @@ def test_bf16_conv_fprop_dgrad_wgrad(case):
     close(dw2[..., :cin_src], 2 * dw_ref, 2e-5, "wgrad accumulate")
 
 
+@pytest.mark.parametrize("case", [(2, 3, 14, 256, 256, 3, 1, 1), (3, 2, 14, 1024, 256, 1, 1, 0), (1, 2, 56, 64, 256, 1, 1, 0),
+                                  (2, 5, 9, 128, 192, 1, 1, 0), (1, 5, 28, 128, 128, 3, 2, 1), (2, 3, 15, 64, 128, 3, 2, 1),
+                                  (2, 3, 56, 256, 512, 1, 2, 0), (1, 4, 9, 128, 256, 1, 2, 0)],
+                         ids=lambda c: "g%d_n%d_h%d_%dto%d_k%d_s%d" % c[:7])
+@pytest.mark.parametrize("mask", ["bits", "affine", "none"])
+def test_bf16_dgrad_fused_with_bn_backward_reduce(case, mask):
+    """mvg_conv_dgrad_bf16_bnreduce == mvg_conv_dgrad_bf16 followed by the reduce pass over its (bf16) result: the same
+    masked gradient bit for bit, the same sums - of the ROUNDED gradient - to summation order.  Stride-2 launches: every
+    parity class brings its partials, the classes a 1x1 filter never touches as epilogue-only tiles."""
+    from rot_mvgaze_amd import ops
+    from rot_mvgaze_amd._lib import ConvDesc
+    G, N, h, cin, cout, k, st, pad = case
+    torch.manual_seed(sum(case) + len(mask))
+    d = ConvDesc.make(G, N, h, h, cin, cout, k, st, pad)
+    rows = N * h * h
+    w = torch.randn(cout, k, k, cin, device=dev()) * (1.0 / (k * k * cout) ** 0.5)
+    _, wt = ops.cast_weights_bf16(d, w, cin, True)
+    gy = torch.randn(G, N, d.ho, d.wo, cout, device=dev()).to(torch.bfloat16)
+    add = torch.randn(G, N, h, h, cin, device=dev()).to(torch.bfloat16)
+    y = (torch.randn(G, rows, cin, device=dev()) * 1.5 + 0.3).to(torch.bfloat16)
+    mean, invstd = torch.randn(G, cin, device=dev()) * 0.1 + 0.3, torch.rand(G, cin, device=dev()) + 0.4
+    scale, shift = torch.rand(G, cin, device=dev()) + 0.5, torch.randn(G, cin, device=dev()) * 0.3
+    bits = torch.randint(0, 256, (G * rows * cin // 8,), dtype=torch.uint8, device=dev()) if mask == "bits" else None
+    ra = (scale, shift) if mask == "affine" else None
+    # reference: two launches
+    dx_ref = torch.empty(G, N, h, h, cin, dtype=torch.bfloat16, device=dev())
+    ops.conv_dgrad(d, gy, wt, dx_ref, None, add)
+    s_ref = [torch.empty(G, cin, device=dev()) for _ in range(2)]
+    dg_ref, db_ref = torch.full((cin,), 0.5, device=dev()), torch.full((cin,), -0.25, device=dev())
+    g2 = dx_ref.view(G, rows, cin)
+    if bits is not None:
+        ops.bn_bwd_reduce_bits(g2, bits, y, mean, invstd, G, rows, cin, s_ref[0], s_ref[1], dg_ref, db_ref, True, dz_out=g2)
+    else:
+        ops.bn_bwd_reduce(g2, None, y, mean, invstd, G, rows, cin, s_ref[0], s_ref[1], dg_ref, db_ref, True, ra, dz_out=g2)
+    # fused
+    dx = torch.empty_like(dx_ref)
+    s = [torch.empty(G, cin, device=dev()) for _ in range(2)]
+    dg, db = torch.full((cin,), 0.5, device=dev()), torch.full((cin,), -0.25, device=dev())
+    ops.conv_dgrad_bf16_bnreduce(d, gy, wt, dx, add, y, bits, mean, invstd, ra, s[0], s[1], dg, db, True)
+    assert torch.equal(dx, dx_ref), "masked gradient"
+    for got, want, name in ((s[0], s_ref[0], "s1"), (s[1], s_ref[1], "s2"), (dg, dg_ref, "dgamma"), (db, db_ref, "dbeta")):
+        err = (got - want).abs().max().item()
+        assert err <= 2e-5 * max(want.abs().max().item(), 1.0) * (rows ** 0.5), f"{name}: {err:.3e}"
+    dx2 = add.clone()                                          # in-place addend
+    s2 = [torch.empty(G, cin, device=dev()) for _ in range(2)]
+    ops.conv_dgrad_bf16_bnreduce(d, gy, wt, dx2, dx2, y, bits, mean, invstd, ra, s2[0], s2[1], None, None, False)
+    assert torch.equal(dx2, dx_ref) and torch.equal(s2[0], s[0]) and torch.equal(s2[1], s[1])
+
+
 @pytest.mark.parametrize("rows,fin,fout,relu", [(3584, 3584, 3584, True), (384, 2048, 1536, False), (70, 3584, 512, True),
                                                 (1000, 512, 1536, True)])
 def test_mixed_linear_fp32_tensors_bf16_products(rows, fin, fout, relu):
@@ -333,8 +382,8 @@ def _check_blocks_backward_teacher_forced(m, tape, dfeat):
     """The backward twin of _check_units_teacher_forced: for every residual block (and the stem), the block's
     RECORDED bf16 input goes through the block on the CPU (fp64 autograd, the same storage rounding in the
     forward so that the ReLU patterns match), the RECORDED gradient of its output is back-propagated, and the
-    result must reproduce the recorded gradient of its input (bf16, three to four roundings deep: 3e-2 of the
-    maximum) and the block's weight / BatchNorm gradients in the fp32 arena (relative L2 3e-2)."""
+    result must reproduce the recorded gradient of its input - masked by the ReLU of the unit it feeds, which the
+    fused backward-data epilogue has applied by then - (bf16, three to four roundings deep: 3e-2 of the maximum) and the block's weight / BatchNorm gradients in the fp32 arena (relative L2 3e-2)."""
     units, blocks, dbg = tape["units"], tape["blocks"], tape["debug"]
     P = dict(m.named_parameters())
     spec = m._backbone.spec
@@ -385,6 +434,10 @@ def _check_blocks_backward_teacher_forced(m, tape, dfeat):
             o.backward(nchw(g_out[g]))
             dxs.append(x.grad.permute(0, 2, 3, 1))
         dx = torch.stack(dxs)
+        if bi > 0 and m._backbone.fuse_bn_split:
+            # the backward-data launch that completes this gradient already applied the ReLU of the unit it feeds (the
+            # previous block's last one, whose stored output is this block's input) and summed it for that unit's BatchNorm
+            dx = dx * (x_rec.double() > 0)
         report.append((float((g_in_rec.double() - dx).norm() / (dx.norm() + 1e-30)), f"block {bi}: gradient wrt the block input"))
         compare(wts, f"block {bi}")
         g_out = g_in_rec.double()

@@ -59,10 +59,10 @@ def dev():
     return torch.device("cuda:0")
 
 
-def build(depth, seed=0, train=True):
+def build(depth, seed=0, train=True, conditioned=False):
     from rot_mvgaze_amd.model import FeatRotationSymm
     m = FeatRotationSymm(backbone_depth=depth, num_iter=3)
-    sd = synth.make_state_dict(depth, seed, 3, perturb_bn=True)
+    sd = synth.make_state_dict(depth, seed, 3, perturb_bn=True, conditioned=conditioned)
     m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
     m.to(dev())
     return m.train() if train else m.eval()
@@ -560,23 +560,30 @@ def test_gradient_arena_slices_are_16_byte_aligned():
         assert off % 4 == 0 and p.data_ptr() % 16 == 0 and m._grad_views[id(p)].data_ptr() % 16 == 0
 
 
-@pytest.mark.parametrize("depth", [18, 50])
-def test_split_path_fused_bn_backward_reduce_switch_gives_the_same_step(depth):
-    """Backbone.fuse_bn_split: the split backward-data launches deliver the BatchNorm-backward sums of the unit they feed.
-    Same forward, same masks, gradients to summation-order noise."""
+@pytest.mark.parametrize("depth,dtype", [(18, torch.float32), (50, torch.float32), (18, torch.bfloat16), (50, torch.bfloat16)])
+def test_split_path_fused_bn_backward_reduce_switch_gives_the_same_step(depth, dtype):
+    """Backbone.fuse_bn_split: the split (and bf16) backward-data launches deliver the BatchNorm-backward sums of the unit
+    they feed.  Same forward, same masks, gradients to summation-order noise (bf16: the sums move dy by an ulp here and
+    there: that comparison runs on the well-conditioned weight recipe with 16 x 128 x 128 inputs - with 36 values per
+    channel in layer4 an ulp of bf16 grows to several per cent on the way down, tests/test_bf16_gpu.py)."""
     grads = []
+    bf = dtype == torch.bfloat16
     for fuse in (False, True):
-        m = build(depth)
+        m = build(depth, conditioned=bf)
+        m.compute_dtype = dtype
         m.ensure_layout()
-        assert m._backbone.split
+        assert m._backbone.split or bf
         m._backbone.fuse_bn_split = fuse
-        d = m(inputs(4, 96, seed=3))
+        d = m(inputs(16, 128, seed=3) if bf else inputs(4, 96, seed=3))
         loss = metrics()(d)
         loss.backward()
         grads.append((loss.item(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}))
     assert grads[0][0] == grads[1][0]
     for k, g in grads[0][1].items():
-        rel_close(grads[1][1][k], g.cpu().numpy(), 2e-4, "fused vs separate reduce (split path): " + k)
+        if bf:      # relative L2 per tensor: sums of bf16-rounded gradients over 10^5 .. 10^6 elements cancel to ~1e-3 of their terms
+            l2_close(grads[1][1][k], g.cpu().numpy(), 5e-2, "fused vs separate reduce (bf16): " + k)
+        else:
+            rel_close(grads[1][1][k], g.cpu().numpy(), 2e-4, "fused vs separate reduce: " + k)
 
 
 @pytest.mark.parametrize("depth,dtype", [(18, torch.float32), (50, torch.float32), (50, torch.bfloat16)])

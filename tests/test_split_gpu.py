@@ -219,8 +219,12 @@ def test_stem_tail_writing_sp_matches_the_fp32_kernel():
 
 
 @pytest.mark.parametrize("case", [(2, 3, 14, 256, 256, 3, 1, 1), (3, 2, 14, 1024, 256, 1, 1, 0), (2, 3, 56, 64, 64, 3, 1, 1),
-                                  (1, 2, 56, 64, 256, 1, 1, 0), (2, 7, 7, 512, 512, 3, 1, 1), (2, 5, 9, 128, 160, 1, 1, 0)],
-                         ids=lambda c: "g%d_n%d_h%d_%dto%d_k%d" % c[:6])
+                                  (1, 2, 56, 64, 256, 1, 1, 0), (2, 7, 7, 512, 512, 3, 1, 1), (2, 5, 9, 128, 160, 1, 1, 0),
+                                  # stride 2: four parity classes in one launch, each with its own partials; a 1x1 filter
+                                  # leaves three of them without taps (epilogue-only tiles); odd maps: ragged classes
+                                  (1, 5, 28, 128, 128, 3, 2, 1), (2, 3, 15, 64, 128, 3, 2, 1), (2, 3, 56, 256, 512, 1, 2, 0),
+                                  (1, 4, 9, 128, 256, 1, 2, 0)],
+                         ids=lambda c: "g%d_n%d_h%d_%dto%d_k%d_s%d" % c[:7])
 @pytest.mark.parametrize("mask", ["bits", "affine", "none"])
 def test_split_dgrad_fused_with_bn_backward_reduce(case, mask):
     """mvg_conv_dgrad_split_bnreduce == mvg_conv_dgrad_split followed by the reduce pass over its result: the same
@@ -261,6 +265,12 @@ def test_split_dgrad_fused_with_bn_backward_reduce(case, mask):
     for got, want, name in ((s[0], s_ref[0], "s1"), (s[1], s_ref[1], "s2"), (dg, dg_ref, "dgamma"), (db, db_ref, "dbeta")):
         err = (got - want).abs().max().item()
         assert err <= 2e-5 * max(want.abs().max().item(), 1.0) * (rows ** 0.5), f"{name}: {err:.3e}"
+    # the addend aliasing the result (the downsample branch adds its gradient into the main branch's): same answer
+    dx2 = add.clone()
+    s2 = [torch.empty(G, cin, device=dev()) for _ in range(2)]
+    ops.conv_dgrad_split_bnreduce(d, gys, wt, dx2, dx2, y, bits, mean, invstd, ra, s2[0], s2[1], None, None, False, None)
+    assert torch.equal(dx2, dx_ref), "masked gradient, in-place addend"
+    assert torch.equal(s2[0], s[0]) and torch.equal(s2[1], s[1])
 
 
 @pytest.mark.parametrize("case", [(2, 3, 14, 256, 256, 3, 1, 1), (1, 5, 28, 128, 128, 3, 2, 1), (3, 2, 14, 1024, 256, 1, 1, 0),
