@@ -112,6 +112,103 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restri
   }
 }
 
+// The same merge with one workgroup per (8 channels, GROUP): grid = (c/8, groups).  bn_finalize_kernel walks the groups
+// one after the other - eight dependent rounds of loads and barriers per call at V = 8 (26 us per call, 1.4 ms of a C5
+// step in 53 calls) - only because the running statistics are updated in group order; here every group's statistics
+// are made at once, (mean, unbiased variance) go to `mv` [groups][2][c] in fp64, and bn_running_update_kernel applies
+// them to the running statistics in group order.  Same arithmetic, same order inside a group: identical results.
+__global__ __launch_bounds__(1024) void bn_finalize_group_kernel(const float *__restrict__ stats, const double *__restrict__ sliced,
+                                                                 int slices, int partials, int rows_per_partial, long long rows,
+                                                                 int c, const float *__restrict__ gamma,
+                                                                 const float *__restrict__ beta, float eps, float *mean_out,
+                                                                 float *invstd_out, float *scale, float *shift,
+                                                                 double *__restrict__ mv) {
+  __shared__ double sh[3][16][8];
+  const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  const int ch = blockIdx.x * 8 + cl;
+  const int g = blockIdx.y, groups = gridDim.y;
+  const double inv_full = 1.0 / (double)rows_per_partial;
+  const float *st = stats + (long long)g * partials * 2 * c;
+  double s = 0.0, q = 0.0, ss = 0.0;
+  if (ch < c && sliced) {
+    for (int k = pl; k < slices; k += 128) {
+      const double *o = sliced + (((long long)g * slices + k) * 3) * c;
+      s += o[ch];
+      q += o[c + ch];
+      ss += o[2 * c + ch];
+    }
+  } else if (ch < c) {
+    const int valid = (int)((rows + rows_per_partial - 1) / rows_per_partial) < partials
+                          ? (int)((rows + rows_per_partial - 1) / rows_per_partial) : partials;
+#pragma unroll 4
+    for (int p = pl; p < valid; p += 128) {
+      const float sp_f = st[((long long)p * 2) * c + ch];
+      const float qp_f = st[((long long)p * 2 + 1) * c + ch];
+      const double sp = sp_f, qp = qp_f;
+      s += sp;
+      q += qp;
+      ss += sp * sp;
+    }
+    ss *= inv_full;
+    const long long last_cnt = rows - (long long)(valid - 1) * rows_per_partial;
+    if (valid > 0 && last_cnt < rows_per_partial && ((valid - 1) & 127) == pl) {
+      const double sp = st[((long long)(valid - 1) * 2) * c + ch];
+      ss += sp * sp * (1.0 / (double)last_cnt - inv_full);
+    }
+  }
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1) {
+    s += __shfl_xor(s, o, 64);
+    q += __shfl_xor(q, o, 64);
+    ss += __shfl_xor(ss, o, 64);
+  }
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) < 8) {
+    sh[0][wv][cl] = s;
+    sh[1][wv][cl] = q;
+    sh[2][wv][cl] = ss;
+  }
+  __syncthreads();
+  if (pl == 0 && ch < c) {
+    s = q = ss = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      s += sh[0][k][cl];
+      q += sh[1][k][cl];
+      ss += sh[2][k][cl];
+    }
+    const double n = (double)rows;
+    const double mean = s / n;
+    double m2 = q + (ss - s * mean);                   // Chan merge of the partials
+    if (m2 < 0.0) m2 = 0.0;
+    const double var = m2 / n;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float fmean = (float)mean;
+    const long long o = (long long)g * c + ch;
+    mean_out[o] = fmean;
+    invstd_out[o] = invstd;
+    const float sc = gamma[ch] * invstd;
+    scale[o] = sc;
+    shift[o] = beta[ch] - fmean * sc;
+    mv[((long long)g * 2) * c + ch] = (double)fmean;
+    mv[((long long)g * 2 + 1) * c + ch] = (double)(float)(rows > 1 ? m2 / (n - 1.0) : var);
+  }
+  (void)groups;
+}
+
+__global__ __launch_bounds__(256) void bn_running_update_kernel(const double *__restrict__ mv, int groups, int c, float momentum,
+                                                                float *running_mean, float *running_var) {
+  const int ch = blockIdx.x * 256 + threadIdx.x;
+  if (ch >= c) return;
+  float rm = running_mean ? running_mean[ch] : 0.f, rv = running_var ? running_var[ch] : 0.f;
+  for (int g = 0; g < groups; ++g) {
+    rm = (1.f - momentum) * rm + momentum * (float)mv[((long long)g * 2) * c + ch];
+    rv = (1.f - momentum) * rv + momentum * (float)mv[((long long)g * 2 + 1) * c + ch];
+  }
+  if (running_mean) running_mean[ch] = rm;
+  if (running_var) running_var[ch] = rv;
+}
+
 // Large partial counts (stem at C2: 25 088 per group) first collapse to <= 64 slices per group with
 // all CUs busy; bn_finalize_kernel then merges the slices.  slice record: (sum, q, sum of s^2/cnt) in
 // fp64, [group][slice][3][c].
@@ -893,17 +990,32 @@ int mvg_bn_finalize(const float *stats, int groups, int partials, int rows_per_p
   ProfScope ps(MVG_K_BN_FINALIZE, st, 0.0, 4.0 * groups * (double)partials * 2 * c);
   const double *sliced = nullptr;
   int slices = 0;
+  // scratch: [groups][2][c] doubles for the group-parallel form, then the slices
+  const size_t mv_floats = (size_t)groups * 2 * c * 2;
+  double *mv = groups > 1 ? (double *)stream_scratch(st, mv_floats) : nullptr;
   if (partials >= 1024) {
     slices = 64;
     const int per_slice = ceil_div(partials, slices);
     slices = ceil_div(partials, per_slice);
-    double *buf = (double *)stream_scratch(st, (size_t)groups * slices * 3 * c * 2);
+    float *base = stream_scratch(st, mv_floats + (size_t)groups * slices * 3 * c * 2);
+    double *buf = base ? (double *)(base + mv_floats) : nullptr;
     if (buf) {
       hipLaunchKernelGGL(bn_partials_slice_kernel, dim3(ceil_div(c, 8), slices, groups), dim3(256), 0, st, stats, partials,
                          rows_per_partial, (long long)rows_per_group, c, per_slice, buf, slices);
       if (check_launch("bn_partials_slice")) return 1;
       sliced = buf;
     }
+  }
+  if (mv) {
+    hipLaunchKernelGGL(bn_finalize_group_kernel, dim3(ceil_div(c, 8), groups), dim3(1024), 0, st, stats, sliced, slices, partials,
+                       rows_per_partial, (long long)rows_per_group, c, gamma, beta, eps, mean, invstd, scale, shift, mv);
+    if (check_launch("bn_finalize(groups)")) return 1;
+    if (running_mean || running_var) {
+      hipLaunchKernelGGL(bn_running_update_kernel, dim3(ceil_div(c, 256)), dim3(256), 0, st, mv, groups, c, momentum, running_mean,
+                         running_var);
+      return check_launch("bn_running_update");
+    }
+    return 0;
   }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(c, 8)), dim3(1024), 0, st, stats, sliced, slices, groups, partials,
                      rows_per_partial, (long long)rows_per_group, c, gamma, beta, running_mean, running_var, momentum, eps, mean,

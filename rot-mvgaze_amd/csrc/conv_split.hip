@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void weights_absmax_kernel(const WPrepItem *__
 }
 
 __global__ __launch_bounds__(256) void weights_prep_batch_kernel(const WPrepItem *__restrict__ items, int mode) {
-  __shared__ float tile[64][65];             // mode 1, 1x1 / Linear weights: the transposed copy goes through LDS
+  __shared__ float tile[64][65];             // 1x1 / Linear weights: the transposed copy goes through LDS
   const WPrepItem it = items[blockIdx.y];
   const float *__restrict__ w = it.w;
   const int cout = it.cout, rs = it.rs, cin = it.cin;
@@ -207,6 +207,42 @@ __global__ __launch_bounds__(256) void weights_prep_batch_kernel(const WPrepItem
   unsigned short *wk = reinterpret_cast<unsigned short *>(it.wk), *wt = reinterpret_cast<unsigned short *>(it.wt);
   const int cin_pad = it.cin_pad;
   const long long total = (long long)cout * rs * cin_pad;
+  if (rs == 1 && cin == cin_pad && (cin % 64) == 0 && (cout % 64) == 0) {
+    // Linear weights (the fusion block in the bf16 path: 3584 x 3584 and the like): 16-byte accesses for the plain copy,
+    // the transposed copy as a tiled transpose (the per-element form below writes it 2 bytes at a stride of cout)
+    uint4 *wk4 = reinterpret_cast<uint4 *>(wk);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total / 8; i += (long long)gridDim.x * 256) {
+      const float4 lo = reinterpret_cast<const float4 *>(w + i * 8)[0], hi = reinterpret_cast<const float4 *>(w + i * 8)[1];
+      wk4[i] = make_uint4(bf16_pack2(lo.x, lo.y), bf16_pack2(lo.z, lo.w), bf16_pack2(hi.x, hi.y), bf16_pack2(hi.z, hi.w));
+    }
+    if (wt) {
+      const int tc = cin / 64, ntiles = (cout / 64) * tc;
+      for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int o0 = (t / tc) * 64, c0 = (t % tc) * 64;
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+          const int r = (threadIdx.x >> 4) + 16 * ps, cq = threadIdx.x & 15;
+          const float4 x = *reinterpret_cast<const float4 *>(w + (long long)(o0 + r) * cin + c0 + 4 * cq);
+          tile[r][4 * cq] = x.x;
+          tile[r][4 * cq + 1] = x.y;
+          tile[r][4 * cq + 2] = x.z;
+          tile[r][4 * cq + 3] = x.w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int idx = threadIdx.x + 256 * q, cl = idx >> 3, o8 = idx & 7;
+          float v[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = tile[o8 * 8 + k][cl];
+          *reinterpret_cast<uint4 *>(wt + (long long)(c0 + cl) * cout + o0 + o8 * 8) =
+              make_uint4(bf16_pack2(v[0], v[1]), bf16_pack2(v[2], v[3]), bf16_pack2(v[4], v[5]), bf16_pack2(v[6], v[7]));
+        }
+      }
+    }
+    return;
+  }
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int c = (int)(i % cin_pad);
     const long long t = i / cin_pad;

@@ -325,17 +325,18 @@ __global__ __launch_bounds__(256) void skinny_bwd_dx_kernel(const float *__restr
   dx[i] = s;
 }
 // dw[j][i] = sum_m dy[m][j] x[m][i];  db[j] = sum_m dy[m][j]
-// 16 columns x 16 row lanes per workgroup; the row lanes are summed through LDS in lane order
-// (deterministic).  One thread per column walking all rows was 47 us for 128 rows x 512 columns.
+// 4 columns x 64 row lanes per workgroup (k / 4 workgroups: 128 for the gaze head's 512 inputs); the row lanes are summed
+// through LDS in lane order (deterministic).  The bias gradient is summed by workgroup 0 with all of its threads - one
+// thread per output walking all rows serially was 290 us of this kernel's 296 at C5's 3584 rows.
 __global__ __launch_bounds__(256) void skinny_bwd_dw_kernel(const float *__restrict__ dy, const float *__restrict__ x,
                                                             float *__restrict__ dw, float *__restrict__ db, int rows,
                                                             int k, int nout, int accumulate) {
-  __shared__ float sh[4][16][17];
-  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
-  const int i = blockIdx.x * 16 + cl;
+  __shared__ float sh[4][64][5];
+  const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2;
+  const int i = blockIdx.x * 4 + cl;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   if (i < k)
-    for (int m = rl; m < rows; m += 16) {
+    for (int m = rl; m < rows; m += 64) {
       const float v = x[(long long)m * k + i];
       for (int j = 0; j < nout; ++j) acc[j] += dy[(long long)m * nout + j] * v;
     }
@@ -344,13 +345,21 @@ __global__ __launch_bounds__(256) void skinny_bwd_dw_kernel(const float *__restr
   if (rl < nout && i < k) {
     const int j = rl;
     float t = 0.f;
-    for (int r = 0; r < 16; ++r) t += sh[j][r][cl];
+    for (int r = 0; r < 64; ++r) t += sh[j][r][cl];
     dw[(long long)j * k + i] = (accumulate ? dw[(long long)j * k + i] : 0.f) + t;
   }
-  if (db && blockIdx.x == 0 && threadIdx.x < nout) {
-    float t = 0.f;
-    for (int m = 0; m < rows; ++m) t += dy[(long long)m * nout + threadIdx.x];
-    db[threadIdx.x] = (accumulate ? db[threadIdx.x] : 0.f) + t;
+  if (db && blockIdx.x == 0) {
+    __shared__ float sb[4][256];
+    float part[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int m = threadIdx.x; m < rows; m += 256)
+      for (int j = 0; j < nout; ++j) part[j] += dy[(long long)m * nout + j];
+    for (int j = 0; j < 4; ++j) sb[j][threadIdx.x] = part[j];
+    __syncthreads();
+    if (threadIdx.x < nout) {
+      float t = 0.f;
+      for (int r = 0; r < 256; ++r) t += sb[threadIdx.x][r];
+      db[threadIdx.x] = (accumulate ? db[threadIdx.x] : 0.f) + t;
+    }
   }
 }
 
@@ -580,7 +589,7 @@ int mvg_linear_skinny_bwd(const float *dy, const float *x, const float *w, const
   }
   if (dw) {
     ProfScope ps(MVG_K_LINEAR_WGRAD, st, 2.0 * rows * (double)k * nout, 4.0 * (double)rows * k);
-    hipLaunchKernelGGL(skinny_bwd_dw_kernel, dim3(ceil_div(k, 16)), dim3(256), 0, st, dy, x, dw, db, rows, k, nout,
+    hipLaunchKernelGGL(skinny_bwd_dw_kernel, dim3(ceil_div(k, 4)), dim3(256), 0, st, dy, x, dw, db, rows, k, nout,
                        accumulate);
     if (check_launch("skinny_bwd_dw")) return 1;
   }

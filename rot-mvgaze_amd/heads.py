@@ -172,7 +172,8 @@ class _Mlp:
             y = out if (last and out is not None) else torch.empty(rows, self.fout_p[l], dtype=torch.float32, device=dev)
             if self._use_mixed(l):
                 assert gen is None
-                self._wbf[l] = ops.cast_weights_bf16(ConvDesc.linear(1, self.fin_p[l], self.fout_p[l]), w, self.fin_p[l], True)
+                if self._wbf[l] is None:                 # (made by FusionHead._prepare_split_weights(mixed=True) at the start of the step)
+                    self._wbf[l] = ops.cast_weights_bf16(ConvDesc.linear(1, self.fin_p[l], self.fout_p[l]), w, self.fin_p[l], True)
                 ops.linear_fprop_mixed(cur, self._wbf[l][0], b, not last, y, rows, self.fin_p[l], self.fout_p[l])
             elif l == 0 and gen is not None:
                 ops.fuser_fprop(gen.img, gen.feat, gen.rel, gen.row_img, gen.row_src, w, b, not last, y, rows, gen.cf, gen.nvec,
@@ -302,20 +303,29 @@ class FusionHead:
         self._wprep_state = None
         self._wsp_versions = None
 
-    def _prepare_split_weights(self, rows: int, dev):
+    def _prepare_split_weights(self, rows: int, dev, mixed: bool = False):
         """The sp copies (KRSC for fprop, CRSK for backward-data) of every fuser / head Linear that runs on the split
-        kernels this step, made by ONE batched launch pair (like Backbone._prepare_weights: persistent destination buffers and
-        a device-resident record table built once per parameter placement)."""
+        kernels this step - or, mixed (the bf16 path), their bf16 copies - made by ONE batched launch pair (like
+        Backbone._prepare_weights: persistent destination buffers and a device-resident record table built once per
+        parameter placement)."""
         mods = [m for m in self.unique_modules()]
-        layers = [(m, l) for m in mods for l in range(m.n) if m._use_split(l, rows)]
-        key = (str(dev), tuple(m.w[l].data_ptr() for m, l in layers))
+        if mixed:
+            mods = [self.lifter] + mods
+            layers = [(m, l) for m in mods for l in range(m.n) if m._use_mixed(l)]
+        else:
+            layers = [(m, l) for m in mods for l in range(m.n) if m._use_split(l, rows)]
+        key = (str(dev), mixed, tuple(m.w[l].data_ptr() for m, l in layers))
         if self._wprep_state is None or self._wprep_state[0] != key:
             wstat = torch.zeros(len(layers), 2, dtype=torch.float32, device=dev)
             rows_t, bufs = [], []
             for i, (m, l) in enumerate(layers):
                 fin, fout = m.fin[l], m.fout[l]
-                wk, wt = ops.sp_empty(fout, fin, device=dev), ops.sp_empty(fin, fout, device=dev)
-                wk.sinv = wt.sinv = wstat[i, 1:2]
+                if mixed:
+                    wk = torch.empty(fout, 1, 1, fin, dtype=torch.bfloat16, device=dev)
+                    wt = torch.empty(fin, 1, 1, fout, dtype=torch.bfloat16, device=dev)
+                else:
+                    wk, wt = ops.sp_empty(fout, fin, device=dev), ops.sp_empty(fin, fout, device=dev)
+                    wk.sinv = wt.sinv = wstat[i, 1:2]
                 bufs.append((m, l, wk, wt))
                 rows_t.append([m.w[l].data_ptr(), wk.data_ptr(), wt.data_ptr(), fout | (1 << 32), fin | (fin << 32), wstat[i].data_ptr()])
             table = torch.tensor(rows_t, dtype=torch.int64).to(dev) if rows_t else None
@@ -323,12 +333,17 @@ class FusionHead:
         _, bufs, table, wstat = self._wprep_state
         for m in mods:
             m._wsp = [None] * m.n
+            m._wbf = [None] * m.n
         if table is None:
             return
-        wstat.zero_()
-        ops.weights_prep_batch(table, len(bufs), 1, 256)
+        if not mixed:
+            wstat.zero_()
+        ops.weights_prep_batch(table, len(bufs), 0 if mixed else 1, 256)
         for m, l, wk, wt in bufs:
-            m._wsp[l] = (wk, wt)
+            if mixed:
+                m._wbf[l] = (wk, wt)
+            else:
+                m._wsp[l] = (wk, wt)
         self._wsp_versions = tuple(m.w[l]._version for m, l, _, _ in bufs)
 
     def unique_modules(self) -> List[_Mlp]:
@@ -400,9 +415,12 @@ class FusionHead:
         for m in [self.lifter] + self.fusers + self.heads:
             m.mixed = self.mixed
             m.split = split_on
+            m._wbf = [None] * m.n                  # this step's bf16 copies: made below in one launch (or per layer on first use)
         self.lifter.split = False                  # V * B rows: stays on the fp32-MFMA kernels
         if split_on:
             self._prepare_split_weights(D * B, dev)
+        elif self.mixed:
+            self._prepare_split_weights(D * B, dev, mixed=True)
         hl, lifted = self.lifter.forward(img_feat.reshape(V * B, cf))
         rel = torch.empty(D, B, 3, 3, dtype=torch.float32, device=dev)
         ops.relative_rotation(rot.detach().to(torch.float32).contiguous(), ix["vi"], ix["vj"], rel, B, V, D)
@@ -440,7 +458,7 @@ class FusionHead:
                 saved.append((X, Hf, Xh, Hh, scales))
             src, src_idx = Fn, ix["partner"]             # view j's feature of the SAME pair, previous iteration
         tape = {"img_feat": img_feat, "lifted": lifted, "hl": hl, "rel": rel, "saved": saved, "V": V, "B": B,
-                "wsp_versions": self._wsp_versions if split_on else None} if keep_tape else None
+                "wsp_versions": self._wsp_versions if (split_on or self.mixed) else None} if keep_tape else None
         return lifted.view(V, B, 3, NV), feats.view(I, D, B, 3, NV), preds.view(I, D, B, 2), tape
 
     # ---------------------------------------------------------------- backward
