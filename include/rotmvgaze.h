@@ -530,6 +530,33 @@ int mvg_conv_dgrad_split_bnreduce(const mvg_conv_desc *d, const void *dy_sp, con
                                   const float *bn_mean, const float *bn_invstd, const float *relu_scale, const float *relu_shift,
                                   float *partials, float *s1, float *s2, float *dgamma, float *dbeta, int accumulate,
                                   float *mx, void *stream);
+/* The 7x7 stride-2 stem (resnet.py:184, ResNet.forward :262) on the split kernels, "row-window" form: the 3-channel image
+ * (stored NHWC with 4 channels) is rewritten as xw [images][h][w/2][8][4] in sp - window ox holds image columns 2 ox - 4 ..
+ * 2 ox + 3, zero outside the image - and the stem becomes a 7 x 1 filter over 32 "channels" (vertical stride 2 / pad 3,
+ * horizontal stride 1 / pad 0): K = 224.  d = the stem's own descriptor (r = s = 7, stride 2, pad 3, cin = 4, even w).
+ *   mvg_stem_rowwindow_split: x_nhwc4 fp32 -> xw_sp (32 * images * h * w/2 sp elements);
+ *   w_sp: the sp copy (mvg_split_weights on a [cout][7][1][32] descriptor) of w'[o][r][j][c] = w[o][r][j - 1][c], zero for
+ *         j = 0 and c = 3;   mvg_stem_fprop_split: y fp32 [groups][n][ho][wo][cout] + BatchNorm partials like
+ *         mvg_conv_fprop_split (mvg_conv_stats_partials_split of a descriptor with the same n, ho, wo);
+ *   mvg_stem_wgrad_split: dw_rw [cout][7][8][4] fp32 in the same tap layout (the caller drops j = 0 and c = 3);
+ *         workspace = splits * cout * 224 floats, splits = mvg_stem_wgrad_splits_split(d).
+ * The stem tail's backward with dy in sp: mvg_bn_relu_maxpool_bwd_reduce_split also leaves mx [groups][c], a bound on a
+ * pixel's gradient (4 x the largest masked window gradient); mvg_bn_relu_maxpool_bwd_apply_split scales dy by the 2^k that
+ * bound allows and writes 2^-k to *dy_sinv. */
+int mvg_stem_rowwindow_split(const float *x_nhwc4, void *xw_sp, int64_t images, int h, int w, void *stream);
+int mvg_stem_fprop_split(const mvg_conv_desc *d, const void *xw_sp, const void *w_sp, const float *w_sinv, float *y, float *stats,
+                         void *stream);
+int mvg_stem_wgrad_splits_split(const mvg_conv_desc *d);
+int mvg_stem_wgrad_split(const mvg_conv_desc *d, const void *xw_sp, const void *dy_sp, const float *dy_sinv, float *dw_rw,
+                         float *workspace, int splits, int accumulate, void *stream);
+int mvg_bn_relu_maxpool_bwd_reduce_split(const float *g_pooled, const uint8_t *argmax, const float *y, const float *mean,
+                                         const float *invstd, const float *scale, const float *shift, int groups,
+                                         int n_per_group, int h, int w, int c, int ho, int wo, float *s1, float *s2,
+                                         float *dgamma, float *dbeta, int accumulate, float *workspace, float *mx, void *stream);
+int mvg_bn_relu_maxpool_bwd_apply_split(const float *g_pooled, const uint8_t *argmax, const float *y, const float *mean,
+                                        const float *invstd, const float *gamma, const float *scale, const float *shift,
+                                        const float *s1, const float *s2, int groups, int n_per_group, int h, int w, int c,
+                                        int ho, int wo, void *dy_s3, const float *mx, float *dy_sinv, void *stream);
 int mvg_conv_wgrad_splits_split(const mvg_conv_desc *d);   /* pixel-split count; workspace = splits * cout*r*s*cin floats */
 int mvg_conv_wgrad_split(const mvg_conv_desc *d, const void *x_sp, const void *dy_sp, const float *dy_sinv, float *dw,
                          float *workspace, int splits, int accumulate, void *stream);

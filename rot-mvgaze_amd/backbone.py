@@ -44,10 +44,11 @@ class GradSink:
 class _Unit:
     """Saved state of one conv + BN (+ReLU) (+residual) for the backward pass."""
     __slots__ = ("spec", "desc", "x_in", "y", "out", "mean", "invstd", "relu", "rows", "w", "trained", "pool",
-                 "relu_affine", "fused_s12", "relu_bits", "split")
+                 "relu_affine", "fused_s12", "relu_bits", "split", "stem_rw")
 
     def __init__(self):
         self.split = False        # conv operands (x_in, out, dy, w) in sp (two fp16 pieces), split-operand kernels (conv_split.hip)
+        self.stem_rw = False      # the stem in row-window form: x_in is the window operand, dy goes out in sp
         self.relu_bits = None     # residual units: the ReLU mask as one byte per 16-byte access (ops.bn_apply_bits)
         self.fused_s12 = None     # BatchNorm-backward sums delivered by the backward-data launch that produced this unit's gradient
 
@@ -86,6 +87,11 @@ class Backbone:
         # stride-2 filter never touches as epilogue-only tiles.  (attribute False: separate reduce passes - the tests
         # compare the two.)
         self.fuse_bn_split = True
+        # split path, training: the 7x7 stem on the split kernels too, in its "row-window" form (mvg_stem_fprop_split: the
+        # image rewritten as [.., W/2, 8 columns x 4 channels] windows, a 7 x 1 filter over 32 channels, K = 224) instead
+        # of the fp32-MFMA kernel on 4-channel taps (K = 196 at a fifth of the matrix rate).  Not when the caller wants
+        # d(loss)/d(img) (the backward-data launch runs on the fp32 kernel) or the width is odd.
+        self.stem_rowwindow = True
         self.split_eval = True      # inference forward on the split kernels too
         self._wk_cache: Dict[str, tuple] = {}     # inference: conv name -> (data_ptr, version, s3 weights)
         # training: one launch per step makes every conv's bf16 / s3 weight copies
@@ -94,6 +100,8 @@ class Backbone:
         self._wprep_state = None
         self._wprep_versions = None
         self._split_now = self.split          # per forward call: off when a view's largest s3 tensor would exceed 2 GiB
+        self._stem_rw = False                 # per forward call: the stem runs in row-window form on the split kernels
+        self._stem_w8 = None
 
     @property
     def bf16(self) -> bool:
@@ -116,15 +124,27 @@ class Backbone:
         backward-data), made by ONE launch: destination buffers and the launch's device-resident table of
         (source, destinations, shape) records are built once per parameter placement and reused every step."""
         mode = 0 if self.bf16 else 1
-        convs = [c for c in self.spec.all_convs() if not (mode == 1 and c.cin == 3)]
-        key = (mode, str(dev), tuple(self.p[c.name + ".weight"].data_ptr() for c in convs))
+        stem_rw = mode == 1 and self._stem_rw
+        convs = [c for c in self.spec.all_convs() if not (mode == 1 and c.cin == 3 and not stem_rw)]
+        key = (mode, stem_rw, str(dev), tuple(self.p[c.name + ".weight"].data_ptr() for c in convs))
         if self._wprep_state is None or self._wprep_state[0] != key:
             out, rows = {}, []
             wstat = torch.zeros(len(convs), 2, dtype=torch.float32, device=dev)      # per conv {max |w| bits, 2^-k} (split path)
+            self._stem_w8 = None
             for ci, c in enumerate(convs):
                 wsrc = self.p[c.name + ".weight"]
                 assert wsrc.is_contiguous(memory_format=torch.channels_last) or (c.k == 1 and wsrc.is_contiguous())
                 rs = c.k * c.k
+                if mode == 1 and c.cin == 3:
+                    # the stem in row-window form: w'[o][r][j][c] = w[o][r][j - 1][c] (j = 0 and c = 3 zero), refreshed from the
+                    # parameter below (9408 floats: layout plumbing), then split like a [cout][7][1][32] filter
+                    assert c.k == 7
+                    self._stem_w8 = torch.zeros(c.cout, 7, 8, 4, dtype=torch.float32, device=dev)
+                    wk = ops.sp_empty(c.cout, 7 * 32, device=dev)
+                    wk.sinv = wstat[ci, 1:2]
+                    out[c.name] = (wk, None)
+                    rows.append([self._stem_w8.data_ptr(), wk.data_ptr(), 0, c.cout | (7 << 32), 32 | (32 << 32), wstat[ci].data_ptr()])
+                    continue
                 if mode == 1:
                     wk = ops.sp_empty(c.cout, rs * c.cin, device=dev)
                     wt = ops.sp_empty(c.cin, rs * c.cout, device=dev)
@@ -142,6 +162,8 @@ class Backbone:
         _, out, table, n, mode, wstat = self._wprep_state
         if mode == 1:
             wstat.zero_()                                  # the max |w| slots are atomicMax targets
+            if self._stem_w8 is not None:
+                self._stem_w8[:, :, 1:, :3].copy_(self.p[self.spec.stem.name + ".weight"].detach().permute(0, 2, 3, 1))
         ops.weights_prep_batch(table, n, mode)
         # the copies live in persistent buffers that the next forward overwrites: remember which parameter versions
         # they hold, so that the backward of an OLDER tape can tell (tapes keep pointers into these buffers)
@@ -176,7 +198,8 @@ class Backbone:
         # sp_out = its consumers do (every unit: the stem's pooled map feeds layer1)
         sp_out = self._split_now and training and not bf
         sp_in = sp_out and c.cin != 3
-        if (sp_in or bf) and self._wprep is not None:
+        stem_rw = sp_out and c.cin == 3 and self._stem_rw          # x is then the row-window operand (ops.stem_rowwindow_split)
+        if (sp_in or bf or stem_rw) and self._wprep is not None:
             w, w_t = self._wprep[c.name]         # this step's copies, made by ONE launch at the start of forward()
         elif sp_in:
             wsrc = self.p[c.name + ".weight"].detach()
@@ -197,12 +220,17 @@ class Backbone:
         mean, invstd, scale, shift = aff[0], aff[1], aff[2], aff[3]
 
         def fprop(stats_buf):
-            if sp_in:
+            if stem_rw:
+                ops.stem_fprop_split(d, x, w, y, stats_buf)
+            elif sp_in:
                 ops.conv_fprop_split(d, x, w, y, stats_buf)
             else:
                 ops.conv_fprop(d, x, w, y, None, False, stats_buf)
         if training:
-            P, rpp = ops.conv_stats_partials_split(d) if sp_in else ops.conv_stats_partials(d, bf)
+            if stem_rw:      # the same row tiles as any split forward with these n, ho, wo
+                P, rpp = ops.conv_stats_partials_split(ConvDesc.make(G, N, d.ho, d.wo, 32, c.cout, 1, 1, 0))
+            else:
+                P, rpp = ops.conv_stats_partials_split(d) if sp_in else ops.conv_stats_partials(d, bf)
             stats = torch.empty(G, P, 2, c.cout, dtype=torch.float32, device=dev)
             fprop(stats)
             ops.bn_finalize(stats, G, P, rpp, rows, c.cout, gamma, beta, rm, rv, BN_MOMENTUM, BN_EPS, mean, invstd,
@@ -274,6 +302,7 @@ class Backbone:
                 c, d, x, y, (None if pool else out), mean, invstd, relu, rows, (w_t if (bf or sp_in) else w)
             u.trained = training
             u.split = sp_in
+            u.stem_rw = stem_rw
             # ReLU without residual: the backward rebuilds the mask from y (saves reading `out` twice)
             u.relu_affine = (scale, shift) if (relu and residual is None and not pool) else None
             if pool:
@@ -292,7 +321,7 @@ class Backbone:
         return x, argmax
 
     def forward(self, imgs: List[Tensor], training: bool, keep_tape: bool, input_bgr: bool = False,
-                input_size: Optional[int] = None):
+                input_size: Optional[int] = None, need_dimg: bool = False):
         """imgs: V tensors [B,3,H,W] fp32 NCHW (the reference's input format, rot_mv.py:188-189), or
         V raw uint8 [B,H,W,3] face patches, put through test_transform of main.py:50-55 on the GPU
         (ToTensor, Resize((input_size, input_size), antialias=True) when the patch has another size,
@@ -324,6 +353,8 @@ class Backbone:
         # fp32-MFMA kernels (64-bit row offsets there; B < 668 per view at 224 x 224 with ResNet-50)
         biggest_view_elems = B * ((H + 3) // 4) * ((W + 3) // 4) * self.spec.blocks[0].convs[-1].cout
         self._split_now = self.split and 4 * biggest_view_elems * self._guard_scale < 0x7FFFFFF0
+        self._stem_rw = (self._split_now and self.stem_rowwindow and training and not self.bf16 and not need_dimg and W % 2 == 0
+                         and self.batch_weight_prep and 32 * B * H * (W // 2) * 4 < 0x7FFFFFF0)
         self._wprep = None
         if training:
             self._wk_cache.clear()               # the weights are about to change: drop the inference copies
@@ -336,6 +367,8 @@ class Backbone:
         if training:
             torch._foreach_add_(self.bn_count_buffers(), V)       # num_batches_tracked += 1 per view call
         s = self.spec
+        if self._stem_rw:
+            x0 = ops.stem_rowwindow_split(x0)
         x, argmax = self._unit_fwd(s.stem, x0, V, B, H, W, training, True, None, ulist, pool=True)
         Hc, Wc = x.shape[2], x.shape[3]
         for blk in s.blocks:
@@ -466,6 +499,14 @@ class Backbone:
         wp = self.p[c.name + ".weight"]
         if u.split:
             ops.conv_wgrad_split(u.desc, u.x_in, dy, sink.view(wp), sink.accumulate(wp))
+        elif u.stem_rw:
+            dw8 = torch.empty(c.cout, 7, 8, 4, dtype=torch.float32, device=dy.device)
+            ops.stem_wgrad_split(u.desc, u.x_in, dy, dw8, False)
+            gv = sink.view(wp).permute(0, 2, 3, 1)                    # [cout, 7, 7, 3] view of the gradient
+            if sink.accumulate(wp):
+                gv.add_(dw8[:, :, 1:, :3])
+            else:
+                gv.copy_(dw8[:, :, 1:, :3])
         elif c.cin == 3:
             dw4 = torch.empty(c.cout, c.k, c.k, u.desc.cin, dtype=torch.float32, device=dy.device)
             ops.conv_wgrad(u.desc, u.x_in, dy, dw4, False)
@@ -571,14 +612,22 @@ class Backbone:
         argmax, scale, shift, H1, W1, Hp, Wp = stem.pool
         sc = stem.spec
         gp, bp = P[sc.bn + ".weight"], P[sc.bn + ".bias"]
-        s12 = torch.empty(2, V, sc.cout, dtype=torch.float32, device=g.device)
+        s12 = torch.empty(3 if stem.stem_rw else 2, V, sc.cout, dtype=torch.float32, device=g.device)
         acc = sink.accumulate(gp)
         assert acc == sink.accumulate(bp)
-        ops.bn_relu_maxpool_bwd_reduce(g, argmax, stem.y, stem.mean, stem.invstd, scale, shift, V, B, H1, W1, sc.cout, Hp, Wp,
-                                       s12[0], s12[1], sink.view(gp), sink.view(bp), acc)
-        dy = torch.empty_like(stem.y)
-        ops.bn_relu_maxpool_bwd_apply(g, argmax, stem.y, stem.mean, stem.invstd, gp.detach(), scale, shift, s12[0], s12[1],
-                                      V, B, H1, W1, sc.cout, Hp, Wp, dy)
+        if stem.stem_rw:
+            # the stem's weight gradient runs on the split kernels: dy goes out in sp, scaled by a bound from the reduce pass
+            ops.bn_relu_maxpool_bwd_reduce_split(g, argmax, stem.y, stem.mean, stem.invstd, scale, shift, V, B, H1, W1, sc.cout, Hp, Wp,
+                                                 s12[0], s12[1], sink.view(gp), sink.view(bp), acc, s12[2])
+            dy = ops.sp_empty(*stem.y.shape, device=g.device)
+            ops.bn_relu_maxpool_bwd_apply_split(g, argmax, stem.y, stem.mean, stem.invstd, gp.detach(), scale, shift, s12[0], s12[1],
+                                                V, B, H1, W1, sc.cout, Hp, Wp, dy, s12[2])
+        else:
+            ops.bn_relu_maxpool_bwd_reduce(g, argmax, stem.y, stem.mean, stem.invstd, scale, shift, V, B, H1, W1, sc.cout, Hp, Wp,
+                                           s12[0], s12[1], sink.view(gp), sink.view(bp), acc)
+            dy = torch.empty_like(stem.y)
+            ops.bn_relu_maxpool_bwd_apply(g, argmax, stem.y, stem.mean, stem.invstd, gp.detach(), scale, shift, s12[0], s12[1],
+                                          V, B, H1, W1, sc.cout, Hp, Wp, dy)
         dx0 = self._conv_bwd(stem, dy, need_dimg, None, sink)
         sink.publish([P[stem.spec.name + ".weight"], P[stem.spec.bn + ".weight"], P[stem.spec.bn + ".bias"]])
         if self._wg_stream is not None and dy.is_cuda:

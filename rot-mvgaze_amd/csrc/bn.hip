@@ -849,14 +849,16 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const T *__rest
                                                                  const float *__restrict__ scale,
                                                                  const float *__restrict__ shift, int lines_per_chunk,
                                                                  int n_per_group, int h, int w, int ho, int wo, int c, int c4n,
-                                                                 int cw, float *__restrict__ partial, int chunks) {
-  __shared__ float4 sh[2][256];
+                                                                 int cw, float *__restrict__ partial, int chunks, int prows) {
+  // prows == 3 (split path): a third partial row bounds max |gradient of a pixel| per channel - 4 x the largest masked
+  // window gradient (a pixel wins at most four of the 3x3 stride-2 windows) - for the sp scale of dy
+  __shared__ float4 sh[3][256];
   const int grp = blockIdx.z;
   const int rl = threadIdx.x / cw, cl = threadIdx.x % cw;
   const int nrl = 256 / cw;
   const int cq = blockIdx.y * cw + cl;
   const bool cok = cq < c4n;
-  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, mxv[4] = {0.f, 0.f, 0.f, 0.f};
   if (cok) {
     const float4 mu4 = reinterpret_cast<const float4 *>(mean + (long long)grp * c)[cq];
     const float4 is4 = reinterpret_cast<const float4 *>(invstd + (long long)grp * c)[cq];
@@ -883,6 +885,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const T *__rest
           const int iy = 2 * oy - 1 + kh, ix = 2 * ox - 1 + kw;          // the winner is an in-bounds pixel
           const float v = Elem<T>::ld1(yimg, ((long long)iy * w + ix) * c + j);
           const float d = __builtin_fmaf(v, sa[j], sb[j]) > 0.f ? g[j] : 0.f;
+          mxv[j] = fmaxf(mxv[j], fabsf(d));
           s1[j] += d;
           s2[j] += d * ((v - mu[j]) * is[j]);
         }
@@ -891,22 +894,25 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const T *__rest
   }
   sh[0][threadIdx.x] = make_float4(s1[0], s1[1], s1[2], s1[3]);
   sh[1][threadIdx.x] = make_float4(s2[0], s2[1], s2[2], s2[3]);
+  sh[2][threadIdx.x] = make_float4(mxv[0], mxv[1], mxv[2], mxv[3]);
   __syncthreads();
   if (rl == 0 && cok) {
-    float4 t1 = sh[0][threadIdx.x], t2 = sh[1][threadIdx.x];
+    float4 t1 = sh[0][threadIdx.x], t2 = sh[1][threadIdx.x], t3 = sh[2][threadIdx.x];
     for (int k = 1; k < nrl; ++k) {
-      const float4 a = sh[0][k * cw + cl], b = sh[1][k * cw + cl];
+      const float4 a = sh[0][k * cw + cl], b = sh[1][k * cw + cl], m = sh[2][k * cw + cl];
       t1.x += a.x; t1.y += a.y; t1.z += a.z; t1.w += a.w;
       t2.x += b.x; t2.y += b.y; t2.z += b.z; t2.w += b.w;
+      t3.x = fmaxf(t3.x, m.x); t3.y = fmaxf(t3.y, m.y); t3.z = fmaxf(t3.z, m.z); t3.w = fmaxf(t3.w, m.w);
     }
-    float4 *p = reinterpret_cast<float4 *>(partial + (((long long)grp * chunks + blockIdx.x) * 2) * c);
+    float4 *p = reinterpret_cast<float4 *>(partial + (((long long)grp * chunks + blockIdx.x) * prows) * c);
     p[cq] = t1;
     p[c4n + cq] = t2;
+    if (prows == 3) p[2 * c4n + cq] = make_float4(4.f * t3.x, 4.f * t3.y, 4.f * t3.z, 4.f * t3.w);
   }
 }
 
 // grid = (ceil(w*c4n / 256), images*h): one thread = one (image, iy, ix, 4 channels) of the conv output
-template <typename T>
+template <typename T, typename TO = T>
 __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const T *__restrict__ gp, const uchar4 *__restrict__ am,
                                                                 const T *__restrict__ y, const float *__restrict__ mean,
                                                                 const float *__restrict__ invstd,
@@ -915,7 +921,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const T *__restr
                                                                 const float *__restrict__ shift, const float *__restrict__ s1,
                                                                 const float *__restrict__ s2, int n_per_group, int h, int w,
                                                                 int ho, int wo, int c4n, float inv_rows,
-                                                                T *__restrict__ dy) {
+                                                                TO *__restrict__ dy, const float *__restrict__ dy_sinv) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= w * c4n) return;
   const int ix = t / c4n, cq = t - ix * c4n;
@@ -937,7 +943,11 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const T *__restr
   o.y = ga.y * is.y * (d.y - a1.y * inv_rows - (v.y - mu.y) * is.y * (a2.y * inv_rows));
   o.z = ga.z * is.z * (d.z - a1.z * inv_rows - (v.z - mu.z) * is.z * (a2.z * inv_rows));
   o.w = ga.w * is.w * (d.w - a1.w * inv_rows - (v.w - mu.w) * is.w * (a2.w * inv_rows));
-  Elem<T>::st4(dy, i, o);
+  if (dy_sinv) {                               // sp result: times 2^k (bn_dy_scale_kernel; exact)
+    const float dsc = 1.f / *dy_sinv;
+    o.x *= dsc; o.y *= dsc; o.z *= dsc; o.w *= dsc;
+  }
+  Elem<TO>::st4(dy, i, o);
 }
 
 static int bwd_chunks(int groups, long long rows, int c) {
@@ -1114,7 +1124,8 @@ template <typename T>
 static int bn_relu_maxpool_bwd_reduce_impl(const T *g_pooled, const uint8_t *argmax, const T *y, const float *mean,
                                            const float *invstd, const float *scale, const float *shift, int groups,
                                            int n_per_group, int h, int w, int c, int ho, int wo, float *s1, float *s2,
-                                           float *dgamma, float *dbeta, int accumulate, float *workspace, void *stream) {
+                                           float *dgamma, float *dbeta, int accumulate, float *workspace, void *stream,
+                                           float *mx = nullptr) {
   MVG_REQUIRE(c % 4 == 0, "bn_relu_maxpool_bwd_reduce: c %% 4 != 0");
   MVG_REQUIRE(workspace != nullptr, "bn_relu_maxpool_bwd_reduce: workspace required");
   hipStream_t st = (hipStream_t)stream;
@@ -1132,24 +1143,24 @@ static int bn_relu_maxpool_bwd_reduce_impl(const T *g_pooled, const uint8_t *arg
                Elem<T>::kBytes * groups * ((double)rows * c + (double)n_per_group * ho * wo * c * 1.25));
   hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel<T>, dim3(chunks, ceil_div(c4n, cw), groups), dim3(256), 0, st, g_pooled,
                      (const uchar4 *)argmax, y, mean, invstd, scale, shift, lpc, n_per_group, h, w, ho, wo, c, c4n, cw, workspace,
-                     chunks);
+                     chunks, mx ? 3 : 2);
   if (check_launch("bn_relu_maxpool_bwd_reduce")) return 1;
-  return bn_bwd_finalize_launch(workspace, groups, chunks, c, s1, s2, dgamma, dbeta, accumulate, st, nullptr);
+  return bn_bwd_finalize_launch(workspace, groups, chunks, c, s1, s2, dgamma, dbeta, accumulate, st, mx);
 }
 
-template <typename T>
+template <typename T, typename TO = T>
 static int bn_relu_maxpool_bwd_apply_impl(const T *g_pooled, const uint8_t *argmax, const T *y, const float *mean,
                                           const float *invstd, const float *gamma, const float *scale, const float *shift,
                                           const float *s1, const float *s2, int groups, int n_per_group, int h, int w, int c,
-                                          int ho, int wo, T *dy, void *stream) {
+                                          int ho, int wo, TO *dy, void *stream, const float *dy_sinv = nullptr) {
   MVG_REQUIRE(c % 4 == 0, "bn_relu_maxpool_bwd_apply: c %% 4 != 0");
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps(MVG_K_BN_BWD_APPLY, st, 0.0,
                Elem<T>::kBytes * groups * ((double)n_per_group * h * w * c * 2 + (double)n_per_group * ho * wo * c * 1.25));
   MVG_REQUIRE((long long)groups * n_per_group * h < 65536, "bn_relu_maxpool: images*h must fit grid.y");
-  hipLaunchKernelGGL(bn_pool_bwd_apply_kernel<T>, dim3(ceil_div((long long)w * (c / 4), 256), groups * n_per_group * h), dim3(256),
+  hipLaunchKernelGGL((bn_pool_bwd_apply_kernel<T, TO>), dim3(ceil_div((long long)w * (c / 4), 256), groups * n_per_group * h), dim3(256),
                      0, st, g_pooled, (const uchar4 *)argmax, y, mean, invstd, gamma, scale, shift, s1, s2, n_per_group, h, w, ho,
-                     wo, c / 4, 1.0f / (float)((long long)n_per_group * h * w), dy);
+                     wo, c / 4, 1.0f / (float)((long long)n_per_group * h * w), dy, dy_sinv);
   return check_launch("bn_relu_maxpool_bwd_apply");
 }
 
@@ -1275,6 +1286,30 @@ int mvg_bn_relu_maxpool_fwd_split(const float *y, const float *scale, const floa
   MVG_REQUIRE(c % 8 == 0, "bn_relu_maxpool_fwd_split: c %% 8 != 0");
   return bn_relu_maxpool_fwd_impl<float, sp_t>(y, scale, shift, (sp_t *)pooled_s3, argmax, groups, n_per_group, h, w, c, ho, wo,
                                                stream);
+}
+
+// the stem tail's backward on the split path: the pooled gradient and y are fp32, dy goes to the stem's wgrad in sp;
+// mx [groups][c] (from the reduce pass) bounds the gradient of a pixel: 4 x the largest masked window gradient
+int mvg_bn_relu_maxpool_bwd_reduce_split(const float *g_pooled, const uint8_t *argmax, const float *y, const float *mean,
+                                         const float *invstd, const float *scale, const float *shift, int groups, int n_per_group,
+                                         int h, int w, int c, int ho, int wo, float *s1, float *s2, float *dgamma, float *dbeta,
+                                         int accumulate, float *workspace, float *mx, void *stream) {
+  MVG_REQUIRE(mx != nullptr, "bn_relu_maxpool_bwd_reduce_split: mx is required");
+  return bn_relu_maxpool_bwd_reduce_impl<float>(g_pooled, argmax, y, mean, invstd, scale, shift, groups, n_per_group, h, w, c, ho, wo,
+                                                s1, s2, dgamma, dbeta, accumulate, workspace, stream, mx);
+}
+
+int mvg_bn_relu_maxpool_bwd_apply_split(const float *g_pooled, const uint8_t *argmax, const float *y, const float *mean,
+                                        const float *invstd, const float *gamma, const float *scale, const float *shift,
+                                        const float *s1, const float *s2, int groups, int n_per_group, int h, int w, int c, int ho,
+                                        int wo, void *dy_s3, const float *mx, float *dy_sinv, void *stream) {
+  MVG_REQUIRE(c % 8 == 0 && mx && dy_sinv, "bn_relu_maxpool_bwd_apply_split: c %% 8 != 0, or mx / dy_sinv missing");
+  const long long rows = (long long)n_per_group * h * w;
+  hipLaunchKernelGGL(bn_dy_scale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, gamma, invstd, s1, s2, mx, groups, c,
+                     1.0f / (float)rows, sqrtf((float)rows), dy_sinv);
+  if (check_launch("bn_dy_scale")) return 1;
+  return bn_relu_maxpool_bwd_apply_impl<float, sp_t>(g_pooled, argmax, y, mean, invstd, gamma, scale, shift, s1, s2, groups,
+                                                     n_per_group, h, w, c, ho, wo, (sp_t *)dy_s3, stream, dy_sinv);
 }
 
 MVG_BN_BITS_FACES(, float)

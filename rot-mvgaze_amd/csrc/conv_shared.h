@@ -143,6 +143,8 @@ struct IgemmParams {
   // split kernels: the operands hold (value * 2^k) for a per-tensor k (elem.h: sp_t); the epilogue multiplies the
   // accumulators by *a_sinv * *b_sinv (device scalars, each 2^-k of its operand; null = 1)
   const float *a_sinv, *b_sinv;
+  int stride_w, pad_w;            // split kernels, forward: horizontal stride / padding (= stride / pad except for the stem's
+                                  // row-window form: a 7 x 1 filter, vertical stride 2, over windows that already step by 2)
   int bn_part_rows;               // fused BatchNorm-backward reduce: rows per partial in bn_part - 2 (s1, s2) or 3 (+ max |dz| per channel)
   const unsigned char *bn_bits;   // the unit's ReLU mask as bits: one byte per 4 channels (fp32: mvg_bn_apply_split) or per 8 (bf16: mvg_bn_apply_bits_bf16)
   // Cross-view fusion (igemm_kernel AMODE = 1, Linear forward): the A operand is never materialised - row m of
@@ -184,6 +186,7 @@ struct WgradParams {
   long long rc_img_bytes, rc_feat_bytes;
   FastDiv ohw_div, wo_div, cin_div, s_div;
   const float *dy_sinv;           // split kernels: 2^-k of the dy operand's per-tensor scale (device scalar, null = 1)
+  int stride_w, pad_w;            // split kernels: horizontal stride / padding (see IgemmParams)
 };
 
 // Sum of the per-split slabs.  A workgroup covers 256/lanes float4 columns; `lanes` threads per column

@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256, DGRAD ? 3 : 4) void igemm_split16_kernel(Igemm
     const int rem = mm - img * ohw;
     const int oy = (int)fdiv((unsigned)rem, c.ow_div), ox = rem - oy * c.out_w;
     const int y0 = DGRAD ? oy + c.cls_cy : oy * p.stride - p.pad;
-    const int x0 = DGRAD ? ox + c.cls_cx : ox * p.stride - p.pad;
+    const int x0 = DGRAD ? ox + c.cls_cx : ox * p.stride_w - p.pad_w;
     const unsigned base = (unsigned)(img * p.src_img_stride * SP_BYTES) + (unsigned)((y0 * p.src_w + x0) * p.src_c) * (unsigned)SP_BYTES;
     unsigned msk = 0;
     for (int t = 0; t < c.ntaps; ++t) {
@@ -503,10 +503,10 @@ __global__ __launch_bounds__(256, 3) void wgrad_split_kernel(WgradParams p) {
     const int cc = (i_cok[j] ? col : 0) - tap * p.cin;
     const int fr = (int)fdiv((unsigned)tap, p.s_div), fs = tap - fr * p.s;
     i_dy[j] = fr - p.pad;
-    i_dx[j] = fs - p.pad;
+    i_dx[j] = fs - p.pad_w;
     i_tconst[j] = (unsigned)((i_dy[j] * p.w + i_dx[j]) * p.cin + cc) * (unsigned)SP_BYTES;
   }
-  const unsigned row_bytes = (unsigned)(p.stride * p.w * p.cin) * (unsigned)SP_BYTES, col_bytes = (unsigned)(p.stride * p.cin) * (unsigned)SP_BYTES;
+  const unsigned row_bytes = (unsigned)(p.stride * p.w * p.cin) * (unsigned)SP_BYTES, col_bytes = (unsigned)(p.stride_w * p.cin) * (unsigned)SP_BYTES;
   const unsigned img_bytes = (unsigned)x_img_elems * (unsigned)SP_BYTES;
   int s_oy = 0, s_ox = 0;
   unsigned s_imgoff = 0;
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(256, 3) void wgrad_split_kernel(WgradParams p) {
       ox = (int)(rem - uy * (unsigned)p.wo);
       imgoff = img * img_bytes;
     }
-    const int iy0 = oy * p.stride, ix0 = ox * p.stride;
+    const int iy0 = oy * p.stride, ix0 = ox * p.stride_w;
     const unsigned pixoff = imgoff + (unsigned)oy * row_bytes + (unsigned)ox * col_bytes;
 #pragma unroll
     for (int j = 0; j < B_CPT; ++j) {
@@ -633,6 +633,28 @@ __global__ __launch_bounds__(256, 3) void wgrad_split_kernel(WgradParams p) {
         }
       }
     }
+}
+
+// The stem's row-window operand (see mvg_stem_fprop_split): one thread per 8-value chunk = image columns (2 ox - 4 + 2 q,
+// + 1) x 4 stored channels of window (n, y, ox), written as the chunk's two fp16 pieces.
+__global__ __launch_bounds__(256) void stem_rowwindow_kernel(const float4 *__restrict__ x, uint4 *__restrict__ xw, long long n, int h, int w) {
+  const int wo = w >> 1;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int q = (int)(i & 3);
+    const long long t = i >> 2;
+    const int ox = (int)(t % wo);
+    const long long row = t / wo;                     // image * h + y
+    const int c0 = 2 * ox - 4 + 2 * q;                // even: both columns in range or both out (w is even)
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c0 >= 0 && c0 < w) {
+      const float4 a = x[row * w + c0], b = x[row * w + c0 + 1];
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    uint4 q1, q2;
+    split2_chunk(v, q1, q2);
+    xw[SP_NP * i] = q1;
+    xw[SP_NP * i + 1] = q2;
+  }
 }
 
 // A stride-2 parity class without taps: dx = addend (or zero) on that class's pixels (float4 vectors)
@@ -814,9 +836,11 @@ struct SplitAffine {       // inference forward: y = acc * scale + shift (+ resi
   int residual_s3, relu, out_s3;
 };
 
+// stride_w / pad_w >= 0: the horizontal stride / padding differ from d->stride / d->pad (the stem's row-window form, whose
+// descriptor the caller has checked itself)
 static int fprop_split_impl(const mvg_conv_desc *d, const void *x_sp, const float *x_sinv, const void *w_sp, const float *w_sinv,
-                            void *y, float *stats, void *stream, const SplitAffine *aff) {
-  if (validate_split(d)) return 2;
+                            void *y, float *stats, void *stream, const SplitAffine *aff, int stride_w = -1, int pad_w = -1) {
+  if (stride_w < 0 && validate_split(d)) return 2;
   IgemmParams p;
   memset(&p, 0, sizeof(p));
   p.a = (const float *)x_sp;
@@ -846,6 +870,8 @@ static int fprop_split_impl(const mvg_conv_desc *d, const void *x_sp, const floa
   p.rs = d->r * d->s;
   p.stride = d->stride;
   p.pad = d->pad;
+  p.stride_w = stride_w >= 0 ? stride_w : d->stride;
+  p.pad_w = stride_w >= 0 ? pad_w : d->pad;
   p.ktotal = d->r * d->s * d->cin;
   p.b_row_len = p.ktotal;
   p.cin = d->cin;
@@ -863,7 +889,8 @@ static int fprop_split_impl(const mvg_conv_desc *d, const void *x_sp, const floa
   p.tap_ns_div = make_fastdiv((unsigned)p.tap_ns);
   p.ohw_div = make_fastdiv((unsigned)(p.out_h * p.out_w));
   p.ow_div = make_fastdiv((unsigned)p.out_w);
-  const double flops = 2.0 * d->groups * (double)p.rows_per_group * d->cout * d->r * d->s * d->cin;
+  // (the stem's row-window form multiplies 7 x 32 values per output where the filter has 7 x 7 x 3: count the filter's)
+  const double flops = 2.0 * d->groups * (double)p.rows_per_group * d->cout * d->r * d->s * d->cin * (stride_w >= 0 ? 147.0 / 224.0 : 1.0);
   const double bytes = (double)SP_BYTES * (d->groups * (double)d->n * d->h * d->w * d->cin + (double)d->cout * d->r * d->s * d->cin) +
                        4.0 * d->groups * (double)p.rows_per_group * d->cout;
   const bool lin = d->r == 1 && d->s == 1 && d->h == 1 && d->w == 1;
@@ -1063,9 +1090,9 @@ int mvg_conv_wgrad_splits_split(const mvg_conv_desc *d) {
   return (int)want;
 }
 
-int mvg_conv_wgrad_split(const mvg_conv_desc *d, const void *x_sp, const void *dy_sp, const float *dy_sinv, float *dw, float *workspace,
-                         int splits, int accumulate, void *stream) {
-  if (validate_split(d)) return 2;
+static int wgrad_split_impl(const mvg_conv_desc *d, const void *x_sp, const void *dy_sp, const float *dy_sinv, float *dw, float *workspace,
+                            int splits, int accumulate, void *stream, int stride_w = -1, int pad_w = -1) {
+  if (stride_w < 0 && validate_split(d)) return 2;
   MVG_REQUIRE(splits >= 1, "wgrad_split: splits < 1");
   MVG_REQUIRE(splits == 1 || workspace != nullptr, "wgrad_split: workspace required for splits > 1");
   WgradParams p;
@@ -1081,6 +1108,8 @@ int mvg_conv_wgrad_split(const mvg_conv_desc *d, const void *x_sp, const void *d
   p.s = d->s;
   p.stride = d->stride;
   p.pad = d->pad;
+  p.stride_w = stride_w >= 0 ? stride_w : d->stride;
+  p.pad_w = stride_w >= 0 ? pad_w : d->pad;
   p.ho = d->ho;
   p.wo = d->wo;
   p.ncols = d->r * d->s * d->cin;
@@ -1103,7 +1132,7 @@ int mvg_conv_wgrad_split(const mvg_conv_desc *d, const void *x_sp, const void *d
   hipStream_t st = (hipStream_t)stream;
   const bool lin = d->r == 1 && d->s == 1 && d->h == 1 && d->w == 1;
   {
-    const double flops = 2.0 * (double)p.pixels * d->cout * d->r * d->s * d->cin;
+    const double flops = 2.0 * (double)p.pixels * d->cout * d->r * d->s * d->cin * (stride_w >= 0 ? 147.0 / 224.0 : 1.0);
     const double bytes = (double)SP_BYTES * ((double)d->groups * d->n * d->h * d->w * d->cin + (double)p.pixels * d->cout) +
                          4.0 * (double)d->cout * d->r * d->s * d->cin;
     ProfScope ps(lin ? MVG_K_LINEAR_WGRAD : MVG_K_CONV_WGRAD, st, flops, bytes);
@@ -1131,6 +1160,68 @@ int mvg_conv_wgrad_split(const mvg_conv_desc *d, const void *x_sp, const void *d
     if (check_launch("wgrad_reduce")) return 1;
   }
   return 0;
+}
+
+int mvg_conv_wgrad_split(const mvg_conv_desc *d, const void *x_sp, const void *dy_sp, const float *dy_sinv, float *dw, float *workspace,
+                         int splits, int accumulate, void *stream) {
+  return wgrad_split_impl(d, x_sp, dy_sp, dy_sinv, dw, workspace, splits, accumulate, stream);
+}
+
+// ---- the 7x7 stride-2 stem on the split kernels ("row-window" form) ------------------------------------------------
+// A 3-channel (stored 4) image has too few channels for a K-step of the implicit GEMM: the fp32-MFMA kernel runs it at
+// ~75 % of ITS peak (117 TFLOP/s with the padding channel).  Rewritten: xw[n][y][ox][j][c], j = 0..7, c = 0..3 holds
+// image column 2 ox - 4 + j (zero outside the image) - the 8 columns the 7 taps of output column ox touch, plus one
+// in front so that pixel pairs stay 16-byte aligned - and the stem becomes a 7 x 1 filter with 32 "channels", vertical
+// stride 2 / padding 3, horizontal stride 1 / padding 0, over ho x wo windows: K = 7 x 32 = 224, the shape
+// igemm_split16_kernel / wgrad_split_kernel are built for.  Weights w'[o][r][j][c] = w[o][r][j - 1][c] (j = 0, c = 3: zero).
+static int stem_desc(const mvg_conv_desc *d, mvg_conv_desc *rw) {
+  MVG_REQUIRE(d != nullptr, "stem (row-window): null descriptor");
+  MVG_REQUIRE(d->r == 7 && d->s == 7 && d->stride == 2 && d->pad == 3 && d->cin == 4, "stem (row-window): 7x7 stride 2 pad 3, 4 stored channels");
+  MVG_REQUIRE(d->w % 2 == 0 && d->ho == (d->h - 1) / 2 + 1 && d->wo == d->w / 2, "stem (row-window): even width; ho, wo inconsistent");
+  MVG_REQUIRE(d->cout % 32 == 0 && d->groups > 0 && d->n > 0, "stem (row-window): cout must be a multiple of 32");
+  *rw = *d;
+  rw->w = d->wo;            // windows per image row
+  rw->cin = 32;
+  rw->s = 1;
+  return 0;
+}
+
+int mvg_stem_rowwindow_split(const float *x_nhwc4, void *xw_sp, int64_t images, int h, int w, void *stream) {
+  MVG_REQUIRE(x_nhwc4 && xw_sp && images > 0 && h > 0 && w > 0 && w % 2 == 0, "stem_rowwindow: bad arguments (even width)");
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = images * h * (w / 2) * 4;                 // one thread per 8-value chunk (two pixels)
+  ProfScope ps(MVG_K_LAYOUT, st, 0.0, 16.0 * (double)images * h * w + 32.0 * (double)n);
+  long long blocks = (n + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(stem_rowwindow_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float4 *)x_nhwc4, (uint4 *)xw_sp, n, h, w);
+  return check_launch("stem_rowwindow");
+}
+
+int mvg_stem_fprop_split(const mvg_conv_desc *d, const void *xw_sp, const void *w_sp, const float *w_sinv, float *y, float *stats,
+                         void *stream) {
+  mvg_conv_desc rw;
+  if (stem_desc(d, &rw)) return 2;
+  return fprop_split_impl(&rw, xw_sp, nullptr, w_sp, w_sinv, y, stats, stream, nullptr, 1, 0);
+}
+
+int mvg_stem_wgrad_splits_split(const mvg_conv_desc *d) {
+  mvg_conv_desc rw;
+  if (stem_desc(d, &rw)) return -1;
+  const long long tiles = (long long)ceil_div(rw.cout, rw.cout >= 128 ? 128 : 64) * ceil_div(7 * 32, 128);
+  const long long pixels = (long long)rw.groups * rw.n * rw.ho * rw.wo;
+  long long want = (3LL * compute_cus()) / tiles, maxs = pixels / 256;
+  if (maxs < 1) maxs = 1;
+  if (want > maxs) want = maxs;
+  if (want < 1) want = 1;
+  if (want > 1024) want = 1024;
+  return (int)want;
+}
+
+int mvg_stem_wgrad_split(const mvg_conv_desc *d, const void *xw_sp, const void *dy_sp, const float *dy_sinv, float *dw_rw, float *workspace,
+                         int splits, int accumulate, void *stream) {
+  mvg_conv_desc rw;
+  if (stem_desc(d, &rw)) return 2;
+  return wgrad_split_impl(&rw, xw_sp, dy_sp, dy_sinv, dw_rw, workspace, splits, accumulate, stream, 1, 0);
 }
 
 }  // extern "C"

@@ -105,11 +105,11 @@ class _BackboneFn(torch.autograd.Function):
         # inside forward): run_views records the caller's grad mode, so that torch.no_grad() inference takes the
         # tape-less path (BatchNorm folded into the conv epilogues) even though the parameters require grad
         keep = model._grad_mode and any(ctx.needs_input_grad)
-        feat, tape = model._backbone.forward(imgs, training, keep, model.input_bgr, model.input_size)
+        ctx.need_dimg = any(ctx.needs_input_grad[3:3 + n_views])
+        feat, tape = model._backbone.forward(imgs, training, keep, model.input_bgr, model.input_size, need_dimg=ctx.need_dimg)
         ctx.model, ctx.tape, ctx.n_views = model, tape, n_views
         if model._debug_keep_tapes:
             model._last_backbone_tape = tape
-        ctx.need_dimg = any(ctx.needs_input_grad[3:3 + n_views])
         return feat
 
     @staticmethod

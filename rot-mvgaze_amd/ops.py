@@ -245,6 +245,47 @@ def split_grad(g: Tensor, rows: int, cols: int, db: Optional[Tensor] = None, acc
     return out
 
 
+def stem_rowwindow_split(x_nhwc4: Tensor) -> Tensor:
+    """[G, N, H, W, 4] fp32 image -> the stem's row-window operand [G, N, H, W/2, 32] in sp (mvg_stem_fprop_split)."""
+    G, N, H, W, C = x_nhwc4.shape
+    assert C == 4 and W % 2 == 0 and x_nhwc4.dtype == torch.float32 and x_nhwc4.is_contiguous()
+    xw = sp_empty(G, N, H, W // 2, 32, device=x_nhwc4.device)
+    check(lib().mvg_stem_rowwindow_split(_p(x_nhwc4), _p(xw), G * N, H, W, _s()), "stem_rowwindow_split")
+    xw.sinv = None
+    return xw
+
+
+def stem_fprop_split(d: ConvDesc, xw: Tensor, w_sp: Tensor, y: Tensor, stats: Optional[Tensor]):
+    check(lib().mvg_stem_fprop_split(C.byref(d), _p(xw), _p(w_sp), _sinv(w_sp), _p(y), _p(stats), _s()), "stem_fprop_split")
+
+
+def stem_wgrad_split(d: ConvDesc, xw: Tensor, dy_sp: Tensor, dw_rw: Tensor, accumulate: bool = False):
+    """dw_rw [cout, 7, 8, 4] fp32 (+)= the stem's weight gradient in the row-window tap layout."""
+    splits = lib().mvg_stem_wgrad_splits_split(C.byref(d))
+    if splits < 1:
+        check(1, "stem_wgrad_splits_split")
+    ws = torch.empty(splits * d.cout * 224, dtype=torch.float32, device=xw.device) if splits > 1 else None
+    check(lib().mvg_stem_wgrad_split(C.byref(d), _p(xw), _p(dy_sp), _sinv(dy_sp), _p(dw_rw), _p(ws), splits, int(accumulate), _s()),
+          "stem_wgrad_split")
+
+
+def bn_relu_maxpool_bwd_reduce_split(g_pooled, argmax, y, mean, invstd, scale, shift, groups, n_per_group, h, w, c, ho, wo, s1, s2,
+                                     dgamma, dbeta, accumulate, mx):
+    n = lib().mvg_bn_bwd_workspace_floats(groups, n_per_group * h * w, c)
+    ws = torch.empty(n, dtype=torch.float32, device=y.device)
+    check(lib().mvg_bn_relu_maxpool_bwd_reduce_split(_p(g_pooled), _p(argmax), _p(y), _p(mean), _p(invstd), _p(scale), _p(shift), groups,
+                                                     n_per_group, h, w, c, ho, wo, _p(s1), _p(s2), _p(dgamma), _p(dbeta), int(accumulate),
+                                                     _p(ws), _p(mx), _s()), "bn_relu_maxpool_bwd_reduce_split")
+
+
+def bn_relu_maxpool_bwd_apply_split(g_pooled, argmax, y, mean, invstd, gamma, scale, shift, s1, s2, groups, n_per_group, h, w, c, ho, wo,
+                                    dy_sp, mx):
+    dy_sp.sinv = torch.empty(1, dtype=torch.float32, device=y.device)
+    check(lib().mvg_bn_relu_maxpool_bwd_apply_split(_p(g_pooled), _p(argmax), _p(y), _p(mean), _p(invstd), _p(gamma), _p(scale), _p(shift),
+                                                    _p(s1), _p(s2), groups, n_per_group, h, w, c, ho, wo, _p(dy_sp), _p(mx), _p(dy_sp.sinv),
+                                                    _s()), "bn_relu_maxpool_bwd_apply_split")
+
+
 def conv_dgrad_bn_partials_split(d: ConvDesc) -> int:
     n = lib().mvg_conv_dgrad_bn_partials_split(C.byref(d))
     if n < 0:

@@ -314,3 +314,94 @@ def test_split_kernels_reject_shapes_they_do_not_cover():
         ops.split_weights(d, torch.randn(64, 1, 1, 48, device=dev()), True)
     with pytest.raises(AssertionError):
         ops.split_f32(torch.randn(4, 12, device=dev()))       # channels not a multiple of 8
+
+
+@pytest.mark.parametrize("G,N,H,W,cout", [(2, 3, 32, 32, 64), (1, 2, 224, 224, 64), (2, 2, 23, 40, 64), (1, 5, 7, 6, 64), (3, 1, 96, 64, 64)],
+                         ids=lambda v: str(v))
+def test_stem_in_row_window_form_on_the_split_kernels(G, N, H, W, cout):
+    """mvg_stem_rowwindow_split / _fprop_split / _wgrad_split: the 7x7 stride-2 stem as a 7 x 1 filter over windows of 8
+    columns x 4 stored channels == conv2d in float64 on the 3-channel image (and never worse than 3x the fp32-MFMA kernel
+    on 4-channel taps); odd heights, ragged row tiles, image borders inside the first / last window."""
+    from rot_mvgaze_amd import ops
+    from rot_mvgaze_amd._lib import ConvDesc
+    torch.manual_seed(G * 1000 + H + W)
+    d = ConvDesc.make(G, N, H, W, 4, cout, 7, 2, 3)
+    x = torch.randn(G, N, H, W, 4, device=dev())
+    x[..., 3] = 0
+    w = torch.randn(cout, 7, 7, 3, device=dev()) * 0.08
+    gy = torch.randn(G, N, d.ho, d.wo, cout, device=dev()) * 3e-4
+    xr = x[..., :3].double().view(G * N, H, W, 3).permute(0, 3, 1, 2)
+    wr = w.double().permute(0, 3, 1, 2).requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, 2, 3)
+    yr.backward(gy.double().view(G * N, d.ho, d.wo, cout).permute(0, 3, 1, 2))
+    y_ref, dw_ref = yr.detach().permute(0, 2, 3, 1).reshape(G, N, d.ho, d.wo, cout), wr.grad.permute(0, 2, 3, 1)
+    # the window operand holds the image exactly (to the sp format's last bit), zero outside it
+    xw = ops.stem_rowwindow_split(x)
+    win = ops.merge_sp(xw).view(G, N, H, W // 2, 8, 4)
+    want = torch.zeros_like(win)
+    for j in range(8):
+        cols = torch.arange(W // 2, device=dev()) * 2 - 4 + j
+        ok = (cols >= 0) & (cols < W)
+        want[:, :, :, ok, j] = x[:, :, :, cols[ok]]
+    sp_close(win, want, "row windows")
+    # weights in the window's tap layout
+    w8 = torch.zeros(cout, 7, 8, 4, device=dev())
+    w8[:, :, 1:, :3] = w
+    dk = ConvDesc(1, 1, 7, 1, 32, cout, 7, 1, 1, 0, 1, 1)
+    wk, _ = ops.split_weights(dk, w8.view(cout, 7, 1, 32).contiguous(), False)
+    y = torch.full((G, N, d.ho, d.wo, cout), float("nan"), device=dev())
+    P, rpp = ops.conv_stats_partials_split(ConvDesc.make(G, N, d.ho, d.wo, 32, cout, 1, 1, 0))
+    stats = torch.full((G, P, 2, cout), float("nan"), device=dev())
+    ops.stem_fprop_split(d, xw, wk, y, stats)
+    w4 = torch.zeros(cout, 7, 7, 4, device=dev())
+    w4[..., :3] = w
+    y32 = torch.empty_like(y)
+    ops.conv_fprop(d, x, w4, y32, None, False, None)
+    e, e32 = rel_l2(y, y_ref), rel_l2(y32, y_ref)
+    assert e <= SPLIT_VS_F64 and e <= SPLIT_VS_FP32_KERNEL * e32 + 1e-7, f"fprop: split {e:.2e}, fp32-MFMA {e32:.2e}"
+    rows = N * d.ho * d.wo
+    assert rel_l2(stats[:, :, 0].sum(1), y_ref.reshape(G, rows, cout).sum(1)) <= 1e-5, "BatchNorm partial sums"
+    # weight gradient, dy scaled by a power of two
+    gscale = 2.0 ** float(torch.floor(torch.log2(2.0 ** 14 / gy.abs().max())))
+    gys = ops.split_f32(gy, gscale)
+    dw8 = torch.full((cout, 7, 8, 4), float("nan"), device=dev())
+    ops.stem_wgrad_split(d, xw, gys, dw8, False)
+    dw32 = torch.empty(cout, 7, 7, 4, device=dev())
+    ops.conv_wgrad(d, x, gy, dw32, False)
+    e, e32 = rel_l2(dw8[:, :, 1:, :3], dw_ref), rel_l2(dw32[..., :3], dw_ref)
+    assert e <= SPLIT_VS_F64 and e <= SPLIT_VS_FP32_KERNEL * e32 + 1e-7, f"wgrad: split {e:.2e}, fp32-MFMA {e32:.2e}"
+    # (the padding tap j = 0 sees real pixels: its "gradient" is not zero, the caller drops it)
+    ops.stem_wgrad_split(d, xw, gys, dw8, True)
+    assert rel_l2(dw8[:, :, 1:, :3], 2 * dw_ref) <= SPLIT_VS_F64, "wgrad accumulate"
+
+
+def test_stem_tail_backward_writing_sp_matches_the_fp32_kernels():
+    """mvg_bn_relu_maxpool_bwd_reduce_split / _apply_split == the fp32 pair, with dy in sp at the scale the reduce pass's
+    bound allows (4 x the largest masked window gradient per channel bounds a pixel's gradient)."""
+    from rot_mvgaze_amd import ops
+    G, N, H, C = 2, 3, 30, 64
+    torch.manual_seed(5)
+    y = torch.randn(G, N, H, H, C, device=dev())
+    scale, shift = torch.rand(G, C, device=dev()) + 0.5, torch.randn(G, C, device=dev()) * 0.3
+    mean, invstd = torch.randn(G, C, device=dev()) * 0.1, torch.rand(G, C, device=dev()) + 0.5
+    gamma = torch.rand(C, device=dev()) + 0.5
+    hp = (H + 2 - 3) // 2 + 1
+    pooled, am = torch.empty(G, N, hp, hp, C, device=dev()), torch.empty(G, N, hp, hp, C, dtype=torch.uint8, device=dev())
+    ops.bn_relu_maxpool_fwd(y, scale, shift, pooled, am, G, N, H, H, C, hp, hp)
+    for gmag in (1.0, 1e-6):
+        g = torch.randn(G, N, hp, hp, C, device=dev()) * gmag
+        s_ref, dg_ref, db_ref = torch.empty(2, G, C, device=dev()), torch.zeros(C, device=dev()), torch.zeros(C, device=dev())
+        ops.bn_relu_maxpool_bwd_reduce(g, am, y, mean, invstd, scale, shift, G, N, H, H, C, hp, hp, s_ref[0], s_ref[1], dg_ref, db_ref, False)
+        dy_ref = torch.empty_like(y)
+        ops.bn_relu_maxpool_bwd_apply(g, am, y, mean, invstd, gamma, scale, shift, s_ref[0], s_ref[1], G, N, H, H, C, hp, hp, dy_ref)
+        s, dg, db = torch.empty(3, G, C, device=dev()), torch.zeros(C, device=dev()), torch.zeros(C, device=dev())
+        ops.bn_relu_maxpool_bwd_reduce_split(g, am, y, mean, invstd, scale, shift, G, N, H, H, C, hp, hp, s[0], s[1], dg, db, False, s[2])
+        assert torch.equal(s[:2], s_ref) and torch.equal(dg, dg_ref) and torch.equal(db, db_ref)
+        assert bool((s[2] <= 4 * g.abs().amax(dim=(1, 2, 3)) * 1.0001).all()) and float(s[2].max()) > 0
+        dy = ops.sp_empty(G, N, H, H, C, device=dev())
+        ops.bn_relu_maxpool_bwd_apply_split(g, am, y, mean, invstd, gamma, scale, shift, s[0], s[1], G, N, H, H, C, hp, hp, dy, s[2])
+        k = float(dy.sinv)
+        assert k > 0 and np.log2(k) == round(np.log2(k)), "dy scale: a power of two"
+        got = ops.merge_sp(dy)
+        assert float((got - dy_ref).abs().max()) <= 2.0 ** -22 * float(dy_ref.abs().max()), "dy"
+        assert float(dy_ref.abs().max()) / k < 2.0 ** 15.01 and float(dy_ref.abs().max()) / k > 2.0 ** 4, "dy sits in fp16's range with headroom to spare, not far below it"
