@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MVG_ABI_VERSION 8
+#define MVG_ABI_VERSION 9
 
 /* ---------------------------------------------------------------- library */
 int mvg_abi_version(void);
