@@ -873,8 +873,8 @@ static int dgrad_bf16_impl(const mvg_conv_desc *d, const void *dy, const void *w
   MVG_REQUIRE(p.a_group_bytes < 0x7FFFFFF0ll && p.b_bytes < 0x7FFFFFF0ll, "bf16 conv: a group / the weights exceed 2 GiB");
   MVG_REQUIRE((long long)d->n * d->h * d->w * d->cin < (1ll << 31), "bf16 conv: a group of dx exceeds 2^31 elements");
   const double flops = 2.0 * d->groups * (double)d->n * d->ho * d->wo * d->cout * d->r * d->s * d->cin;
-  const double bytes = 2.0 * (d->groups * (double)d->n * d->ho * d->wo * d->cout + (double)d->cout * d->r * d->s * d->cin +
-                              d->groups * (double)d->n * d->h * d->w * d->cin);
+  const double bytes = 2.0 * (d->groups * (double)d->n * d->ho * d->wo * d->cout + (double)d->cout * d->r * d->s * d->cin) +
+                       (bnf ? 4.125 : 2.0) * d->groups * (double)d->n * d->h * d->w * d->cin;      // (fused reduce: + y and the mask bits)
   const bool lin = d->r == 1 && d->s == 1 && d->h == 1 && d->w == 1;
   ProfScope ps(lin ? MVG_K_LINEAR_DGRAD : MVG_K_CONV_DGRAD, (hipStream_t)stream, flops, bytes);
   const int step = d->stride;

@@ -970,8 +970,9 @@ static int dgrad_split_impl(const mvg_conv_desc *d, const void *dy_sp, const flo
   MVG_REQUIRE(p.a_group_bytes < 0x7FFFFFF0ll && p.b_bytes < 0x7FFFFFF0ll, "split conv: a group / the weights exceed 2 GiB");
   MVG_REQUIRE((long long)d->n * d->h * d->w * d->cin < (1ll << 31), "split conv: a group of dx exceeds 2^31 elements");
   const double flops = 2.0 * d->groups * (double)d->n * d->ho * d->wo * d->cout * d->r * d->s * d->cin;
+  // (with the BatchNorm reduce on board the launch also reads that unit's y and mask bits: its algorithmic bytes)
   const double bytes = (double)SP_BYTES * (d->groups * (double)d->n * d->ho * d->wo * d->cout + (double)d->cout * d->r * d->s * d->cin) +
-                       4.0 * d->groups * (double)d->n * d->h * d->w * d->cin;
+                       (bnf ? 8.25 : 4.0) * d->groups * (double)d->n * d->h * d->w * d->cin;
   const bool lin = d->r == 1 && d->s == 1 && d->h == 1 && d->w == 1;
   ProfScope ps(lin ? MVG_K_LINEAR_DGRAD : MVG_K_CONV_DGRAD, (hipStream_t)stream, flops, bytes);
   const int step = d->stride;

@@ -44,7 +44,20 @@ for (cin, cout, k, st, pad, h, need_dx) in layers:
     stats = torch.empty(G, P, 2, cout, device=dev)
     gy = torch.randn_like(y)
     dw = torch.empty_like(w)
-    if split and cin > 4:
+    if split and cin == 4:
+        # the stem in row-window form (the window operand is built by the input transform, not a conv op)
+        xw = ops.stem_rowwindow_split(x)
+        w8 = torch.zeros(cout, 7, 8, 4, device=dev)
+        w8[:, :, 1:, :3] = w[..., :3]
+        wk, _ = ops.split_weights(ConvDesc(1, 1, 7, 1, 32, cout, 7, 1, 1, 0, 1, 1), w8.view(cout, 7, 1, 32), False)
+        Ps, _ = ops.conv_stats_partials_split(ConvDesc.make(G, N, d.ho, d.wo, 32, cout, 1, 1, 0))
+        stats_s = torch.empty(G, Ps, 2, cout, device=dev)
+        gys = ops.split_f32(gy)
+        torch.cuda.synchronize()
+        ops.stem_fprop_split(d, xw, wk, y, stats_s)
+        ops.stem_wgrad_split(d, xw, gys, torch.empty(cout, 7, 8, 4, device=dev))
+        n_ops += 2
+    elif split:
         xs, gys = ops.split_f32(x), ops.split_f32(gy)
         wk, wts = ops.split_weights(d, w, True)
         Ps, _ = ops.conv_stats_partials_split(d)
@@ -53,8 +66,13 @@ for (cin, cout, k, st, pad, h, need_dx) in layers:
         ops.conv_wgrad_split(d, xs, gys, dw)
         n_ops += 2
         if need_dx:
+            # as in the step: backward-data carries the BatchNorm-backward reduce of the unit it feeds (mask bits, in-place addend)
             dx = torch.randn_like(x)
-            ops.conv_dgrad_split(d, gys, wts, dx, dx)
+            rows = N * h * h
+            bits = torch.randint(0, 16, (G * rows * cin // 4,), dtype=torch.uint8, device=dev)
+            mean, invstd = torch.zeros(G, cin, device=dev), torch.ones(G, cin, device=dev)
+            s12, dgb = torch.empty(3, G, cin, device=dev), torch.zeros(2, cin, device=dev)
+            ops.conv_dgrad_split_bnreduce(d, gys, wts, dx, dx, x, bits, mean, invstd, None, s12[0], s12[1], dgb[0], dgb[1], False, s12[2])
             n_ops += 1
     else:
         ops.conv_fprop(d, x, w, y, None, False, stats)

@@ -41,7 +41,7 @@ rd = 2.0 * fetch["conv"][1] * 1024.0
 wr = write["conv"][1] * 1024.0
 out = {"workload": sys.argv[3], "kernels": sys.argv[5] if len(sys.argv) > 5 else "fp32mfma",
        "kernel_family": "conv fprop/dgrad/wgrad ops = the implicit-GEMM kernels (fp32-MFMA or split-operand) + their fix-up / slab-reduce kernels "
-                        "(the layout passes that split operands are NOT conv ops: the training step's BatchNorm passes write s3 directly)",
+                        "(the layout passes that split operands are NOT conv ops: the training step's BatchNorm passes write sp directly)",
        "ops": n, "kernel_launches": fetch["conv"][0], "read_bytes_per_op": rd / n, "write_bytes_per_op": wr / n,
        "traffic_bytes_per_launch": (rd + wr) / n,
        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over scripts/conv_pass.py (every conv "

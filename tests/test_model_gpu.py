@@ -294,14 +294,27 @@ def test_backward_strict_with_imposed_relu_pattern(monkeypatch, depth, batch, hw
     """Every parameter gradient (and d/d img) against the fp64 oracle evaluated with the SAME
     ReLU activation pattern as the HIP forward (oracle._relu): isolates the backward kernels from
     the handful of boundary ReLU decisions that fp32 reduction order flips."""
+    _strict_backward_check(monkeypatch, depth, batch, hw, gtol, kernels, True)
+
+
+@pytest.mark.parametrize("depth,batch,hw,gtol", [(18, 4, 96, GTOL), (50, 2, 160, 2 * GTOL), (18, 64, 224, GTOL / 2)])
+def test_backward_strict_without_image_gradients_stem_on_the_split_kernels(monkeypatch, depth, batch, hw, gtol):
+    """The same check as a training step runs it - the images need no gradient - which is when the 7x7 stem runs on the
+    split kernels in its row-window form (forward, weight gradient, the stem tail's backward writing dy in sp)."""
+    _strict_backward_check(monkeypatch, depth, batch, hw, gtol, "split", False)
+
+
+def _strict_backward_check(monkeypatch, depth, batch, hw, gtol, kernels, img_grad):
     from oracle import restatement as R
     select_kernels(monkeypatch, kernels)
     m = build(depth)
     m._debug_keep_tapes = True
     data = inputs(batch, hw, seed=99)
-    data["img_0"].requires_grad_(True)
-    data["img_1"].requires_grad_(True)
+    if img_grad:
+        data["img_0"].requires_grad_(True)
+        data["img_1"].requires_grad_(True)
     data = m(data)
+    assert m._backbone._stem_rw == (kernels == "split" and not img_grad)
     masks = _captured_masks(m)            # before backward: it releases the saved activations
     loss = metrics()(data)
     loss.backward()
@@ -340,6 +353,8 @@ def test_backward_strict_with_imposed_relu_pattern(monkeypatch, depth, batch, hw
     errs.sort(reverse=True)                  # worst first (round 1 forgot the sort and checked one tensor only)
     assert errs[0][0] <= gtol, "worst gradients (max-norm relative error): " + ", ".join(f"{k} {e:.2e}" for e, k in errs[:8])
     assert n == len(leaves) - 2          # everything but the unused fc.weight / fc.bias
+    if not img_grad:
+        return
     if full:                             # pool flips move single pixels: relative L2 instead of the max norm
         l2_close(data["img_0"].grad, od["img_0"].grad.numpy(), 1e-3, "grad img_0")
         l2_close(data["img_1"].grad, od["img_1"].grad.numpy(), 1e-3, "grad img_1")
