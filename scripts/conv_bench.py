@@ -64,7 +64,21 @@ for (cin, cout, k, st, pad, h), cnt in shapes.items():
     rows = N * h * h
     mean, invstd = torch.randn(G, cin, device=dev) * 0.1, torch.rand(G, cin, device=dev) + 0.5
     s12, dgb = torch.empty(2, G, cin, device=dev), torch.zeros(2, cin, device=dev)
-    if split and cin > 8:
+    if split and cin == 4:
+        # the stem in row-window form (mvg_stem_fprop_split / _wgrad_split); flops counted for the 7x7x3 filter
+        xw = ops.stem_rowwindow_split(x)
+        w8 = torch.zeros(cout, 7, 8, 4, device=dev)
+        w8[:, :, 1:, :3] = w32[..., :3]
+        wk8, _ = ops.split_weights(ConvDesc(1, 1, 7, 1, 32, cout, 7, 1, 1, 0, 1, 1), w8.view(cout, 7, 1, 32), False)
+        Ps, _ = ops.conv_stats_partials_split(ConvDesc.make(G, N, d.ho, d.wo, 32, cout, 1, 1, 0))
+        stats_s = torch.empty(G, Ps, 2, cout, device=dev)
+        gys = ops.split_f32(gy)
+        dw8 = torch.empty(cout, 7, 8, 4, device=dev)
+        flops = flops * 3 / 4
+        tf = timeit(lambda: ops.stem_fprop_split(d, xw, wk8, y, stats_s))
+        td = float("nan")
+        tw = timeit(lambda: ops.stem_wgrad_split(d, xw, gys, dw8))
+    elif split and cin > 8:
         xs, gys = ops.split_f32(x), ops.split_f32(gy)
         wk, wts = ops.split_weights(d, w32, True)
         Ps, _ = ops.conv_stats_partials_split(d)

@@ -599,3 +599,37 @@ def test_bad_arguments_fail_with_a_message():
     with pytest.raises(RuntimeError):
         ops.conv_fprop(bad, torch.zeros(1, 1, 8, 8, 8, device=dev()), torch.zeros(8, 3, 3, 8, device=dev()),
                        torch.empty(1, 1, 3, 8, 8, device=dev()), None, False, None)
+
+
+@pytest.mark.parametrize("G,P,C,rows", [(4, 98, 512, 98 * 64), (8, 1219, 64, 1219 * 64 - 17), (1, 40, 256, 40 * 64), (3, 2500, 128, 2500 * 64 - 3)])
+def test_bn_finalize_with_and_without_registered_scratch_agree_bit_for_bit(G, P, C, rows):
+    """mvg_bn_finalize has two forms: with a registered workspace, one workgroup per (8 channels, group) + a
+    running-statistics kernel (and slices above 1024 partials); without one, a single kernel that walks the groups.
+    Same arithmetic in the same order: identical mean / invstd / scale / shift and running statistics."""
+    import ctypes as C_
+    from rot_mvgaze_amd import ops
+    from rot_mvgaze_amd._lib import lib
+    torch.manual_seed(G * P + C)
+    stats = torch.randn(G, P, 2, C, device=dev())
+    stats[:, :, 1].abs_()                                   # centred sums of squares are non-negative
+    gamma, beta = torch.rand(C, device=dev()) + 0.5, torch.randn(C, device=dev())
+    outs = []
+    for with_scratch in (True, False):
+        rm, rv = torch.zeros(C, device=dev()), torch.ones(C, device=dev())
+        o = [torch.full((G, C), float("nan"), device=dev()) for _ in range(4)]
+        if with_scratch:
+            ops.bn_finalize(stats, G, P, 64, rows, C, gamma, beta, rm, rv, 0.1, 1e-5, *o)
+        else:
+            side = torch.cuda.Stream()                       # a stream nobody registered a workspace for
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                rc = lib().mvg_bn_finalize(C_.c_void_p(stats.data_ptr()), G, P, 64, rows, C, C_.c_void_p(gamma.data_ptr()),
+                                           C_.c_void_p(beta.data_ptr()), C_.c_void_p(rm.data_ptr()), C_.c_void_p(rv.data_ptr()),
+                                           C_.c_float(0.1), C_.c_float(1e-5), *[C_.c_void_p(t.data_ptr()) for t in o],
+                                           C_.c_void_p(side.cuda_stream))
+            assert rc == 0
+            side.synchronize()
+        torch.cuda.synchronize()
+        outs.append(o + [rm, rv])
+    for a, b, name in zip(outs[0], outs[1], ("mean", "invstd", "scale", "shift", "running_mean", "running_var")):
+        assert torch.equal(a, b), name
