@@ -263,7 +263,6 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 4 : 2) void igemm_bf16_dma_kerne
   constexpr int ROW = BK;                     // elements per (unpadded) LDS row = 128 bytes
   constexpr int A_PASSES = BM / 32, B_PASSES = BN / 32;      // 32 rows (8 rows x 4 waves) per pass
   constexpr int A_ELEMS = BM * ROW, B_ELEMS = BN * ROW;
-  constexpr int LDO = BN + 4;
   constexpr int OP_ELEMS = STAGES * (A_ELEMS + B_ELEMS);      // ushort
   constexpr int EPI_PASSES = STAGES == 1 ? 2 : 1;
   constexpr int EPI_ELEMS = bf16_epilogue_bytes<BM, BN, EPI_PASSES, DGRAD>() / 2;
