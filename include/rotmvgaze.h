@@ -402,6 +402,20 @@ int mvg_conv_dgrad_bf16_bnreduce(const mvg_conv_desc *d, const void *dy, const v
                                  const void *bn_y, const uint8_t *bn_bits, const float *bn_mean, const float *bn_invstd,
                                  const float *relu_scale, const float *relu_shift, float *partials, float *s1, float *s2,
                                  float *dgamma, float *dbeta, int accumulate, void *stream);
+/* The 7x7 stride-2 stem (resnet.py:184) on the LDS-DMA bf16 kernels as FOLDED row windows: xw [images][h][w/4][16][4]
+ * bf16 - window m holds image columns 4 m - 4 .. 4 m + 11 x (R, G, B, 0), zero outside the image, made straight from
+ * the NCHW fp32 input - serves output columns 2 m and 2 m + 1 as 2 * cout GEMM columns, so the kernel's output
+ * [.., wo/2, 2 cout] is y [.., wo, cout] in memory.  d = the stem's descriptor (r = s = 7, stride 2, pad 3; w % 4 == 0;
+ * n * ho * wo / 2 a multiple of 64).  w_fold: bf16 [2 cout][7][16][4] with w_fold[par * cout + o][r][j][c] =
+ * w[o][r][j - 1 - 2 par][c] (zero elsewhere).  stats: BatchNorm partials of y, groups * 2 P * 2 * cout floats with
+ * P = mvg_conv_stats_partials_bf16 of a descriptor with n, ho, wo / 2 (64 outputs per partial, like every bf16 forward).
+ * mvg_stem_wgrad_bf16: dw_fold fp32 in the same layout (the caller adds the two parities' taps);
+ * workspace = splits * 2 cout * 448 floats, splits = mvg_stem_wgrad_splits_bf16(d). */
+int mvg_stem_rowwindow_bf16(const float *x_nchw, void *xw, int64_t images, int h, int w, void *stream);
+int mvg_stem_fprop_bf16(const mvg_conv_desc *d, const void *xw, const void *w_fold, void *y, float *stats, void *stream);
+int mvg_stem_wgrad_splits_bf16(const mvg_conv_desc *d);
+int mvg_stem_wgrad_bf16(const mvg_conv_desc *d, const void *xw, const void *dy, float *dw_fold, float *workspace, int splits,
+                        int accumulate, void *stream);
 /* like mvg_conv_wgrad / mvg_conv_wgrad_splits; x, dy bf16, dw (and the slabs in workspace) fp32 */
 int mvg_conv_wgrad_bf16(const mvg_conv_desc *d, const void *x, const void *dy, float *dw, float *workspace,
                         int splits, int accumulate, void *stream);

@@ -139,6 +139,10 @@ SIGNATURES = {
     "mvg_conv_dgrad_bn_partials_bf16": (_I, [_D]),
     "mvg_conv_dgrad_bf16_bnreduce": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "mvg_conv_wgrad_bf16": (_I, [_D, _P, _P, _P, _P, _I, _I, _P]),
+    "mvg_stem_rowwindow_bf16": (_I, [_P, _P, _I64, _I, _I, _P]),
+    "mvg_stem_fprop_bf16": (_I, [_D, _P, _P, _P, _P, _P]),
+    "mvg_stem_wgrad_splits_bf16": (_I, [_D]),
+    "mvg_stem_wgrad_bf16": (_I, [_D, _P, _P, _P, _P, _I, _I, _P]),
     "mvg_conv_wgrad_splits_bf16": (_I, [_D]),
     "mvg_linear_fprop_mixed": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "mvg_linear_dgrad_mixed": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),

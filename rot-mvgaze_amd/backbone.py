@@ -124,7 +124,7 @@ class Backbone:
         backward-data), made by ONE launch: destination buffers and the launch's device-resident table of
         (source, destinations, shape) records are built once per parameter placement and reused every step."""
         mode = 0 if self.bf16 else 1
-        stem_rw = mode == 1 and self._stem_rw
+        stem_rw = self._stem_rw
         convs = [c for c in self.spec.all_convs() if not (mode == 1 and c.cin == 3 and not stem_rw)]
         key = (mode, stem_rw, str(dev), tuple(self.p[c.name + ".weight"].data_ptr() for c in convs))
         if self._wprep_state is None or self._wprep_state[0] != key:
@@ -145,6 +145,15 @@ class Backbone:
                     out[c.name] = (wk, None)
                     rows.append([self._stem_w8.data_ptr(), wk.data_ptr(), 0, c.cout | (7 << 32), 32 | (32 << 32), wstat[ci].data_ptr()])
                     continue
+                if mode == 0 and c.cin == 3 and stem_rw:
+                    # bf16 path, folded windows (16 columns x 4 channels serve two output columns): two copies of the filter,
+                    # w'[par * cout + o][r][j][c] = w[o][r][j - 1 - 2 par][c], cast like a [2 cout][7][1][64] filter
+                    assert c.k == 7
+                    self._stem_w8 = torch.zeros(2 * c.cout, 7, 16, 4, dtype=torch.float32, device=dev)
+                    wk = torch.empty(2 * c.cout, 7, 1, 64, dtype=torch.bfloat16, device=dev)
+                    out[c.name] = (wk, None)
+                    rows.append([self._stem_w8.data_ptr(), wk.data_ptr(), 0, (2 * c.cout) | (7 << 32), 64 | (64 << 32), wstat[ci].data_ptr()])
+                    continue
                 if mode == 1:
                     wk = ops.sp_empty(c.cout, rs * c.cin, device=dev)
                     wt = ops.sp_empty(c.cin, rs * c.cout, device=dev)
@@ -164,6 +173,10 @@ class Backbone:
             wstat.zero_()                                  # the max |w| slots are atomicMax targets
             if self._stem_w8 is not None:
                 self._stem_w8[:, :, 1:, :3].copy_(self.p[self.spec.stem.name + ".weight"].detach().permute(0, 2, 3, 1))
+        elif self._stem_w8 is not None:
+            wsrc, co = self.p[self.spec.stem.name + ".weight"].detach().permute(0, 2, 3, 1), self.spec.stem.cout
+            self._stem_w8[:co, :, 1:8, :3].copy_(wsrc)
+            self._stem_w8[co:, :, 3:10, :3].copy_(wsrc)
         ops.weights_prep_batch(table, n, mode)
         # the copies live in persistent buffers that the next forward overwrites: remember which parameter versions
         # they hold, so that the backward of an OLDER tape can tell (tapes keep pointers into these buffers)
@@ -198,7 +211,7 @@ class Backbone:
         # sp_out = its consumers do (every unit: the stem's pooled map feeds layer1)
         sp_out = self._split_now and training and not bf
         sp_in = sp_out and c.cin != 3
-        stem_rw = sp_out and c.cin == 3 and self._stem_rw          # x is then the row-window operand (ops.stem_rowwindow_split)
+        stem_rw = c.cin == 3 and self._stem_rw and (sp_out or bf)  # x is then the row-window operand (ops.stem_rowwindow_split / _bf16)
         if (sp_in or bf or stem_rw) and self._wprep is not None:
             w, w_t = self._wprep[c.name]         # this step's copies, made by ONE launch at the start of forward()
         elif sp_in:
@@ -220,14 +233,19 @@ class Backbone:
         mean, invstd, scale, shift = aff[0], aff[1], aff[2], aff[3]
 
         def fprop(stats_buf):
-            if stem_rw:
+            if stem_rw and bf:
+                ops.stem_fprop_bf16(d, x, w, y, stats_buf)
+            elif stem_rw:
                 ops.stem_fprop_split(d, x, w, y, stats_buf)
             elif sp_in:
                 ops.conv_fprop_split(d, x, w, y, stats_buf)
             else:
                 ops.conv_fprop(d, x, w, y, None, False, stats_buf)
         if training:
-            if stem_rw:      # the same row tiles as any split forward with these n, ho, wo
+            if stem_rw and bf:   # two output columns per GEMM row: twice the partials of a forward over n x ho x wo/2 rows
+                P, rpp = ops.conv_stats_partials(ConvDesc.make(G, N, d.ho, d.wo // 2, 64, 2 * c.cout, 1, 1, 0), True)
+                P *= 2
+            elif stem_rw:    # the same row tiles as any split forward with these n, ho, wo
                 P, rpp = ops.conv_stats_partials_split(ConvDesc.make(G, N, d.ho, d.wo, 32, c.cout, 1, 1, 0))
             else:
                 P, rpp = ops.conv_stats_partials_split(d) if sp_in else ops.conv_stats_partials(d, bf)
@@ -337,10 +355,16 @@ class Backbone:
         dev = imgs[0].device
         if self.bf16 and raw:
             raise NotImplementedError("raw uint8 input with the bf16 path: normalise to fp32 NCHW first")
-        x0 = torch.empty(V, B, H, W, 8 if self.bf16 else 4, dtype=self.act_dtype, device=dev)
+        bf_rw = self.bf16 and self.stem_rowwindow and training and W % 4 == 0 and (B * ((H - 1) // 2 + 1) * (W // 4)) % 64 == 0 \
+            and self.batch_weight_prep
+        x0 = torch.empty(V, B, H, W // 4, 64, dtype=self.act_dtype, device=dev) if bf_rw else \
+            torch.empty(V, B, H, W, 8 if self.bf16 else 4, dtype=self.act_dtype, device=dev)
         for v, im in enumerate(imgs):
             assert im.shape == imgs[0].shape and im.is_cuda and im.dtype == imgs[0].dtype
-            if self.bf16:
+            if bf_rw:
+                assert im.dtype == torch.float32
+                ops.stem_rowwindow_bf16(im.detach().contiguous(), x0[v])     # the stem's folded windows, straight from NCHW
+            elif self.bf16:
                 assert im.dtype == torch.float32
                 ops.nchw_to_nhwc8_bf16(im.detach().contiguous(), x0[v], B, 3, H, W)
             elif raw:
@@ -355,6 +379,10 @@ class Backbone:
         self._split_now = self.split and 4 * biggest_view_elems * self._guard_scale < 0x7FFFFFF0
         self._stem_rw = (self._split_now and self.stem_rowwindow and training and not self.bf16 and not need_dimg and W % 2 == 0
                          and self.batch_weight_prep and 32 * B * H * (W // 2) * 4 < 0x7FFFFFF0)
+        if self.bf16:        # folded windows: width % 4, whole 64-row partials (n * ho * wo / 2), the stem's weights through the batch
+            ho, wo = (H - 1) // 2 + 1, W // 2
+            self._stem_rw = (self.stem_rowwindow and training and W % 4 == 0 and (B * ho * (wo // 2)) % 64 == 0 and self.batch_weight_prep
+                             and self.spec.stem.k == 7)
         self._wprep = None
         if training:
             self._wk_cache.clear()               # the weights are about to change: drop the inference copies
@@ -367,7 +395,9 @@ class Backbone:
         if training:
             torch._foreach_add_(self.bn_count_buffers(), V)       # num_batches_tracked += 1 per view call
         s = self.spec
-        if self._stem_rw:
+        if self.bf16:
+            assert self._stem_rw == bf_rw
+        elif self._stem_rw:
             x0 = ops.stem_rowwindow_split(x0)
         x, argmax = self._unit_fwd(s.stem, x0, V, B, H, W, training, True, None, ulist, pool=True)
         Hc, Wc = x.shape[2], x.shape[3]
@@ -499,6 +529,15 @@ class Backbone:
         wp = self.p[c.name + ".weight"]
         if u.split:
             ops.conv_wgrad_split(u.desc, u.x_in, dy, sink.view(wp), sink.accumulate(wp))
+        elif u.stem_rw and self.bf16:
+            dw16 = torch.empty(2 * c.cout, 7, 16, 4, dtype=torch.float32, device=dy.device)
+            ops.stem_wgrad_bf16(u.desc, u.x_in, dy, dw16, False)
+            gv = sink.view(wp).permute(0, 2, 3, 1)                    # [cout, 7, 7, 3] view of the gradient
+            if sink.accumulate(wp):
+                gv.add_(dw16[:c.cout, :, 1:8, :3])
+            else:
+                gv.copy_(dw16[:c.cout, :, 1:8, :3])
+            gv.add_(dw16[c.cout:, :, 3:10, :3])                       # the odd output columns' taps
         elif u.stem_rw:
             dw8 = torch.empty(c.cout, 7, 8, 4, dtype=torch.float32, device=dy.device)
             ops.stem_wgrad_split(u.desc, u.x_in, dy, dw8, False)
@@ -612,10 +651,11 @@ class Backbone:
         argmax, scale, shift, H1, W1, Hp, Wp = stem.pool
         sc = stem.spec
         gp, bp = P[sc.bn + ".weight"], P[sc.bn + ".bias"]
-        s12 = torch.empty(3 if stem.stem_rw else 2, V, sc.cout, dtype=torch.float32, device=g.device)
+        stem_sp = stem.stem_rw and not self.bf16
+        s12 = torch.empty(3 if stem_sp else 2, V, sc.cout, dtype=torch.float32, device=g.device)
         acc = sink.accumulate(gp)
         assert acc == sink.accumulate(bp)
-        if stem.stem_rw:
+        if stem_sp:
             # the stem's weight gradient runs on the split kernels: dy goes out in sp, scaled by a bound from the reduce pass
             ops.bn_relu_maxpool_bwd_reduce_split(g, argmax, stem.y, stem.mean, stem.invstd, scale, shift, V, B, H1, W1, sc.cout, Hp, Wp,
                                                  s12[0], s12[1], sink.view(gp), sink.view(bp), acc, s12[2])

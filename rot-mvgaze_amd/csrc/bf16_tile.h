@@ -83,11 +83,18 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
       q += __shfl_xor(q, 32, 64);
       if (ACC16) q += __shfl_xor(q, 16, 64);
       if (lh == 0 && col < p.ncols) {
-        const long long P = p.stats_partials ? p.stats_partials : (long long)c.mtiles_per_group * WGM;
-        const long long pi = (long long)mtile * WGM + wm;
-        float *st = p.stats + (((long long)g * P + pi) * 2) * p.ncols;
-        st[col] = csum * osc;
-        st[p.ncols + col] = q * (osc * osc);
+        long long P = p.stats_partials ? p.stats_partials : (long long)c.mtiles_per_group * WGM;
+        long long pi = (long long)mtile * WGM + wm;
+        int nc = p.ncols, ch = col;
+        if (p.stats_fold) {                      // columns c and c + ncols/2 are the same channel (two output columns per row)
+          nc = p.ncols >> 1;
+          pi = 2 * pi + (col >= nc);
+          ch = col - (col >= nc ? nc : 0);
+          P *= 2;
+        }
+        float *st = p.stats + (((long long)g * P + pi) * 2) * nc;
+        st[ch] = csum * osc;
+        st[nc + ch] = q * (osc * osc);
       }
     }
   }

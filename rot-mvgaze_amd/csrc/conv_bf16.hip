@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(IgemmParams p) {
       a_x0[i] = ox + c.cls_cx;
     } else {
       a_y0[i] = oy * p.stride - p.pad;
-      a_x0[i] = ox * p.stride - p.pad;
+      a_x0[i] = ox * p.stride_w - p.pad_w;
     }
     a_img[i] = (unsigned)(img * p.src_img_stride) * EA;
   }
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 4 : 2) void igemm_bf16_dma_kerne
     const int rem = mm - img * ohw;
     const int oy = (int)fdiv((unsigned)rem, c.ow_div), ox = rem - oy * c.out_w;
     const int y0 = DGRAD ? oy + c.cls_cy : oy * p.stride - p.pad;
-    const int x0 = DGRAD ? ox + c.cls_cx : ox * p.stride - p.pad;
+    const int x0 = DGRAD ? ox + c.cls_cx : ox * p.stride_w - p.pad_w;
     a_base[i] = (unsigned)(img * p.src_img_stride * 2) + (unsigned)((y0 * p.src_w + x0) * p.src_c) * 2u + (unsigned)a_kv * 16u;
     unsigned msk = 0;
     for (int t = 0; t < c.ntaps; ++t) {
@@ -478,10 +478,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradParams p) {
     const int cc = (i_cok[j] ? col : 0) - tap * p.cin;
     const int fr = (int)fdiv((unsigned)tap, p.s_div), fs = tap - fr * p.s;
     i_dy[j] = fr - p.pad;
-    i_dx[j] = fs - p.pad;
+    i_dx[j] = fs - p.pad_w;
     i_tconst[j] = (unsigned)((i_dy[j] * p.w + i_dx[j]) * p.cin + cc) * EB;
   }
-  const unsigned row_bytes = (unsigned)(p.stride * p.w * p.cin) * EB, col_bytes = (unsigned)(p.stride * p.cin) * EB;
+  const unsigned row_bytes = (unsigned)(p.stride * p.w * p.cin) * EB, col_bytes = (unsigned)(p.stride_w * p.cin) * EB;
   const unsigned img_bytes = (unsigned)x_img_elems * EB;
   int s_oy = 0, s_ox = 0;
   unsigned s_imgoff = 0;
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradParams p) {
       ox = (int)(rem - uy * (unsigned)p.wo);
       imgoff = img * img_bytes;
     }
-    const int iy0 = oy * p.stride, ix0 = ox * p.stride;
+    const int iy0 = oy * p.stride, ix0 = ox * p.stride_w;
     const unsigned pixoff = imgoff + (unsigned)oy * row_bytes + (unsigned)ox * col_bytes;
 #pragma unroll
     for (int j = 0; j < B_CPT; ++j) {
@@ -659,6 +659,31 @@ __global__ __launch_bounds__(256) void dgrad_empty_class_bf16_kernel(u32x4 *__re
   }
 }
 
+// The stem's folded row-window operand (mvg_stem_fprop_bf16): window m of an image row holds image columns 4 m - 4 ..
+// 4 m + 11 x 4 channels (3 real) in bf16 - 64 values, the K-step of the LDS-DMA kernel - straight from the NCHW fp32
+// input.  One thread per 8-value chunk = two columns.
+__global__ __launch_bounds__(256) void stem_rowwindow_bf16_kernel(const float *__restrict__ x, uint4 *__restrict__ xw, long long n, int h, int w) {
+  const int wm = w >> 2;
+  const long long plane = (long long)h * w;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int q = (int)(i & 7);
+    const long long t = i >> 3;
+    const int m = (int)(t % wm);
+    const long long row = t / wm;                    // image * h + y
+    const long long img = row / h;
+    const int yy = (int)(row - img * h);
+    const int c0 = 4 * m - 4 + 2 * q;                 // even: both columns in range or both out (w % 4 == 0)
+    uint4 o = make_uint4(0u, 0u, 0u, 0u);
+    if (c0 >= 0 && c0 < w) {
+      const float *src = x + img * 3 * plane + (long long)yy * w + c0;
+      const float2 r = *reinterpret_cast<const float2 *>(src), g = *reinterpret_cast<const float2 *>(src + plane),
+                   b = *reinterpret_cast<const float2 *>(src + 2 * plane);
+      o = make_uint4(bf16_pack2(r.x, g.x), bf16_pack2(b.x, 0.f), bf16_pack2(r.y, g.y), bf16_pack2(b.y, 0.f));
+    }
+    xw[i] = o;
+  }
+}
+
 // fp32 KRSC weights -> bf16 KRSC (cin zero-padded to cin_pad) and, optionally, the transposed CRSK copy the
 // backward-data kernel reads ([cin_pad][r*s][cout]).  One thread per (o, tap, c).
 __global__ __launch_bounds__(256) void cast_weights_bf16_kernel(const float *__restrict__ w, unsigned short *__restrict__ wk,
@@ -760,9 +785,11 @@ int mvg_cast_weights_bf16(const mvg_conv_desc *d, const float *w, int cin_src, v
   return check_launch("cast_weights_bf16");
 }
 
+// stride_w >= 0: horizontal stride / padding differ from d->stride / d->pad, and the BatchNorm partials of GEMM columns
+// c and c + cout/2 are two partials of channel c (the stem's folded row-window form, whose descriptor the caller checked)
 static int fprop_bf16_impl(const mvg_conv_desc *d, const void *x, const void *wgt, void *y, const float *bias, int relu,
-                           float *stats, void *stream, bool f32io) {
-  if (validate_bf16(d)) return 2;
+                           float *stats, void *stream, bool f32io, int stride_w = -1, int pad_w = -1) {
+  if (stride_w < 0 && validate_bf16(d)) return 2;
   const long long EA = f32io ? 4 : 2;
   IgemmParams p;
   memset(&p, 0, sizeof(p));
@@ -785,6 +812,9 @@ static int fprop_bf16_impl(const mvg_conv_desc *d, const void *x, const void *wg
   p.rs = d->r * d->s;
   p.stride = d->stride;
   p.pad = d->pad;
+  p.stride_w = stride_w >= 0 ? stride_w : d->stride;
+  p.pad_w = stride_w >= 0 ? pad_w : d->pad;
+  p.stats_fold = stride_w >= 0 ? 1 : 0;
   p.ktotal = d->r * d->s * d->cin;
   p.b_row_len = p.ktotal;
   p.cin = d->cin;
@@ -803,7 +833,7 @@ static int fprop_bf16_impl(const mvg_conv_desc *d, const void *x, const void *wg
   p.ohw_div = make_fastdiv((unsigned)(p.out_h * p.out_w));
   p.ow_div = make_fastdiv((unsigned)p.out_w);
   const double acin = d->cin == 8 && d->r == 7 ? 3.0 : (double)d->cin;       // the stem's channels 3..7 are zero padding
-  const double flops = 2.0 * d->groups * (double)p.rows_per_group * d->cout * d->r * d->s * acin;
+  const double flops = 2.0 * d->groups * (double)p.rows_per_group * d->cout * d->r * d->s * acin * (stride_w >= 0 ? 147.0 / 448.0 : 1.0);
   const double bytes = 2.0 * (d->groups * (double)d->n * d->h * d->w * acin + (double)d->cout * d->r * d->s * acin +
                               d->groups * (double)p.rows_per_group * d->cout);
   const bool lin = d->r == 1 && d->s == 1 && d->h == 1 && d->w == 1;
@@ -967,6 +997,45 @@ int mvg_conv_dgrad_bf16_bnreduce(const mvg_conv_desc *d, const void *dy, const v
                                 bn_invstd);
 }
 
+// ---- the 7x7 stride-2 stem on the LDS-DMA kernels: folded row windows -------------------------------------------------
+// These kernels' K-step is 64 channels of ONE tap; the stem offers 8 stored channels per tap (3 real): round 2 ran it on
+// the register-staged kernel with K = 49 x 8 = 392 (1.05 ms of a C5 step).  Folded: window m of an image row = image
+// columns 4 m - 4 .. 4 m + 11 x 4 channels = 64 values serves TWO output columns - ox = 2 m through filter taps at
+// j = s + 1, ox = 2 m + 1 at j = s + 3 - as 2 x cout GEMM columns, whose [.., wo/2, 2 cout] output IS y [.., wo, cout]
+// in memory.  A 7 x 1 filter over 64 "channels", vertical stride 2 / pad 3, horizontal stride 1 / pad 0: K = 448 per
+// two outputs (224 each; the filter has 147).  BatchNorm partials: columns c and c + cout are two partials of channel c.
+static int stem_fold_desc(const mvg_conv_desc *d, mvg_conv_desc *rw) {
+  MVG_REQUIRE(d != nullptr, "stem (folded windows): null descriptor");
+  MVG_REQUIRE(d->r == 7 && d->s == 7 && d->stride == 2 && d->pad == 3, "stem (folded windows): 7x7 stride 2 pad 3");
+  MVG_REQUIRE(d->w % 4 == 0 && d->ho == (d->h - 1) / 2 + 1 && d->wo == d->w / 2, "stem (folded windows): width %% 4; ho, wo inconsistent");
+  MVG_REQUIRE(d->cout % 32 == 0 && d->groups > 0 && d->n > 0, "stem (folded windows): cout must be a multiple of 32");
+  MVG_REQUIRE(((long long)d->n * d->ho * (d->wo / 2)) % 64 == 0, "stem (folded windows): n * ho * wo / 2 must be a multiple of 64 (BatchNorm partials)");
+  *rw = *d;
+  rw->w = d->w / 4;
+  rw->wo = d->wo / 2;
+  rw->cin = 64;
+  rw->cout = 2 * d->cout;
+  rw->s = 1;
+  return 0;
+}
+
+int mvg_stem_rowwindow_bf16(const float *x_nchw, void *xw, int64_t images, int h, int w, void *stream) {
+  MVG_REQUIRE(x_nchw && xw && images > 0 && h > 0 && w > 0 && w % 4 == 0, "stem_rowwindow_bf16: bad arguments (width %% 4)");
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = images * h * (w / 4) * 8;
+  ProfScope ps(MVG_K_LAYOUT, st, 0.0, 12.0 * (double)images * h * w + 16.0 * (double)n);
+  long long blocks = (n + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(stem_rowwindow_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x_nchw, (uint4 *)xw, n, h, w);
+  return check_launch("stem_rowwindow_bf16");
+}
+
+int mvg_stem_fprop_bf16(const mvg_conv_desc *d, const void *xw, const void *w_fold, void *y, float *stats, void *stream) {
+  mvg_conv_desc rw;
+  if (stem_fold_desc(d, &rw)) return 2;
+  return fprop_bf16_impl(&rw, xw, w_fold, y, nullptr, 0, stats, stream, false, 1, 0);
+}
+
 static mvg_conv_desc linear_desc_bf16(int rows, int fin, int fout) {
   mvg_conv_desc d = {1, rows, 1, 1, fin, fout, 1, 1, 1, 0, 1, 1};
   return d;
@@ -1008,8 +1077,8 @@ int mvg_conv_wgrad_splits_bf16(const mvg_conv_desc *d) {
 }
 
 static int wgrad_bf16_impl(const mvg_conv_desc *d, const void *x, const void *dy, float *dw, float *db, float *workspace,
-                           int splits, int accumulate, void *stream, bool f32in) {
-  if (validate_bf16(d)) return 2;
+                           int splits, int accumulate, void *stream, bool f32in, int stride_w = -1, int pad_w = -1) {
+  if (stride_w < 0 && validate_bf16(d)) return 2;
   const long long EB = f32in ? 4 : 2;
   MVG_REQUIRE(!db || f32in, "wgrad_bf16: the bias gradient rides on the fp32-operand form only");
   MVG_REQUIRE(splits >= 1, "wgrad_bf16: splits < 1");
@@ -1026,6 +1095,8 @@ static int wgrad_bf16_impl(const mvg_conv_desc *d, const void *x, const void *dy
   p.s = d->s;
   p.stride = d->stride;
   p.pad = d->pad;
+  p.stride_w = stride_w >= 0 ? stride_w : d->stride;
+  p.pad_w = stride_w >= 0 ? pad_w : d->pad;
   p.ho = d->ho;
   p.wo = d->wo;
   p.ncols = d->r * d->s * d->cin;
@@ -1051,7 +1122,7 @@ static int wgrad_bf16_impl(const mvg_conv_desc *d, const void *x, const void *dy
   const bool lin = d->r == 1 && d->s == 1 && d->h == 1 && d->w == 1;
   {
     const double acin = d->cin == 8 && d->r == 7 ? 3.0 : (double)d->cin;
-    const double flops = 2.0 * (double)p.pixels * d->cout * d->r * d->s * acin;
+    const double flops = 2.0 * (double)p.pixels * d->cout * d->r * d->s * acin * (stride_w >= 0 ? 147.0 / 448.0 : 1.0);
     const double bytes = 2.0 * ((double)d->groups * d->n * d->h * d->w * acin + (double)p.pixels * d->cout) +
                          4.0 * (double)d->cout * d->r * d->s * acin;
     ProfScope ps(lin ? MVG_K_LINEAR_WGRAD : MVG_K_CONV_WGRAD, st, flops, bytes);
@@ -1094,6 +1165,26 @@ static int wgrad_bf16_impl(const mvg_conv_desc *d, const void *x, const void *dy
 int mvg_conv_wgrad_bf16(const mvg_conv_desc *d, const void *x, const void *dy, float *dw, float *workspace, int splits,
                         int accumulate, void *stream) {
   return wgrad_bf16_impl(d, x, dy, dw, nullptr, workspace, splits, accumulate, stream, false);
+}
+
+int mvg_stem_wgrad_splits_bf16(const mvg_conv_desc *d) {
+  mvg_conv_desc rw;
+  if (stem_fold_desc(d, &rw)) return -1;
+  const long long tiles = (long long)ceil_div(rw.cout, 128) * ceil_div(7 * 64, 128);
+  const long long pixels = (long long)rw.groups * rw.n * rw.ho * rw.wo;
+  long long want = (2LL * compute_cus()) / tiles, maxs = pixels / 512;
+  if (maxs < 1) maxs = 1;
+  if (want > maxs) want = maxs;
+  if (want < 1) want = 1;
+  if (want > 1024) want = 1024;
+  return (int)want;
+}
+
+int mvg_stem_wgrad_bf16(const mvg_conv_desc *d, const void *xw, const void *dy, float *dw_fold, float *workspace, int splits,
+                        int accumulate, void *stream) {
+  mvg_conv_desc rw;
+  if (stem_fold_desc(d, &rw)) return 2;
+  return wgrad_bf16_impl(&rw, xw, dy, dw_fold, nullptr, workspace, splits, accumulate, stream, false, 1, 0);
 }
 
 int mvg_linear_wgrad_mixed(const float *x, const float *dy, float *dw, float *db, int rows, int fin, int fout, float *workspace,

@@ -143,8 +143,10 @@ struct IgemmParams {
   // split kernels: the operands hold (value * 2^k) for a per-tensor k (elem.h: sp_t); the epilogue multiplies the
   // accumulators by *a_sinv * *b_sinv (device scalars, each 2^-k of its operand; null = 1)
   const float *a_sinv, *b_sinv;
-  int stride_w, pad_w;            // split kernels, forward: horizontal stride / padding (= stride / pad except for the stem's
+  int stride_w, pad_w;            // split / bf16 kernels, forward: horizontal stride / padding (= stride / pad except for the stem's
                                   // row-window form: a 7 x 1 filter, vertical stride 2, over windows that already step by 2)
+  int stats_fold;                 // bf16 stem (two output columns per window as 2 x cout GEMM columns): the BatchNorm partials of
+                                  // columns c and c + ncols/2 are written as partials 2 pi and 2 pi + 1 of channel c
   int bn_part_rows;               // fused BatchNorm-backward reduce: rows per partial in bn_part - 2 (s1, s2) or 3 (+ max |dz| per channel)
   const unsigned char *bn_bits;   // the unit's ReLU mask as bits: one byte per 4 channels (fp32: mvg_bn_apply_split) or per 8 (bf16: mvg_bn_apply_bits_bf16)
   // Cross-view fusion (igemm_kernel AMODE = 1, Linear forward): the A operand is never materialised - row m of

@@ -297,7 +297,6 @@ __global__ __launch_bounds__(256, DGRAD ? 3 : 4) void igemm_split16_kernel(Igemm
   constexpr int QA = BM * SLOTS / 64;                         // ... of which the first 16 fill the A rows
   constexpr int A_PER = QA / NW, B_PER = (NQ - QA) / NW;      // per wave: 4 and 4 / 2
   static_assert(QA % NW == 0 && (NQ - QA) % NW == 0, "whole instructions per wave");
-  constexpr int LDO = BN + 4;
   constexpr int EPI_B = bf16_epilogue_bytes<BM, BN, 2, DGRAD>();
   constexpr int INFO_OFF = STAGE_B > EPI_B ? STAGE_B : EPI_B;  // row table behind the stage / the epilogue tile
   constexpr int SMEM_B = INFO_OFF + BM * 8;

@@ -286,6 +286,27 @@ def bn_relu_maxpool_bwd_apply_split(g_pooled, argmax, y, mean, invstd, gamma, sc
                                                     _s()), "bn_relu_maxpool_bwd_apply_split")
 
 
+def stem_rowwindow_bf16(x_nchw: Tensor, out: Tensor):
+    """[B, 3, H, W] fp32 NCHW -> out [B, H, W/4, 64] bf16: the stem's folded row windows (mvg_stem_fprop_bf16)."""
+    B, Cc, H, W = x_nchw.shape
+    assert Cc == 3 and W % 4 == 0 and x_nchw.dtype == torch.float32 and x_nchw.is_contiguous()
+    assert out.dtype == torch.bfloat16 and out.shape == (B, H, W // 4, 64) and out.is_contiguous()
+    check(lib().mvg_stem_rowwindow_bf16(_p(x_nchw), _p(out), B, H, W, _s()), "stem_rowwindow_bf16")
+
+
+def stem_fprop_bf16(d: ConvDesc, xw: Tensor, w_fold: Tensor, y: Tensor, stats: Optional[Tensor]):
+    check(lib().mvg_stem_fprop_bf16(C.byref(d), _p(xw), _p(w_fold), _p(y), _p(stats), _s()), "stem_fprop_bf16")
+
+
+def stem_wgrad_bf16(d: ConvDesc, xw: Tensor, dy: Tensor, dw_fold: Tensor, accumulate: bool = False):
+    """dw_fold [2 cout, 7, 16, 4] fp32 (+)= the stem's weight gradient in the folded-window tap layout."""
+    splits = lib().mvg_stem_wgrad_splits_bf16(C.byref(d))
+    if splits < 1:
+        check(1, "stem_wgrad_splits_bf16")
+    ws = torch.empty(splits * 2 * d.cout * 448, dtype=torch.float32, device=xw.device) if splits > 1 else None
+    check(lib().mvg_stem_wgrad_bf16(C.byref(d), _p(xw), _p(dy), _p(dw_fold), _p(ws), splits, int(accumulate), _s()), "stem_wgrad_bf16")
+
+
 def conv_dgrad_bn_partials_split(d: ConvDesc) -> int:
     n = lib().mvg_conv_dgrad_bn_partials_split(C.byref(d))
     if n < 0:

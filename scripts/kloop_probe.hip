@@ -851,6 +851,11 @@ int main(int argc, char **argv) {
       {"h2_4prod_wpc3", k_h2<128, 128, 4, 3, 4, false>, 128, 128, 256, 0, 1},
       {"h2_3prod_wpc4", k_h2<128, 128, 4, 4, 3, false>, 128, 128, 256, 0, 1},
       {"h2_3prod_wpc3_nodma", k_h2<128, 128, 4, 3, 3, true>, 128, 128, 256, 0, 1},
+      // larger wave tiles (fewer LDS fragment reads per MFMA: 0.25 instead of 0.33), two workgroups per CU
+      {"h2_256x128_4w_wpc2", k_h2<256, 128, 4, 2, 3, false>, 256, 128, 256, 0, 1},
+      {"h2_128x256_4w_wpc2", k_h2<128, 256, 4, 2, 3, false>, 128, 256, 256, 0, 1},
+      {"h2_256x256_8w_wpc1", k_h2<256, 256, 8, 1, 3, false>, 256, 256, 512, 0, 1},
+      {"h2_256x128_4w_wpc2_nodma", k_h2<256, 128, 4, 2, 3, true>, 256, 128, 256, 0, 1},
       {"h2x2_wpc2_early", k_h2x2<128, 128, 4, 2, true>, 128, 128, 256, 0, 1},
       {"h2x2_wpc2_late", k_h2x2<128, 128, 4, 2, false>, 128, 128, 256, 0, 1},
       {"h2x2_256x128_wpc1", k_h2x2<256, 128, 8, 1, true>, 256, 128, 512, 0, 1},

@@ -212,6 +212,62 @@ def test_bf16_dgrad_fused_with_bn_backward_reduce(case, mask):
     assert torch.equal(dx2, dx_ref) and torch.equal(s2[0], s[0]) and torch.equal(s2[1], s[1])
 
 
+@pytest.mark.parametrize("G,N,H,W", [(2, 4, 32, 32), (1, 2, 224, 224), (2, 2, 24, 64), (3, 8, 17, 32)], ids=lambda v: str(v))
+def test_bf16_stem_as_folded_row_windows(G, N, H, W):
+    """mvg_stem_rowwindow_bf16 / _fprop_bf16 / _wgrad_bf16: the 7x7 stride-2 stem as a 7 x 1 filter over windows of 16
+    columns x 4 channels that serve two output columns each == conv2d in float64 on the bf16-rounded image and weights;
+    BatchNorm partials folded back to 64 channels; the weight gradient un-folded by adding the two parities' taps."""
+    from rot_mvgaze_amd import ops
+    from rot_mvgaze_amd._lib import ConvDesc
+    cout = 64
+    x = bf(rnd((G * N, 3, H, W), 1, "x")).float()
+    w = rnd((cout, 3, 7, 7), 2, "w", 1.0 / np.sqrt(147))
+    wb = bf(w).float()
+    d = ConvDesc.make(G, N, H, W, 8, cout, 7, 2, 3)
+    xr, wr = x.double(), wb.double().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, 2, 3)
+    gy = bf(rnd(tuple(yr.shape), 3, "gy")).float()
+    yr.backward(gy.double())
+    # windows: image columns 4 m - 4 .. 4 m + 11, zero outside
+    xw = torch.empty(G * N, H, W // 4, 64, dtype=torch.bfloat16, device=dev())
+    ops.stem_rowwindow_bf16(x.to(dev()), xw)
+    win = xw.float().cpu().view(G * N, H, W // 4, 16, 4)
+    want = torch.zeros_like(win)
+    xn = x.permute(0, 2, 3, 1)                                # NHWC3
+    for j in range(16):
+        cols = torch.arange(W // 4) * 4 - 4 + j
+        ok = (cols >= 0) & (cols < W)
+        want[:, :, ok, j, :3] = xn[:, :, cols[ok]]
+    assert torch.equal(win, want), "folded windows"
+    # weights in the folded tap layout
+    w16 = torch.zeros(2 * cout, 7, 16, 4)
+    w16[:cout, :, 1:8, :3] = w.permute(0, 2, 3, 1)
+    w16[cout:, :, 3:10, :3] = w.permute(0, 2, 3, 1)
+    wf = w16.to(torch.bfloat16).to(dev())
+    y = torch.full((G, N, d.ho, d.wo, cout), float("nan"), dtype=torch.bfloat16, device=dev())
+    P, rpp = ops.conv_stats_partials(ConvDesc.make(G, N, d.ho, d.wo // 2, 64, 2 * cout, 1, 1, 0), True)
+    stats = torch.full((G, 2 * P, 2, cout), float("nan"), device=dev())
+    ops.stem_fprop_bf16(d, xw, wf, y, stats)
+    y_ref = yr.detach().reshape(G, N, cout, d.ho, d.wo).permute(0, 1, 3, 4, 2)
+    close(y, y_ref, OUT_RTOL, "fprop")
+    rows = N * d.ho * d.wo
+    mean, invstd, scale, shift = (torch.empty(G, cout, device=dev()) for _ in range(4))
+    ops.bn_finalize(stats, G, 2 * P, rpp, rows, cout, torch.ones(cout, device=dev()), torch.zeros(cout, device=dev()),
+                    torch.zeros(cout, device=dev()), torch.ones(cout, device=dev()), 0.1, 1e-5, mean, invstd, scale, shift)
+    yg = y_ref.reshape(G, rows, cout)
+    close(mean, yg.mean(1), 1e-4, "bn mean from the folded partials")
+    close(invstd, 1.0 / torch.sqrt(yg.var(1, unbiased=False) + 1e-5), 1e-4, "bn invstd from the folded partials")
+    # weight gradient
+    gyd = bf(to_nhwc(gy.reshape(G, N, cout, d.ho, d.wo))).to(dev())
+    dw16 = torch.full((2 * cout, 7, 16, 4), float("nan"), device=dev())
+    ops.stem_wgrad_bf16(d, xw, gyd, dw16, False)
+    dw = dw16[:cout, :, 1:8, :3] + dw16[cout:, :, 3:10, :3]
+    dw_ref = wr.grad.permute(0, 2, 3, 1)
+    close(dw, dw_ref, 2e-5, "wgrad")
+    ops.stem_wgrad_bf16(d, xw, gyd, dw16, True)
+    close(dw16[:cout, :, 1:8, :3] + dw16[cout:, :, 3:10, :3], 2 * dw_ref, 2e-5, "wgrad accumulate")
+
+
 @pytest.mark.parametrize("rows,fin,fout,relu", [(3584, 3584, 3584, True), (384, 2048, 1536, False), (70, 3584, 512, True),
                                                 (1000, 512, 1536, True)])
 def test_mixed_linear_fp32_tensors_bf16_products(rows, fin, fout, relu):
@@ -322,6 +378,16 @@ def test_bf16_stem_tail_and_pools():
     assert torch.equal(o[..., :3], img.permute(0, 2, 3, 1).to(torch.bfloat16)) and float(o[..., 3:].float().abs().max()) == 0
 
 
+def _unit_input(u):
+    """The recorded input of a unit as [G, N, H, W, C] fp32 on the CPU.  The stem in folded-window form keeps its windows
+    [G, N, H, W/4, 16 columns x 4 channels]: window m, j = 4..7 are image columns 4 m .. 4 m + 3."""
+    x = u.x_in.float().cpu()
+    if getattr(u, "stem_rw", False):
+        G, N, H, Wq, _ = x.shape
+        return x.view(G, N, H, Wq, 16, 4)[:, :, :, :, 4:8, :].reshape(G, N, H, Wq * 4, 4)
+    return x
+
+
 def _check_units_teacher_forced(m, img_feat):
     """Every conv + BatchNorm unit of the recorded bf16 forward, recomputed on the CPU FROM THE UNIT'S OWN
     RECORDED INPUT: conv output (bf16 rounding of the fp32 result), batch statistics (from the fp32 result),
@@ -339,7 +405,7 @@ def _check_units_teacher_forced(m, img_feat):
     for ui, u in enumerate(units):
         c, d = u.spec, u.desc
         G, N = u.y.shape[0], u.y.shape[1]
-        x = u.x_in.float().cpu().reshape(G * N, d.h, d.w, d.cin).permute(0, 3, 1, 2)[:, :c.cin]
+        x = _unit_input(u).reshape(G * N, d.h, d.w, -1).permute(0, 3, 1, 2)[:, :c.cin]
         w = q(P[c.name + ".weight"].detach().float().cpu().contiguous())
         y_ref = F.conv2d(x, w, None, c.stride, c.pad)                              # fp32, the stored y is its rounding
         y_got = u.y.float().cpu().reshape(G * N, d.ho, d.wo, c.cout).permute(0, 3, 1, 2)
@@ -443,7 +509,7 @@ def _check_blocks_backward_teacher_forced(m, tape, dfeat):
         g_out = g_in_rec.double()
     # stem: conv7x7 -> BN -> ReLU -> max pool, gradient of the pooled map = the last recorded gradient
     c, wts = spec.stem, {}
-    x_rec = units[0].x_in.float().cpu()[..., :3]
+    x_rec = _unit_input(units[0])[..., :3]
     for g in range(G):
         o = F.max_pool2d(unit(nchw(x_rec[g]), c, wts, True), 3, 2, 1)
         o.backward(nchw(g_out[g]))
