@@ -558,6 +558,7 @@ int mvg_conv_dgrad_split_bnreduce(const mvg_conv_desc *d, const void *dy_sp, con
  * pixel's gradient (4 x the largest masked window gradient); mvg_bn_relu_maxpool_bwd_apply_split scales dy by the 2^k that
  * bound allows and writes 2^-k to *dy_sinv. */
 int mvg_stem_rowwindow_split(const float *x_nhwc4, void *xw_sp, int64_t images, int h, int w, void *stream);
+int mvg_stem_rowwindow_split_nchw(const float *x_nchw, void *xw_sp, int64_t images, int h, int w, void *stream);   /* from [images][3][h][w] */
 int mvg_stem_fprop_split(const mvg_conv_desc *d, const void *xw_sp, const void *w_sp, const float *w_sinv, float *y, float *stats,
                          void *stream);
 int mvg_stem_wgrad_splits_split(const mvg_conv_desc *d);

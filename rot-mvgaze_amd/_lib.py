@@ -86,6 +86,7 @@ SIGNATURES = {
     "mvg_bn_relu_maxpool_fwd_split": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mvg_avgpool_fwd_split": (_I, [_P, _P, _I, _I, _I, _P]),
     "mvg_stem_rowwindow_split": (_I, [_P, _P, _I64, _I, _I, _P]),
+    "mvg_stem_rowwindow_split_nchw": (_I, [_P, _P, _I64, _I, _I, _P]),
     "mvg_stem_fprop_split": (_I, [_D, _P, _P, _P, _P, _P, _P]),
     "mvg_stem_wgrad_splits_split": (_I, [_D]),
     "mvg_stem_wgrad_split": (_I, [_D, _P, _P, _P, _P, _P, _I, _I, _P]),

@@ -355,15 +355,35 @@ class Backbone:
         dev = imgs[0].device
         if self.bf16 and raw:
             raise NotImplementedError("raw uint8 input with the bf16 path: normalise to fp32 NCHW first")
-        bf_rw = self.bf16 and self.stem_rowwindow and training and W % 4 == 0 and (B * ((H - 1) // 2 + 1) * (W // 4)) % 64 == 0 \
-            and self.batch_weight_prep
-        x0 = torch.empty(V, B, H, W // 4, 64, dtype=self.act_dtype, device=dev) if bf_rw else \
-            torch.empty(V, B, H, W, 8 if self.bf16 else 4, dtype=self.act_dtype, device=dev)
+        # The split kernels address one view of an sp tensor (4 bytes per element) with 32-bit offsets: the largest one
+        # (layer1's output: (H/4) x (W/4) x 64 or 256 channels per image) must stay below 2 GiB, or this call runs on the
+        # fp32-MFMA kernels (64-bit row offsets there; B < 668 per view at 224 x 224 with ResNet-50)
+        biggest_view_elems = B * ((H + 3) // 4) * ((W + 3) // 4) * self.spec.blocks[0].convs[-1].cout
+        self._split_now = self.split and 4 * biggest_view_elems * self._guard_scale < 0x7FFFFFF0
+        # the stem's form for this call (see stem_rowwindow)
+        if self.bf16:        # folded windows: width % 4, whole 64-row partials (n * ho * wo / 2), the stem's weights through the batch
+            ho, wo = (H - 1) // 2 + 1, W // 2
+            self._stem_rw = (self.stem_rowwindow and training and W % 4 == 0 and (B * ho * (wo // 2)) % 64 == 0 and self.batch_weight_prep
+                             and self.spec.stem.k == 7)
+        else:
+            self._stem_rw = (self._split_now and self.stem_rowwindow and training and not need_dimg and W % 2 == 0
+                             and self.batch_weight_prep and 32 * B * H * (W // 2) * 4 < 0x7FFFFFF0)
+        direct = self._stem_rw and not raw              # windows straight from the NCHW input: no NHWC image is built
+        if direct and self.bf16:
+            x0 = torch.empty(V, B, H, W // 4, 64, dtype=self.act_dtype, device=dev)
+        elif direct:
+            x0 = ops.sp_empty(V, B, H, W // 2, 32, device=dev)
+            x0.sinv = None
+        else:
+            x0 = torch.empty(V, B, H, W, 8 if self.bf16 else 4, dtype=self.act_dtype, device=dev)
         for v, im in enumerate(imgs):
             assert im.shape == imgs[0].shape and im.is_cuda and im.dtype == imgs[0].dtype
-            if bf_rw:
+            if direct:
                 assert im.dtype == torch.float32
-                ops.stem_rowwindow_bf16(im.detach().contiguous(), x0[v])     # the stem's folded windows, straight from NCHW
+                if self.bf16:
+                    ops.stem_rowwindow_bf16(im.detach().contiguous(), x0[v])
+                else:
+                    ops.stem_rowwindow_split_nchw(im.detach().contiguous(), x0[v])
             elif self.bf16:
                 assert im.dtype == torch.float32
                 ops.nchw_to_nhwc8_bf16(im.detach().contiguous(), x0[v], B, 3, H, W)
@@ -372,17 +392,8 @@ class Backbone:
             else:
                 assert im.dtype == torch.float32
                 ops.nchw_to_nhwc4(im.detach().contiguous(), x0[v], B, 3, H, W)
-        # The split kernels address one view of an sp tensor (4 bytes per element) with 32-bit offsets: the largest one
-        # (layer1's output: (H/4) x (W/4) x 64 or 256 channels per image) must stay below 2 GiB, or this call runs on the
-        # fp32-MFMA kernels (64-bit row offsets there; B < 668 per view at 224 x 224 with ResNet-50)
-        biggest_view_elems = B * ((H + 3) // 4) * ((W + 3) // 4) * self.spec.blocks[0].convs[-1].cout
-        self._split_now = self.split and 4 * biggest_view_elems * self._guard_scale < 0x7FFFFFF0
-        self._stem_rw = (self._split_now and self.stem_rowwindow and training and not self.bf16 and not need_dimg and W % 2 == 0
-                         and self.batch_weight_prep and 32 * B * H * (W // 2) * 4 < 0x7FFFFFF0)
-        if self.bf16:        # folded windows: width % 4, whole 64-row partials (n * ho * wo / 2), the stem's weights through the batch
-            ho, wo = (H - 1) // 2 + 1, W // 2
-            self._stem_rw = (self.stem_rowwindow and training and W % 4 == 0 and (B * ho * (wo // 2)) % 64 == 0 and self.batch_weight_prep
-                             and self.spec.stem.k == 7)
+        if self._stem_rw and not direct:                # raw uint8 input: windows from the normalised NHWC4 image
+            x0 = ops.stem_rowwindow_split(x0)
         self._wprep = None
         if training:
             self._wk_cache.clear()               # the weights are about to change: drop the inference copies
@@ -395,10 +406,6 @@ class Backbone:
         if training:
             torch._foreach_add_(self.bn_count_buffers(), V)       # num_batches_tracked += 1 per view call
         s = self.spec
-        if self.bf16:
-            assert self._stem_rw == bf_rw
-        elif self._stem_rw:
-            x0 = ops.stem_rowwindow_split(x0)
         x, argmax = self._unit_fwd(s.stem, x0, V, B, H, W, training, True, None, ulist, pool=True)
         Hc, Wc = x.shape[2], x.shape[3]
         for blk in s.blocks:

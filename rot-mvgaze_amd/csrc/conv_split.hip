@@ -656,6 +656,32 @@ __global__ __launch_bounds__(256) void stem_rowwindow_kernel(const float4 *__res
   }
 }
 
+// ... and straight from the module's NCHW fp32 input (3 planes), skipping the NHWC4 image
+__global__ __launch_bounds__(256) void stem_rowwindow_nchw_kernel(const float *__restrict__ x, uint4 *__restrict__ xw, long long n, int h, int w) {
+  const int wo = w >> 1;
+  const long long plane = (long long)h * w;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int q = (int)(i & 3);
+    const long long t = i >> 2;
+    const int ox = (int)(t % wo);
+    const long long row = t / wo;                     // image * h + y
+    const long long img = row / h;
+    const int yy = (int)(row - img * h);
+    const int c0 = 2 * ox - 4 + 2 * q;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c0 >= 0 && c0 < w) {
+      const float *src = x + img * 3 * plane + (long long)yy * w + c0;
+      const float2 r = *reinterpret_cast<const float2 *>(src), g = *reinterpret_cast<const float2 *>(src + plane),
+                   b = *reinterpret_cast<const float2 *>(src + 2 * plane);
+      v[0] = r.x; v[1] = g.x; v[2] = b.x; v[4] = r.y; v[5] = g.y; v[6] = b.y;
+    }
+    uint4 q1, q2;
+    split2_chunk(v, q1, q2);
+    xw[SP_NP * i] = q1;
+    xw[SP_NP * i + 1] = q2;
+  }
+}
+
 // A stride-2 parity class without taps: dx = addend (or zero) on that class's pixels (float4 vectors)
 __global__ __launch_bounds__(256) void dgrad_empty_class_split_kernel(float4 *__restrict__ dx, const float4 *__restrict__ addend,
                                                                       long long n, int sub_h, int sub_w, int full_h, int full_w,
@@ -1195,6 +1221,17 @@ int mvg_stem_rowwindow_split(const float *x_nhwc4, void *xw_sp, int64_t images, 
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(stem_rowwindow_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float4 *)x_nhwc4, (uint4 *)xw_sp, n, h, w);
   return check_launch("stem_rowwindow");
+}
+
+int mvg_stem_rowwindow_split_nchw(const float *x_nchw, void *xw_sp, int64_t images, int h, int w, void *stream) {
+  MVG_REQUIRE(x_nchw && xw_sp && images > 0 && h > 0 && w > 0 && w % 2 == 0, "stem_rowwindow (NCHW): bad arguments (even width)");
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = images * h * (w / 2) * 4;
+  ProfScope ps(MVG_K_LAYOUT, st, 0.0, 12.0 * (double)images * h * w + 32.0 * (double)n);
+  long long blocks = (n + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(stem_rowwindow_nchw_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x_nchw, (uint4 *)xw_sp, n, h, w);
+  return check_launch("stem_rowwindow_nchw");
 }
 
 int mvg_stem_fprop_split(const mvg_conv_desc *d, const void *xw_sp, const void *w_sp, const float *w_sinv, float *y, float *stats,

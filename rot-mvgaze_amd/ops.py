@@ -255,6 +255,14 @@ def stem_rowwindow_split(x_nhwc4: Tensor) -> Tensor:
     return xw
 
 
+def stem_rowwindow_split_nchw(x_nchw: Tensor, out: Tensor):
+    """[B, 3, H, W] fp32 NCHW -> out (one view of an sp_empty(V, B, H, W/2, 32)): the windows straight from the module's input."""
+    B, Cc, H, W = x_nchw.shape
+    assert Cc == 3 and W % 2 == 0 and x_nchw.dtype == torch.float32 and x_nchw.is_contiguous() and is_sp(out) and out.is_contiguous()
+    assert sp_shape(out) == (B, H, W // 2, 32)
+    check(lib().mvg_stem_rowwindow_split_nchw(_p(x_nchw), _p(out), B, H, W, _s()), "stem_rowwindow_split_nchw")
+
+
 def stem_fprop_split(d: ConvDesc, xw: Tensor, w_sp: Tensor, y: Tensor, stats: Optional[Tensor]):
     check(lib().mvg_stem_fprop_split(C.byref(d), _p(xw), _p(w_sp), _sinv(w_sp), _p(y), _p(stats), _s()), "stem_fprop_split")
 

@@ -344,6 +344,11 @@ def test_stem_in_row_window_form_on_the_split_kernels(G, N, H, W, cout):
         ok = (cols >= 0) & (cols < W)
         want[:, :, :, ok, j] = x[:, :, :, cols[ok]]
     sp_close(win, want, "row windows")
+    xw2 = ops.sp_empty(G, N, H, W // 2, 32, device=dev())
+    for g in range(G):                                  # ... and straight from the module's NCHW input, view by view
+        ops.stem_rowwindow_split_nchw(x[g, ..., :3].permute(0, 3, 1, 2).contiguous(), xw2[g])
+    assert torch.equal(xw2, xw), "windows from NCHW == windows from NHWC4"
+
     # weights in the window's tap layout
     w8 = torch.zeros(cout, 7, 8, 4, device=dev())
     w8[:, :, 1:, :3] = w
