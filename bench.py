@@ -385,7 +385,7 @@ def main():
         roofline = {"bound": "mfma",
                     "kernel": ("igemm_bf16_kernel/wgrad_bf16_kernel (bf16 MFMA implicit-GEMM conv: fprop+dgrad+wgrad)" if bf16 else
                                "igemm_split16_kernel/wgrad_split_kernel (fp32-accurate implicit-GEMM conv on the fp16 MFMA: operands as two fp16 "
-                               "pieces, three MFMAs per product; the 3-channel stem on the fp32 MFMA: fprop+dgrad+wgrad)" if split else
+                               "pieces, three MFMAs per product; the 3-channel stem as row windows on the same kernels: fprop+dgrad+wgrad)" if split else
                                "igemm_kernel/wgrad_kernel (fp32 MFMA implicit-GEMM conv: fprop+dgrad+wgrad)"),
                     "peak_basis": ("dense bf16 MFMA 2500 TFLOP/s" if bf16 else
                                    "dense fp16 MFMA 2500 TFLOP/s / 3 MFMAs per fp32-accurate product = 833.3 fp32-equivalent TFLOP/s (round 2's six-bf16-MFMA "
