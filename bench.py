@@ -209,6 +209,9 @@ def main():
     ap.add_argument("--nccl-channels", type=int, default=int(os.environ.get("NCCL_MAX_NCHANNELS", "4")),
                     help="N > 1: NCCL_MAX_NCHANNELS for the gradient all-reduce")
     ap.add_argument("--no-optimizer", action="store_true", help="time forward+loss+backward only (no Adam step)")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="queue every launch from Python each step instead of replaying the step's hipGraph (N = 1 training runs "
+                         "capture zero_grad + forward + loss + backward + Adam once: rot_mvgaze_amd/graph.py)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the backward-weight kernels on the compute stream (per-kernel profiling: rocprofv3 --stats)")
     ap.add_argument("--dtype", default=None, choices=["f32", "bf16"],
@@ -289,7 +292,10 @@ def main():
     del inp
     criterion = MultiViewIterationLoss(rel_weight=0.01, reference_decay=1.0, iter_decay=0.5)
     from rot_mvgaze_amd.optim import Adam
-    optimizer = None if args.no_optimizer else Adam(model.parameters(), lr=1e-4, weight_decay=1e-6)   # trainer.py:54
+    # N = 1 training: the whole step is captured in a hipGraph (the optimizer's step counter / lr then live on the device)
+    use_graph = (world == 1 and not force_dist and args.mode == "train" and not args.no_graph and not args.no_optimizer
+                 and not args.no_overlap)
+    optimizer = None if args.no_optimizer else Adam(model.parameters(), lr=1e-4, weight_decay=1e-6, capturable=use_graph)   # trainer.py:54
     reducer = GradAllReducer(model, bucket_mb=args.bucket_mb, force=force_dist, reserved_cus=args.reserved_cus) \
         if (world > 1 or force_dist) else None
 
@@ -318,8 +324,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    run = step
+    graphed = None
+    if use_graph:
+        from rot_mvgaze_amd.graph import GraphedStep
+        graphed = GraphedStep(model, step, optimizer, warmup=2)       # 2 eager steps, then the capture (which executes nothing)
+        run = graphed.run
     for _ in range(args.warmup):
-        step()
+        run()
     fence()
     # hipEvents on the compute stream at every step boundary (recording an event costs no synchronisation):
     # the per-step durations give the median SURVEY 8(d) asks for next to the wall-clock mean
@@ -327,7 +339,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         marks[i].record()
-        loss = step()
+        loss = run()
     marks[args.steps].record()
     host_ms = (time.perf_counter() - t0) / max(args.steps, 1) * 1e3      # host time to QUEUE a step (no synchronisation inside)
     fence()
@@ -452,6 +464,8 @@ def main():
                                         ("" if args.no_optimizer else " + fused Adam step")),
                        "weights": "random init, seed 0 (kaiming-normal convs, default Linear)",
                        "rccl_ranks": (dist.get_world_size() if (world > 1 or force_dist) else 1),
+                       "step_launch": ("one hipGraphLaunch per step (zero_grad + forward + loss + backward + Adam captured once; "
+                                       "rot_mvgaze_amd/graph.py)" if graphed is not None else "eager: every kernel queued from Python"),
                        "dp": ({"bucket_mb": args.bucket_mb, "buckets": len(reducer.buckets) if hasattr(reducer, "buckets") else None,
                                "reserved_cus": reducer.reserved_cus, "nccl_max_nchannels": int(os.environ.get("NCCL_MAX_NCHANNELS", "0")),
                                "backend": os.environ.get("MVG_DIST_BACKEND", "nccl"), "params_broadcast_from_rank0": True}

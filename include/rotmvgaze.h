@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MVG_ABI_VERSION 9
+#define MVG_ABI_VERSION 10
 
 /* ---------------------------------------------------------------- library */
 int mvg_abi_version(void);
@@ -335,8 +335,9 @@ int mvg_scale_by(const float *x, const float *scale, float *out, int64_t n, void
  * dw (+)= dy^T @ x, db (+)= colsum(dy); dx / dw may be NULL to skip. */
 int mvg_linear_skinny_fwd(const float *x, const float *w, const float *bias, float *y, int rows, int k,
                           int nout, void *stream);
+/* dx_absmax (may be NULL): a device float slot that receives max |dx| (its bits, by atomicMax: the caller clears it) */
 int mvg_linear_skinny_bwd(const float *dy, const float *x, const float *w, const float *mask, float *dx,
-                          float *dw, float *db, int rows, int k, int nout, int accumulate, void *stream);
+                          float *dw, float *db, int rows, int k, int nout, int accumulate, float *dx_absmax, void *stream);
 
 /* ---------------------------------------------------------------- optimizer
  * torch.optim.Adam step (trainer.py:54,141-143: betas (0.9, 0.999), eps 1e-8, coupled L2
@@ -344,6 +345,11 @@ int mvg_linear_skinny_bwd(const float *dy, const float *x, const float *w, const
  * gradients in two arenas with identical offsets, so one launch updates every parameter. */
 int mvg_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
                   float beta1, float beta2, float eps, float weight_decay, int step, void *stream);
+/* The same step with nothing from the host but the launch itself (a step captured in a hipGraph replays it): lr_dev = one
+ * device float (CyclicLR writes it when it steps, trainer.py:58-62,147), state3 = three device floats {step, 1 - beta1^step,
+ * sqrt(1 - beta2^step)} - zero-initialised, advanced by a one-thread launch in front of the update. */
+int mvg_adam_step_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, const float *lr_dev,
+                      float *state3, float beta1, float beta2, float eps, float weight_decay, void *stream);
 
 /* ---------------------------------------------------------------- loss
  * gaze_angular_loss losses/gaze_loss.py:42-52 over pitchyaw_to_vector utils/math.py:52-60:
@@ -357,6 +363,12 @@ int mvg_gaze_angular_loss(const float *pred, const float *gt, int n, float row_w
  * StereoL1Loss, which fixes 'angular'): loss[0] = mean over the n elements of |pred - label|^p, p in {1, 2};
  * dpred (optional, n floats) = d loss / d pred (zero where pred == label, like torch.abs). */
 int mvg_gaze_lp_loss(const float *pred, const float *label, int n, int p, float *loss, float *dpred, void *stream);
+/* IterationLoss(StereoL1Loss) (stereo_loss.py:46-54,65-84) over the head's stacked predictions in ONE launch: pred
+ * [iters][dirs * batch][2], gt [dirs * batch][2]; host_weights [iters * dirs] (HOST array, copied into the launch): row r of
+ * iteration i weighs host_weights[i * dirs + r / batch] / batch.  loss[0] = the weighted sum of the angular errors (degrees),
+ * dpred (may be NULL) = its gradient. */
+int mvg_gaze_angular_loss_multi(const float *pred, const float *gt, int iters, int dirs, int batch, const float *host_weights,
+                                float *loss, float *dpred, void *stream);
 
 /* ---------------------------------------------------------------- stereo pair index (HOST)
  * GazeDataset.__init__'s idx_to_kv build, dataset/gaze.py:39-73, driven by CPython's
@@ -575,6 +587,42 @@ int mvg_bn_relu_maxpool_bwd_apply_split(const float *g_pooled, const uint8_t *ar
 int mvg_conv_wgrad_splits_split(const mvg_conv_desc *d);   /* pixel-split count; workspace = splits * cout*r*s*cin floats */
 int mvg_conv_wgrad_split(const mvg_conv_desc *d, const void *x_sp, const void *dy_sp, const float *dy_sinv, float *dw,
                          float *workspace, int splits, int accumulate, void *stream);
+
+/* ---------------------------------------------------------------- the fusion block on the split kernels
+ * ImageFeatFuser / gaze head Linears (rot_mv.py:35-50,179-184,234-254; blocks.py:41-47) with >= 1024 rows: every tensor a
+ * split kernel reads carries a per-tensor power-of-two scale (the reference computes these in plain fp32 and has no range
+ * limit; fp16 pieces do), found WITHOUT extra passes: fp32 results leave max |.| in a device slot from the producing
+ * launch's epilogue (float bits, atomicMax: order-independent; the caller clears the slots once per step), sp results are
+ * stored times the 2^k a bound allows.
+ *   mvg_absmax_multi: max |x| of up to 8 small tensors (HOST arrays of device pointers / counts / slots) in one launch.
+ *   mvg_fuse_build_split: the operands built from a feature tensor F [.][3][nvec], straight into sp:
+ *       xf[m] = [ img_feat[row_img[m]] | rel[m] @ F[row_src_f[m]] ]  (next iteration's fuser input; NULL = not wanted)
+ *       xh[m] = [ img_feat[row_img[m]] |          F[row_src_h[m]] ]  (this iteration's head input;  NULL = not wanted)
+ *     scaled from am_img / am_feat (max |img_feat|, max |F|: |rel @ f| <= sqrt(3) max |f|); *xf_sinv / *xh_sinv = 2^-k.
+ *   mvg_linear_fprop_split: out = relu?(x W^T + bias); out fp32 (out_absmax, may be NULL, receives max |out|) or sp
+ *     (out_sp: stored times 2^k from the bound fin * 2^30 * x_sinv * w_sinv + *bias_absmax >= |out|; *out_sinv = 2^-k).
+ *   mvg_linear_dgrad_split: dx = (dy W) [* (relu_mask_sp > 0)] [+ addend], out_absmax as above.
+ *   mvg_linear_wgrad_split: dw (+)= dy^T x with BOTH operands scaled (x_sinv may be NULL).
+ *   mvg_split_colsum: g [rows][cols] fp32 -> sp times the 2^k that *absmax (max |g| bits) allows, *out_sinv = 2^-k, and
+ *     db (may be NULL) (+)= the column sums of g - the Linear's bias gradient - in one pass (cols % 32 == 0).
+ *   mvg_fuse_unbuild: the backward of mvg_fuse_build_split for one iteration: dfeat [segments][batch][3][nvec] =
+ *     dxh[.][cf:] + sum over d with seg[d] == s of rel[d]^T @ dxn[d][cf:]; da [views][batch][cf] (+)= sum over d with
+ *     vi[d] == v of (dxh + dxn)[d][:cf]; max |dfeat| into *absmax (may be NULL).  dxh / dxn: [dirs][batch][cf + 3 nvec]. */
+int mvg_absmax_multi(const float *const *host_ptrs, const int64_t *host_counts, float *const *host_out_slots, int n, void *stream);
+int mvg_fuse_build_split(const float *img_feat, const float *feat, const float *rel, const int32_t *row_img, const int32_t *row_src_f,
+                         const int32_t *row_src_h, void *xf_sp, void *xh_sp, const float *am_img, const float *am_feat,
+                         float *xf_sinv, float *xh_sinv, int rows, int cf, int nvec, void *stream);
+int mvg_fuse_unbuild(const float *dxh, const float *dxn, const float *rel, const int32_t *seg, const int32_t *vi, float *dfeat, float *da,
+                     int da_accumulate, int segments, int views, int dirs, int batch, int cf, int nvec, float *absmax, void *stream);
+int mvg_linear_fprop_split(int rows, int fin, int fout, const void *x_sp, const float *x_sinv, const void *w_sp, const float *w_sinv,
+                           const float *bias, int relu, void *out, int out_sp, float *out_sinv, const float *bias_absmax,
+                           float *out_absmax, void *stream);
+int mvg_linear_dgrad_split(int rows, int fin, int fout, const void *dy_sp, const float *dy_sinv, const void *wt_sp, const float *w_sinv,
+                           float *dx, const float *addend, const void *relu_mask_sp, float *out_absmax, void *stream);
+int mvg_linear_wgrad_split(int rows, int fin, int fout, const void *x_sp, const float *x_sinv, const void *dy_sp, const float *dy_sinv,
+                           float *dw, float *workspace, int splits, int accumulate, void *stream);
+int mvg_split_colsum(const float *g, int rows, int cols, const float *absmax, void *out_sp, float *out_sinv, float *db, int accumulate,
+                     void *stream);
 
 #ifdef __cplusplus
 }

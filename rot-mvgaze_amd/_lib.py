@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "librotmvgaze_hip.so")
 
 K_FAMILIES = 18
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class ConvDesc(C.Structure):
@@ -129,9 +129,19 @@ SIGNATURES = {
     "mvg_axpby": (_I, [_P, _P, _F, _F, _I64, _P]),
     "mvg_scale_by": (_I, [_P, _P, _P, _I64, _P]),
     "mvg_linear_skinny_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
-    "mvg_linear_skinny_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "mvg_linear_skinny_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "mvg_adam_step": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _I, _P]),
     "mvg_gaze_angular_loss": (_I, [_P, _P, _I, _F, _P, _I, _P, _P, _P]),
+    "mvg_gaze_angular_loss_multi": (_I, [_P, _P, _I, _I, _I, C.POINTER(C.c_float), _P, _P, _P]),
+    "mvg_adam_step_dev": (_I, [_P, _P, _P, _P, _I64, _P, _P, _F, _F, _F, _F, _P]),
+    # the fusion block on the split kernels
+    "mvg_absmax_multi": (_I, [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p), _I, _P]),
+    "mvg_fuse_build_split": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "mvg_fuse_unbuild": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "mvg_linear_fprop_split": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P]),
+    "mvg_linear_dgrad_split": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mvg_linear_wgrad_split": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "mvg_split_colsum": (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _P]),
     # bf16 storage path (same argument lists as the fp32 entry points)
     "mvg_cast_weights_bf16": (_I, [_D, _P, _I, _P, _P, _P]),
     "mvg_conv_fprop_bf16": (_I, [_D, _P, _P, _P, _P, _I, _P, _P]),

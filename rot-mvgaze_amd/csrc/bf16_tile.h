@@ -36,7 +36,12 @@ constexpr int bf16_epilogue_bytes() {
   return (BM / PASSES) * (BN + 4) * 4 + BM * 4 + (BNF ? 4 * BN * 4 : 0);
 }
 
-template <int BM, int BN, int WGM, bool DGRAD, bool F32IO, int PASSES = 1, bool ACC16 = false, bool BNF = false, class AccT>
+// LIN (split kernels running a Linear layer of the fusion block): the epilogue can also (i) leave max |stored value| of an
+// fp32 result in *p.out_absmax (atomicMax on the float's bits: order-independent), the bound the next split of that
+// tensor scales by, and (ii) store an sp result times the power of two 2^k that a bound on the result allows -
+// |acc| <= ktotal * 2^30 in the operands' scaled units, so |result| <= ktotal * 2^30 * osc + max |bias| - with
+// *p.out_sinv = 2^-k for the consumers (IgemmParams::out_sinv / bias_absmax).
+template <int BM, int BN, int WGM, bool DGRAD, bool F32IO, int PASSES = 1, bool ACC16 = false, bool BNF = false, bool LIN = false, class AccT>
 __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmClass &c, AccT &acc,
                                               unsigned short *smem, int tid, int g, int mtile, int ntile) {
   constexpr int WGN = 2, NT = WGM * WGN * 64;
@@ -53,6 +58,14 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
   const long long row_base = (long long)mtile * BM + wm * WTM;
   // split operands carry per-tensor power-of-two scales: exact to undo on the accumulators
   const float osc = F32IO ? (p.a_sinv ? *p.a_sinv : 1.f) * (p.b_sinv ? *p.b_sinv : 1.f) : 1.f;
+  float lin_scale = 1.f, lin_max = 0.f;
+  if constexpr (LIN && F32IO) {
+    if (!DGRAD && p.out_s3 && p.out_sinv) {
+      const float bound = (float)p.ktotal * 1073741824.f * osc + (p.bias_absmax ? *p.bias_absmax : 0.f);
+      lin_scale = sp_scale_for(bound);
+      if (tid == 0 && mtile == 0 && ntile == 0 && g == 0) *p.out_sinv = 1.f / lin_scale;
+    }
+  }
   if (!DGRAD && p.stats) {
     // per-wave partial over its WTM rows: column sum and sum of squares centred on the partial's own mean
     long long cnt_ll = c.rows_per_group - row_base;
@@ -211,6 +224,10 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
         }
       }
       if (!DGRAD && p.out_s3) {                // the next conv's operand, written directly (one chunk per lane)
+        if constexpr (LIN) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) x[k] *= lin_scale;
+        }
         uint4 q1, q2;
         split2_chunk(x, q1, q2);
         uint4 *dst = reinterpret_cast<uint4 *>(p.out) + (((long long)g * gelems + off + col) >> 3) * SP_NP;
@@ -261,6 +278,10 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
           bn_s1[k] += x[k];
           bn_s2[k] += x[k] * ((yy[k] - bn_mu[k]) * bn_is[k]);
         }
+      }
+      if constexpr (LIN) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) lin_max = fmaxf(lin_max, fabsf(x[k]));
       }
       *reinterpret_cast<float4 *>(out_f + off + col) = make_float4(x[0], x[1], x[2], x[3]);
       *reinterpret_cast<float4 *>(out_f + off + col + 4) = make_float4(x[4], x[5], x[6], x[7]);
@@ -332,6 +353,22 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
     for (int it = 0; it < PR * CV / NT; ++it) store_rows(it);
   }
   }  // passes
+  if constexpr (LIN && F32IO) {
+    if (p.out_absmax) {                        // ONE atomic per workgroup (atomics on one address serialise at ~12 ns each)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) lin_max = fmaxf(lin_max, __shfl_xor(lin_max, o, 64));
+      __syncthreads();                         // the staging tile has been read out
+      float *wred = reinterpret_cast<float *>(smem);
+      if (lane == 0) wred[wave] = lin_max;
+      __syncthreads();
+      if (tid == 0) {
+        float mx = wred[0];
+        for (int k = 1; k < NT / 64; ++k) mx = fmaxf(mx, wred[k]);
+        if (mx > 0.f) atomicMax(p.out_absmax, __float_as_uint(mx));
+      }
+      __syncthreads();                         // (the fused reduce below reuses the tile)
+    }
+  }
   if (bnf) {
     constexpr int RL = NT / CV;                // threads (row lanes) per 8-channel column group
     __syncthreads();                           // the staging tile has been read out

@@ -143,6 +143,12 @@ struct IgemmParams {
   // split kernels: the operands hold (value * 2^k) for a per-tensor k (elem.h: sp_t); the epilogue multiplies the
   // accumulators by *a_sinv * *b_sinv (device scalars, each 2^-k of its operand; null = 1)
   const float *a_sinv, *b_sinv;
+  // split kernels running a Linear of the fusion block (igemm_split16_kernel<.., LIN = true>): out_absmax receives max |result| of
+  // an fp32 result (atomicMax on the bits; the caller clears it); an sp result (out_s3) is stored times 2^k from the bound
+  // ktotal * 2^30 * a_sinv * b_sinv + *bias_absmax and *out_sinv receives 2^-k
+  unsigned *out_absmax;
+  float *out_sinv;
+  const float *bias_absmax;
   int stride_w, pad_w;            // split / bf16 kernels, forward: horizontal stride / padding (= stride / pad except for the stem's
                                   // row-window form: a 7 x 1 filter, vertical stride 2, over windows that already step by 2)
   int stats_fold;                 // bf16 stem (two output columns per window as 2 x cout GEMM columns): the BatchNorm partials of
@@ -188,6 +194,7 @@ struct WgradParams {
   long long rc_img_bytes, rc_feat_bytes;
   FastDiv ohw_div, wo_div, cin_div, s_div;
   const float *dy_sinv;           // split kernels: 2^-k of the dy operand's per-tensor scale (device scalar, null = 1)
+  const float *x_sinv;            // ... and of the x operand's (a Linear's scaled input / hidden activation; null = 1: BatchNorm outputs)
   int stride_w, pad_w;            // split kernels: horizontal stride / padding (see IgemmParams)
 };
 

@@ -110,6 +110,47 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float *__restr
   db[c] = s;
 }
 
+// A gradient g [rows][cols] of the fusion block on its way into the split kernels, ONE launch: g -> sp times the 2^k that
+// max |g| allows (the maximum was left in *absmax - float bits - by g's producer: the LIN epilogue's atomicMax, or
+// fuse_unbuild / skinny_bwd_dx), *out_sinv = 2^-k, and db (+)= the column sums of g (the Linear's bias gradient).
+// Workgroup = 32 columns (4 chunks of 8) x 64 row lanes; the row lanes are added through LDS in lane order (reproducible).
+__global__ __launch_bounds__(256) void split_colsum_kernel(const float *__restrict__ g, int rows, int cols, const unsigned *__restrict__ absmax,
+                                                           uint4 *__restrict__ out, float *__restrict__ out_sinv, float *__restrict__ db,
+                                                           int accumulate) {
+  __shared__ float sh[64][33];
+  const float scale = sp_scale_for(__uint_as_float(*absmax));
+  if (blockIdx.x == 0 && threadIdx.x == 0) *out_sinv = 1.f / scale;
+  const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2;
+  const int c8 = blockIdx.x * 4 + cl, c8n = cols >> 3;
+  float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int r = rl; r < rows; r += 64) {
+    const float4 *src = reinterpret_cast<const float4 *>(g + (long long)r * cols + c8 * 8);
+    const float4 lo = src[0], hi = src[1];
+    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    float w[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      sum[k] += v[k];
+      w[k] = v[k] * scale;
+    }
+    uint4 q1, q2;
+    split2_chunk(w, q1, q2);
+    uint4 *dst = out + SP_NP * ((long long)r * c8n + c8);
+    dst[0] = q1;
+    dst[1] = q2;
+  }
+  if (db == nullptr) return;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) sh[rl][cl * 8 + k] = sum[k];
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const int col = blockIdx.x * 32 + threadIdx.x;
+    float t = accumulate ? db[col] : 0.f;
+    for (int r = 0; r < 64; ++r) t += sh[r][threadIdx.x];
+    db[col] = t;
+  }
+}
+
 // Every conv's weight copies of one training step in TWO launches (grid.y = conv): (1) max |w| per conv, (2) the
 // copies.  mode 1: fp32 KRSC -> sp KRSC (+ sp CRSK), both scaled by 2^k with max |w| * 2^k just below 2^15, and
 // wstat[conv] = {max |w| bits, 2^-k} for the consumers' epilogues; mode 0: -> bf16 KRSC (cin zero-padded to cin_pad)
@@ -286,7 +327,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int sp_row_swz(int R) { return ((R >> 1) & 1) | (((R >> 2) & 1) << 2); }
 
-template <int BN, bool DGRAD>
+template <int BN, bool DGRAD, bool LIN = false>
 __global__ __launch_bounds__(256, DGRAD ? 3 : 4) void igemm_split16_kernel(IgemmParams p) {
   constexpr int BM = 128, WGM = 2, WGN = 2, NW = 4;
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -432,7 +473,7 @@ __global__ __launch_bounds__(256, DGRAD ? 3 : 4) void igemm_split16_kernel(Igemm
     }
     __syncthreads();                                         // everyone is done reading before the next DMA lands
   }
-  bf16_epilogue<BM, BN, WGM, DGRAD, true, 2, true, DGRAD>(p, c, acc, reinterpret_cast<unsigned short *>(smem), tid, g, mtile, ntile);
+  bf16_epilogue<BM, BN, WGM, DGRAD, true, 2, true, DGRAD, LIN>(p, c, acc, reinterpret_cast<unsigned short *>(smem), tid, g, mtile, ntile);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -615,7 +656,7 @@ __global__ __launch_bounds__(256, 3) void wgrad_split_kernel(WgradParams p) {
   }
 
   float *out = p.out + (long long)split * p.cout * p.ncols;
-  const float osc = p.dy_sinv ? *p.dy_sinv : 1.f;
+  const float osc = (p.dy_sinv ? *p.dy_sinv : 1.f) * (p.x_sinv ? *p.x_sinv : 1.f);
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -711,7 +752,7 @@ static int validate_split(const mvg_conv_desc *d) {
 }
 
 template <bool DGRAD>
-static int launch_igemm_split(IgemmParams &p, hipStream_t st) {
+static int launch_igemm_split(IgemmParams &p, hipStream_t st, bool lin = false) {
   const int bn = p.ncols >= 128 ? 128 : 64;
   const int bm = SP_BM;
   p.ntiles = ceil_div(p.ncols, bn);
@@ -735,7 +776,10 @@ static int launch_igemm_split(IgemmParams &p, hipStream_t st) {
   MVG_REQUIRE(tiles < (1LL << 31), "split conv: grid too large");
   if (tiles <= 0) return 0;
   dim3 grid((unsigned)tiles), block(256);
-  if (bn == 128) hipLaunchKernelGGL((igemm_split16_kernel<128, DGRAD>), grid, block, 0, st, p);
+  if (lin) {                 // a Linear of the fusion block: the epilogue's scale / abs-max features compiled in
+    if (bn == 128) hipLaunchKernelGGL((igemm_split16_kernel<128, DGRAD, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((igemm_split16_kernel<64, DGRAD, true>), grid, block, 0, st, p);
+  } else if (bn == 128) hipLaunchKernelGGL((igemm_split16_kernel<128, DGRAD>), grid, block, 0, st, p);
   else hipLaunchKernelGGL((igemm_split16_kernel<64, DGRAD>), grid, block, 0, st, p);
   return check_launch(DGRAD ? "conv_dgrad_split" : "conv_fprop_split");
 }
@@ -859,6 +903,10 @@ struct SplitAffine {       // inference forward: y = acc * scale + shift (+ resi
   const float *scale, *shift;
   const void *residual;
   int residual_s3, relu, out_s3;
+  // Linear layers of the fusion block (LIN kernels): see IgemmParams::out_absmax / out_sinv / bias_absmax
+  int lin;
+  float *out_absmax, *out_sinv;
+  const float *bias_absmax;
 };
 
 // stride_w / pad_w >= 0: the horizontal stride / padding differ from d->stride / d->pad (the stem's row-window form, whose
@@ -881,6 +929,9 @@ static int fprop_split_impl(const mvg_conv_desc *d, const void *x_sp, const floa
     p.addend_s3 = aff->residual_s3;
     p.relu = aff->relu;
     p.out_s3 = aff->out_s3;
+    p.out_absmax = (unsigned *)aff->out_absmax;
+    p.out_sinv = aff->out_sinv;
+    p.bias_absmax = aff->bias_absmax;
   }
   p.groups = d->groups;
   p.out_h = d->ho;
@@ -923,7 +974,7 @@ static int fprop_split_impl(const mvg_conv_desc *d, const void *x_sp, const floa
   p.stats_partials = ceil_div(p.rows_per_group, SP_BM) * 2;    // = mvg_conv_stats_partials_split
   p.ncls = 1;
   class_from_params(p.cls[0], p);
-  return launch_igemm_split<false>(p, (hipStream_t)stream);
+  return launch_igemm_split<false>(p, (hipStream_t)stream, aff && aff->lin);
 }
 
 int mvg_conv_fprop_split(const mvg_conv_desc *d, const void *x_sp, const float *x_sinv, const void *w_sp, const float *w_sinv, float *y,
@@ -935,7 +986,7 @@ int mvg_conv_fprop_split_affine(const mvg_conv_desc *d, const void *x_sp, const 
                                 void *out, int out_s3, const float *scale, const float *shift, const void *residual, int residual_s3,
                                 int relu, void *stream) {
   MVG_REQUIRE(scale && shift && out, "fprop_split_affine: scale, shift and out are required");
-  const SplitAffine a = {scale, shift, residual, residual_s3, relu, out_s3};
+  const SplitAffine a = {scale, shift, residual, residual_s3, relu, out_s3, 0, nullptr, nullptr, nullptr};
   return fprop_split_impl(d, x_sp, x_sinv, w_sp, w_sinv, out, nullptr, stream, &a);
 }
 
@@ -948,7 +999,8 @@ struct SplitBnFuse {       // fused BatchNorm-backward reduce of the unit whose 
 };
 
 static int dgrad_split_impl(const mvg_conv_desc *d, const void *dy_sp, const float *dy_sinv, const void *w_crsk_sp, const float *w_sinv,
-                            float *dx, const float *addend, void *stream, const SplitBnFuse *bnf, const void *relu_mask_sp = nullptr) {
+                            float *dx, const float *addend, void *stream, const SplitBnFuse *bnf, const void *relu_mask_sp = nullptr,
+                            bool lin_kernel = false, float *out_absmax = nullptr) {
   if (validate_split(d)) return 2;
   IgemmParams p;
   memset(&p, 0, sizeof(p));
@@ -960,6 +1012,7 @@ static int dgrad_split_impl(const mvg_conv_desc *d, const void *dy_sp, const flo
   p.addend = addend;
   p.mask = (const float *)relu_mask_sp;
   p.mask_s3 = relu_mask_sp != nullptr;
+  p.out_absmax = (unsigned *)out_absmax;
   if (bnf) {
     p.bn_y = bnf->y;
     p.bn_bits = bnf->bits;
@@ -1062,7 +1115,7 @@ static int dgrad_split_impl(const mvg_conv_desc *d, const void *dy_sp, const flo
       cls_k[j - 1] = tk;
     }
   m.no_remap = m.ncls > 1;
-  return launch_igemm_split<true>(m, (hipStream_t)stream);
+  return launch_igemm_split<true>(m, (hipStream_t)stream, lin_kernel);
 }
 
 int mvg_conv_dgrad_split(const mvg_conv_desc *d, const void *dy_sp, const float *dy_sinv, const void *w_crsk_sp, const float *w_sinv,
@@ -1117,7 +1170,7 @@ int mvg_conv_wgrad_splits_split(const mvg_conv_desc *d) {
 }
 
 static int wgrad_split_impl(const mvg_conv_desc *d, const void *x_sp, const void *dy_sp, const float *dy_sinv, float *dw, float *workspace,
-                            int splits, int accumulate, void *stream, int stride_w = -1, int pad_w = -1) {
+                            int splits, int accumulate, void *stream, int stride_w = -1, int pad_w = -1, const float *x_sinv = nullptr) {
   if (stride_w < 0 && validate_split(d)) return 2;
   MVG_REQUIRE(splits >= 1, "wgrad_split: splits < 1");
   MVG_REQUIRE(splits == 1 || workspace != nullptr, "wgrad_split: workspace required for splits > 1");
@@ -1126,6 +1179,7 @@ static int wgrad_split_impl(const mvg_conv_desc *d, const void *x_sp, const void
   p.x = (const float *)x_sp;
   p.dy = (const float *)dy_sp;
   p.dy_sinv = dy_sinv;
+  p.x_sinv = x_sinv;
   p.h = d->h;
   p.w = d->w;
   p.cin = d->cin;
@@ -1191,6 +1245,47 @@ static int wgrad_split_impl(const mvg_conv_desc *d, const void *x_sp, const void
 int mvg_conv_wgrad_split(const mvg_conv_desc *d, const void *x_sp, const void *dy_sp, const float *dy_sinv, float *dw, float *workspace,
                          int splits, int accumulate, void *stream) {
   return wgrad_split_impl(d, x_sp, dy_sp, dy_sinv, dw, workspace, splits, accumulate, stream);
+}
+
+// ---- the fusion block's Linear layers on the split kernels (heads.py: a Linear = a 1x1 conv on a 1x1 map) ----------------
+static mvg_conv_desc linear_desc(int rows, int fin, int fout) {
+  mvg_conv_desc d;
+  memset(&d, 0, sizeof(d));
+  d.groups = 1; d.n = rows; d.h = d.w = d.ho = d.wo = 1; d.cin = fin; d.cout = fout; d.r = d.s = 1; d.stride = 1; d.pad = 0;
+  return d;
+}
+
+int mvg_split_colsum(const float *g, int rows, int cols, const float *absmax, void *out_sp, float *out_sinv, float *db, int accumulate,
+                     void *stream) {
+  MVG_REQUIRE(g && absmax && out_sp && out_sinv && rows > 0 && cols > 0 && cols % 32 == 0, "split_colsum: null argument or cols %% 32 != 0");
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(MVG_K_COLSUM, st, 0.0, (4.0 + SP_BYTES) * (double)rows * cols);
+  hipLaunchKernelGGL(split_colsum_kernel, dim3(cols / 32), dim3(256), 0, st, g, rows, cols, (const unsigned *)absmax, (uint4 *)out_sp, out_sinv,
+                     db, accumulate);
+  return check_launch("split_colsum");
+}
+
+int mvg_linear_fprop_split(int rows, int fin, int fout, const void *x_sp, const float *x_sinv, const void *w_sp, const float *w_sinv,
+                           const float *bias, int relu, void *out, int out_sp, float *out_sinv, const float *bias_absmax,
+                           float *out_absmax, void *stream) {
+  MVG_REQUIRE(bias != nullptr && out != nullptr, "linear_fprop_split: bias and out are required");
+  MVG_REQUIRE(!out_sp || out_sinv, "linear_fprop_split: an sp result needs out_sinv (it is stored scaled)");
+  MVG_REQUIRE(!(out_sp && out_absmax), "linear_fprop_split: out_absmax is for fp32 results");
+  const mvg_conv_desc d = linear_desc(rows, fin, fout);
+  const SplitAffine a = {nullptr, bias, nullptr, 0, relu, out_sp, 1, out_absmax, out_sinv, bias_absmax};
+  return fprop_split_impl(&d, x_sp, x_sinv, w_sp, w_sinv, out, nullptr, stream, &a);
+}
+
+int mvg_linear_dgrad_split(int rows, int fin, int fout, const void *dy_sp, const float *dy_sinv, const void *wt_sp, const float *w_sinv,
+                           float *dx, const float *addend, const void *relu_mask_sp, float *out_absmax, void *stream) {
+  const mvg_conv_desc d = linear_desc(rows, fin, fout);
+  return dgrad_split_impl(&d, dy_sp, dy_sinv, wt_sp, w_sinv, dx, addend, stream, nullptr, relu_mask_sp, true, out_absmax);
+}
+
+int mvg_linear_wgrad_split(int rows, int fin, int fout, const void *x_sp, const float *x_sinv, const void *dy_sp, const float *dy_sinv,
+                           float *dw, float *workspace, int splits, int accumulate, void *stream) {
+  const mvg_conv_desc d = linear_desc(rows, fin, fout);
+  return wgrad_split_impl(&d, x_sp, dy_sp, dy_sinv, dw, workspace, splits, accumulate, stream, -1, -1, x_sinv);
 }
 
 // ---- the 7x7 stride-2 stem on the split kernels ("row-window" form) ------------------------------------------------

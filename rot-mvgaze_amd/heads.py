@@ -418,8 +418,8 @@ class FusionHead:
             m._wbf = [None] * m.n                  # this step's bf16 copies: made below in one launch (or per layer on first use)
         self.lifter.split = False                  # V * B rows: stays on the fp32-MFMA kernels
         if split_on:
-            self._prepare_split_weights(D * B, dev)
-        elif self.mixed:
+            return self._forward_split(img_feat, rot, keep_tape, ix)
+        if self.mixed:
             self._prepare_split_weights(D * B, dev, mixed=True)
         hl, lifted = self.lifter.forward(img_feat.reshape(V * B, cf))
         rel = torch.empty(D, B, 3, 3, dtype=torch.float32, device=dev)
@@ -457,9 +457,188 @@ class FusionHead:
             if keep_tape:
                 saved.append((X, Hf, Xh, Hh, scales))
             src, src_idx = Fn, ix["partner"]             # view j's feature of the SAME pair, previous iteration
-        tape = {"img_feat": img_feat, "lifted": lifted, "hl": hl, "rel": rel, "saved": saved, "V": V, "B": B,
-                "wsp_versions": self._wsp_versions if (split_on or self.mixed) else None} if keep_tape else None
+        # the tape remembers which kernel family (and which weight copies) its forward ran on: backward dispatches on
+        # that, not on the modules' per-call state, which a later forward (a small validation batch, another
+        # compute_dtype) may have changed in between
+        tape = {"img_feat": img_feat, "lifted": lifted, "hl": hl, "rel": rel, "saved": saved, "V": V, "B": B, "mode": "mixed" if self.mixed else "fp32",
+                "wbf": {id(m): list(m._wbf) for m in [self.lifter] + self.fusers + self.heads},
+                "wsp_versions": self._wsp_versions if self.mixed else None} if keep_tape else None
         return lifted.view(V, B, 3, NV), feats.view(I, D, B, 3, NV), preds.view(I, D, B, 2), tape
+
+    # ---------------------------------------------------------------- the split-operand path (fp32 model, >= SPLIT_MIN_ROWS rows)
+    _SLOTS = 64
+
+    def _forward_split(self, img_feat: Tensor, rot: Tensor, keep_tape: bool, ix: dict):
+        """The fuser / head Linears on the split kernels (conv_split.hip), every operand with its own power-of-two scale.
+
+        Per iteration: fuser L1 (hidden activation written in sp, scaled from a bound), fuser L2 (fp32 features + their
+        abs-max from the epilogue), ONE builder launch that writes this iteration's head input and the next iteration's
+        fuser input straight into sp (mvg_fuse_build_split), head L1, head L2 (512 -> 2).  No fp32 copy of an operand is
+        ever made and no separate abs-max / split pass runs: the scales come from device slots that the producing launches
+        fill (a 64-float arena owned by this call's tape)."""
+        V, B, cf = img_feat.shape
+        dev = img_feat.device
+        D, I, NV = ix["D"], self.I, NUM_FEAT_VEC
+        rows, kin = D * B, self.kin
+        assert 2 + I <= 8 and 11 * I + 2 <= self._SLOTS
+        self._prepare_split_weights(rows, dev)
+        st = torch.zeros(self._SLOTS, dtype=torch.float32, device=dev)          # abs-max slots must start at zero
+        names: Dict[str, int] = {}
+
+        def slot(name: str) -> Tensor:
+            i = names.setdefault(name, len(names))
+            return st[i:i + 1]
+
+        def sp(r: int, c: int, name: str) -> Tensor:
+            t = ops.sp_empty(r, c, device=dev)
+            t.sinv = slot(name)
+            return t
+        for m in [self.lifter] + self.fusers + self.heads:
+            m.split = False                          # (the modules' own forward / backward are the fp32-MFMA path: the lifter's)
+        hl, lifted = self.lifter.forward(img_feat.reshape(V * B, cf))
+        rel = torch.empty(D, B, 3, 3, dtype=torch.float32, device=dev)
+        ops.relative_rotation(rot.detach().to(torch.float32).contiguous(), ix["vi"], ix["vj"], rel, B, V, D)
+        rel_fuse = None if self.v.ignore_rotmat else rel
+        rt = self._row_tables(V, B, dev)
+        img2d = img_feat.reshape(V * B, cf)
+        ops.absmax_multi([img2d, lifted] + [self.fusers[it].b[0].detach() for it in range(I)],
+                         [slot("am_img"), slot("am_lift")] + [slot(f"bam{it}") for it in range(I)])
+        feats = torch.empty(I, rows, ROT_DIM, dtype=torch.float32, device=dev)
+        preds = torch.empty(I, rows, 2, dtype=torch.float32, device=dev)
+        hh = torch.empty(I, rows, self.heads[0].fout[0], dtype=torch.float32, device=dev)
+        xf = sp(rows, kin, "xf0")
+        ops.fuse_build_split(img2d, lifted, rel_fuse, rt["img"], rt["view"], None, xf, None, slot("am_img"), slot("am_lift"), rows, cf, NV)
+        saved = []
+        for it in range(I):
+            fu, hd = self.fusers[it], self.heads[it]
+            wf0, wf1, wh0 = fu._wsp[0], fu._wsp[1], hd._wsp[0]
+            hid, hhid = fu.fout[0], hd.fout[0]
+            h = sp(rows, hid, f"h{it}")
+            ops.linear_fprop_split(xf, wf0[0], fu.b[0].detach(), True, h, rows, kin, hid, bias_absmax=slot(f"bam{it}"))
+            ops.linear_fprop_split(h, wf1[0], fu.b[1].detach(), False, feats[it], rows, hid, ROT_DIM, out_absmax=slot(f"amF{it}"))
+            xh = sp(rows, kin, f"xh{it}")
+            xf_next = sp(rows, kin, f"xf{it + 1}") if it + 1 < I else None
+            ops.fuse_build_split(img2d, feats[it], rel_fuse, rt["img"], rt["partner"], rt["ident"], xf_next, xh, slot("am_img"),
+                                 slot(f"amF{it}"), rows, cf, NV)
+            ops.linear_fprop_split(xh, wh0[0], hd.b[0].detach(), True, hh[it], rows, kin, hhid)
+            ops.linear_skinny_fwd(hh[it], hd.w[1].detach(), hd.b[1].detach(), preds[it], rows, hhid, 2)
+            if keep_tape:
+                saved.append((xf, h, xh, hh[it], wf0, wf1, wh0))
+            xf = xf_next
+        tape = {"img_feat": img_feat, "lifted": lifted, "hl": hl, "rel": rel, "saved": saved, "V": V, "B": B, "mode": "split",
+                "st": st, "slot": slot, "wsp_versions": self._wsp_versions} if keep_tape else None
+        return lifted.view(V, B, 3, NV), feats.view(I, D, B, 3, NV), preds.view(I, D, B, 2), tape
+
+    def _backward_split(self, tape: dict, d_lifted: Optional[Tensor], d_feats: Optional[Tensor], d_preds: Optional[Tensor],
+                        sink: GradSink, side=None) -> Tensor:
+        """Backward of _forward_split.  Per iteration, on the critical path: head L2 backward (its dx with the abs-max),
+        [split + bias gradient -> head L1 dgrad], ONE mvg_fuse_unbuild (dF_it from the head input's and the next fuser
+        input's gradients, the image-feature gradient sums), then for fuser L2 and L1: split + bias gradient (one launch,
+        scaled from the slot the producer filled) -> dgrad (with the next abs-max in its epilogue).  Weight gradients run
+        on the side stream."""
+        V, B, cf, v = tape["V"], tape["B"], self.cf, self.v
+        img_feat, rel, st, slot = tape["img_feat"], tape["rel"], tape["st"], tape["slot"]
+        dev = img_feat.device
+        ix = self._indices(V, dev)
+        D, NV, I = ix["D"], NUM_FEAT_VEC, self.I
+        rows, kin = D * B, self.kin
+        wr = _Written(sink, side)
+        rel_fuse = None if v.ignore_rotmat else rel
+        da = torch.empty(V, B, cf, dtype=torch.float32, device=dev)
+        da_live = False
+        dXn: Optional[Tensor] = None                 # gradient of the NEXT iteration's fuser input
+
+        def sp(r: int, c: int, name: str) -> Tensor:
+            t = ops.sp_empty(r, c, device=dev)
+            t.sinv = slot(name)
+            return t
+
+        def wgrad(x_sp, g_sp, p, fin, fout, acc):
+            wr.off_path(lambda: ops.linear_wgrad_split(x_sp, g_sp, sink.view(p), rows, fin, fout, acc), x_sp, g_sp, st)
+
+        for it in range(I - 1, -1, -1):
+            xf, h, xh, hh, wf0, wf1, wh0 = tape["saved"][it]
+            fu, hd = self.fusers[it], self.heads[it]
+            hid, hhid = fu.fout[0], hd.fout[0]
+            dXh = None
+            if d_preds is not None:
+                gp = d_preds[it].reshape(rows, 2).contiguous()
+                a1, ab1 = wr.acc(hd.w[1]), wr.acc(hd.b[1])
+                assert a1 == ab1
+                dhh = torch.empty(rows, hhid, dtype=torch.float32, device=dev)
+                ops.linear_skinny_bwd(gp, hh, hd.w[1].detach(), hh, dhh, sink.view(hd.w[1]), sink.view(hd.b[1]), rows, hhid, 2, a1,
+                                      dx_absmax=slot(f"am_dhh{it}"))
+                a0, ab0 = wr.acc(hd.w[0]), wr.acc(hd.b[0])
+                assert a0 == ab0
+                g_hh = sp(rows, hhid, f"g_hh{it}")
+                ops.split_colsum(dhh, rows, hhid, slot(f"am_dhh{it}"), g_hh, sink.view(hd.b[0]), ab0)
+                wgrad(xh, g_hh, hd.w[0], kin, hhid, a0)
+                dXh = torch.empty(rows, kin, dtype=torch.float32, device=dev)
+                ops.linear_dgrad_split(g_hh, wh0[1], dXh, rows, kin, hhid)
+            else:
+                self._zero_grads(hd, sink, wr)
+            ext = d_feats[it].reshape(rows, ROT_DIM).contiguous() if d_feats is not None else None
+            if dXh is None and dXn is None and ext is None:
+                self._zero_grads(fu, sink, wr)
+                if not v.share_weights:
+                    sink.publish(hd.parameters() + fu.parameters())
+                continue
+            am_dF = slot(f"am_dF{it}")
+            if dXh is None and dXn is None:
+                dF = ext.clone()
+            else:
+                dF = torch.empty(rows, ROT_DIM, dtype=torch.float32, device=dev)
+                ops.fuse_unbuild(dXh, dXn, rel_fuse, ix["partner"], ix["vi"], dF, da, da_live, D, V, D, B, cf, NV,
+                                 absmax=am_dF if ext is None else None)
+                da_live = True
+                if ext is not None:
+                    ops.axpby(ext, dF, 1.0, 1.0)
+            if ext is not None:
+                ops.absmax_multi([dF], [am_dF])
+            # fuser layer 2: features <- hidden
+            a1, ab1 = wr.acc(fu.w[1]), wr.acc(fu.b[1])
+            assert a1 == ab1
+            g_F = sp(rows, ROT_DIM, f"g_F{it}")
+            ops.split_colsum(dF, rows, ROT_DIM, am_dF, g_F, sink.view(fu.b[1]), ab1)
+            wgrad(h, g_F, fu.w[1], hid, ROT_DIM, a1)
+            dh = torch.empty(rows, hid, dtype=torch.float32, device=dev)
+            ops.linear_dgrad_split(g_F, wf1[1], dh, rows, hid, ROT_DIM, relu_mask_sp=h, out_absmax=slot(f"am_dh{it}"))     # (g W) * (h > 0)
+            # fuser layer 1: hidden <- the built input
+            a0, ab0 = wr.acc(fu.w[0]), wr.acc(fu.b[0])
+            assert a0 == ab0
+            g_h = sp(rows, hid, f"g_h{it}")
+            ops.split_colsum(dh, rows, hid, slot(f"am_dh{it}"), g_h, sink.view(fu.b[0]), ab0)
+            wgrad(xf, g_h, fu.w[0], kin, hid, a0)
+            dXn = torch.empty(rows, kin, dtype=torch.float32, device=dev)
+            ops.linear_dgrad_split(g_h, wf0[1], dXn, rows, kin, hid)
+            if not v.share_weights:
+                sink.publish(hd.parameters() + fu.parameters())
+        if v.share_weights:
+            sink.publish(self.heads[0].parameters() + self.fusers[0].parameters())
+        dlift, dlift_live = None, False
+        if dXn is not None:
+            # iteration 0 read the partner VIEW's lifted feature: sum the directions per source view (and the last image-feature terms)
+            dlift = torch.empty(V * B, ROT_DIM, dtype=torch.float32, device=dev)
+            ops.fuse_unbuild(None, dXn, rel_fuse, ix["vj"], ix["vi"], dlift, da, da_live, V, V, D, B, cf, NV)
+            da_live = dlift_live = True
+        if d_lifted is not None:
+            ext = d_lifted.reshape(V * B, ROT_DIM).contiguous()
+            if dlift_live:
+                ops.axpby(ext, dlift, 1.0, 1.0)
+            else:
+                dlift, dlift_live = ext.clone(), True
+        dimg = da
+        if dlift_live:
+            self.lifter.split = self.lifter.mixed = False
+            self.lifter.backward(img_feat.reshape(V * B, cf), tape["hl"], dlift, sink, wr,
+                                 dx_addend=dimg.view(V * B, cf) if da_live else None, dx_out=dimg.view(V * B, cf))
+            da_live = True
+        else:
+            self._zero_grads(self.lifter, sink, wr)
+        sink.publish(self.lifter.parameters())
+        if not da_live:
+            dimg.zero_()
+        return dimg
 
     # ---------------------------------------------------------------- backward
     def backward(self, tape: dict, d_lifted: Optional[Tensor], d_feats: Optional[Tensor], d_preds: Optional[Tensor],
@@ -472,6 +651,14 @@ class FusionHead:
             raise RuntimeError("backward of a tape whose sp weight copies were overwritten by a later forward with DIFFERENT "
                                "weights (forward, optimizer step, forward, then backward of the first call): run backward "
                                "before the weights change")
+        if tape.get("mode") == "split":
+            return self._backward_split(tape, d_lifted, d_feats, d_preds, sink, side)
+        # the kernel family this tape's forward ran on (not whatever a later forward left on the modules)
+        for m in [self.lifter] + self.fusers + self.heads:
+            m.split = False
+            m.mixed = tape.get("mode") == "mixed"
+            if "wbf" in tape:
+                m._wbf = list(tape["wbf"][id(m)])
         img_feat, rel = tape["img_feat"], tape["rel"]
         dev = img_feat.device
         ix = self._indices(V, dev)

@@ -118,23 +118,16 @@ class StereoL1Loss(AbstractLoss):
 
 class _FusedIterLossFn(torch.autograd.Function):
     """sum_it w_it * sum_d c_d * mean_b theta(pred[it,d,b], gt[d,b]) over the head's stacked
-    prediction buffer [I,D,B,2]: I launches, gradient written once for all rows."""
+    prediction buffer [I,D,B,2]: one launch, gradient written once for all rows."""
 
     @staticmethod
     def forward(ctx, preds: Tensor, gt_dir: Tensor, iter_w, dir_w):
         I, D, B, _ = preds.shape
         p = preds.detach().contiguous()
-        loss = torch.zeros(1, dtype=torch.float32, device=p.device)
+        loss = torch.empty(1, dtype=torch.float32, device=p.device)
         dpred = torch.empty_like(p) if ctx.needs_input_grad[0] else None
-        uniform = all(abs(w - dir_w[0]) == 0.0 for w in dir_w)
-        for it in range(I):
-            if uniform:
-                ops.gaze_angular_loss(p[it], gt_dir, D * B, iter_w[it] * dir_w[0] / B, loss, True,
-                                      dpred[it] if dpred is not None else None, None)
-            else:
-                for d in range(D):
-                    ops.gaze_angular_loss(p[it, d], gt_dir[d], B, iter_w[it] * dir_w[d] / B, loss, True,
-                                          dpred[it, d] if dpred is not None else None, None)
+        # every iteration and direction in ONE launch (row weight = iter_w[it] * dir_w[d] / B)
+        ops.gaze_angular_loss_multi(p, gt_dir.contiguous(), I, D, B, [iter_w[it] * dir_w[d] for it in range(I) for d in range(D)], loss, dpred)
         ctx.dpred = dpred
         return loss.reshape(())
 

@@ -626,9 +626,9 @@ def linear_skinny_fwd(x, w, bias, y, rows, k, nout):
     check(lib().mvg_linear_skinny_fwd(_p(x), _p(w), _p(bias), _p(y), rows, k, nout, _s()), "linear_skinny_fwd")
 
 
-def linear_skinny_bwd(dy, x, w, mask, dx, dw, db, rows, k, nout, accumulate=False):
+def linear_skinny_bwd(dy, x, w, mask, dx, dw, db, rows, k, nout, accumulate=False, dx_absmax=None):
     check(lib().mvg_linear_skinny_bwd(_p(dy), _p(x), _p(w), _p(mask), _p(dx), _p(dw), _p(db), rows, k, nout,
-                                      int(accumulate), _s()), "linear_skinny_bwd")
+                                      int(accumulate), _p(dx_absmax), _s()), "linear_skinny_bwd")
 
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step):
@@ -647,6 +647,72 @@ def gaze_angular_loss(pred, gt, n, row_weight, loss, accumulate=False, dpred=Non
 
 def gaze_lp_loss(pred, label, n, p, loss, dpred=None):
     check(lib().mvg_gaze_lp_loss(_p(pred), _p(label), n, p, _p(loss), _p(dpred), _s()), "gaze_lp_loss")
+
+
+# ---------------------------------------------------------------- the fusion block on the split kernels
+# Device "slots" are 1-element fp32 views into one per-model statistics arena that heads.FusionHead clears once per
+# step: abs-max slots hold a float's bits (atomicMax), sinv slots the 2^-k of a scaled sp tensor.
+def absmax_multi(tensors, slots):
+    """slots[i] <- max |tensors[i]| (bits), one launch for up to 8 small fp32 tensors."""
+    n = len(tensors)
+    assert 1 <= n <= 8 and n == len(slots)
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in tensors])
+    cnts = (C.c_int64 * n)(*[t.numel() for t in tensors])
+    outs = (C.c_void_p * n)(*[t.data_ptr() for t in slots])
+    for t in tensors:
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+    check(lib().mvg_absmax_multi(ptrs, cnts, outs, n, _s()), "absmax_multi")
+
+
+def fuse_build_split(img_feat, feat, rel, row_img, row_src_f, row_src_h, xf_sp, xh_sp, am_img, am_feat, rows, cf, nvec):
+    """xf_sp / xh_sp (sp tensors or None) <- the next fuser input / this head input built from `feat`; their .sinv slots are written."""
+    check(lib().mvg_fuse_build_split(_p(img_feat), _p(feat), _p(rel), _p(row_img), _p(row_src_f), _p(row_src_h), _p(xf_sp), _p(xh_sp),
+                                     _p(am_img), _p(am_feat), _sinv(xf_sp), _sinv(xh_sp), rows, cf, nvec, _s()), "fuse_build_split")
+
+
+def fuse_unbuild(dxh, dxn, rel, seg, vi, dfeat, da, da_accumulate, segments, views, dirs, batch, cf, nvec, absmax=None):
+    check(lib().mvg_fuse_unbuild(_p(dxh), _p(dxn), _p(rel), _p(seg), _p(vi), _p(dfeat), _p(da), int(da_accumulate), segments, views, dirs,
+                                 batch, cf, nvec, _p(absmax), _s()), "fuse_unbuild")
+
+
+def linear_fprop_split(x_sp, w_sp, bias, relu, out, rows, fin, fout, bias_absmax=None, out_absmax=None):
+    """out = relu?(x W^T + bias) on the split kernels; out: an fp32 tensor, or an sp tensor whose .sinv slot receives its 2^-k."""
+    check(lib().mvg_linear_fprop_split(rows, fin, fout, _p(x_sp), _sinv(x_sp), _p(w_sp), _sinv(w_sp), _p(bias), int(relu), _p(out),
+                                       int(is_sp(out)), _sinv(out) if is_sp(out) else None, _p(bias_absmax), _p(out_absmax), _s()),
+          "linear_fprop_split")
+
+
+def linear_dgrad_split(dy_sp, wt_sp, dx, rows, fin, fout, addend=None, relu_mask_sp=None, out_absmax=None):
+    check(lib().mvg_linear_dgrad_split(rows, fin, fout, _p(dy_sp), _sinv(dy_sp), _p(wt_sp), _sinv(wt_sp), _p(dx), _p(addend),
+                                       _p(relu_mask_sp), _p(out_absmax), _s()), "linear_dgrad_split")
+
+
+def linear_wgrad_split(x_sp, dy_sp, dw, rows, fin, fout, accumulate=False):
+    d = ConvDesc.make(1, rows, 1, 1, fin, fout, 1, 1, 0)
+    splits = lib().mvg_conv_wgrad_splits_split(C.byref(d))
+    if splits < 1:
+        check(1, "conv_wgrad_splits_split")
+    ws = torch.empty(splits * dw.numel(), dtype=torch.float32, device=dw.device) if splits > 1 else None
+    check(lib().mvg_linear_wgrad_split(rows, fin, fout, _p(x_sp), _sinv(x_sp), _p(dy_sp), _sinv(dy_sp), _p(dw), _p(ws), splits,
+                                       int(accumulate), _s()), "linear_wgrad_split")
+
+
+def split_colsum(g, rows, cols, absmax, out_sp, db=None, accumulate=False):
+    """out_sp <- g in sp, scaled from the abs-max slot its producer filled (out_sp.sinv slot written); db (+)= column sums of g."""
+    assert g.dtype == torch.float32 and g.is_contiguous() and g.numel() == rows * cols and cols % 32 == 0
+    check(lib().mvg_split_colsum(_p(g), rows, cols, _p(absmax), _p(out_sp), _sinv(out_sp), _p(db), int(accumulate), _s()), "split_colsum")
+
+
+def gaze_angular_loss_multi(pred, gt, iters, dirs, batch, weights, loss, dpred=None):
+    w = (C.c_float * (iters * dirs))(*[float(x) for x in weights])
+    check(lib().mvg_gaze_angular_loss_multi(_p(pred), _p(gt), iters, dirs, batch, w, _p(loss), _p(dpred), _s()), "gaze_angular_loss_multi")
+
+
+def adam_step_dev(param, grad, exp_avg, exp_avg_sq, lr_dev, state3, beta1, beta2, eps, weight_decay):
+    check(lib().mvg_adam_step_dev(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), _p(lr_dev), _p(state3), beta1, beta2, eps,
+                                  weight_decay, _s()), "adam_step_dev")
+    for t in (param, exp_avg, exp_avg_sq):
+        torch.autograd.graph.increment_version(t)
 
 
 # ---------------------------------------------------------------- profiling

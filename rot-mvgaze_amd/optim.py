@@ -17,7 +17,7 @@ from . import ops
 
 
 class Adam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, capturable=False):
         if lr < 0 or eps < 0 or weight_decay < 0 or not (0 <= betas[0] < 1 and 0 <= betas[1] < 1):
             raise ValueError("invalid Adam hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
@@ -25,6 +25,22 @@ class Adam(torch.optim.Optimizer):
             raise NotImplementedError("one parameter group (the reference uses one)")
         self._flat: Dict[int, dict] = {}
         self._pending = None          # moments restored by load_state_dict, adopted by the next step()
+        # capturable (like torch.optim.Adam's flag): the step counter, the bias corrections and the learning rate live on
+        # the DEVICE (mvg_adam_step_dev), so that a step captured in a hipGraph (rot_mvgaze_amd.graph.GraphedStep) replays
+        # with nothing from the host; the learning rate is pushed to the device by sync_lr() - outside a capture - whenever
+        # the scheduler changed it (the reference steps CyclicLR once per epoch, trainer.py:147).
+        self.capturable = bool(capturable)
+
+    def sync_lr(self):
+        """capturable: copy param_groups[0]['lr'] to the device scalar the captured update reads (no-op when unchanged)."""
+        lr = float(self.param_groups[0]["lr"])
+        for st in self._flat.values():
+            if "lr_dev" in st and st["lr_host"] != lr:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("Adam(capturable=True): the learning rate changed inside a graph capture; call "
+                                       "optimizer.sync_lr() before capturing / replaying")
+                st["lr_dev"].fill_(lr)
+                st["lr_host"] = lr
 
     def _owners(self):
         owners = {}
@@ -71,8 +87,20 @@ class Adam(torch.optim.Optimizer):
                       "exp_avg_sq": torch.zeros_like(arena_p)}
                 self._flat[id(model)] = st
             st["step"] += 1
-            ops.adam_step(arena_p, arena_g, st["exp_avg"], st["exp_avg_sq"], float(g["lr"]), float(g["betas"][0]),
-                          float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), st["step"])
+            if self.capturable:
+                if "lr_dev" not in st:
+                    if torch.cuda.is_current_stream_capturing():
+                        raise RuntimeError("Adam(capturable=True): run one eager step before capturing (its device state is created then)")
+                    st["lr_dev"] = torch.full((1,), float(g["lr"]), dtype=torch.float32, device=arena_p.device)
+                    st["lr_host"] = float(g["lr"])
+                    # {step, 1 - beta1^step, sqrt(1 - beta2^step)}: advanced on the device by every (captured or eager) step
+                    st["state3"] = torch.tensor([float(st["step"] - 1), 0.0, 0.0], dtype=torch.float32).to(arena_p.device)
+                self.sync_lr()
+                ops.adam_step_dev(arena_p, arena_g, st["exp_avg"], st["exp_avg_sq"], st["lr_dev"], st["state3"], float(g["betas"][0]),
+                                  float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]))
+            else:
+                ops.adam_step(arena_p, arena_g, st["exp_avg"], st["exp_avg_sq"], float(g["lr"]), float(g["betas"][0]),
+                              float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), st["step"])
             # the parameters alias the arena through `.data` (their own version counters): mark them modified, as an
             # in-place torch op would (the inference path's cache of split weights keys on the version)
             for (p, _, _) in entries:
@@ -88,6 +116,8 @@ class Adam(torch.optim.Optimizer):
         for model in self._owners():
             st = self._flat.get(id(model))
             if st is not None:
+                if "state3" in st:                  # capturable: the device counter is the truth (graph replays advance it)
+                    st["step"] = int(round(float(st["state3"][0].item())))
                 flat.append({"step": st["step"], "exp_avg": st["exp_avg"].detach().clone(),
                              "exp_avg_sq": st["exp_avg_sq"].detach().clone()})
         sd["mvg_arena_state"] = flat

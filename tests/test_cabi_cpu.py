@@ -33,7 +33,7 @@ def test_header_symbols_exported(built_lib):
     for name in declared:
         assert hasattr(built_lib, name), f"{name} declared in include/rotmvgaze.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert built_lib.mvg_abi_version() == _lib.ABI_VERSION == 9
+    assert built_lib.mvg_abi_version() == _lib.ABI_VERSION == 10
 
 
 def test_pair_index_bit_exact(built_lib, golden_dir):
