@@ -530,18 +530,21 @@ int mvg_conv_dgrad_split(const mvg_conv_desc *d, const void *dy_sp, const float 
  * relu_shift).  relu_bits as in mvg_bn_apply_bits (1 byte per 4 channels).  mvg_avgpool_fwd_split pools an sp map.
  * dy is stored times 2^k, k from the bound  max over (group, channel) of |gamma invstd| (mx + |s1|/n + sqrt(n) |s2|/n) >= |dy|,
  * mx [groups][c] = max |masked gradient| per (group, channel), left by mvg_bn_bwd_reduce_split or
- * mvg_conv_dgrad_split_bnreduce; *dy_sinv receives 2^-k for mvg_conv_dgrad_split / _wgrad_split. */
+ * mvg_conv_dgrad_split_bnreduce; *dy_sinv receives 2^-k for mvg_conv_dgrad_split / _wgrad_split.  The reduce entries
+ * (mvg_bn_bwd_reduce_split, mvg_conv_dgrad_split_bnreduce, mvg_bn_relu_maxpool_bwd_reduce_split) take the unit's gamma and
+ * dy_sinv (both NULL, or both given): their finalize launch then leaves *dy_sinv itself - partials, dgamma / dbeta and the
+ * bound in ONE launch, folded into the last-arriving workgroups - and the apply entry is told so (dy_sinv_ready != 0). */
 int mvg_bn_apply_split(const float *y, const float *scale, const float *shift, const void *residual, int residual_s3,
                        const float *res_scale, const float *res_shift, int relu, void *out_s3, uint8_t *relu_bits,
                        int groups, int64_t rows_per_group, int c, void *stream);
 int mvg_bn_bwd_reduce_split(const float *g, const uint8_t *relu_bits, const float *y, const float *mean, const float *invstd,
                             const float *relu_scale, const float *relu_shift, int groups, int64_t rows_per_group, int c,
                             float *s1, float *s2, float *dgamma, float *dbeta, int accumulate, float *workspace,
-                            float *dz_out, float *mx, void *stream);
+                            float *dz_out, float *mx, const float *gamma, float *dy_sinv, void *stream);
 int mvg_bn_bwd_apply_split(const float *g, const float *y, const float *mean, const float *invstd, const float *gamma,
                            const float *s1, const float *s2, const float *relu_scale, const float *relu_shift,
                            int groups, int64_t rows_per_group, int c, void *dy_s3, const float *mx, float *dy_sinv,
-                           void *stream);
+                           int dy_sinv_ready, void *stream);
 int mvg_bn_relu_maxpool_fwd_split(const float *y, const float *scale, const float *shift, void *pooled_s3,
                                   uint8_t *argmax, int groups, int n_per_group, int h, int w, int c, int ho, int wo,
                                   void *stream);
@@ -555,7 +558,7 @@ int mvg_conv_dgrad_split_bnreduce(const mvg_conv_desc *d, const void *dy_sp, con
                                   const float *w_sinv, float *dx, const float *addend, const float *bn_y, const uint8_t *bn_bits,
                                   const float *bn_mean, const float *bn_invstd, const float *relu_scale, const float *relu_shift,
                                   float *partials, float *s1, float *s2, float *dgamma, float *dbeta, int accumulate,
-                                  float *mx, void *stream);
+                                  float *mx, const float *bn_gamma, float *dx_dy_sinv, void *stream);
 /* The 7x7 stride-2 stem (resnet.py:184, ResNet.forward :262) on the split kernels, "row-window" form: the 3-channel image
  * (stored NHWC with 4 channels) is rewritten as xw [images][h][w/2][8][4] in sp - window ox holds image columns 2 ox - 4 ..
  * 2 ox + 3, zero outside the image - and the stem becomes a 7 x 1 filter over 32 "channels" (vertical stride 2 / pad 3,
@@ -579,11 +582,12 @@ int mvg_stem_wgrad_split(const mvg_conv_desc *d, const void *xw_sp, const void *
 int mvg_bn_relu_maxpool_bwd_reduce_split(const float *g_pooled, const uint8_t *argmax, const float *y, const float *mean,
                                          const float *invstd, const float *scale, const float *shift, int groups,
                                          int n_per_group, int h, int w, int c, int ho, int wo, float *s1, float *s2,
-                                         float *dgamma, float *dbeta, int accumulate, float *workspace, float *mx, void *stream);
+                                         float *dgamma, float *dbeta, int accumulate, float *workspace, float *mx, const float *gamma,
+                                         float *dy_sinv, void *stream);
 int mvg_bn_relu_maxpool_bwd_apply_split(const float *g_pooled, const uint8_t *argmax, const float *y, const float *mean,
                                         const float *invstd, const float *gamma, const float *scale, const float *shift,
                                         const float *s1, const float *s2, int groups, int n_per_group, int h, int w, int c,
-                                        int ho, int wo, void *dy_s3, const float *mx, float *dy_sinv, void *stream);
+                                        int ho, int wo, void *dy_s3, const float *mx, float *dy_sinv, int dy_sinv_ready, void *stream);
 int mvg_conv_wgrad_splits_split(const mvg_conv_desc *d);   /* pixel-split count; workspace = splits * cout*r*s*cin floats */
 int mvg_conv_wgrad_split(const mvg_conv_desc *d, const void *x_sp, const void *dy_sp, const float *dy_sinv, float *dw,
                          float *workspace, int splits, int accumulate, void *stream);

@@ -81,8 +81,8 @@ SIGNATURES = {
     "mvg_colsum_absmax": (_I, [_P, _I, _I, _P, _I, _P, _P, _P]),
     "mvg_split_f32_dev": (_I, [_P, _P, _I64, _P, _P]),
     "mvg_bn_apply_split": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _I, _I64, _I, _P]),
-    "mvg_bn_bwd_apply_split": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _P, _P, _P, _P]),
-    "mvg_bn_bwd_reduce_split": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
+    "mvg_bn_bwd_apply_split": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _P, _P, _P, _I, _P]),
+    "mvg_bn_bwd_reduce_split": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
     "mvg_bn_relu_maxpool_fwd_split": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mvg_avgpool_fwd_split": (_I, [_P, _P, _I, _I, _I, _P]),
     "mvg_stem_rowwindow_split": (_I, [_P, _P, _I64, _I, _I, _P]),
@@ -90,10 +90,10 @@ SIGNATURES = {
     "mvg_stem_fprop_split": (_I, [_D, _P, _P, _P, _P, _P, _P]),
     "mvg_stem_wgrad_splits_split": (_I, [_D]),
     "mvg_stem_wgrad_split": (_I, [_D, _P, _P, _P, _P, _P, _I, _I, _P]),
-    "mvg_bn_relu_maxpool_bwd_reduce_split": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
-    "mvg_bn_relu_maxpool_bwd_apply_split": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "mvg_bn_relu_maxpool_bwd_reduce_split": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
+    "mvg_bn_relu_maxpool_bwd_apply_split": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
     "mvg_conv_dgrad_bn_partials_split": (_I, [_D]),
-    "mvg_conv_dgrad_split_bnreduce": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "mvg_conv_dgrad_split_bnreduce": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
     "mvg_conv_wgrad_splits_split": (_I, [_D]),
     "mvg_conv_wgrad_split": (_I, [_D, _P, _P, _P, _P, _P, _I, _I, _P]),
     "mvg_bn_apply_bits": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _P]),

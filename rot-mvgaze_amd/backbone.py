@@ -452,9 +452,9 @@ class Backbone:
         gp, bp = self.p[c.bn + ".weight"], self.p[c.bn + ".bias"]
         if u.fused_s12 is not None and u.split:
             # split path, fused: g arrived masked and the sums came with it; dy goes out in s3
-            s12, u.fused_s12 = u.fused_s12, None
+            (s12, sinv), u.fused_s12 = u.fused_s12, None
             dy = ops.sp_empty(*u.y.shape, device=g.device)
-            ops.bn_bwd_apply_split(g, u.y, u.mean, u.invstd, gp.detach(), s12[0], s12[1], G, u.rows, c.cout, dy, None, s12[2])
+            ops.bn_bwd_apply_split(g, u.y, u.mean, u.invstd, gp.detach(), s12[0], s12[1], G, u.rows, c.cout, dy, None, s12[2], sinv)
             return dy, (g if need_dz else None)
         if u.fused_s12 is not None:
             # g arrived masked by this unit's ReLU and its sums (incl. dgamma / dbeta) came with it
@@ -470,15 +470,16 @@ class Backbone:
         if u.split:
             # split path: g and y are fp32, dy goes to the conv kernels in s3; residual units carry their mask as bits
             assert not (u.relu and ra is None) or u.relu_bits is not None
+            sinv = torch.empty(1, dtype=torch.float32, device=g.device)       # dy's 2^-k: left by the reduce pass's finalize launch
             if u.relu_bits is not None:
                 ops.bn_bwd_reduce_split(g, u.relu_bits, u.y, u.mean, u.invstd, G, u.rows, c.cout, s12[0], s12[1], sink.view(gp),
-                                        sink.view(bp), acc, s12[2], None, dz_out=g)
+                                        sink.view(bp), acc, s12[2], None, dz_out=g, gamma=gp.detach(), dy_sinv=sinv)
             else:
                 ops.bn_bwd_reduce_split(g, None, u.y, u.mean, u.invstd, G, u.rows, c.cout, s12[0], s12[1], sink.view(gp),
-                                        sink.view(bp), acc, s12[2], ra)
+                                        sink.view(bp), acc, s12[2], ra, gamma=gp.detach(), dy_sinv=sinv)
             dy = ops.sp_empty(*u.y.shape, device=g.device)
             ops.bn_bwd_apply_split(g, u.y, u.mean, u.invstd, gp.detach(), s12[0], s12[1], G, u.rows, c.cout, dy,
-                                   None if u.relu_bits is not None else ra, s12[2])
+                                   None if u.relu_bits is not None else ra, s12[2], sinv)
             return dy, (g if need_dz else None)
         if need_dz:
             # the reduce pass writes the masked gradient dz over g: the apply pass then reads (dz, y) only - no
@@ -590,10 +591,11 @@ class Backbone:
                 acc = sink.accumulate(gp)
                 assert acc == sink.accumulate(bp)
                 s12 = torch.empty(3, dx.shape[0], c.cout, dtype=torch.float32, device=dx.device)     # s1, s2, max |dz| per channel
+                sinv = torch.empty(1, dtype=torch.float32, device=dx.device)      # 2^-k of the dy that U's apply pass will write
                 ops.conv_dgrad_split_bnreduce(u.desc, dy, u.w, dx, addend, U.y, U.relu_bits, U.mean, U.invstd,
                                               None if U.relu_bits is not None else U.relu_affine, s12[0], s12[1], sink.view(gp),
-                                              sink.view(bp), acc, s12[2])
-                U.fused_s12 = s12
+                                              sink.view(bp), acc, s12[2], gp.detach(), sinv)
+                U.fused_s12 = (s12, sinv)
                 return
             ops.conv_dgrad_split(u.desc, dy, u.w, dx, addend)
             return
@@ -664,11 +666,12 @@ class Backbone:
         assert acc == sink.accumulate(bp)
         if stem_sp:
             # the stem's weight gradient runs on the split kernels: dy goes out in sp, scaled by a bound from the reduce pass
+            sinv = torch.empty(1, dtype=torch.float32, device=g.device)
             ops.bn_relu_maxpool_bwd_reduce_split(g, argmax, stem.y, stem.mean, stem.invstd, scale, shift, V, B, H1, W1, sc.cout, Hp, Wp,
-                                                 s12[0], s12[1], sink.view(gp), sink.view(bp), acc, s12[2])
+                                                 s12[0], s12[1], sink.view(gp), sink.view(bp), acc, s12[2], gp.detach(), sinv)
             dy = ops.sp_empty(*stem.y.shape, device=g.device)
             ops.bn_relu_maxpool_bwd_apply_split(g, argmax, stem.y, stem.mean, stem.invstd, gp.detach(), scale, shift, s12[0], s12[1],
-                                                V, B, H1, W1, sc.cout, Hp, Wp, dy, s12[2])
+                                                V, B, H1, W1, sc.cout, Hp, Wp, dy, s12[2], sinv)
         else:
             ops.bn_relu_maxpool_bwd_reduce(g, argmax, stem.y, stem.mean, stem.invstd, scale, shift, V, B, H1, W1, sc.cout, Hp, Wp,
                                            s12[0], s12[1], sink.view(gp), sink.view(bp), acc)

@@ -20,6 +20,25 @@ void prof_end(int family, hipStream_t s);
 // ordered by the stream, so every kernel sequence that finishes with its scratch before the next launch on that
 // stream may share it (stream-K pieces, bn_finalize slices).  The library allocates nothing.
 float *stream_scratch(hipStream_t st, size_t floats);
+// ... and its arrival-counter area (kCounterFloats 32-bit counters, all zero between kernels), or nullptr.  Kernels that
+// fold a "finalize" step into their last-arriving workgroup count arrivals here (bn.hip).
+constexpr size_t kCounterFloats = 4096;
+unsigned *stream_counters(hipStream_t st);
+
+// Cross-workgroup hand-off (MI355X_MICROARCH.md, "Valid forms"): every storing wave has waited for its stores and the
+// workgroup has met at a barrier BEFORE thread 0 calls this; it releases the workgroup's stores at agent scope, counts the
+// arrival, and - when this workgroup is the `expected`-th, i.e. last - resets the counter and acquires, so that after
+// the barrier that follows, plain loads of the other workgroups' data are fresh.  Returns 1 for the last arriver.
+__device__ __forceinline__ int arrive_and_check_last(unsigned *counter, unsigned expected) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (old + 1u != expected) return 0;
+  __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  return 1;
+}
 // device CUs minus mvg_set_reserved_cus(): what stream-K grids, wgrad splits and split-K plan for
 int compute_cus();
 
@@ -29,7 +48,10 @@ int compute_cus();
 // raw_mean / raw_invstd != nullptr: the partials' second row is the uncentred sum(dz * y); s2 = invstd * (it - mean * s1).
 int bn_bwd_finalize_launch(const float *partial, int groups, int chunks, int c, float *s1, float *s2, float *dgamma,
                            float *dbeta, int accumulate, hipStream_t st, float *mx = nullptr, const float *raw_mean = nullptr,
-                           const float *raw_invstd = nullptr);
+                           const float *raw_invstd = nullptr, const float *gamma = nullptr, const float *invstd = nullptr,
+                           long long rows = 0, float *dy_sinv = nullptr);
+// (gamma, invstd, rows, dy_sinv: split path - the same launch also leaves *dy_sinv = 2^-k for the unit's dy, from the bound
+// max |gamma invstd| (mx + |s1| / rows + sqrt(rows) |s2| / rows): what bn_dy_scale_kernel computes)
 
 struct ProfScope {
   int fam;

@@ -1133,8 +1133,10 @@ int mvg_conv_dgrad_split_bnreduce(const mvg_conv_desc *d, const void *dy_sp, con
                                   const float *w_sinv, float *dx, const float *addend, const float *bn_y, const uint8_t *bn_bits,
                                   const float *bn_mean, const float *bn_invstd, const float *relu_scale, const float *relu_shift,
                                   float *partials, float *s1, float *s2, float *dgamma, float *dbeta, int accumulate,
-                                  float *mx, void *stream) {
+                                  float *mx, const float *bn_gamma, float *dx_dy_sinv, void *stream) {
+  // (dx_dy_sinv: receives the 2^-k of the dy that mvg_bn_bwd_apply_split will make from dx - the NEXT unit down the chain)
   MVG_REQUIRE(bn_y && bn_mean && bn_invstd && partials && s1 && s2, "dgrad_split_bnreduce: null argument");
+  MVG_REQUIRE((bn_gamma == nullptr) == (dx_dy_sinv == nullptr) && (!dx_dy_sinv || mx), "dgrad_split_bnreduce: bn_gamma, dx_dy_sinv (and mx) go together");
   MVG_REQUIRE(!(bn_bits && relu_scale) && ((relu_scale == nullptr) == (relu_shift == nullptr)),
               "dgrad_split_bnreduce: give the ReLU mask either as bits or as (relu_scale, relu_shift)");
   const int P = mvg_conv_dgrad_bn_partials_split(d);
@@ -1142,7 +1144,8 @@ int mvg_conv_dgrad_split_bnreduce(const mvg_conv_desc *d, const void *dy_sp, con
   const SplitBnFuse f = {bn_y, bn_bits, bn_mean, bn_invstd, relu_scale, relu_shift, partials, mx ? 3 : 2};
   if (dgrad_split_impl(d, dy_sp, dy_sinv, w_crsk_sp, w_sinv, dx, addend, stream, &f)) return 1;
   ProfScope ps(MVG_K_BN_BWD_REDUCE, (hipStream_t)stream, 0.0, 8.0 * d->groups * (double)P * d->cin);
-  return bn_bwd_finalize_launch(partials, d->groups, P, d->cin, s1, s2, dgamma, dbeta, accumulate, (hipStream_t)stream, mx);
+  return bn_bwd_finalize_launch(partials, d->groups, P, d->cin, s1, s2, dgamma, dbeta, accumulate, (hipStream_t)stream, mx, nullptr, nullptr,
+                                bn_gamma, bn_invstd, (long long)d->n * d->h * d->w, dx_dy_sinv);
 }
 
 static void wgrad_split_tile(const mvg_conv_desc *d, int &bm, int &bn) {

@@ -278,20 +278,23 @@ def stem_wgrad_split(d: ConvDesc, xw: Tensor, dy_sp: Tensor, dw_rw: Tensor, accu
 
 
 def bn_relu_maxpool_bwd_reduce_split(g_pooled, argmax, y, mean, invstd, scale, shift, groups, n_per_group, h, w, c, ho, wo, s1, s2,
-                                     dgamma, dbeta, accumulate, mx):
+                                     dgamma, dbeta, accumulate, mx, gamma=None, dy_sinv=None):
+    """gamma + dy_sinv (a 1-element device tensor): the finalize launch also leaves the 2^-k of the dy the apply pass will write."""
     n = lib().mvg_bn_bwd_workspace_floats(groups, n_per_group * h * w, c)
     ws = torch.empty(n, dtype=torch.float32, device=y.device)
     check(lib().mvg_bn_relu_maxpool_bwd_reduce_split(_p(g_pooled), _p(argmax), _p(y), _p(mean), _p(invstd), _p(scale), _p(shift), groups,
                                                      n_per_group, h, w, c, ho, wo, _p(s1), _p(s2), _p(dgamma), _p(dbeta), int(accumulate),
-                                                     _p(ws), _p(mx), _s()), "bn_relu_maxpool_bwd_reduce_split")
+                                                     _p(ws), _p(mx), _p(gamma), _p(dy_sinv), _s(True)), "bn_relu_maxpool_bwd_reduce_split")
 
 
 def bn_relu_maxpool_bwd_apply_split(g_pooled, argmax, y, mean, invstd, gamma, scale, shift, s1, s2, groups, n_per_group, h, w, c, ho, wo,
-                                    dy_sp, mx):
-    dy_sp.sinv = torch.empty(1, dtype=torch.float32, device=y.device)
+                                    dy_sp, mx, dy_sinv=None):
+    """dy_sinv: the slot the reduce pass already filled (else this call computes the scale itself)."""
+    ready = dy_sinv is not None
+    dy_sp.sinv = dy_sinv if ready else torch.empty(1, dtype=torch.float32, device=y.device)
     check(lib().mvg_bn_relu_maxpool_bwd_apply_split(_p(g_pooled), _p(argmax), _p(y), _p(mean), _p(invstd), _p(gamma), _p(scale), _p(shift),
                                                     _p(s1), _p(s2), groups, n_per_group, h, w, c, ho, wo, _p(dy_sp), _p(mx), _p(dy_sp.sinv),
-                                                    _s()), "bn_relu_maxpool_bwd_apply_split")
+                                                    int(ready), _s()), "bn_relu_maxpool_bwd_apply_split")
 
 
 def stem_rowwindow_bf16(x_nchw: Tensor, out: Tensor):
@@ -323,7 +326,8 @@ def conv_dgrad_bn_partials_split(d: ConvDesc) -> int:
 
 
 def conv_dgrad_split_bnreduce(d: ConvDesc, dy_s3, wt_s3, dx, addend, bn_y, bn_bits, bn_mean, bn_invstd, relu_affine, s1, s2, dgamma,
-                              dbeta, accumulate: bool, mx: Optional[Tensor] = None):
+                              dbeta, accumulate: bool, mx: Optional[Tensor] = None, bn_gamma: Optional[Tensor] = None,
+                              dx_dy_sinv: Optional[Tensor] = None):
     """conv_dgrad_split + the BatchNorm-backward reduce pass of the unit whose output gradient dx is, in one launch.
     mx [groups, cin]: receives max |dx| per (group, channel) (bn_bwd_apply_split's bound)."""
     P = conv_dgrad_bn_partials_split(d)
@@ -331,7 +335,8 @@ def conv_dgrad_split_bnreduce(d: ConvDesc, dy_s3, wt_s3, dx, addend, bn_y, bn_bi
     rs, rh = relu_affine if relu_affine is not None else (None, None)
     check(lib().mvg_conv_dgrad_split_bnreduce(C.byref(d), _p(dy_s3), _sinv(dy_s3), _p(wt_s3), _sinv(wt_s3), _p(dx), _p(addend), _p(bn_y),
                                               _p(bn_bits), _p(bn_mean), _p(bn_invstd), _p(rs), _p(rh), _p(part), _p(s1), _p(s2),
-                                              _p(dgamma), _p(dbeta), int(accumulate), _p(mx), _s()), "conv_dgrad_split_bnreduce")
+                                              _p(dgamma), _p(dbeta), int(accumulate), _p(mx), _p(bn_gamma), _p(dx_dy_sinv), _s(True)),
+          "conv_dgrad_split_bnreduce")
 
 
 def conv_dgrad_bf16_bnreduce(d: ConvDesc, dy, wt, dx, addend, bn_y, bn_bits, bn_mean, bn_invstd, relu_affine, s1, s2, dgamma, dbeta,
@@ -369,25 +374,26 @@ def bn_apply_split(y, scale, shift, residual, relu, out_s3, groups, rows_per_gro
 
 
 def bn_bwd_reduce_split(g, relu_bits, y, mean, invstd, groups, rows_per_group, c, s1, s2, dgamma, dbeta, accumulate, mx,
-                        relu_affine=None, dz_out=None):
+                        relu_affine=None, dz_out=None, gamma=None, dy_sinv=None):
     """The backward reduce pass of a unit whose dy goes out in sp: s1, s2 (+ dgamma, dbeta) and mx [groups, c] = max |masked
     gradient| per (group, channel)."""
     rs, rh = relu_affine if relu_affine is not None else (None, None)
     n = lib().mvg_bn_bwd_workspace_floats(groups, rows_per_group, c)
     ws = torch.empty(n, dtype=torch.float32, device=g.device)
     check(lib().mvg_bn_bwd_reduce_split(_p(g), _p(relu_bits), _p(y), _p(mean), _p(invstd), _p(rs), _p(rh), groups, rows_per_group, c,
-                                        _p(s1), _p(s2), _p(dgamma), _p(dbeta), int(accumulate), _p(ws), _p(dz_out), _p(mx), _s()),
-          "bn_bwd_reduce_split")
+                                        _p(s1), _p(s2), _p(dgamma), _p(dbeta), int(accumulate), _p(ws), _p(dz_out), _p(mx), _p(gamma),
+                                        _p(dy_sinv), _s(True)), "bn_bwd_reduce_split")
 
 
-def bn_bwd_apply_split(g, y, mean, invstd, gamma, s1, s2, groups, rows_per_group, c, dy_s3, relu_affine=None, mx=None):
+def bn_bwd_apply_split(g, y, mean, invstd, gamma, s1, s2, groups, rows_per_group, c, dy_s3, relu_affine=None, mx=None, dy_sinv=None):
     """dy (sp) = BatchNorm backward of the masked gradient g, scaled by the 2^k that its bound - from ``mx`` [groups, c] (max
     |masked gradient| per (group, channel), left by the reduce pass) - allows; dy_s3.sinv receives 2^-k."""
     rs, rh = relu_affine if relu_affine is not None else (None, None)
     assert mx is not None and mx.dtype == torch.float32 and mx.numel() == groups * c
-    dy_s3.sinv = torch.empty(1, dtype=torch.float32, device=g.device)
+    ready = dy_sinv is not None             # the reduce pass / fused backward-data launch already left 2^-k there
+    dy_s3.sinv = dy_sinv if ready else torch.empty(1, dtype=torch.float32, device=g.device)
     check(lib().mvg_bn_bwd_apply_split(_p(g), _p(y), _p(mean), _p(invstd), _p(gamma), _p(s1), _p(s2), _p(rs), _p(rh), groups,
-                                       rows_per_group, c, _p(dy_s3), _p(mx), _p(dy_s3.sinv), _s()), "bn_bwd_apply_split")
+                                       rows_per_group, c, _p(dy_s3), _p(mx), _p(dy_s3.sinv), int(ready), _s()), "bn_bwd_apply_split")
 
 
 def bn_relu_maxpool_fwd_split(y, scale, shift, pooled_s3, argmax, groups, n_per_group, h, w, c, ho, wo):

@@ -271,6 +271,21 @@ def test_split_dgrad_fused_with_bn_backward_reduce(case, mask):
     ops.conv_dgrad_split_bnreduce(d, gys, wt, dx2, dx2, y, bits, mean, invstd, ra, s2[0], s2[1], None, None, False, None)
     assert torch.equal(dx2, dx_ref), "masked gradient, in-place addend"
     assert torch.equal(s2[0], s[0]) and torch.equal(s2[1], s[1])
+    # ONE finalize launch (partials -> s1 / s2 / max, dgamma / dbeta and dy's scale, folded into the last-arriving workgroups)
+    # against the three-launch form: the reduce entry given the unit's gamma leaves the 2^-k that mvg_bn_bwd_apply_split computes
+    gamma = torch.rand(cin, device=dev()) + 0.5
+    dx3 = torch.empty_like(dx_ref)
+    s3 = [torch.empty(G, cin, device=dev()) for _ in range(2)]
+    dg3, db3 = torch.full((cin,), 0.5, device=dev()), torch.full((cin,), -0.25, device=dev())
+    am3 = torch.full((G, cin), float("nan"), device=dev())
+    sinv = torch.full((1,), float("nan"), device=dev())
+    ops.conv_dgrad_split_bnreduce(d, gys, wt, dx3, add, y, bits, mean, invstd, ra, s3[0], s3[1], dg3, db3, True, am3, gamma, sinv)
+    assert torch.equal(dx3, dx) and torch.equal(s3[0], s[0]) and torch.equal(s3[1], s[1]) and torch.equal(am3, am)
+    assert torch.equal(dg3, dg) and torch.equal(db3, db)
+    dy_a, dy_b = ops.sp_empty(G, rows, cin, device=dev()), ops.sp_empty(G, rows, cin, device=dev())
+    ops.bn_bwd_apply_split(dx.view(G, rows, cin), y, mean, invstd, gamma, s[0], s[1], G, rows, cin, dy_a, None, am)            # computes the scale itself
+    ops.bn_bwd_apply_split(dx.view(G, rows, cin), y, mean, invstd, gamma, s[0], s[1], G, rows, cin, dy_b, None, am, sinv)      # takes the finalize launch's
+    assert float(sinv) == float(dy_a.sinv) and torch.equal(dy_a, dy_b)
 
 
 @pytest.mark.parametrize("case", [(2, 3, 14, 256, 256, 3, 1, 1), (1, 5, 28, 128, 128, 3, 2, 1), (3, 2, 14, 1024, 256, 1, 1, 0),
