@@ -591,6 +591,13 @@ int mvg_bn_relu_maxpool_bwd_apply_split(const float *g_pooled, const uint8_t *ar
 int mvg_conv_wgrad_splits_split(const mvg_conv_desc *d);   /* pixel-split count; workspace = splits * cout*r*s*cin floats */
 int mvg_conv_wgrad_split(const mvg_conv_desc *d, const void *x_sp, const void *dy_sp, const float *dy_sinv, float *dw,
                          float *workspace, int splits, int accumulate, void *stream);
+/* The same launch WITHOUT its slab reduce (splits > 1: workspace receives the per-split partial gradients), and the reduces
+ * of up to 8 such gradients in ONE launch (a residual block's convs): dw[i] (+)= the sum over host_splits[i] slabs of
+ * host_n[i] floats, fixed order.  Host arrays; the launch copies them. */
+int mvg_conv_wgrad_split_slabs(const mvg_conv_desc *d, const void *x_sp, const void *dy_sp, const float *dy_sinv, float *workspace,
+                               int splits, void *stream);
+int mvg_wgrad_reduce_batch(const float *const *host_slabs, float *const *host_dw, const int64_t *host_n, const int32_t *host_splits,
+                           const int32_t *host_accumulate, int n, void *stream);
 
 /* ---------------------------------------------------------------- the fusion block on the split kernels
  * ImageFeatFuser / gaze head Linears (rot_mv.py:35-50,179-184,234-254; blocks.py:41-47) with >= 1024 rows: every tensor a

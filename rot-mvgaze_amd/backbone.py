@@ -99,6 +99,7 @@ class Backbone:
         self._wprep: Optional[Dict[str, tuple]] = None
         self._wprep_state = None
         self._wprep_versions = None
+        self._wg_defer: Optional[list] = None # backward: (slabs, dw, splits, accumulate) of the split wgrads whose reduce is pending
         self._split_now = self.split          # per forward call: off when a view's largest s3 tensor would exceed 2 GiB
         self._stem_rw = False                 # per forward call: the stem runs in row-window form on the split kernels
         self._stem_w8 = None
@@ -536,7 +537,8 @@ class Backbone:
         c = u.spec
         wp = self.p[c.name + ".weight"]
         if u.split:
-            ops.conv_wgrad_split(u.desc, u.x_in, dy, sink.view(wp), sink.accumulate(wp))
+            # (slabs now, their sums in ONE launch per residual block: _flush_wgrad_reduces)
+            ops.conv_wgrad_split(u.desc, u.x_in, dy, sink.view(wp), sink.accumulate(wp), defer=self._wg_defer)
         elif u.stem_rw and self.bf16:
             dw16 = torch.empty(2 * c.cout, 7, 16, 4, dtype=torch.float32, device=dy.device)
             ops.stem_wgrad_bf16(u.desc, u.x_in, dy, dw16, False)
@@ -564,6 +566,16 @@ class Backbone:
                 gv.copy_(dw4[..., :3])
         else:
             ops.conv_wgrad(u.desc, u.x_in, dy, sink.view(wp), sink.accumulate(wp))
+
+    def _flush_wgrad_reduces(self, dev):
+        """The slab sums of the weight gradients launched since the last flush, in one launch on the stream that wrote the slabs."""
+        if not self._wg_defer:
+            return
+        if self.overlap_wgrad and dev.type == "cuda":
+            with torch.cuda.stream(self._side(dev)):
+                ops.wgrad_reduce_batch(self._wg_defer)
+        else:
+            ops.wgrad_reduce_batch(self._wg_defer)
 
     def _dgrad(self, u: _Unit, dy: Tensor, dx: Tensor, addend: Optional[Tensor], fuse_for: Optional[_Unit] = None,
                sink: Optional[GradSink] = None):
@@ -619,6 +631,7 @@ class Backbone:
                                "(PyTorch raises its version-counter error in the same situation)")
         g = torch.empty(V, B, Hc, Wc, self.fc_dim, dtype=self.act_dtype, device=dfeat.device)
         ops.avgpool_bwd(dfeat.contiguous(), g, V * B, Hc * Wc, self.fc_dim)
+        self._wg_defer = []
         P = self.p
         blocks = tape["blocks"]
         for bi in range(len(blocks) - 1, -1, -1):
@@ -651,6 +664,7 @@ class Backbone:
                 self._dgrad(ud, dyd, d, d, prev_last, sink)               # d += dgrad (aliasing addend): now final
                 done += [P[ud.spec.name + ".weight"], P[ud.spec.bn + ".weight"], P[ud.spec.bn + ".bias"]]
                 ud.y = ud.out = None
+            self._flush_wgrad_reduces(g.device)               # this block's weight gradients are final once their slabs are summed
             sink.publish(done)
             g = d
             if "debug" in tape:
@@ -679,6 +693,8 @@ class Backbone:
             ops.bn_relu_maxpool_bwd_apply(g, argmax, stem.y, stem.mean, stem.invstd, gp.detach(), scale, shift, s12[0], s12[1],
                                           V, B, H1, W1, sc.cout, Hp, Wp, dy)
         dx0 = self._conv_bwd(stem, dy, need_dimg, None, sink)
+        self._flush_wgrad_reduces(g.device)
+        self._wg_defer = None
         sink.publish([P[stem.spec.name + ".weight"], P[stem.spec.bn + ".weight"], P[stem.spec.bn + ".bias"]])
         if self._wg_stream is not None and dy.is_cuda:
             torch.cuda.current_stream().wait_stream(self._wg_stream)      # gradients complete for the optimizer

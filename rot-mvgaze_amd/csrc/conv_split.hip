@@ -675,6 +675,50 @@ __global__ __launch_bounds__(256, 3) void wgrad_split_kernel(WgradParams p) {
     }
 }
 
+// The slab sums of SEVERAL weight gradients in one launch (a residual block's 3-4 convs: round 3 ran one 10 us reduce
+// launch behind every wgrad launch, 63 per ResNet-50 step).  Same arithmetic and order as wgrad_reduce_kernel per item.
+struct ReduceItem {
+  const float *slabs;
+  float *dw;
+  long long n4;
+  int splits, accumulate, lanes, block0;          // block0: first workgroup of this item
+};
+struct ReduceBatch {
+  ReduceItem it[8];
+  int n;
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(ReduceBatch b) {
+  __shared__ float4 sh[256];
+  int k = 0;
+  for (int i = 1; i < b.n; ++i) k += (int)blockIdx.x >= b.it[i].block0;
+  const ReduceItem &r = b.it[k];
+  const int cols = 256 / r.lanes;
+  const int c = threadIdx.x % cols, l = threadIdx.x / cols;
+  const long long i = (long long)(blockIdx.x - r.block0) * cols + c;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < r.n4)
+    for (int q = l; q < r.splits; q += r.lanes) {
+      const float4 v = reinterpret_cast<const float4 *>(r.slabs)[(long long)q * r.n4 + i];
+      s.x += v.x;
+      s.y += v.y;
+      s.z += v.z;
+      s.w += v.w;
+    }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (l == 0 && i < r.n4) {
+    float4 t = r.accumulate ? reinterpret_cast<const float4 *>(r.dw)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < r.lanes; ++q) {
+      const float4 v = sh[q * cols + c];
+      t.x += v.x;
+      t.y += v.y;
+      t.z += v.z;
+      t.w += v.w;
+    }
+    reinterpret_cast<float4 *>(r.dw)[i] = t;
+  }
+}
+
 // The stem's row-window operand (see mvg_stem_fprop_split): one thread per 8-value chunk = image columns (2 ox - 4 + 2 q,
 // + 1) x 4 stored channels of window (n, y, ox), written as the chunk's two fp16 pieces.
 __global__ __launch_bounds__(256) void stem_rowwindow_kernel(const float4 *__restrict__ x, uint4 *__restrict__ xw, long long n, int h, int w) {
@@ -1173,7 +1217,8 @@ int mvg_conv_wgrad_splits_split(const mvg_conv_desc *d) {
 }
 
 static int wgrad_split_impl(const mvg_conv_desc *d, const void *x_sp, const void *dy_sp, const float *dy_sinv, float *dw, float *workspace,
-                            int splits, int accumulate, void *stream, int stride_w = -1, int pad_w = -1, const float *x_sinv = nullptr) {
+                            int splits, int accumulate, void *stream, int stride_w = -1, int pad_w = -1, const float *x_sinv = nullptr,
+                            bool slabs_only = false) {
   if (stride_w < 0 && validate_split(d)) return 2;
   MVG_REQUIRE(splits >= 1, "wgrad_split: splits < 1");
   MVG_REQUIRE(splits == 1 || workspace != nullptr, "wgrad_split: workspace required for splits > 1");
@@ -1234,7 +1279,7 @@ static int wgrad_split_impl(const mvg_conv_desc *d, const void *x_sp, const void
 #undef MVG_WGRAD_SPLIT
     if (check_launch("conv_wgrad_split")) return 1;
   }
-  if (splits > 1) {
+  if (splits > 1 && !slabs_only) {
     const long long n = (long long)d->cout * p.ncols;
     ProfScope ps(MVG_K_WGRAD_REDUCE, st, 0.0, 4.0 * n * (splits + 1));
     const int lanes = splits >= 32 ? 16 : (splits >= 8 ? 4 : 1);
@@ -1248,6 +1293,40 @@ static int wgrad_split_impl(const mvg_conv_desc *d, const void *x_sp, const void
 int mvg_conv_wgrad_split(const mvg_conv_desc *d, const void *x_sp, const void *dy_sp, const float *dy_sinv, float *dw, float *workspace,
                          int splits, int accumulate, void *stream) {
   return wgrad_split_impl(d, x_sp, dy_sp, dy_sinv, dw, workspace, splits, accumulate, stream);
+}
+
+int mvg_conv_wgrad_split_slabs(const mvg_conv_desc *d, const void *x_sp, const void *dy_sp, const float *dy_sinv, float *workspace, int splits,
+                               void *stream) {
+  MVG_REQUIRE(splits > 1 && workspace, "wgrad_split_slabs: splits > 1 and a workspace (the slabs ARE the result)");
+  return wgrad_split_impl(d, x_sp, dy_sp, dy_sinv, workspace, workspace, splits, 0, stream, -1, -1, nullptr, true);
+}
+
+int mvg_wgrad_reduce_batch(const float *const *host_slabs, float *const *host_dw, const int64_t *host_n, const int32_t *host_splits,
+                           const int32_t *host_accumulate, int n, void *stream) {
+  MVG_REQUIRE(host_slabs && host_dw && host_n && host_splits && host_accumulate && n >= 1 && n <= 8, "wgrad_reduce_batch: 1..8 items");
+  ReduceBatch b;
+  memset(&b, 0, sizeof(b));
+  b.n = n;
+  long long blocks = 0;
+  double bytes = 0.0;
+  for (int i = 0; i < n; ++i) {
+    MVG_REQUIRE(host_slabs[i] && host_dw[i] && host_n[i] > 0 && host_n[i] % 4 == 0 && host_splits[i] > 1, "wgrad_reduce_batch: bad item");
+    ReduceItem &r = b.it[i];
+    r.slabs = host_slabs[i];
+    r.dw = host_dw[i];
+    r.n4 = host_n[i] / 4;
+    r.splits = host_splits[i];
+    r.accumulate = host_accumulate[i];
+    r.lanes = r.splits >= 32 ? 16 : (r.splits >= 8 ? 4 : 1);
+    r.block0 = (int)blocks;
+    blocks += (r.n4 + 256 / r.lanes - 1) / (256 / r.lanes);
+    bytes += 4.0 * host_n[i] * (r.splits + 1);
+  }
+  MVG_REQUIRE(blocks < (1LL << 31), "wgrad_reduce_batch: grid too large");
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(MVG_K_WGRAD_REDUCE, st, 0.0, bytes);
+  hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, st, b);
+  return check_launch("wgrad_reduce_batch");
 }
 
 // ---- the fusion block's Linear layers on the split kernels (heads.py: a Linear = a 1x1 conv on a 1x1 map) ----------------

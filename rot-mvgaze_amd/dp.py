@@ -117,11 +117,12 @@ class GradAllReducer:
         if cur > start:
             self.buckets.append([start, cur])
             self.last_param_bucket[id(entries[-1][0])] = len(self.buckets) - 1
-        self._param_end = {id(p): off + n for (p, off, n) in entries}
         self._entries = entries
+        # a bucket is complete when EVERY parameter inside it has been published this backward (not when some later
+        # parameter has: a parameter the backward never reaches would otherwise ship last step's gradient)
+        self._bucket_params = [[id(p) for (p, off, n) in entries if s <= off < e] for (s, e) in self.buckets]
         self._published = set()
         self._next = 0
-        self._done_upto = 0
         if arena.is_cuda and self._side is None:
             self._side = torch.cuda.Stream(device=arena.device)
         self._built_for = arena.data_ptr()
@@ -154,8 +155,8 @@ class GradAllReducer:
         self._build()
         for p in params:
             self._published.add(id(p))
-            self._done_upto = max(self._done_upto, self._param_end[id(p)])
-        while self._next < len(self.buckets) and self.buckets[self._next][1] <= self._done_upto:
+        # buckets ship in arena order (= grad-ready order), each as soon as all of its parameters are final
+        while self._next < len(self.buckets) and all(pid in self._published for pid in self._bucket_params[self._next]):
             self._launch(self._next)
             self._next += 1
 
@@ -165,7 +166,10 @@ class GradAllReducer:
         # gradient flows into the image features, say) leaves those slices of the arena holding the PREVIOUS step's
         # gradients.  A bucket none of whose parameters was published this backward is skipped (every rank skips the
         # same ones: the model is the same everywhere); in a partly published bucket the stale slices are zeroed first,
-        # so that nothing stale is averaged into gradients that are still attached from an earlier step.
+        # so that nothing stale is averaged into gradients that are still attached from an earlier step.  (Those zeroed
+        # slices are the one place where an N-rank run hands the optimizer something else than a 1-rank run of the same
+        # code would - there the stale .grad of an unreached parameter stays attached; callers that rely on it zero_grad
+        # every step, as the reference trainer does: trainer.py:141.)
         while self._next < len(self.buckets):
             s, e = self.buckets[self._next]
             inside = [(p, off, n) for (p, off, n) in self._entries if s <= off < e]
@@ -179,4 +183,3 @@ class GradAllReducer:
             torch.cuda.current_stream().wait_stream(self._side)
         self._published = set()
         self._next = 0
-        self._done_upto = 0

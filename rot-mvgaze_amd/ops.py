@@ -352,14 +352,33 @@ def conv_dgrad_bf16_bnreduce(d: ConvDesc, dy, wt, dx, addend, bn_y, bn_bits, bn_
                                              int(accumulate), _s()), "conv_dgrad_bf16_bnreduce")
 
 
-def conv_wgrad_split(d: ConvDesc, x_s3: Tensor, dy_s3: Tensor, dw: Tensor, accumulate: bool = False):
+def conv_wgrad_split(d: ConvDesc, x_s3: Tensor, dy_s3: Tensor, dw: Tensor, accumulate: bool = False, defer: Optional[list] = None):
+    """defer (a list): with more than one pixel split, only the slabs are written and (slabs, dw, splits, accumulate) is appended
+    for ONE wgrad_reduce_batch launch over the list (the caller's: at the end of a residual block, on the same stream)."""
     splits = lib().mvg_conv_wgrad_splits_split(C.byref(d))
     if splits < 1:
         check(1, "conv_wgrad_splits_split")
     ws = torch.empty(splits * dw.numel(), dtype=torch.float32, device=dw.device) if splits > 1 else None
     assert getattr(x_s3, "sinv", None) is None, "conv_wgrad_split: the activation operand is stored unscaled"
+    if defer is not None and splits > 1:
+        check(lib().mvg_conv_wgrad_split_slabs(C.byref(d), _p(x_s3), _p(dy_s3), _sinv(dy_s3), _p(ws), splits, _s()), "conv_wgrad_split_slabs")
+        defer.append((ws, dw, splits, bool(accumulate)))
+        return
     check(lib().mvg_conv_wgrad_split(C.byref(d), _p(x_s3), _p(dy_s3), _sinv(dy_s3), _p(dw), _p(ws), splits, int(accumulate), _s()),
           "conv_wgrad_split")
+
+
+def wgrad_reduce_batch(items: list):
+    """items: (slabs, dw, splits, accumulate) records left by conv_wgrad_split(defer=...): their slab sums, 8 per launch."""
+    for i in range(0, len(items), 8):
+        chunk = items[i:i + 8]
+        n = len(chunk)
+        for ws, dw, splits, acc in chunk:
+            assert dw.dtype == torch.float32 and ws.numel() == splits * dw.numel() and dw.numel() % 4 == 0
+        check(lib().mvg_wgrad_reduce_batch((C.c_void_p * n)(*[c[0].data_ptr() for c in chunk]), (C.c_void_p * n)(*[c[1].data_ptr() for c in chunk]),
+                                           (C.c_int64 * n)(*[c[1].numel() for c in chunk]), (C.c_int32 * n)(*[c[2] for c in chunk]),
+                                           (C.c_int32 * n)(*[int(c[3]) for c in chunk]), n, _s()), "wgrad_reduce_batch")
+    items.clear()
 
 
 def bn_apply_split(y, scale, shift, residual, relu, out_s3, groups, rows_per_group, c, residual_affine=None, want_bits=False):

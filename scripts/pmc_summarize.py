@@ -70,17 +70,24 @@ def mfma(d, out):
                      "valu_insts_per_mfma": round(c["SQ_INSTS_VALU"] / c["SQ_INSTS_MFMA"], 2),
                      "mfma_busy_cycles_per_mfma": round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / c["SQ_INSTS_MFMA"], 1),
                      "gpu_Mcycles": round(cyc / 1e6, 3)}
+    # the family total = exactly the kernels that issued MFMAs (the rows below: their launches and cycles add up to it);
+    # everything else that ran in the profiled command is listed under "not_counted" so that nothing disappears
     tot = collections.Counter()
     n = 0
+    not_counted = {}
     for k, c in acc.items():
-        if "split" in k:
+        if c["SQ_INSTS_MFMA"] > 0:
             for kk, v in c.items():
                 tot[kk] += v
             n += launches[k]
-    summarise("all split conv kernels", tot, n)
+        else:
+            not_counted[k] = {"launches": launches[k], "gpu_Mcycles": round(c["GRBM_GUI_ACTIVE"] / 8.0 / 1e6, 3)}
+    summarise("all kernels that issue MFMAs (cycle-weighted total of the rows below)", tot, n)
     for k, c in sorted(acc.items(), key=lambda kv: -kv[1]["SQ_VALU_MFMA_BUSY_CYCLES"]):
         summarise(k, c, launches[k])
-    json.dump({"kernels": res, "note": "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs): the share of "
+    rows_sum = sum(v["gpu_Mcycles"] for k, v in res.items() if not k.startswith("all kernels"))
+    assert abs(rows_sum - res[next(iter(res))]["gpu_Mcycles"]) < 1e-2 * max(rows_sum, 1.0), "the table does not add up"
+    json.dump({"kernels": res, "not_counted_no_mfma": not_counted, "note": "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs): the share of "
                "SIMD-cycles with the matrix pipe busy, at whatever clock the chip held (the time-based roofline fraction in bench.py is "
                "this figure times held clock / 2.4 GHz)"}, open(out, "w"), indent=1)
     for k, v in list(res.items())[:8]:

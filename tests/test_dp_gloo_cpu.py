@@ -169,3 +169,70 @@ def test_bucket_boundaries_follow_grad_ready_order():
     assert fired == [0, 1]
     (p3, off3, n3) = entries[3]
     assert float(arena[off3:off3 + n3].abs().max()) == 0.0 and float(arena[off3 - 1]) == 7.0     # the unpublished half was zeroed
+
+
+def test_a_parameter_published_out_of_order_does_not_release_the_buckets_before_it():
+    """Completeness is per bucket, from the set of published parameters: publishing a LATER parameter must not
+    ship an earlier bucket whose own parameters have not been published (it would average last step's gradient)."""
+    from rot_mvgaze_amd.dp import GradAllReducer
+    m = _FakeModel([300, 300, 300, 300, 100], 0)
+    red = GradAllReducer(m, bucket_mb=600 * 4 / (1 << 20))
+    red._build()
+    fired = []
+    red._launch = fired.append
+    m._on_grads_ready(m.params[2:4])              # bucket 1's parameters first
+    assert fired == []                            # bucket 0 is not complete: nothing ships (buckets go in arena order)
+    m._on_grads_ready(m.params[0:1])
+    assert fired == []
+    m._on_grads_ready(m.params[1:2])
+    assert fired == [0, 1]
+    # an unpublished parameter in the MIDDLE (bucket 0 never completes): bucket 0 ships at the end with the stale half zeroed
+    arena, entries = m.grad_arena()
+    m._on_backward_done()
+    arena.fill_(3.0)
+    del fired[:]
+    m._on_grads_ready([m.params[0]] + m.params[2:5])
+    assert fired == []
+    m._on_backward_done()
+    assert fired == [0, 1, 2]
+    (p1, off1, n1) = entries[1]
+    assert float(arena[off1:off1 + n1].abs().max()) == 0.0 and float(arena[off1 - 1]) == 3.0 and float(arena[off1 + n1]) == 3.0
+
+
+def test_buckets_follow_the_models_grad_ready_order():
+    """The arena order the reducer buckets over is the order backward finishes parameters in: heads + fusers of iteration
+    I-1 .. 0, the lifter, then the backbone from layer4 down to the stem (model.py:_ensure_layout builds it from the same
+    spec; checked here on the spec, without a GPU) - so bucket k's all-reduce can start while backward is still above it."""
+    from rot_mvgaze_amd.arch import backbone_spec, state_dict_shapes, DEFAULT_VARIANT
+    depth, I = 50, 3
+    spec = backbone_spec(depth)
+    names = []
+    for it in range(I - 1, -1, -1):
+        names += [f"_gaze_estimators.{it}.", f"_img_fusers.{it}._fuser."]
+    names += ["_lifter._lifter."]
+    for blk in reversed(spec.blocks):
+        cs = [blk.convs[-1]] + list(reversed(blk.convs[:-1])) + ([blk.downsample] if blk.downsample else [])
+        names += [c.name for c in cs]
+    names += [spec.stem.name]
+    # groups of parameters as backward publishes them -> one fake parameter per group, sized like the real ones
+    shapes = {n: s for n, s, k in state_dict_shapes(depth, I, DEFAULT_VARIANT)}
+    sizes = []
+    for pre in names:
+        sizes.append(sum(int(np.prod(s)) for n, s in shapes.items() if n.startswith(pre) and "running" not in n and "num_batches" not in n))
+    assert sizes[0] > 0 and all(sz > 0 for sz in sizes)
+    m = _FakeModel(sizes, 0)
+    from rot_mvgaze_amd.dp import GradAllReducer
+    red = GradAllReducer(m, bucket_mb=25.0)
+    red._build()
+    order = []
+    red._launch = order.append
+    for p in m.params:                              # backward publishes group after group
+        m._on_grads_ready([p])
+    m._on_backward_done()
+    assert order == list(range(len(red.buckets))) and len(red.buckets) >= 5
+    # the fusion block's three iterations (60 M of the 89.6 M parameters: one (head, fuser) pair of ~80 MB per bucket at 25 MB
+    # granularity) ship before any backbone gradient exists
+    head_elems = sum(sizes[:2 * I])
+    assert [e0 for (s0, e0) in red.buckets[:I]] == [sum(sizes[:2 * (k + 1)]) for k in range(I)]
+    first_backbone_bucket = next(b for b, (s0, e0) in enumerate(red.buckets) if e0 > head_elems + sizes[2 * I])
+    assert first_backbone_bucket == I

@@ -111,8 +111,9 @@ def check_outputs(data, g, prefix, tol):
 
 
 # The fp32 model's training convs run on one of two kernel families, both held to the same bounds: "split" (default:
-# fp32 values as three bf16 pieces, six bf16 MFMAs per product, conv_split.hip) and "fp32mfma" (MVG_SPLIT=0: the
-# v_mfma_f32_32x32x2_f32 kernels of conv_igemm.hip, which also serve the stem, the Linears and inference).
+# fp32 values as two fp16 pieces ("sp") with a per-tensor power-of-two scale, three fp16 MFMAs per product, conv_split.hip) and
+# "fp32mfma" (MVG_SPLIT=0: the v_mfma_f32_32x32x2_f32 kernels of conv_igemm.hip, which also serve the lifter, small-row Linears
+# and the stem's backward-data).
 KERNELS = ["split", "fp32mfma"]
 
 
