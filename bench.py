@@ -224,9 +224,11 @@ def main():
     ap.add_argument("--nccl-channels", type=int, default=int(os.environ.get("NCCL_MAX_NCHANNELS", "4")),
                     help="N > 1: NCCL_MAX_NCHANNELS for the gradient all-reduce")
     ap.add_argument("--no-optimizer", action="store_true", help="time forward+loss+backward only (no Adam step)")
-    ap.add_argument("--no-graph", action="store_true",
-                    help="queue every launch from Python each step instead of replaying the step's hipGraph (N = 1 training runs "
-                         "capture zero_grad + forward + loss + backward + Adam once: rot_mvgaze_amd/graph.py)")
+    ap.add_argument("--graph", action="store_true",
+                    help="N = 1 training: capture zero_grad + forward + loss + backward + Adam once in a hipGraph and replay it "
+                         "(rot_mvgaze_amd/graph.py).  Host time per step drops from ~20 ms to 0.15 ms; the GPU time does not (the eager "
+                         "step is GPU-bound) and the capture is single-stream - a captured side stream replays 1.4-1.7x slower on "
+                         "ROCm 7.0 - so the weight-gradient overlap (+6 %) is lost: off by default (profiles/README.md, round 4)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the backward-weight kernels on the compute stream (per-kernel profiling: rocprofv3 --stats)")
     ap.add_argument("--dtype", default=None, choices=["f32", "bf16"],
@@ -308,8 +310,7 @@ def main():
     criterion = MultiViewIterationLoss(rel_weight=0.01, reference_decay=1.0, iter_decay=0.5)
     from rot_mvgaze_amd.optim import Adam
     # N = 1 training: the whole step is captured in a hipGraph (the optimizer's step counter / lr then live on the device)
-    use_graph = (world == 1 and not force_dist and args.mode == "train" and not args.no_graph and not args.no_optimizer
-                 and not args.no_overlap)
+    use_graph = world == 1 and not force_dist and args.mode == "train" and args.graph and not args.no_optimizer
     optimizer = None if args.no_optimizer else Adam(model.parameters(), lr=1e-4, weight_decay=1e-6, capturable=use_graph)   # trainer.py:54
     reducer = GradAllReducer(model, bucket_mb=args.bucket_mb, force=force_dist, reserved_cus=args.reserved_cus) \
         if (world > 1 or force_dist) else None

@@ -696,7 +696,7 @@ class Backbone:
         self._flush_wgrad_reduces(g.device)
         self._wg_defer = None
         sink.publish([P[stem.spec.name + ".weight"], P[stem.spec.bn + ".weight"], P[stem.spec.bn + ".bias"]])
-        if self._wg_stream is not None and dy.is_cuda:
+        if self._wg_stream is not None and dy.is_cuda and (self.overlap_wgrad or not torch.cuda.is_current_stream_capturing()):
             torch.cuda.current_stream().wait_stream(self._wg_stream)      # gradients complete for the optimizer
         if not need_dimg:
             return None

@@ -9,6 +9,13 @@ kernels forks from / joins the capturing stream through events - so the step is 
 the host one hipGraphLaunch.  (The reference's caller: /root/reference/trainer.py:119-147 - model(data), metrics(data),
 zero_grad, backward, optimizer.step per iteration.)
 
+Measured on MI355X / ROCm 7.0 (scripts/graph_probe.py, profiles/README.md round 4): a replay costs the host 0.08-0.15 ms
+instead of 5-20 ms, and takes exactly the GPU time of the eager step WITHOUT the side stream (C4's share 27.98 vs 27.80 ms,
+C2 9.73 vs 9.74): the eager step is GPU-bound, so the graph buys host time, not throughput.  A capture that includes the
+weight-gradient side stream (fork / join events -> a branching graph) replays 1.45-1.7x SLOWER than the eager step (38.0 vs
+26.2 ms, 15.3 vs 9.0): the capture is therefore taken single-stream (overlap_wgrad off), which gives up the ~6 % the
+overlap is worth on one GPU.  Use it where the host is the bottleneck (many ranks per host, small per-GPU batches).
+
 PyTorch here is plumbing only: ``torch.cuda.CUDAGraph`` is hipStreamBeginCapture / hipGraphInstantiate / hipGraphLaunch
 plus a private pool of the caching allocator, which is what keeps every buffer the captured launches point at alive
 and un-recycled between replays.
@@ -33,6 +40,8 @@ class GraphedStep:
         self.model, self.optimizer = model, optimizer
         self._step_fn = step_fn
         dev = next(model.parameters()).device
+        model.ensure_layout()
+        model._backbone.overlap_wgrad = False          # single-stream capture (see the module docstring)
         # eager warm-up on a side stream (allocator pools, weight-copy tables, scratch registration, the optimizer's
         # device state): capture must find nothing left to set up
         s = torch.cuda.Stream(device=dev)

@@ -278,7 +278,11 @@ def _captured_masks(m, V=2):
     hl = (f32(ht["hl"][0]) > 0).cpu()            # hidden activations are lists (one entry per hidden layer)
     masks["lift"] = [hl[v * B:(v + 1) * B] for v in range(V)]
     D = V * (V - 1)
-    for it, (X, H1, Xh, Hh, _scales) in enumerate(ht["saved"]):
+    for it, rec in enumerate(ht["saved"]):
+        if ht.get("mode") == "split":            # heads._forward_split: (xf, h, xh, hh, weight copies...) - h in (scaled) sp, hh fp32
+            H1, Hh = [rec[1]], [rec[3]]
+        else:
+            (X, H1, Xh, Hh, _scales) = rec
         h1, hh = (f32(H1[0]) > 0).cpu(), (f32(Hh[0]) > 0).cpu()
         masks[("fuse", it)] = [h1[d * B:(d + 1) * B] for d in range(D)]
         masks[("head", it)] = [hh[d * B:(d + 1) * B] for d in range(D)]
