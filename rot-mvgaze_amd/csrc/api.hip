@@ -36,23 +36,12 @@ struct Scratch {
 };
 static std::mutex g_scratch_mu;
 static Scratch g_scratch[32];
-// The first MVG_COUNTER_BYTES of a registered workspace are arrival counters (zeroed at registration, left at zero by
-// every kernel that uses them: the last arriver resets its counter); scratch proper starts behind them.
 float *stream_scratch(hipStream_t st, size_t floats) {
   std::lock_guard<std::mutex> lk(g_scratch_mu);
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   for (auto &e : g_scratch)
-    if (e.ptr && e.st == st && e.dev == dev)
-      return e.floats >= floats + kCounterFloats ? e.ptr + kCounterFloats : nullptr;
-  return nullptr;
-}
-unsigned *stream_counters(hipStream_t st) {
-  std::lock_guard<std::mutex> lk(g_scratch_mu);
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  for (auto &e : g_scratch)
-    if (e.ptr && e.st == st && e.dev == dev) return e.floats >= kCounterFloats ? reinterpret_cast<unsigned *>(e.ptr) : nullptr;
+    if (e.ptr && e.st == st && e.dev == dev) return e.floats >= floats ? e.ptr : nullptr;
   return nullptr;
 }
 
@@ -149,12 +138,6 @@ int mvg_set_scratch(void *ptr, size_t bytes, void *stream) {
     return 0;
   }
   MVG_REQUIRE(slot != nullptr, "set_scratch: more than 32 (device, stream) workspaces registered");
-  if (bytes >= mvg::kCounterFloats * sizeof(float) &&
-      hipMemsetAsync(ptr, 0, mvg::kCounterFloats * sizeof(float), st) != hipSuccess) {      // the arrival counters start at zero
-    (void)hipGetLastError();
-    mvg::set_error("set_scratch: clearing the counter area failed");
-    return 1;
-  }
   slot->dev = dev;
   slot->st = st;
   slot->ptr = (float *)ptr;
@@ -167,7 +150,7 @@ size_t mvg_scratch_bytes(void) {
   // workgroup, at most four workgroups per CU
   int cus = mvg_device_cus();
   if (cus <= 0) cus = 256;
-  return (size_t)cus * 4 * 2 * 128 * 128 * sizeof(float) + mvg::kCounterFloats * sizeof(float);
+  return (size_t)cus * 4 * 2 * 128 * 128 * sizeof(float);
 }
 
 int mvg_device_cus(void) {

@@ -253,82 +253,59 @@ __global__ __launch_bounds__(256) void bn_partials_slice_kernel(const float *__r
   }
 }
 
-// ---- finalize in ONE launch (the form mvg_bn_finalize takes when the stream has a registered workspace) ----------
-// grid = (c/8, S, groups), 256 threads = 8 channels x 32 partial lanes.  Phase 1: every workgroup collapses its slice of
-// the partials (bn_partials_slice_kernel's arithmetic); the LAST slice to arrive for a (channel block, group) merges the
-// slices in slice order and finalizes that group's statistics (bn_finalize_group_kernel's arithmetic); the last GROUP
-// to arrive for a channel block applies the running-statistics updates in group order (bn_running_update_kernel).
-// Round 3 ran these as two or three launches per conv + BN unit (131 launches of 5-18 us per ResNet-50 step).
-// Hand-offs: common.h arrive_and_check_last (agent-scope release / acquire around a counter that returns to zero).
-__global__ __launch_bounds__(256) void bn_finalize_fused_kernel(const float *__restrict__ stats, int partials, int rows_per_partial,
-                                                                long long rows, int c, int per_slice, int S, double *sliced,
-                                                                double *mv, unsigned *counters, const float *__restrict__ gamma,
-                                                                const float *__restrict__ beta, float eps, float momentum,
-                                                                float *mean_out, float *invstd_out, float *scale, float *shift,
-                                                                float *running_mean, float *running_var) {
-  __shared__ double sh[3][32][8];
-  __shared__ int s_last;
-  const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
-  const int cb = blockIdx.x, ch = cb * 8 + cl, g = blockIdx.z, groups = gridDim.z, cblocks = gridDim.x;
-  const float *st = stats + (long long)g * partials * 2 * c;
-  const int valid = (int)((rows + rows_per_partial - 1) / rows_per_partial) < partials
-                        ? (int)((rows + rows_per_partial - 1) / rows_per_partial) : partials;
-  const int p0 = blockIdx.y * per_slice;
-  const int p1 = p0 + per_slice < valid ? p0 + per_slice : valid;
+// ---- every group's statistics AND the running statistics in ONE workgroup per 8 channels -------------------------
+// grid = c/8, 1024 threads = 8 channels x 128 lanes, the lanes divided between the groups (views): every (channel,
+// group) merges its partials (or slices) with 128 / groups lanes, bn_finalize_group_kernel's arithmetic; the per-group
+// (mean, unbiased variance) meet in LDS and one thread per channel applies the running-statistics updates in group
+// order.  Replaces bn_finalize_group_kernel + bn_running_update_kernel (two launches per conv + BN unit, 106 per
+// ResNet-50 step) without any cross-workgroup hand-off.  (Folding them into last-arriving workgroups of ONE grid was
+// measured in round 4 and lost: an agent-scope release per workgroup - an L2 write-back - on grids of thousands of
+// workgroups cost 37 us per call, 2.96 ms per C3 step against 1.02.)
+__global__ __launch_bounds__(1024) void bn_finalize_allgroups_kernel(const float *__restrict__ stats, const double *__restrict__ sliced,
+                                                                     int slices, int groups, int lpg, int partials, int rows_per_partial,
+                                                                     long long rows, int c, const float *__restrict__ gamma,
+                                                                     const float *__restrict__ beta, float eps, float momentum,
+                                                                     float *mean_out, float *invstd_out, float *scale, float *shift,
+                                                                     float *running_mean, float *running_var) {
+  __shared__ double sh[3][128][8];
+  __shared__ float sh_mv[2][8][8];                 // [mean | unbiased variance][group][channel]
+  const int cl = threadIdx.x & 7, l = threadIdx.x >> 3;
+  const int g = l / lpg, pl = l - g * lpg;
+  const int ch = blockIdx.x * 8 + cl;
   double s = 0.0, q = 0.0, ss = 0.0;
-  if (ch < c) {
-    const double inv_full = 1.0 / (double)rows_per_partial;
-#pragma unroll 4
-    for (int p = p0 + pl; p < p1; p += 32) {
-      const double sp = st[((long long)p * 2) * c + ch], qp = st[((long long)p * 2 + 1) * c + ch];
-      const long long cnt = rows - (long long)p * rows_per_partial;
-      s += sp;
-      q += qp;
-      ss += sp * sp * (cnt >= rows_per_partial ? inv_full : 1.0 / (double)cnt);
-    }
-  }
-  sh[0][pl][cl] = s;
-  sh[1][pl][cl] = q;
-  sh[2][pl][cl] = ss;
-  __syncthreads();
-  if (pl == 0)
-    for (int k = 1; k < 32; ++k) {
-      s += sh[0][k][cl];
-      q += sh[1][k][cl];
-      ss += sh[2][k][cl];
-    }
-  if (S > 1) {
-    if (pl == 0 && ch < c) {
-      double *o = sliced + (((long long)g * S + blockIdx.y) * 3) * c;
-      o[ch] = s;
-      o[c + ch] = q;
-      o[2 * c + ch] = ss;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = arrive_and_check_last(counters + (long long)cb * groups + g, (unsigned)S);
-    __syncthreads();
-    if (!s_last) return;
-    s = q = ss = 0.0;
-    if (ch < c)
-      for (int k = pl; k < S; k += 32) {
-        const double *o = sliced + (((long long)g * S + k) * 3) * c;
+  if (ch < c && g < groups) {
+    if (sliced) {
+      for (int k = pl; k < slices; k += lpg) {
+        const double *o = sliced + (((long long)g * slices + k) * 3) * c;
         s += o[ch];
         q += o[c + ch];
         ss += o[2 * c + ch];
       }
-    sh[0][pl][cl] = s;
-    sh[1][pl][cl] = q;
-    sh[2][pl][cl] = ss;
-    __syncthreads();
-    if (pl == 0)
-      for (int k = 1; k < 32; ++k) {
-        s += sh[0][k][cl];
-        q += sh[1][k][cl];
-        ss += sh[2][k][cl];
+    } else {
+      const float *st = stats + (long long)g * partials * 2 * c;
+      const double inv_full = 1.0 / (double)rows_per_partial;
+      const int valid = (int)((rows + rows_per_partial - 1) / rows_per_partial) < partials
+                            ? (int)((rows + rows_per_partial - 1) / rows_per_partial) : partials;
+#pragma unroll 4
+      for (int p = pl; p < valid; p += lpg) {
+        const double sp = st[((long long)p * 2) * c + ch], qp = st[((long long)p * 2 + 1) * c + ch];
+        const long long cnt = rows - (long long)p * rows_per_partial;
+        s += sp;
+        q += qp;
+        ss += sp * sp * (cnt >= rows_per_partial ? inv_full : 1.0 / (double)cnt);
       }
+    }
   }
-  if (pl == 0 && ch < c) {
+  sh[0][l][cl] = s;
+  sh[1][l][cl] = q;
+  sh[2][l][cl] = ss;
+  __syncthreads();
+  if (pl == 0 && g < groups && ch < c) {
+    for (int k = 1; k < lpg; ++k) {                  // fixed order
+      s += sh[0][l + k][cl];
+      q += sh[1][l + k][cl];
+      ss += sh[2][l + k][cl];
+    }
     const double n = (double)rows;
     const double mean = s / n;
     double m2 = q + (ss - s * mean);                   // Chan merge of the partials
@@ -342,22 +319,15 @@ __global__ __launch_bounds__(256) void bn_finalize_fused_kernel(const float *__r
     const float sc = gamma[ch] * invstd;
     scale[o] = sc;
     shift[o] = beta[ch] - fmean * sc;
-    mv[((long long)g * 2) * c + ch] = (double)fmean;
-    mv[((long long)g * 2 + 1) * c + ch] = (double)(float)(rows > 1 ? m2 / (n - 1.0) : var);
+    sh_mv[0][g][cl] = fmean;
+    sh_mv[1][g][cl] = (float)(rows > 1 ? m2 / (n - 1.0) : var);
   }
-  if (running_mean == nullptr && running_var == nullptr) return;
-  if (groups > 1) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = arrive_and_check_last(counters + (long long)cblocks * groups + cb, (unsigned)groups);
-    __syncthreads();
-    if (!s_last) return;
-  }
-  if (pl == 0 && ch < c) {
+  __syncthreads();
+  if (l == 0 && ch < c && (running_mean || running_var)) {
     float rm = running_mean ? running_mean[ch] : 0.f, rv = running_var ? running_var[ch] : 0.f;
     for (int gg = 0; gg < groups; ++gg) {
-      rm = (1.f - momentum) * rm + momentum * (float)mv[((long long)gg * 2) * c + ch];
-      rv = (1.f - momentum) * rv + momentum * (float)mv[((long long)gg * 2 + 1) * c + ch];
+      rm = (1.f - momentum) * rm + momentum * sh_mv[0][gg][cl];
+      rv = (1.f - momentum) * rv + momentum * sh_mv[1][gg][cl];
     }
     if (running_mean) running_mean[ch] = rm;
     if (running_var) running_var[ch] = rv;
@@ -654,89 +624,33 @@ __global__ __launch_bounds__(256) void bn_bwd_dgamma_kernel(const float *__restr
   if (dbeta) dbeta[ch] = (accumulate ? dbeta[ch] : 0.f) + (float)tb;
 }
 
-// The three kernels above in ONE launch (the form bn_bwd_finalize_launch takes when the stream has a registered workspace):
-// every (16 channels, group) workgroup merges its partials; the last GROUP to arrive for a channel block adds the groups
-// into dgamma / dbeta (group order) and - split path, when the unit's gamma / invstd are given - folds its 16 channels'
-// share of bn_dy_scale_kernel's bound; the last CHANNEL BLOCK to arrive takes the maximum and writes *dy_sinv.
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_fused_kernel(const float *__restrict__ partial, int chunks, int c, float *s1, float *s2,
-                                                                     float *mx, const float *__restrict__ raw_mean,
-                                                                     const float *__restrict__ raw_invstd, float *dgamma, float *dbeta,
-                                                                     int accumulate, const float *__restrict__ gamma,
+// bn_bwd_dgamma_kernel and bn_dy_scale_kernel (below) in ONE workgroup: dgamma / dbeta over the groups in group order,
+// and the bound that scales the unit's dy (split path) - two 5 us launches per unit became one (53 fewer per step).
+__global__ __launch_bounds__(1024) void bn_bwd_dgamma_dyscale_kernel(const float *__restrict__ s1, const float *__restrict__ s2,
+                                                                     const float *__restrict__ mx, int groups, int c, float *dgamma,
+                                                                     float *dbeta, int accumulate, const float *__restrict__ gamma,
                                                                      const float *__restrict__ invstd, float inv_rows, float sqrt_rows,
-                                                                     float *dy_sinv, float *bound_part, unsigned *counters) {
-  __shared__ double sh[3][64][16];
-  __shared__ int s_last;
+                                                                     float *__restrict__ dy_sinv) {
   __shared__ float sh_b[16];
-  const int prows = mx ? 3 : 2;
-  const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
-  const int cb = blockIdx.x, ch = cb * 16 + cl, cblocks = gridDim.x;
-  const int g = blockIdx.y, groups = gridDim.y;
-  double a = 0.0, b = 0.0, m = 0.0;
-  if (ch < c)
-    for (int k = pl; k < chunks; k += 64) {
-      a += partial[(((long long)g * chunks + k) * prows) * c + ch];
-      b += partial[(((long long)g * chunks + k) * prows + 1) * c + ch];
-      if (mx) m = fmax(m, (double)partial[(((long long)g * chunks + k) * prows + 2) * c + ch]);
-    }
-  sh[0][pl][cl] = a;
-  sh[1][pl][cl] = b;
-  sh[2][pl][cl] = m;
-  __syncthreads();
-  for (int o = 32; o > 0; o >>= 1) {
-    if (pl < o) {
-      sh[0][pl][cl] += sh[0][pl + o][cl];
-      sh[1][pl][cl] += sh[1][pl + o][cl];
-      sh[2][pl][cl] = fmax(sh[2][pl][cl], sh[2][pl + o][cl]);
-    }
-    __syncthreads();
-  }
-  if (pl == 0 && ch < c) {
-    s1[(long long)g * c + ch] = (float)sh[0][0][cl];
-    double t2 = sh[1][0][cl];
-    if (raw_mean) t2 = (double)raw_invstd[(long long)g * c + ch] * (t2 - (double)raw_mean[(long long)g * c + ch] * sh[0][0][cl]);
-    s2[(long long)g * c + ch] = (float)t2;
-    if (mx) mx[(long long)g * c + ch] = (float)sh[2][0][cl];
-  }
-  if (!dgamma && !dbeta && !dy_sinv) return;
-  if (groups > 1) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = arrive_and_check_last(counters + cb, (unsigned)groups);
-    __syncthreads();
-    if (!s_last) return;
-  }
   float bd = 0.f;
-  if (pl == 0 && ch < c) {
+  for (int ch = threadIdx.x; ch < c; ch += 1024) {
     double tg = 0.0, tb = 0.0;
-    for (int gg = 0; gg < groups; ++gg) {
-      const float v1 = s1[(long long)gg * c + ch], v2 = s2[(long long)gg * c + ch];
+    for (int g = 0; g < groups; ++g) {
+      const float v1 = s1[(long long)g * c + ch], v2 = s2[(long long)g * c + ch];
       tb += (double)v1;
       tg += (double)v2;
-      if (dy_sinv)
-        bd = fmaxf(bd, fabsf(gamma[ch] * invstd[(long long)gg * c + ch]) *
-                           (mx[(long long)gg * c + ch] + fabsf(v1) * inv_rows + sqrt_rows * fabsf(v2) * inv_rows));
+      bd = fmaxf(bd, fabsf(gamma[ch] * invstd[(long long)g * c + ch]) * (mx[(long long)g * c + ch] + fabsf(v1) * inv_rows + sqrt_rows * fabsf(v2) * inv_rows));
     }
     if (dgamma) dgamma[ch] = (accumulate ? dgamma[ch] : 0.f) + (float)tg;
     if (dbeta) dbeta[ch] = (accumulate ? dbeta[ch] : 0.f) + (float)tb;
   }
-  if (!dy_sinv) return;
-  if (pl == 0) sh_b[cl] = bd;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) bd = fmaxf(bd, __shfl_xor(bd, o, 64));
+  if ((threadIdx.x & 63) == 0) sh_b[threadIdx.x >> 6] = bd;
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int k = 1; k < 16; ++k) bd = fmaxf(bd, sh_b[k]);
-    bound_part[cb] = bd;
-  }
-  if (cblocks > 1) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = arrive_and_check_last(counters + cblocks, (unsigned)cblocks);
-    __syncthreads();
-    if (!s_last) return;
-  }
-  if (threadIdx.x == 0) {
-    float t = 0.f;
-    for (int k = 0; k < cblocks; ++k) t = fmaxf(t, bound_part[k]);
-    *dy_sinv = 1.f / sp_scale_for(t);
+    *dy_sinv = 1.f / sp_scale_for(bd);
   }
 }
 
@@ -1194,28 +1108,17 @@ static int grid_for(long long n4) {
 int bn_bwd_finalize_launch(const float *partial, int groups, int chunks, int c, float *s1, float *s2, float *dgamma,
                            float *dbeta, int accumulate, hipStream_t st, float *mx, const float *raw_mean, const float *raw_invstd,
                            const float *gamma, const float *invstd, long long rows, float *dy_sinv) {
-  const int cblocks = ceil_div(c, 16);
-  unsigned *counters = stream_counters(st);
-  float *bound_part = stream_scratch(st, (size_t)cblocks);
-  const bool want_sinv = dy_sinv && gamma && invstd && mx;
-  if (counters && bound_part && (size_t)cblocks + 1 <= kCounterFloats) {
-    // one launch: partials -> s1 / s2 / mx, dgamma / dbeta, and the bound that scales dy (last-arriver hand-offs)
-    hipLaunchKernelGGL(bn_bwd_finalize_fused_kernel, dim3(cblocks, groups), dim3(1024), 0, st, partial, chunks, c, s1, s2, mx, raw_mean,
-                       raw_invstd, dgamma, dbeta, accumulate, gamma, invstd, rows > 0 ? 1.0f / (float)rows : 0.f,
-                       rows > 0 ? sqrtf((float)rows) : 0.f, want_sinv ? dy_sinv : nullptr, bound_part, counters);
-    return check_launch("bn_bwd_finalize(fused)");
-  }
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(c, 16), groups), dim3(1024), 0, st, partial, groups, chunks, c, s1, s2, mx,
                      raw_mean, raw_invstd);
   if (check_launch("bn_bwd_finalize")) return 1;
+  if (dy_sinv && gamma && invstd && mx && rows > 0) {       // split path: dgamma / dbeta and dy's scale in one launch
+    hipLaunchKernelGGL(bn_bwd_dgamma_dyscale_kernel, dim3(1), dim3(1024), 0, st, s1, s2, mx, groups, c, dgamma, dbeta, accumulate, gamma, invstd,
+                       1.0f / (float)rows, sqrtf((float)rows), dy_sinv);
+    return check_launch("bn_bwd_dgamma_dyscale");
+  }
   if (dgamma || dbeta) {
     hipLaunchKernelGGL(bn_bwd_dgamma_kernel, dim3(ceil_div(c, 256)), dim3(256), 0, st, s1, s2, groups, c, dgamma, dbeta, accumulate);
-    if (check_launch("bn_bwd_dgamma")) return 1;
-  }
-  if (want_sinv) {
-    hipLaunchKernelGGL(bn_dy_scale_kernel, dim3(1), dim3(1024), 0, st, gamma, invstd, s1, s2, mx, groups, c, 1.0f / (float)rows,
-                       sqrtf((float)rows), dy_sinv);
-    return check_launch("bn_dy_scale");
+    return check_launch("bn_bwd_dgamma");
   }
   return 0;
 }
@@ -1232,25 +1135,42 @@ int mvg_bn_finalize(const float *stats, int groups, int partials, int rows_per_p
   MVG_REQUIRE(groups > 0 && partials > 0 && c > 0 && rows_per_group > 0, "bn_finalize: bad sizes");
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps(MVG_K_BN_FINALIZE, st, 0.0, 4.0 * groups * (double)partials * 2 * c);
-  // with a registered workspace: ONE launch (slices, per-group statistics and the running statistics by last-arriver
-  // hand-offs); scratch = [groups][2][c] doubles + the slices
-  {
-    int per_slice = ceil_div(partials, 64);
-    if (per_slice < 128) per_slice = 128;
-    const int S = ceil_div(partials, per_slice);
-    const int cblocks = ceil_div(c, 8);
-    const size_t mv_floats = (size_t)groups * 2 * c * 2, sl_floats = S > 1 ? (size_t)groups * S * 3 * c * 2 : 0;
-    float *base = stream_scratch(st, mv_floats + sl_floats);
-    unsigned *counters = stream_counters(st);
-    if (base && counters && (size_t)cblocks * (groups + 1) <= kCounterFloats) {
-      hipLaunchKernelGGL(bn_finalize_fused_kernel, dim3(cblocks, S, groups), dim3(256), 0, st, stats, partials, rows_per_partial,
-                         (long long)rows_per_group, c, per_slice, S, (double *)(base + mv_floats), (double *)base, counters, gamma, beta, eps,
-                         momentum, mean, invstd, scale, shift, running_mean, running_var);
-      return check_launch("bn_finalize(fused)");
-    }
-  }
   const double *sliced = nullptr;
   int slices = 0;
+  // scratch: [groups][2][c] doubles for the group-parallel form, then the slices
+  const size_t mv_floats = (size_t)groups * 2 * c * 2;
+  double *mv = groups > 1 ? (double *)stream_scratch(st, mv_floats) : nullptr;
+  if (partials >= 1024) {
+    slices = 64;
+    const int per_slice = ceil_div(partials, slices);
+    slices = ceil_div(partials, per_slice);
+    float *base = stream_scratch(st, mv_floats + (size_t)groups * slices * 3 * c * 2);
+    double *buf = base ? (double *)(base + mv_floats) : nullptr;
+    if (buf) {
+      hipLaunchKernelGGL(bn_partials_slice_kernel, dim3(ceil_div(c, 8), slices, groups), dim3(256), 0, st, stats, partials,
+                         rows_per_partial, (long long)rows_per_group, c, per_slice, buf, slices);
+      if (check_launch("bn_partials_slice")) return 1;
+      sliced = buf;
+    }
+  }
+  if (groups > 1 && groups <= 8 && (partials < 1024 || sliced)) {
+    // every group's statistics and the running statistics in ONE launch (the workgroup's lanes divided between the groups)
+    hipLaunchKernelGGL(bn_finalize_allgroups_kernel, dim3(ceil_div(c, 8)), dim3(1024), 0, st, stats, sliced, slices, groups, 128 / groups,
+                       partials, rows_per_partial, (long long)rows_per_group, c, gamma, beta, eps, momentum, mean, invstd, scale, shift,
+                       running_mean, running_var);
+    return check_launch("bn_finalize(all groups)");
+  }
+  if (mv) {
+    hipLaunchKernelGGL(bn_finalize_group_kernel, dim3(ceil_div(c, 8), groups), dim3(1024), 0, st, stats, sliced, slices, partials,
+                       rows_per_partial, (long long)rows_per_group, c, gamma, beta, eps, mean, invstd, scale, shift, mv);
+    if (check_launch("bn_finalize(groups)")) return 1;
+    if (running_mean || running_var) {
+      hipLaunchKernelGGL(bn_running_update_kernel, dim3(ceil_div(c, 256)), dim3(256), 0, st, mv, groups, c, momentum, running_mean,
+                         running_var);
+      return check_launch("bn_running_update");
+    }
+    return 0;
+  }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(c, 8)), dim3(1024), 0, st, stats, sliced, slices, groups, partials,
                      rows_per_partial, (long long)rows_per_group, c, gamma, beta, running_mean, running_var, momentum, eps, mean,
                      invstd, scale, shift);

@@ -20,25 +20,6 @@ void prof_end(int family, hipStream_t s);
 // ordered by the stream, so every kernel sequence that finishes with its scratch before the next launch on that
 // stream may share it (stream-K pieces, bn_finalize slices).  The library allocates nothing.
 float *stream_scratch(hipStream_t st, size_t floats);
-// ... and its arrival-counter area (kCounterFloats 32-bit counters, all zero between kernels), or nullptr.  Kernels that
-// fold a "finalize" step into their last-arriving workgroup count arrivals here (bn.hip).
-constexpr size_t kCounterFloats = 4096;
-unsigned *stream_counters(hipStream_t st);
-
-// Cross-workgroup hand-off (MI355X_MICROARCH.md, "Valid forms"): every storing wave has waited for its stores and the
-// workgroup has met at a barrier BEFORE thread 0 calls this; it releases the workgroup's stores at agent scope, counts the
-// arrival, and - when this workgroup is the `expected`-th, i.e. last - resets the counter and acquires, so that after
-// the barrier that follows, plain loads of the other workgroups' data are fresh.  Returns 1 for the last arriver.
-__device__ __forceinline__ int arrive_and_check_last(unsigned *counter, unsigned expected) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  const unsigned old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (old + 1u != expected) return 0;
-  __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  return 1;
-}
 // device CUs minus mvg_set_reserved_cus(): what stream-K grids, wgrad splits and split-K plan for
 int compute_cus();
 
