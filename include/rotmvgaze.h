@@ -594,10 +594,6 @@ int mvg_conv_wgrad_split(const mvg_conv_desc *d, const void *x_sp, const void *d
 /* The same launch WITHOUT its slab reduce (splits > 1: workspace receives the per-split partial gradients), and the reduces
  * of up to 8 such gradients in ONE launch (a residual block's convs): dw[i] (+)= the sum over host_splits[i] slabs of
  * host_n[i] floats, fixed order.  Host arrays; the launch copies them. */
-/* A/B switch of the backward-weight kernel (process-wide; default 1): 1 = wgrad_split16_kernel (LDS-DMA loader,
- * v_mfma_f32_16x16x32_f16, one stage), 0 = round 3's wgrad_split_kernel (register-staged loader, 32x32x16).  Same results to
- * summation order; kept so that scripts/conv_bench.py can time both on one box. */
-int mvg_set_wgrad_split_variant(int v);
 int mvg_conv_wgrad_split_slabs(const mvg_conv_desc *d, const void *x_sp, const void *dy_sp, const float *dy_sinv, float *workspace,
                                int splits, void *stream);
 int mvg_wgrad_reduce_batch(const float *const *host_slabs, float *const *host_dw, const int64_t *host_n, const int32_t *host_splits,

@@ -97,7 +97,6 @@ SIGNATURES = {
     "mvg_conv_wgrad_splits_split": (_I, [_D]),
     "mvg_conv_wgrad_split": (_I, [_D, _P, _P, _P, _P, _P, _I, _I, _P]),
     "mvg_conv_wgrad_split_slabs": (_I, [_D, _P, _P, _P, _P, _I, _P]),
-    "mvg_set_wgrad_split_variant": (_I, [_I]),
     "mvg_wgrad_reduce_batch": (_I, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int32),
                                     C.POINTER(C.c_int32), _I, _P]),
     "mvg_bn_apply_bits": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _P]),

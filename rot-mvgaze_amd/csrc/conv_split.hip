@@ -482,6 +482,11 @@ __global__ __launch_bounds__(256, DGRAD ? 3 : 4) void igemm_split16_kernel(Igemm
 // [piece][k][m] (rows padded by 32 elements) and the fragments come from ds_read_b64_tr_b16 (v_mfma_f32_32x32x16_f16,
 // three products per 16 pixels).  A K-step is 16 pixels: 20 KB per stage, two stages; a thread's two piece vectors of
 // one 8-channel chunk are 32 contiguous bytes in memory.  The result is multiplied by dy's 2^-k (p.dy_sinv).
+// Round 4 measured the forward kernel's recipe here too (LDS-DMA loader into a row-contiguous image, ds_read_b64_tr_b16
+// fragments, v_mfma_f32_16x16x32_f16, K-step 32; commit history + profiles/r04_wgrad_dma_*_ab.txt): 19.1 ms per C3 step with
+// one 32 KB stage at three workgroups per CU, 29.4 ms with two stages at two per CU, against this kernel's 15.2-15.9 ms -
+// K here is the pixel axis (hundreds of steps, both operands streamed once), and the register-staged two-stage pipeline
+// with a 16-pixel step keeps more loads in flight per CU than a DMA stage that must drain before it is multiplied.
 // ------------------------------------------------------------------------------------------
 template <int BM, int BN, bool INCR>
 __global__ __launch_bounds__(256, 3) void wgrad_split_kernel(WgradParams p) {
@@ -675,245 +680,6 @@ __global__ __launch_bounds__(256, 3) void wgrad_split_kernel(WgradParams p) {
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// wgrad_split16_kernel (round 4): the same GEMM on the forward kernel's recipe - LDS-DMA loader, v_mfma_f32_16x16x32_f16,
-// ONE 32 KB stage, several workgroups per CU covering each other's DMA waits.
-//   * K-step = 32 pixels.  LDS images are pixel-major and ROW-CONTIGUOUS like memory: row k of the A image holds the
-//     BM / 8 chunks x 2 pieces (16-byte slots, 512 bytes for BM = 128) that pixel k's row of dy contributes; one LDS-DMA
-//     wave-instruction fills 64 consecutive slots = two whole rows from two contiguous 512-byte spans (wgrad_split_kernel
-//     loads through registers: buffer_load -> VGPR -> ds_write_b128, 13 LDS cycles per KB against the DMA's 4).
-//   * fragments by ds_read_b64_tr_b16 (the transposing read: lane t of a 16-lane group receives column t of a 4 x 16
-//     block of b16): the A / B fragment of a 16x16x32 MFMA for lane l is k = 8 (l >> 4) .. + 7 of column l & 15 = two reads
-//     of 4 rows each.  Bank conflicts: a 32-lane half (two k-groups, 8 rows) touches, per row, two 16-byte slots 32
-//     bytes apart; the slot index is XORed with swz(k) = (k & 1) | ((k >> 1 & 1) << 2) | ((k >> 3 & 1) << 3) - applied to the
-//     SOURCE address of the DMA (its LDS destination is linear in the lane) and to the read address - which spreads the
-//     8 rows over the 16 slots of a 256-byte bank line: conflict-free.
-//   * the B operand is gathered (pixel at tap, channel): a lane's slot - hence its (tap, channel chunk, piece) - is the
-//     same in every instruction it issues, only the pixel row changes; the 32 pixels of a K-step are decoded once by
-//     threads 0..31 into an LDS row table (double-buffered: step kt + 1's rows are written while step kt's DMA flies).
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int wg_swz(int k) { return (k & 1) | (((k >> 1) & 1) << 2) | (((k >> 3) & 1) << 3); }
-
-template <int BM, int BN, bool INCR, int STAGES = 2>
-__global__ __launch_bounds__(256, STAGES == 2 ? 2 : 3) void wgrad_split16_kernel(WgradParams p) {
-  constexpr int BK = 32, WGM = 2, WGN = 2, NW = 4;
-  constexpr int WTM = BM / WGM, WTN = BN / WGN, TM = WTM / 16, TN = WTN / 16;
-  constexpr int SA = BM / 8 * SP_NP, SB = BN / 8 * SP_NP;        // 16-byte slots per pixel row
-  constexpr int ROWA = SA * 16, ROWB = SB * 16;
-  constexpr int A_BYTES = BK * ROWA, B_BYTES = BK * ROWB;
-  constexpr int QA = BK * SA / 64, QB = BK * SB / 64;            // DMA wave-instructions per stage
-  constexpr int A_PER = QA / NW, B_PER = QB / NW;
-  static_assert(QA % NW == 0 && QB % NW == 0 && SA <= 64 && SB <= 64, "whole instructions per wave");
-  constexpr int STAGE_B = A_BYTES + B_BYTES;
-  constexpr int TAB_OFF = STAGES * STAGE_B;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[TAB_OFF + 2 * BK * 16];
-  uint4 *rowtab = reinterpret_cast<uint4 *>(smem + TAB_OFF);      // [2][32]: {byte offset of the pixel's tap-(0,0) input, iy0, ix0, in range}
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WGN, wn = wave % WGN;
-  const int tiles = p.mtiles * p.ntiles;
-  const int logical = xcd_remap(blockIdx.x, gridDim.x);
-  const int split = logical / tiles;
-  const int tile = logical - split * tiles;
-  const int ntile = tile % p.ntiles, mtile = tile / p.ntiles;
-  const long long m_begin = (long long)split * p.pixels_per_split;
-  long long m_end = m_begin + p.pixels_per_split;
-  if (m_end > p.pixels) m_end = p.pixels;
-  const int m_count = m_end > m_begin ? (int)(m_end - m_begin) : 0;
-  const int ohw = p.ho * p.wo;
-  const long long img0 = m_begin / ohw;
-  const unsigned rem0 = (unsigned)(m_begin - img0 * ohw);
-
-  const char *dy = reinterpret_cast<const char *>(p.dy);
-  const char *x = reinterpret_cast<const char *>(p.x);
-  const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(dy + m_begin * p.cout * SP_BYTES, (long long)SP_BYTES * m_count * p.cout);
-  const long long x_img_elems = (long long)p.h * p.w * p.cin;
-  const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(x + img0 * x_img_elems * SP_BYTES, p.x_bytes - (long long)SP_BYTES * img0 * x_img_elems);
-  typedef __attribute__((address_space(3))) void *lds_vp;
-
-  // ---- A loader: instruction Q = wave + 4 i covers LDS slots [64 Q, 64 Q + 64) of the A image
-  unsigned a_off[A_PER];
-#pragma unroll
-  for (int i = 0; i < A_PER; ++i) {
-    const int sl = (wave + NW * i) * 64 + lane;
-    const int k = sl / SA, s = (sl % SA) ^ wg_swz(k);             // source slot: (chunk, piece) = (s >> 1, s & 1)
-    const int chunk = mtile * (BM / 8) + (s >> 1);
-    a_off[i] = pred_off((unsigned)(k * p.cout) * (unsigned)SP_BYTES + (unsigned)chunk * 32u + (unsigned)(s & 1) * 16u, chunk * 8 < p.cout);
-  }
-  // ---- B loader: the lane's slot fixes (tap, channel chunk, piece); the row comes from the table
-  int b_row[B_PER], b_dy[B_PER], b_dx[B_PER];
-  unsigned b_const[B_PER];
-#pragma unroll
-  for (int i = 0; i < B_PER; ++i) {
-    const int sl = (wave + NW * i) * 64 + lane;
-    const int k = sl / SB, s = (sl % SB) ^ wg_swz(k);
-    const int col = ntile * BN + (s >> 1) * 8;
-    const bool cok = col < p.ncols;
-    const int tap = (int)fdiv((unsigned)(cok ? col : 0), p.cin_div);
-    const int cc = (cok ? col : 0) - tap * p.cin;
-    const int fr = (int)fdiv((unsigned)tap, p.s_div), fs = tap - fr * p.s;
-    b_row[i] = k;
-    b_dy[i] = cok ? fr - p.pad : 0x40000000;                       // (an out-of-range column never passes the bounds test)
-    b_dx[i] = fs - p.pad_w;
-    b_const[i] = (unsigned)(((fr - p.pad) * p.w + (fs - p.pad_w)) * p.cin + cc) * (unsigned)SP_BYTES + (unsigned)(s & 1) * 16u;
-  }
-  const unsigned row_bytes = (unsigned)(p.stride * p.w * p.cin) * (unsigned)SP_BYTES, col_bytes = (unsigned)(p.stride_w * p.cin) * (unsigned)SP_BYTES;
-  const unsigned img_bytes = (unsigned)x_img_elems * (unsigned)SP_BYTES;
-  // ---- row decoder state (threads 0..31: pixel kt * 32 + tid of this split)
-  int s_oy = 0, s_ox = 0;
-  unsigned s_imgoff = 0;
-  if (INCR && tid < BK) {
-    const unsigned pix = rem0 + (unsigned)tid;
-    const unsigned img = fdiv(pix, p.ohw_div);
-    const unsigned rem = pix - img * (unsigned)ohw;
-    const unsigned oy = fdiv(rem, p.wo_div);
-    s_oy = (int)oy;
-    s_ox = (int)(rem - oy * (unsigned)p.wo);
-    s_imgoff = img * img_bytes;
-  }
-  auto write_rows = [&](int kt) {                                  // threads 0..31: the table of K-step kt
-    if (tid < BK) {
-      int oy, ox;
-      unsigned imgoff;
-      if constexpr (INCR) {
-        oy = s_oy;
-        ox = s_ox;
-        imgoff = s_imgoff;
-        unsigned nx = (unsigned)s_ox + BK;                         // advance 32 pixels: columns wrap into rows, rows into the
-        const unsigned q = fdiv(nx, p.wo_div);                     // next image (at most once: ho * wo >= 2 * BK)
-        nx -= q * (unsigned)p.wo;
-        s_ox = (int)nx;
-        const int noy = s_oy + (int)q;
-        const bool wrap = noy >= p.ho;
-        s_oy = wrap ? noy - p.ho : noy;
-        s_imgoff += wrap ? img_bytes : 0u;
-      } else {
-        const unsigned pix = rem0 + (unsigned)(kt * BK + tid);
-        const unsigned img = fdiv(pix, p.ohw_div);
-        const unsigned rem = pix - img * (unsigned)ohw;
-        const unsigned uy = fdiv(rem, p.wo_div);
-        oy = (int)uy;
-        ox = (int)(rem - uy * (unsigned)p.wo);
-        imgoff = img * img_bytes;
-      }
-      const bool mok = kt * BK + tid < m_count;
-      rowtab[(kt & 1) * BK + tid] = make_uint4(imgoff + (unsigned)oy * row_bytes + (unsigned)ox * col_bytes, (unsigned)(oy * p.stride),
-                                              (unsigned)(ox * p.stride_w), mok ? 1u : 0u);
-    }
-  };
-  auto issue = [&](int kt) {
-    unsigned char *stg = smem + (STAGES == 2 ? (kt & 1) * STAGE_B : 0);
-#pragma unroll
-    for (int i = 0; i < A_PER; ++i) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_vp)(stg + (wave + NW * i) * 1024), 16, (int)a_off[i], 0, 0, 0);
-      a_off[i] += (unsigned)(BK * p.cout) * (unsigned)SP_BYTES;     // (bit 31 of a predicated-off offset survives: the sums stay < 2^31)
-    }
-#pragma unroll
-    for (int i = 0; i < B_PER; ++i) {
-      const uint4 r = rowtab[(kt & 1) * BK + b_row[i]];
-      const bool ok = (r.w != 0u) & ((unsigned)((int)r.y + b_dy[i]) < (unsigned)p.h) & ((unsigned)((int)r.z + b_dx[i]) < (unsigned)p.w);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_vp)(stg + A_BYTES + (wave + NW * i) * 1024), 16, (int)pred_off(r.x + b_const[i], ok), 0, 0,
-                                               0);
-    }
-  };
-
-  f32x4 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
-
-  // fragment addresses (first read: rows 8 kg + q; the second read is 4 rows further: + 4 * ROW bytes, same swizzle)
-  const int kg = lane >> 4, t16 = lane & 15, fq = t16 >> 2, fp = t16 & 3;
-  const int kf = 8 * kg + fq;
-  int fa_off[TM][SP_NP], fb_off[TN][SP_NP];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int pc = 0; pc < SP_NP; ++pc) {
-      const int chunk = (wm * WTM + i * 16) / 8 + (fp >> 1);
-      fa_off[i][pc] = kf * ROWA + (((chunk * 2 + pc) ^ wg_swz(kf)) << 4) + (fp & 1) * 8;
-    }
-#pragma unroll
-  for (int j = 0; j < TN; ++j)
-#pragma unroll
-    for (int pc = 0; pc < SP_NP; ++pc) {
-      const int chunk = (wn * WTN + j * 16) / 8 + (fp >> 1);
-      fb_off[j][pc] = A_BYTES + kf * ROWB + (((chunk * 2 + pc) ^ wg_swz(kf)) << 4) + (fp & 1) * 8;
-    }
-  typedef s16x4 __attribute__((address_space(3))) * lds_p4;
-  auto frag = [&](const unsigned char *stg, int off, int row_bytes_) {
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p4)(stg + off));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p4)(stg + off + 4 * row_bytes_));
-    typedef short s16x8 __attribute__((ext_vector_type(8)));
-    const s16x8 z = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(f16x8, z);
-  };
-
-  const int KT = (m_count + BK - 1) / BK;
-  auto compute = [&](const unsigned char *stg) {
-    f16x8 av[SP_NP][TM], bv[SP_NP][TN];
-#pragma unroll
-    for (int pc = 0; pc < SP_NP; ++pc) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i) av[pc][i] = frag(stg, fa_off[i][pc], ROWA);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bv[pc][j] = frag(stg, fb_off[j][pc], ROWB);
-    }
-    SPLIT16_ONE(0, 1) SPLIT16_ONE(1, 0) SPLIT16_ONE(0, 0)
-  };
-  write_rows(0);
-  __syncthreads();
-  if constexpr (STAGES == 2) {
-    // two stages: step kt + 1's DMA is in flight while step kt is multiplied (K = the split's pixels: hundreds of steps)
-    if (KT > 0) issue(0);
-    write_rows(1);
-    for (int kt = 0; kt < KT; ++kt) {
-      __syncthreads();                                       // rows of step kt + 1 are in the table; stage (kt + 1) & 1 has been read out
-      if (kt + 1 < KT) {
-        issue(kt + 1);
-        write_rows(kt + 2);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_PER + B_PER) : "memory");       // all but the newest stage's loads have landed
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      __syncthreads();
-      compute(smem + (kt & 1) * STAGE_B);
-    }
-  } else {
-    for (int kt = 0; kt < KT; ++kt) {
-      issue(kt);
-      write_rows(kt + 1);                                     // the next step's rows, published by the barrier below
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      compute(smem);
-      __syncthreads();                                         // everyone is done reading before the next DMA lands
-    }
-  }
-
-  float *out = p.out + (long long)split * p.cout * p.ncols;
-  const float osc = (p.dy_sinv ? *p.dy_sinv : 1.f) * (p.x_sinv ? *p.x_sinv : 1.f);
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = ntile * BN + wn * WTN + j * 16 + (lane & 15);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int row = mtile * BM + wm * WTM + i * 16 + 4 * (lane >> 4) + e;
-        if (row < p.cout && col < p.ncols) {
-          const long long off = (long long)row * p.ncols + col;
-          float v = acc[i][j][e] * osc;
-          if (p.accumulate) v += out[off];
-          out[off] = v;
-        }
-      }
-    }
-}
-
 // The slab sums of SEVERAL weight gradients in one launch (a residual block's 3-4 convs: round 3 ran one 10 us reduce
 // launch behind every wgrad launch, 63 per ResNet-50 step).  Same arithmetic and order as wgrad_reduce_kernel per item.
 struct ReduceItem {
@@ -1036,6 +802,8 @@ static int validate_split(const mvg_conv_desc *d) {
 
 template <bool DGRAD>
 static int launch_igemm_split(IgemmParams &p, hipStream_t st, bool lin = false) {
+  // (128 x 64 tiles for the short-K, write-heavy 1x1 layers - 64 -> 256 at 56 x 56 and the like - were measured in round 4:
+  // within 2 % of 128 x 128 on every such shape, forward and backward-data)
   const int bn = p.ncols >= 128 ? 128 : 64;
   const int bm = SP_BM;
   p.ntiles = ceil_div(p.ncols, bn);
@@ -1431,8 +1199,6 @@ int mvg_conv_dgrad_split_bnreduce(const mvg_conv_desc *d, const void *dy_sp, con
                                 bn_gamma, bn_invstd, (long long)d->n * d->h * d->w, dx_dy_sinv);
 }
 
-static int g_wgrad_variant = 1;          // 1: wgrad_split16_kernel (LDS-DMA loader, 16x16x32); 0: wgrad_split_kernel (round 3)
-
 static void wgrad_split_tile(const mvg_conv_desc *d, int &bm, int &bn) {
   const int ncols = d->r * d->s * d->cin;
   bm = d->cout >= 128 ? 128 : 64;
@@ -1507,14 +1273,11 @@ static int wgrad_split_impl(const mvg_conv_desc *d, const void *x_sp, const void
     ProfScope ps(lin ? MVG_K_LINEAR_WGRAD : MVG_K_CONV_WGRAD, st, flops, bytes);
     MVG_REQUIRE((long long)p.mtiles * p.ntiles * splits < (1LL << 31), "wgrad_split: grid too large");
     dim3 grid(p.mtiles * p.ntiles * splits), block(256);
-    const bool dma = g_wgrad_variant != 0;
-    const bool incr = (long long)d->ho * d->wo >= (dma ? 64 : 32);        // at most one image wrap per K-step (32 / 16 pixels)
-#define MVG_WGRAD_SPLIT(BM_, BN_)                                                                        \
-  do {                                                                                                   \
-    if (dma && incr) hipLaunchKernelGGL((wgrad_split16_kernel<BM_, BN_, true>), grid, block, 0, st, p);  \
-    else if (dma) hipLaunchKernelGGL((wgrad_split16_kernel<BM_, BN_, false>), grid, block, 0, st, p);    \
-    else if (incr) hipLaunchKernelGGL((wgrad_split_kernel<BM_, BN_, true>), grid, block, 0, st, p);      \
-    else hipLaunchKernelGGL((wgrad_split_kernel<BM_, BN_, false>), grid, block, 0, st, p);               \
+    const bool incr = (long long)d->ho * d->wo >= 32;        // at most one image wrap per 16-pixel step
+#define MVG_WGRAD_SPLIT(BM_, BN_)                                                                  \
+  do {                                                                                             \
+    if (incr) hipLaunchKernelGGL((wgrad_split_kernel<BM_, BN_, true>), grid, block, 0, st, p);     \
+    else hipLaunchKernelGGL((wgrad_split_kernel<BM_, BN_, false>), grid, block, 0, st, p);         \
   } while (0)
     if (bm == 128 && bn == 128) MVG_WGRAD_SPLIT(128, 128);
     else if (bm == 64 && bn == 128) MVG_WGRAD_SPLIT(64, 128);
@@ -1537,12 +1300,6 @@ static int wgrad_split_impl(const mvg_conv_desc *d, const void *x_sp, const void
 int mvg_conv_wgrad_split(const mvg_conv_desc *d, const void *x_sp, const void *dy_sp, const float *dy_sinv, float *dw, float *workspace,
                          int splits, int accumulate, void *stream) {
   return wgrad_split_impl(d, x_sp, dy_sp, dy_sinv, dw, workspace, splits, accumulate, stream);
-}
-
-int mvg_set_wgrad_split_variant(int v) {
-  MVG_REQUIRE(v == 0 || v == 1, "wgrad variant: 0 (register-staged loader, 32x32x16) or 1 (LDS-DMA loader, 16x16x32)");
-  g_wgrad_variant = v;
-  return 0;
 }
 
 int mvg_conv_wgrad_split_slabs(const mvg_conv_desc *d, const void *x_sp, const void *dy_sp, const float *dy_sinv, float *workspace, int splits,

@@ -86,12 +86,6 @@ for (cin, cout, k, st, pad, h), cnt in shapes.items():
         tf = timeit(lambda: ops.conv_fprop_split(d, xs, wk, y, stats_s))
         td = timeit(lambda: ops.conv_dgrad_split(d, gys, wts, dx))
         tw = timeit(lambda: ops.conv_wgrad_split(d, xs, gys, dw))
-        if os.environ.get("WGRAD_AB") == "1":          # the round-3 kernel on the same box, for the A/B column
-            from rot_mvgaze_amd._lib import lib
-            lib().mvg_set_wgrad_split_variant(0)
-            tw_old = timeit(lambda: ops.conv_wgrad_split(d, xs, gys, dw))
-            lib().mvg_set_wgrad_split_variant(1)
-            wg_ab = wg_ab + [(cin, cout, k, st, h, cnt, tw_old, tw)] if "wg_ab" in dir() else [(cin, cout, k, st, h, cnt, tw_old, tw)]
         bits = torch.randint(0, 16, (G * rows * cin // 4,), dtype=torch.uint8, device=dev)
         mx = torch.empty(G, cin, device=dev)
         tdf = timeit(lambda: ops.conv_dgrad_split_bnreduce(d, gys, wts, dx, None, x, bits, mean, invstd, None, s12[0], s12[1], dgb[0], dgb[1], False, mx))
@@ -113,10 +107,5 @@ for (cin, cout, k, st, pad, h), cnt in shapes.items():
             tot[name][0] += t * cnt; tot[name][1] += flops * cnt
 for name, (t, f) in tot.items():
     print(f"{name}: {t*1e3:.2f} ms total, {f/t/1e12:.1f} TF/s")
-if "wg_ab" in dir():
-    print("wgrad A/B (ms): round-3 kernel (register-staged, 32x32x16) vs wgrad_split16_kernel (LDS-DMA, 16x16x32)")
-    for (cin, cout, k, st, h, cnt, a, b) in wg_ab:
-        print(f"{cin:5d} {cout:5d} {k} {st} {h:4d} {cnt:3d} | {a*1e3:8.3f} {b*1e3:8.3f}  x{a/b:5.2f}")
-    print(f"total: {sum(c[5]*c[6] for c in wg_ab)*1e3:.2f} -> {sum(c[5]*c[7] for c in wg_ab)*1e3:.2f} ms")
 tt = sum(v[0] for k, v in tot.items() if k != "dgrad+bn"); ff = sum(v[1] for k, v in tot.items() if k != "dgrad+bn")
 print(f"all: {tt*1e3:.2f} ms, {ff/tt/1e12:.1f} TF/s")
