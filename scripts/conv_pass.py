@@ -35,6 +35,8 @@ for blk in spec.blocks:
     H = h
 n_ops = 0
 flops = 0.0
+op_log = []          # (op, shape, algorithmic read bytes, algorithmic write bytes) in launch order: scripts/pmc_per_op.py joins it
+                     # with the per-dispatch counters of a rocprofv3 --pmc pass over this script
 for (cin, cout, k, st, pad, h, need_dx) in layers:
     d = ConvDesc.make(G, N, h, h, cin, cout, k, st, pad)
     x = torch.randn(G, N, h, h, cin, device=dev)
@@ -65,6 +67,9 @@ for (cin, cout, k, st, pad, h, need_dx) in layers:
         ops.conv_fprop_split(d, xs, wk, y, stats_s)
         ops.conv_wgrad_split(d, xs, gys, dw)
         n_ops += 2
+        shp = f"{cin}->{cout} k{k} s{st} hw{h}"
+        op_log.append(("fprop", shp, 4.0 * (x.numel() + w.numel()), 4.0 * y.numel() + 4.0 * stats_s.numel()))
+        op_log.append(("wgrad", shp, 4.0 * (x.numel() + gy.numel()), 4.0 * w.numel()))
         if need_dx:
             # as in the step: backward-data carries the BatchNorm-backward reduce of the unit it feeds (mask bits, in-place addend)
             dx = torch.randn_like(x)
@@ -74,6 +79,7 @@ for (cin, cout, k, st, pad, h, need_dx) in layers:
             s12, dgb = torch.empty(3, G, cin, device=dev), torch.zeros(2, cin, device=dev)
             ops.conv_dgrad_split_bnreduce(d, gys, wts, dx, dx, x, bits, mean, invstd, None, s12[0], s12[1], dgb[0], dgb[1], False, s12[2])
             n_ops += 1
+            op_log.append(("dgrad+bn", shp, 4.0 * (gy.numel() + w.numel() + 2 * x.numel()) + bits.numel(), 4.0 * x.numel()))
     else:
         ops.conv_fprop(d, x, w, y, None, False, stats)
         ops.conv_wgrad(d, x, gy, dw)
@@ -86,3 +92,6 @@ for (cin, cout, k, st, pad, h, need_dx) in layers:
     torch.cuda.synchronize()
     del x, y, gy, stats
 print(f"conv ops: {n_ops}  flops: {flops:.4e}")
+if os.environ.get("CONV_PASS_LOG"):
+    import json
+    json.dump(op_log, open(os.environ["CONV_PASS_LOG"], "w"))
