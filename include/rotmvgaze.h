@@ -514,18 +514,18 @@ int mvg_conv_stats_partials_split(const mvg_conv_desc *d, int32_t *rows_per_part
 int mvg_conv_fprop_split(const mvg_conv_desc *d, const void *x_sp, const float *x_sinv, const void *w_sp, const float *w_sinv,
                          float *y, float *stats, void *stream);
 /* inference forward with BatchNorm folded into the epilogue (like mvg_conv_fprop_affine): out = relu?(conv * scale +
- * shift (+ residual)); residual fp32 or sp (residual_s3; unscaled), the result fp32 or sp (out_s3; unscaled) - in sp the
+ * shift (+ residual)); residual fp32 or sp (residual_sp; unscaled), the result fp32 or sp (out_sp; unscaled) - in sp the
  * next conv reads it directly (resnet.py:60-75,113-133 in eval mode) */
 int mvg_conv_fprop_split_affine(const mvg_conv_desc *d, const void *x_sp, const float *x_sinv, const void *w_sp, const float *w_sinv,
-                                void *out, int out_s3, const float *scale, const float *shift, const void *residual,
-                                int residual_s3, int relu, void *stream);
+                                void *out, int out_sp, const float *scale, const float *shift, const void *residual,
+                                int residual_sp, int relu, void *stream);
 /* relu_mask_sp (may be NULL; stride-1 launches): an sp tensor shaped like dx - dx is zeroed where it is <= 0 (the ReLU of a
  * Linear's hidden layer, whose activation the forward wrote in sp) */
 int mvg_conv_dgrad_split(const mvg_conv_desc *d, const void *dy_sp, const float *dy_sinv, const void *w_crsk_sp,
                          const float *w_sinv, float *dx, const float *addend, const void *relu_mask_sp, void *stream);
 /* The BatchNorm passes on the split path: the conv output y and every gradient g stay fp32; what the next conv
  * reads is written in sp - the normalised activation (mvg_bn_apply_split, residual = the previous block's sp output
- * when residual_s3 != 0, else the raw fp32 downsample output with its res_scale / res_shift), the stem's pooled map
+ * when residual_sp != 0, else the raw fp32 downsample output with its res_scale / res_shift), the stem's pooled map
  * (mvg_bn_relu_maxpool_fwd_split) and dy (mvg_bn_bwd_apply_split: g already masked, or the mask from relu_scale /
  * relu_shift).  relu_bits as in mvg_bn_apply_bits (1 byte per 4 channels).  mvg_avgpool_fwd_split pools an sp map.
  * dy is stored times 2^k, k from the bound  max over (group, channel) of |gamma invstd| (mx + |s1|/n + sqrt(n) |s2|/n) >= |dy|,
@@ -534,8 +534,8 @@ int mvg_conv_dgrad_split(const mvg_conv_desc *d, const void *dy_sp, const float 
  * (mvg_bn_bwd_reduce_split, mvg_conv_dgrad_split_bnreduce, mvg_bn_relu_maxpool_bwd_reduce_split) take the unit's gamma and
  * dy_sinv (both NULL, or both given): their finalize launch then leaves *dy_sinv itself - partials, dgamma / dbeta and the
  * bound in ONE launch, folded into the last-arriving workgroups - and the apply entry is told so (dy_sinv_ready != 0). */
-int mvg_bn_apply_split(const float *y, const float *scale, const float *shift, const void *residual, int residual_s3,
-                       const float *res_scale, const float *res_shift, int relu, void *out_s3, uint8_t *relu_bits,
+int mvg_bn_apply_split(const float *y, const float *scale, const float *shift, const void *residual, int residual_sp,
+                       const float *res_scale, const float *res_shift, int relu, void *out_sp, uint8_t *relu_bits,
                        int groups, int64_t rows_per_group, int c, void *stream);
 int mvg_bn_bwd_reduce_split(const float *g, const uint8_t *relu_bits, const float *y, const float *mean, const float *invstd,
                             const float *relu_scale, const float *relu_shift, int groups, int64_t rows_per_group, int c,
@@ -543,12 +543,12 @@ int mvg_bn_bwd_reduce_split(const float *g, const uint8_t *relu_bits, const floa
                             float *dz_out, float *mx, const float *gamma, float *dy_sinv, void *stream);
 int mvg_bn_bwd_apply_split(const float *g, const float *y, const float *mean, const float *invstd, const float *gamma,
                            const float *s1, const float *s2, const float *relu_scale, const float *relu_shift,
-                           int groups, int64_t rows_per_group, int c, void *dy_s3, const float *mx, float *dy_sinv,
+                           int groups, int64_t rows_per_group, int c, void *dy_sp, const float *mx, float *dy_sinv,
                            int dy_sinv_ready, void *stream);
-int mvg_bn_relu_maxpool_fwd_split(const float *y, const float *scale, const float *shift, void *pooled_s3,
+int mvg_bn_relu_maxpool_fwd_split(const float *y, const float *scale, const float *shift, void *pooled_sp,
                                   uint8_t *argmax, int groups, int n_per_group, int h, int w, int c, int ho, int wo,
                                   void *stream);
-int mvg_avgpool_fwd_split(const void *x_s3, float *y, int n, int hw, int c, void *stream);
+int mvg_avgpool_fwd_split(const void *x_sp, float *y, int n, int hw, int c, void *stream);
 /* mvg_conv_dgrad_split fused with the BatchNorm-backward reduce pass of the unit whose output gradient dx is (stride 1
  * or 2: a stride-2 launch's parity classes - those a 1x1 filter never touches included - each bring their partials): dx is stored masked by that unit's ReLU (bn_bits from mvg_bn_apply_split, or fma(bn_y, relu_scale,
  * relu_shift) > 0, or no mask) and s1 / s2 / dgamma / dbeta come out of the same launch + a finalize; mx [groups][cin] (may be
@@ -587,7 +587,7 @@ int mvg_bn_relu_maxpool_bwd_reduce_split(const float *g_pooled, const uint8_t *a
 int mvg_bn_relu_maxpool_bwd_apply_split(const float *g_pooled, const uint8_t *argmax, const float *y, const float *mean,
                                         const float *invstd, const float *gamma, const float *scale, const float *shift,
                                         const float *s1, const float *s2, int groups, int n_per_group, int h, int w, int c,
-                                        int ho, int wo, void *dy_s3, const float *mx, float *dy_sinv, int dy_sinv_ready, void *stream);
+                                        int ho, int wo, void *dy_sp, const float *mx, float *dy_sinv, int dy_sinv_ready, void *stream);
 int mvg_conv_wgrad_splits_split(const mvg_conv_desc *d);   /* pixel-split count; workspace = splits * cout*r*s*cin floats */
 int mvg_conv_wgrad_split(const mvg_conv_desc *d, const void *x_sp, const void *dy_sp, const float *dy_sinv, float *dw,
                          float *workspace, int splits, int accumulate, void *stream);

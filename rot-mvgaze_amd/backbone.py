@@ -93,14 +93,14 @@ class Backbone:
         # d(loss)/d(img) (the backward-data launch runs on the fp32 kernel) or the width is odd.
         self.stem_rowwindow = True
         self.split_eval = True      # inference forward on the split kernels too
-        self._wk_cache: Dict[str, tuple] = {}     # inference: conv name -> (data_ptr, version, s3 weights)
-        # training: one launch per step makes every conv's bf16 / s3 weight copies
+        self._wk_cache: Dict[str, tuple] = {}     # inference: conv name -> (data_ptr, version, sp weights)
+        # training: one launch per step makes every conv's bf16 / sp weight copies
         self.batch_weight_prep = True
         self._wprep: Optional[Dict[str, tuple]] = None
         self._wprep_state = None
         self._wprep_versions = None
         self._wg_defer: Optional[list] = None # backward: (slabs, dw, splits, accumulate) of the split wgrads whose reduce is pending
-        self._split_now = self.split          # per forward call: off when a view's largest s3 tensor would exceed 2 GiB
+        self._split_now = self.split          # per forward call: off when a view's largest sp tensor would exceed 2 GiB
         self._stem_rw = False                 # per forward call: the stem runs in row-window form on the split kernels
         self._stem_w8 = None
 
@@ -185,7 +185,7 @@ class Backbone:
         return out
 
     def invalidate_weight_cache(self):
-        """Forget the inference path's cached s3 copies of the conv weights.  The cache is keyed on each parameter's
+        """Forget the inference path's cached sp copies of the conv weights.  The cache is keyed on each parameter's
         (data_ptr, version counter); writes that bypass the counter - ``p.data.copy_()`` / ``p.data.mul_()`` (EMA,
         clipping) or writes to ``model.param_arena()`` - must be followed by this call (or by
         ``torch.autograd.graph.increment_version(p)``), otherwise ``torch.no_grad()`` inference keeps using the old
@@ -208,7 +208,7 @@ class Backbone:
         cin = (8 if bf else 4) if c.cin == 3 else c.cin
         d = ConvDesc.make(G, N, H, W, cin, c.cout, c.k, c.stride, c.pad)
         dev = x.device
-        # split path: training steps of the fp32 model; sp_in = this conv reads s3 operands (all but the stem),
+        # split path: training steps of the fp32 model; sp_in = this conv reads sp operands (all but the stem),
         # sp_out = its consumers do (every unit: the stem's pooled map feeds layer1)
         sp_out = self._split_now and training and not bf
         sp_in = sp_out and c.cin != 3
@@ -259,11 +259,11 @@ class Backbone:
             ops.bn_eval_affine(1, c.cout, gamma, beta, rm, rv, BN_EPS, scale[:1], shift[:1])
             sp_eval = self._split_now and self.split_eval
             if sp_eval and c.cin != 3:
-                # ... on the split kernels: the epilogue writes the next conv's s3 operand directly (the downsample
+                # ... on the split kernels: the epilogue writes the next conv's sp operand directly (the downsample
                 # branch, read only as a residual, stays fp32)
                 wsrc = self.p[c.name + ".weight"].detach()
                 assert wsrc.is_contiguous(memory_format=torch.channels_last) or (c.k == 1 and wsrc.is_contiguous())
-                # the s3 copy of the weights is kept between calls while the parameter is unchanged (its version counter:
+                # the sp copy of the weights is kept between calls while the parameter is unchanged (its version counter:
                 # load_state_dict, optimizer steps - the fused Adam bumps it explicitly - and broadcasts all move it)
                 hit = self._wk_cache.get(c.name)
                 if hit is not None and hit[0] == wsrc.data_ptr() and hit[1] == wsrc._version:
@@ -452,7 +452,7 @@ class Backbone:
         G = u.y.shape[0]
         gp, bp = self.p[c.bn + ".weight"], self.p[c.bn + ".bias"]
         if u.fused_s12 is not None and u.split:
-            # split path, fused: g arrived masked and the sums came with it; dy goes out in s3
+            # split path, fused: g arrived masked and the sums came with it; dy goes out in sp
             (s12, sinv), u.fused_s12 = u.fused_s12, None
             dy = ops.sp_empty(*u.y.shape, device=g.device)
             ops.bn_bwd_apply_split(g, u.y, u.mean, u.invstd, gp.detach(), s12[0], s12[1], G, u.rows, c.cout, dy, None, s12[2], sinv)
@@ -469,7 +469,7 @@ class Backbone:
         acc = sink.accumulate(gp)
         assert acc == sink.accumulate(bp)
         if u.split:
-            # split path: g and y are fp32, dy goes to the conv kernels in s3; residual units carry their mask as bits
+            # split path: g and y are fp32, dy goes to the conv kernels in sp; residual units carry their mask as bits
             assert not (u.relu and ra is None) or u.relu_bits is not None
             sinv = torch.empty(1, dtype=torch.float32, device=g.device)       # dy's 2^-k: left by the reduce pass's finalize launch
             if u.relu_bits is not None:
@@ -625,7 +625,7 @@ class Backbone:
         if need_dimg and self.bf16:
             raise NotImplementedError("d(loss)/d(img) is not produced by the bf16 path")
         if tape.get("wprep_versions") is not None and tape["wprep_versions"] != getattr(self, "_wprep_versions", None):
-            raise RuntimeError("backward of a tape whose bf16 / s3 weight copies were overwritten by a later forward with "
+            raise RuntimeError("backward of a tape whose bf16 / sp weight copies were overwritten by a later forward with "
                                "DIFFERENT weights (forward, optimizer step, forward, then backward of the first call): "
                                "backward-data would run with the new weights.  Run backward before the weights change "
                                "(PyTorch raises its version-counter error in the same situation)")

@@ -60,7 +60,7 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
   const float osc = F32IO ? (p.a_sinv ? *p.a_sinv : 1.f) * (p.b_sinv ? *p.b_sinv : 1.f) : 1.f;
   float lin_scale = 1.f, lin_max = 0.f;
   if constexpr (LIN && F32IO) {
-    if (!DGRAD && p.out_s3 && p.out_sinv) {
+    if (!DGRAD && p.out_sp && p.out_sinv) {
       const float bound = (float)p.ktotal * 1073741824.f * osc + (p.bias_absmax ? *p.bias_absmax : 0.f);
       lin_scale = sp_scale_for(bound);
       if (tid == 0 && mtile == 0 && ntile == 0 && g == 0) *p.out_sinv = 1.f / lin_scale;
@@ -207,8 +207,8 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
       for (int k = 0; k < 8; ++k) x[k] = fmaxf(x[k], 0.f);
     }
     if constexpr (F32IO) {
-      if (!DGRAD && p.addend) {                // forward residual (fp32, or s3: the previous block's output), then ReLU
-        if (p.addend_s3) {                     // (an activation in sp storage: scale 1)
+      if (!DGRAD && p.addend) {                // forward residual (fp32, or sp: the previous block's output), then ReLU
+        if (p.addend_sp) {                     // (an activation in sp storage: scale 1)
           const uint4 *q = reinterpret_cast<const uint4 *>(p.addend) + (((long long)g * gelems + off + col) >> 3) * SP_NP;
           float r[8];
           merge2_chunk(q[0], q[1], r);
@@ -223,7 +223,7 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
           for (int k = 0; k < 8; ++k) x[k] = fmaxf(x[k], 0.f);
         }
       }
-      if (!DGRAD && p.out_s3) {                // the next conv's operand, written directly (one chunk per lane)
+      if (!DGRAD && p.out_sp) {                // the next conv's operand, written directly (one chunk per lane)
         if constexpr (LIN) {
 #pragma unroll
           for (int k = 0; k < 8; ++k) x[k] *= lin_scale;
@@ -237,7 +237,7 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
       }
       if (DGRAD && mask_f) {
         float mm[8];
-        if (p.mask_s3) {                       // the producer's activation in sp storage (a Linear's hidden layer)
+        if (p.mask_sp) {                       // the producer's activation in sp storage (a Linear's hidden layer)
           const uint4 *q = reinterpret_cast<const uint4 *>(p.mask) + (((long long)g * gelems + off + col) >> 3) * SP_NP;
           merge2_chunk(q[0], q[1], mm);
         } else {

@@ -346,7 +346,7 @@ __global__ void bn_eval_affine_kernel(int groups, int c, const float *gamma, con
 
 // ---- apply: out = [relu](y*scale + shift [+ residual]) -------------------------------------
 // TO / TR: storage of the output and of the residual when they differ from y's (the split path: y fp32 from the conv,
-// out in s3 for the next conv, residual s3 (identity) or fp32 (raw downsample output)); same access width as T.
+// out in sp for the next conv, residual sp (identity) or fp32 (raw downsample output)); same access width as T.
 template <typename T, typename TO = T, typename TR = T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T *__restrict__ y, const float *__restrict__ scale,
                                                        const float *__restrict__ shift,
@@ -754,8 +754,8 @@ __device__ __forceinline__ void st8_sp(sp_t *p, long long chunk, const F8 &x) {
   q[1] = q2;
 }
 
-template <bool RES_S3>
-__global__ __launch_bounds__(256) void bn_apply_s3_kernel(const float *__restrict__ y, const float *__restrict__ scale,
+template <bool RES_SP>
+__global__ __launch_bounds__(256) void bn_apply_sp_kernel(const float *__restrict__ y, const float *__restrict__ scale,
                                                           const float *__restrict__ shift, const void *__restrict__ residual,
                                                           const float *__restrict__ res_scale,
                                                           const float *__restrict__ res_shift, int relu, sp_t *__restrict__ out,
@@ -784,7 +784,7 @@ __global__ __launch_bounds__(256) void bn_apply_s3_kernel(const float *__restric
     }
     const F8 v = ld8(y, base + i);
     F8 r, o;
-    if (residual) r = RES_S3 ? ld8_sp(reinterpret_cast<const sp_t *>(residual), base + i) : ld8(reinterpret_cast<const float *>(residual), base + i);
+    if (residual) r = RES_SP ? ld8_sp(reinterpret_cast<const sp_t *>(residual), base + i) : ld8(reinterpret_cast<const float *>(residual), base + i);
     unsigned m = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -823,7 +823,7 @@ __global__ __launch_bounds__(1024) void bn_dy_scale_kernel(const float *__restri
   }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_apply_s3_kernel(const float *__restrict__ g, const float *__restrict__ y,
+__global__ __launch_bounds__(256) void bn_bwd_apply_sp_kernel(const float *__restrict__ g, const float *__restrict__ y,
                                                               const float *__restrict__ mean, const float *__restrict__ invstd,
                                                               const float *__restrict__ gamma, const float *__restrict__ s1,
                                                               const float *__restrict__ s2, const float *__restrict__ mscale,
@@ -1392,29 +1392,29 @@ int mvg_bn_bwd_reduce_split(const float *g, const uint8_t *relu_bits, const floa
                                    dbeta, accumulate, workspace, dz_out, stream, relu_bits, mx, gamma, dy_sinv);
 }
 
-int mvg_bn_apply_split(const float *y, const float *scale, const float *shift, const void *residual, int residual_s3,
-                       const float *res_scale, const float *res_shift, int relu, void *out_s3, uint8_t *relu_bits, int groups,
+int mvg_bn_apply_split(const float *y, const float *scale, const float *shift, const void *residual, int residual_sp,
+                       const float *res_scale, const float *res_shift, int relu, void *out_sp, uint8_t *relu_bits, int groups,
                        int64_t rows_per_group, int c, void *stream) {
   MVG_REQUIRE(c % 8 == 0, "bn_apply_split: c %% 8 != 0");
-  MVG_REQUIRE(!(residual_s3 && res_scale), "bn_apply_split: an s3 residual is already normalised (no res_scale / res_shift)");
+  MVG_REQUIRE(!(residual_sp && res_scale), "bn_apply_split: an sp residual is already normalised (no res_scale / res_shift)");
   MVG_REQUIRE((res_scale == nullptr) == (res_shift == nullptr) && (residual || !res_scale),
               "bn_apply_split: res_scale / res_shift go together and need a residual");
   hipStream_t st = (hipStream_t)stream;
   const long long n8 = rows_per_group * (c / 8);
-  ProfScope ps(MVG_K_BN_APPLY, st, 0.0, 8.0 * groups * (double)n8 * (4.0 + SP_BYTES + (residual ? (residual_s3 ? (double)SP_BYTES : 4.0) : 0.0)));
+  ProfScope ps(MVG_K_BN_APPLY, st, 0.0, 8.0 * groups * (double)n8 * (4.0 + SP_BYTES + (residual ? (residual_sp ? (double)SP_BYTES : 4.0) : 0.0)));
   const dim3 grid(grid_for(n8), groups), block(256);
-  if (residual && residual_s3)
-    hipLaunchKernelGGL(bn_apply_s3_kernel<true>, grid, block, 0, st, y, scale, shift, residual, res_scale, res_shift, relu,
-                       (sp_t *)out_s3, n8, c / 8, c, (unsigned short *)relu_bits);
+  if (residual && residual_sp)
+    hipLaunchKernelGGL(bn_apply_sp_kernel<true>, grid, block, 0, st, y, scale, shift, residual, res_scale, res_shift, relu,
+                       (sp_t *)out_sp, n8, c / 8, c, (unsigned short *)relu_bits);
   else
-    hipLaunchKernelGGL(bn_apply_s3_kernel<false>, grid, block, 0, st, y, scale, shift, residual, res_scale, res_shift, relu,
-                       (sp_t *)out_s3, n8, c / 8, c, (unsigned short *)relu_bits);
+    hipLaunchKernelGGL(bn_apply_sp_kernel<false>, grid, block, 0, st, y, scale, shift, residual, res_scale, res_shift, relu,
+                       (sp_t *)out_sp, n8, c / 8, c, (unsigned short *)relu_bits);
   return check_launch("bn_apply_split");
 }
 
 int mvg_bn_bwd_apply_split(const float *g, const float *y, const float *mean, const float *invstd, const float *gamma,
                            const float *s1, const float *s2, const float *relu_scale, const float *relu_shift, int groups,
-                           int64_t rows_per_group, int c, void *dy_s3, const float *mx, float *dy_sinv, int dy_sinv_ready, void *stream) {
+                           int64_t rows_per_group, int c, void *dy_sp, const float *mx, float *dy_sinv, int dy_sinv_ready, void *stream) {
   MVG_REQUIRE(c % 8 == 0, "bn_bwd_apply_split: c %% 8 != 0");
   MVG_REQUIRE(mx && dy_sinv, "bn_bwd_apply_split: mx (max |masked gradient| per (group, channel) from the reduce pass) and dy_sinv are required");
   MVG_REQUIRE((relu_scale == nullptr) == (relu_shift == nullptr), "bn_bwd_apply_split: relu_scale and relu_shift go together");
@@ -1426,15 +1426,15 @@ int mvg_bn_bwd_apply_split(const float *g, const float *y, const float *mean, co
                        sqrtf((float)rows_per_group), dy_sinv);
     if (check_launch("bn_dy_scale")) return 1;
   }
-  hipLaunchKernelGGL(bn_bwd_apply_s3_kernel, dim3(grid_for(n8), groups), dim3(256), 0, st, g, y, mean, invstd, gamma, s1, s2,
-                     relu_scale, relu_shift, n8, 1.0f / (float)rows_per_group, c / 8, c, (sp_t *)dy_s3, dy_sinv);
+  hipLaunchKernelGGL(bn_bwd_apply_sp_kernel, dim3(grid_for(n8), groups), dim3(256), 0, st, g, y, mean, invstd, gamma, s1, s2,
+                     relu_scale, relu_shift, n8, 1.0f / (float)rows_per_group, c / 8, c, (sp_t *)dy_sp, dy_sinv);
   return check_launch("bn_bwd_apply_split");
 }
 
-int mvg_bn_relu_maxpool_fwd_split(const float *y, const float *scale, const float *shift, void *pooled_s3, uint8_t *argmax,
+int mvg_bn_relu_maxpool_fwd_split(const float *y, const float *scale, const float *shift, void *pooled_sp, uint8_t *argmax,
                                   int groups, int n_per_group, int h, int w, int c, int ho, int wo, void *stream) {
   MVG_REQUIRE(c % 8 == 0, "bn_relu_maxpool_fwd_split: c %% 8 != 0");
-  return bn_relu_maxpool_fwd_impl<float, sp_t>(y, scale, shift, (sp_t *)pooled_s3, argmax, groups, n_per_group, h, w, c, ho, wo,
+  return bn_relu_maxpool_fwd_impl<float, sp_t>(y, scale, shift, (sp_t *)pooled_sp, argmax, groups, n_per_group, h, w, c, ho, wo,
                                                stream);
 }
 
@@ -1453,7 +1453,7 @@ int mvg_bn_relu_maxpool_bwd_reduce_split(const float *g_pooled, const uint8_t *a
 int mvg_bn_relu_maxpool_bwd_apply_split(const float *g_pooled, const uint8_t *argmax, const float *y, const float *mean,
                                         const float *invstd, const float *gamma, const float *scale, const float *shift,
                                         const float *s1, const float *s2, int groups, int n_per_group, int h, int w, int c, int ho,
-                                        int wo, void *dy_s3, const float *mx, float *dy_sinv, int dy_sinv_ready, void *stream) {
+                                        int wo, void *dy_sp, const float *mx, float *dy_sinv, int dy_sinv_ready, void *stream) {
   MVG_REQUIRE(c % 8 == 0 && mx && dy_sinv, "bn_relu_maxpool_bwd_apply_split: c %% 8 != 0, or mx / dy_sinv missing");
   const long long rows = (long long)n_per_group * h * w;
   if (!dy_sinv_ready) {
@@ -1462,7 +1462,7 @@ int mvg_bn_relu_maxpool_bwd_apply_split(const float *g_pooled, const uint8_t *ar
     if (check_launch("bn_dy_scale")) return 1;
   }
   return bn_relu_maxpool_bwd_apply_impl<float, sp_t>(g_pooled, argmax, y, mean, invstd, gamma, scale, shift, s1, s2, groups,
-                                                     n_per_group, h, w, c, ho, wo, (sp_t *)dy_s3, stream, dy_sinv);
+                                                     n_per_group, h, w, c, ho, wo, (sp_t *)dy_sp, stream, dy_sinv);
 }
 
 MVG_BN_BITS_FACES(, float)

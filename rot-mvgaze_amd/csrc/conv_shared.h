@@ -138,13 +138,13 @@ struct IgemmParams {
   float *bn_part;
   int bn_parts;
   // split kernels, inference forward (BatchNorm folded: y = acc * scale + bias (+ residual) [relu]): the residual
-  // and / or the result in s3 (the next conv's operand format) instead of fp32
-  int addend_s3, out_s3, mask_s3;
+  // and / or the result in sp (the next conv's operand format) instead of fp32
+  int addend_sp, out_sp, mask_sp;
   // split kernels: the operands hold (value * 2^k) for a per-tensor k (elem.h: sp_t); the epilogue multiplies the
   // accumulators by *a_sinv * *b_sinv (device scalars, each 2^-k of its operand; null = 1)
   const float *a_sinv, *b_sinv;
   // split kernels running a Linear of the fusion block (igemm_split16_kernel<.., LIN = true>): out_absmax receives max |result| of
-  // an fp32 result (atomicMax on the bits; the caller clears it); an sp result (out_s3) is stored times 2^k from the bound
+  // an fp32 result (atomicMax on the bits; the caller clears it); an sp result (out_sp) is stored times 2^k from the bound
   // ktotal * 2^30 * a_sinv * b_sinv + *bias_absmax and *out_sinv receives 2^-k
   unsigned *out_absmax;
   float *out_sinv;

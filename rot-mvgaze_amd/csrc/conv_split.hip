@@ -950,10 +950,10 @@ int mvg_conv_stats_partials_split(const mvg_conv_desc *d, int32_t *rows_per_part
   return ceil_div(rows, SP_BM) * 2;
 }
 
-struct SplitAffine {       // inference forward: y = acc * scale + shift (+ residual) [relu], result fp32 or s3
+struct SplitAffine {       // inference forward: y = acc * scale + shift (+ residual) [relu], result fp32 or sp
   const float *scale, *shift;
   const void *residual;
-  int residual_s3, relu, out_s3;
+  int residual_sp, relu, out_sp;
   // Linear layers of the fusion block (LIN kernels): see IgemmParams::out_absmax / out_sinv / bias_absmax
   int lin;
   float *out_absmax, *out_sinv;
@@ -977,9 +977,9 @@ static int fprop_split_impl(const mvg_conv_desc *d, const void *x_sp, const floa
     p.scale = aff->scale;
     p.bias = aff->shift;
     p.addend = (const float *)aff->residual;
-    p.addend_s3 = aff->residual_s3;
+    p.addend_sp = aff->residual_sp;
     p.relu = aff->relu;
-    p.out_s3 = aff->out_s3;
+    p.out_sp = aff->out_sp;
     p.out_absmax = (unsigned *)aff->out_absmax;
     p.out_sinv = aff->out_sinv;
     p.bias_absmax = aff->bias_absmax;
@@ -1034,10 +1034,10 @@ int mvg_conv_fprop_split(const mvg_conv_desc *d, const void *x_sp, const float *
 }
 
 int mvg_conv_fprop_split_affine(const mvg_conv_desc *d, const void *x_sp, const float *x_sinv, const void *w_sp, const float *w_sinv,
-                                void *out, int out_s3, const float *scale, const float *shift, const void *residual, int residual_s3,
+                                void *out, int out_sp, const float *scale, const float *shift, const void *residual, int residual_sp,
                                 int relu, void *stream) {
   MVG_REQUIRE(scale && shift && out, "fprop_split_affine: scale, shift and out are required");
-  const SplitAffine a = {scale, shift, residual, residual_s3, relu, out_s3, 0, nullptr, nullptr, nullptr};
+  const SplitAffine a = {scale, shift, residual, residual_sp, relu, out_sp, 0, nullptr, nullptr, nullptr};
   return fprop_split_impl(d, x_sp, x_sinv, w_sp, w_sinv, out, nullptr, stream, &a);
 }
 
@@ -1062,7 +1062,7 @@ static int dgrad_split_impl(const mvg_conv_desc *d, const void *dy_sp, const flo
   p.out = dx;
   p.addend = addend;
   p.mask = (const float *)relu_mask_sp;
-  p.mask_s3 = relu_mask_sp != nullptr;
+  p.mask_sp = relu_mask_sp != nullptr;
   p.out_absmax = (unsigned *)out_absmax;
   if (bnf) {
     p.bn_y = bnf->y;

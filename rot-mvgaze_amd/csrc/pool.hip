@@ -308,11 +308,11 @@ MVG_AVGPOOL_FACES(, float)
 MVG_AVGPOOL_FACES(_bf16, uint16_t)
 #undef MVG_AVGPOOL_FACES
 
-int mvg_avgpool_fwd_split(const void *x_s3, float *y, int n, int hw, int c, void *stream) {
+int mvg_avgpool_fwd_split(const void *x_sp, float *y, int n, int hw, int c, void *stream) {
   MVG_REQUIRE(c % 8 == 0, "avgpool_split: c %% 8 != 0");
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps(MVG_K_POOL, st, 0.0, (double)n * (6.0 * hw + 4.0) * c);
-  hipLaunchKernelGGL(avgpool_fwd_kernel<sp_t>, dim3(ceil_div((long long)n * (c / 4), 256)), dim3(256), 0, st, (const sp_t *)x_s3,
+  hipLaunchKernelGGL(avgpool_fwd_kernel<sp_t>, dim3(ceil_div((long long)n * (c / 4), 256)), dim3(256), 0, st, (const sp_t *)x_sp,
                      (float4 *)y, n, hw, c / 4);
   return check_launch("avgpool_fwd_split");
 }

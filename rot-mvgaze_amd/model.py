@@ -297,7 +297,7 @@ class MultiViewGaze(nn.Module):
         return self._grad_arena, [(p, self._grad_offsets[id(p)], p.numel()) for p in self._grad_order]
 
     def invalidate_weight_cache(self) -> None:
-        """``torch.no_grad()`` inference keeps s3 copies of the conv weights between calls, keyed on every parameter's
+        """``torch.no_grad()`` inference keeps sp copies of the conv weights between calls, keyed on every parameter's
         version counter.  The counter misses writes through ``p.data`` (``p.data.copy_`` / ``mul_``: EMA, clipping) and
         writes to ``param_arena()``: call this after such a write (or ``torch.autograd.graph.increment_version(p)``).
         ``load_state_dict``, the fused Adam, the data-parallel broadcast, ``train()`` and training forwards are covered."""

@@ -217,11 +217,11 @@ def conv_fprop_split(d: ConvDesc, x_sp: Tensor, w_sp: Tensor, y: Tensor, stats: 
     check(lib().mvg_conv_fprop_split(C.byref(d), _p(x_sp), _sinv(x_sp), _p(w_sp), _sinv(w_sp), _p(y), _p(stats), _s()), "conv_fprop_split")
 
 
-def conv_fprop_split_affine(d: ConvDesc, x_s3: Tensor, w_s3: Tensor, out: Tensor, scale: Tensor, shift: Tensor,
+def conv_fprop_split_affine(d: ConvDesc, x_sp: Tensor, w_sp: Tensor, out: Tensor, scale: Tensor, shift: Tensor,
                             residual: Optional[Tensor], relu: bool):
     """Inference forward on the split kernels, BatchNorm folded: out = relu?(conv * scale + shift (+ residual)).
     out / residual: fp32 tensors or (unscaled) sp tensors."""
-    check(lib().mvg_conv_fprop_split_affine(C.byref(d), _p(x_s3), _sinv(x_s3), _p(w_s3), _sinv(w_s3), _p(out), int(is_sp(out)), _p(scale),
+    check(lib().mvg_conv_fprop_split_affine(C.byref(d), _p(x_sp), _sinv(x_sp), _p(w_sp), _sinv(w_sp), _p(out), int(is_sp(out)), _p(scale),
                                             _p(shift), _p(residual), int(is_sp(residual)), int(relu), _s()), "conv_fprop_split_affine")
 
 
@@ -325,7 +325,7 @@ def conv_dgrad_bn_partials_split(d: ConvDesc) -> int:
     return n
 
 
-def conv_dgrad_split_bnreduce(d: ConvDesc, dy_s3, wt_s3, dx, addend, bn_y, bn_bits, bn_mean, bn_invstd, relu_affine, s1, s2, dgamma,
+def conv_dgrad_split_bnreduce(d: ConvDesc, dy_sp, wt_sp, dx, addend, bn_y, bn_bits, bn_mean, bn_invstd, relu_affine, s1, s2, dgamma,
                               dbeta, accumulate: bool, mx: Optional[Tensor] = None, bn_gamma: Optional[Tensor] = None,
                               dx_dy_sinv: Optional[Tensor] = None):
     """conv_dgrad_split + the BatchNorm-backward reduce pass of the unit whose output gradient dx is, in one launch.
@@ -333,7 +333,7 @@ def conv_dgrad_split_bnreduce(d: ConvDesc, dy_s3, wt_s3, dx, addend, bn_y, bn_bi
     P = conv_dgrad_bn_partials_split(d)
     part = torch.empty(d.groups * P * 3 * d.cin, dtype=torch.float32, device=dx.device)
     rs, rh = relu_affine if relu_affine is not None else (None, None)
-    check(lib().mvg_conv_dgrad_split_bnreduce(C.byref(d), _p(dy_s3), _sinv(dy_s3), _p(wt_s3), _sinv(wt_s3), _p(dx), _p(addend), _p(bn_y),
+    check(lib().mvg_conv_dgrad_split_bnreduce(C.byref(d), _p(dy_sp), _sinv(dy_sp), _p(wt_sp), _sinv(wt_sp), _p(dx), _p(addend), _p(bn_y),
                                               _p(bn_bits), _p(bn_mean), _p(bn_invstd), _p(rs), _p(rh), _p(part), _p(s1), _p(s2),
                                               _p(dgamma), _p(dbeta), int(accumulate), _p(mx), _p(bn_gamma), _p(dx_dy_sinv), _s(True)),
           "conv_dgrad_split_bnreduce")
@@ -352,19 +352,19 @@ def conv_dgrad_bf16_bnreduce(d: ConvDesc, dy, wt, dx, addend, bn_y, bn_bits, bn_
                                              int(accumulate), _s()), "conv_dgrad_bf16_bnreduce")
 
 
-def conv_wgrad_split(d: ConvDesc, x_s3: Tensor, dy_s3: Tensor, dw: Tensor, accumulate: bool = False, defer: Optional[list] = None):
+def conv_wgrad_split(d: ConvDesc, x_sp: Tensor, dy_sp: Tensor, dw: Tensor, accumulate: bool = False, defer: Optional[list] = None):
     """defer (a list): with more than one pixel split, only the slabs are written and (slabs, dw, splits, accumulate) is appended
     for ONE wgrad_reduce_batch launch over the list (the caller's: at the end of a residual block, on the same stream)."""
     splits = lib().mvg_conv_wgrad_splits_split(C.byref(d))
     if splits < 1:
         check(1, "conv_wgrad_splits_split")
     ws = torch.empty(splits * dw.numel(), dtype=torch.float32, device=dw.device) if splits > 1 else None
-    assert getattr(x_s3, "sinv", None) is None, "conv_wgrad_split: the activation operand is stored unscaled"
+    assert getattr(x_sp, "sinv", None) is None, "conv_wgrad_split: the activation operand is stored unscaled"
     if defer is not None and splits > 1:
-        check(lib().mvg_conv_wgrad_split_slabs(C.byref(d), _p(x_s3), _p(dy_s3), _sinv(dy_s3), _p(ws), splits, _s()), "conv_wgrad_split_slabs")
+        check(lib().mvg_conv_wgrad_split_slabs(C.byref(d), _p(x_sp), _p(dy_sp), _sinv(dy_sp), _p(ws), splits, _s()), "conv_wgrad_split_slabs")
         defer.append((ws, dw, splits, bool(accumulate)))
         return
-    check(lib().mvg_conv_wgrad_split(C.byref(d), _p(x_s3), _p(dy_s3), _sinv(dy_s3), _p(dw), _p(ws), splits, int(accumulate), _s()),
+    check(lib().mvg_conv_wgrad_split(C.byref(d), _p(x_sp), _p(dy_sp), _sinv(dy_sp), _p(dw), _p(ws), splits, int(accumulate), _s()),
           "conv_wgrad_split")
 
 
@@ -381,13 +381,13 @@ def wgrad_reduce_batch(items: list):
     items.clear()
 
 
-def bn_apply_split(y, scale, shift, residual, relu, out_s3, groups, rows_per_group, c, residual_affine=None, want_bits=False):
-    """y fp32 -> normalised (+ residual) (ReLU) activation in s3.  residual: an s3 tensor (identity) or the raw fp32
+def bn_apply_split(y, scale, shift, residual, relu, out_sp, groups, rows_per_group, c, residual_affine=None, want_bits=False):
+    """y fp32 -> normalised (+ residual) (ReLU) activation in sp.  residual: an sp tensor (identity) or the raw fp32
     downsample output with residual_affine = its (scale, shift).  want_bits: also return the ReLU mask bytes."""
     bits = torch.empty(groups * rows_per_group * c // 4, dtype=torch.uint8, device=y.device) if want_bits else None
     rs, rh = residual_affine if residual_affine is not None else (None, None)
-    res_s3 = is_sp(residual)
-    check(lib().mvg_bn_apply_split(_p(y), _p(scale), _p(shift), _p(residual), int(res_s3), _p(rs), _p(rh), int(relu), _p(out_s3),
+    res_sp = is_sp(residual)
+    check(lib().mvg_bn_apply_split(_p(y), _p(scale), _p(shift), _p(residual), int(res_sp), _p(rs), _p(rh), int(relu), _p(out_sp),
                                    _p(bits), groups, rows_per_group, c, _s()), "bn_apply_split")
     return bits
 
@@ -404,24 +404,24 @@ def bn_bwd_reduce_split(g, relu_bits, y, mean, invstd, groups, rows_per_group, c
                                         _p(dy_sinv), _s(True)), "bn_bwd_reduce_split")
 
 
-def bn_bwd_apply_split(g, y, mean, invstd, gamma, s1, s2, groups, rows_per_group, c, dy_s3, relu_affine=None, mx=None, dy_sinv=None):
+def bn_bwd_apply_split(g, y, mean, invstd, gamma, s1, s2, groups, rows_per_group, c, dy_sp, relu_affine=None, mx=None, dy_sinv=None):
     """dy (sp) = BatchNorm backward of the masked gradient g, scaled by the 2^k that its bound - from ``mx`` [groups, c] (max
-    |masked gradient| per (group, channel), left by the reduce pass) - allows; dy_s3.sinv receives 2^-k."""
+    |masked gradient| per (group, channel), left by the reduce pass) - allows; dy_sp.sinv receives 2^-k."""
     rs, rh = relu_affine if relu_affine is not None else (None, None)
     assert mx is not None and mx.dtype == torch.float32 and mx.numel() == groups * c
     ready = dy_sinv is not None             # the reduce pass / fused backward-data launch already left 2^-k there
-    dy_s3.sinv = dy_sinv if ready else torch.empty(1, dtype=torch.float32, device=g.device)
+    dy_sp.sinv = dy_sinv if ready else torch.empty(1, dtype=torch.float32, device=g.device)
     check(lib().mvg_bn_bwd_apply_split(_p(g), _p(y), _p(mean), _p(invstd), _p(gamma), _p(s1), _p(s2), _p(rs), _p(rh), groups,
-                                       rows_per_group, c, _p(dy_s3), _p(mx), _p(dy_s3.sinv), int(ready), _s()), "bn_bwd_apply_split")
+                                       rows_per_group, c, _p(dy_sp), _p(mx), _p(dy_sp.sinv), int(ready), _s()), "bn_bwd_apply_split")
 
 
-def bn_relu_maxpool_fwd_split(y, scale, shift, pooled_s3, argmax, groups, n_per_group, h, w, c, ho, wo):
-    check(lib().mvg_bn_relu_maxpool_fwd_split(_p(y), _p(scale), _p(shift), _p(pooled_s3), _p(argmax), groups, n_per_group, h, w, c,
+def bn_relu_maxpool_fwd_split(y, scale, shift, pooled_sp, argmax, groups, n_per_group, h, w, c, ho, wo):
+    check(lib().mvg_bn_relu_maxpool_fwd_split(_p(y), _p(scale), _p(shift), _p(pooled_sp), _p(argmax), groups, n_per_group, h, w, c,
                                               ho, wo, _s()), "bn_relu_maxpool_fwd_split")
 
 
-def avgpool_fwd_split(x_s3, y, n, hw, c):
-    check(lib().mvg_avgpool_fwd_split(_p(x_s3), _p(y), n, hw, c, _s()), "avgpool_fwd_split")
+def avgpool_fwd_split(x_sp, y, n, hw, c):
+    check(lib().mvg_avgpool_fwd_split(_p(x_sp), _p(y), n, hw, c, _s()), "avgpool_fwd_split")
 
 
 # ---- Linear layers of the fusion block in the bf16 path: fp32 tensors, bf16 matrix product (weights = bf16 copies)

@@ -292,8 +292,8 @@ def test_split_dgrad_fused_with_bn_backward_reduce(case, mask):
                                   (1, 2, 56, 64, 256, 1, 1, 0), (2, 7, 7, 512, 2048, 1, 1, 0), (2, 2, 7, 512, 512, 3, 1, 1)],
                          ids=lambda c: "g%d_n%d_h%d_%dto%d_k%d_s%d" % c[:7])
 @pytest.mark.parametrize("res", [None, "s3", "fp32"])
-@pytest.mark.parametrize("relu,out_s3", [(True, True), (False, False)])
-def test_split_inference_forward_with_folded_batchnorm(case, res, relu, out_s3):
+@pytest.mark.parametrize("relu,out_sp", [(True, True), (False, False)])
+def test_split_inference_forward_with_folded_batchnorm(case, res, relu, out_sp):
     """mvg_conv_fprop_split_affine (out = relu?(conv * scale + shift (+ residual)), result and residual in s3 or fp32)
     against float64 and against the fp32-MFMA inference kernel mvg_conv_fprop_affine."""
     from rot_mvgaze_amd import ops
@@ -314,9 +314,9 @@ def test_split_inference_forward_with_folded_batchnorm(case, res, relu, out_s3):
     want = torch.empty(G, N, d.ho, d.wo, cout, device=dev())
     ops.conv_fprop_affine(d, x, w, want, scale, shift, r, relu)
     wk, _ = ops.split_weights(d, w, False)
-    out = ops.sp_empty(G, N, d.ho, d.wo, cout, device=dev()) if out_s3 else torch.empty_like(want)
+    out = ops.sp_empty(G, N, d.ho, d.wo, cout, device=dev()) if out_sp else torch.empty_like(want)
     ops.conv_fprop_split_affine(d, ops.split_f32(x), wk, out, scale, shift, ops.split_f32(r) if res == "s3" else r, relu)
-    got = ops.merge_sp(out) if out_s3 else out
+    got = ops.merge_sp(out) if out_sp else out
     e_split, e_fp32 = rel_l2(got, ref), rel_l2(want, ref)
     assert e_split <= SPLIT_VS_F64 and e_split <= SPLIT_VS_FP32_KERNEL * e_fp32 + 1e-7, f"split {e_split:.2e}, fp32-MFMA kernel {e_fp32:.2e}"
 
