@@ -1153,8 +1153,10 @@ int mvg_bn_finalize(const float *stats, int groups, int partials, int rows_per_p
       sliced = buf;
     }
   }
-  if (groups > 1 && groups <= 8 && (partials < 1024 || sliced)) {
-    // every group's statistics and the running statistics in ONE launch (the workgroup's lanes divided between the groups)
+  if (groups > 1 && groups <= 4 && (partials < 1024 || sliced)) {
+    // every group's statistics and the running statistics in ONE launch (the workgroup's lanes divided between the groups:
+    // >= 32 lanes per group; with 8 groups - C5's shapes - 16 lanes per group made the call slower than the two launches
+    // below: bn_finalize 1.00 -> 1.39 ms per C5 step)
     hipLaunchKernelGGL(bn_finalize_allgroups_kernel, dim3(ceil_div(c, 8)), dim3(1024), 0, st, stats, sliced, slices, groups, 128 / groups,
                        partials, rows_per_partial, (long long)rows_per_group, c, gamma, beta, eps, momentum, mean, invstd, scale, shift,
                        running_mean, running_var);
