@@ -432,6 +432,8 @@ int mvg_stem_wgrad_bf16(const mvg_conv_desc *d, const void *xw, const void *dy, 
 int mvg_conv_wgrad_bf16(const mvg_conv_desc *d, const void *x, const void *dy, float *dw, float *workspace,
                         int splits, int accumulate, void *stream);
 int mvg_conv_wgrad_splits_bf16(const mvg_conv_desc *d);
+/* the launch without its slab reduce (splits > 1), for mvg_wgrad_reduce_batch - see mvg_conv_wgrad_split_slabs */
+int mvg_conv_wgrad_bf16_slabs(const mvg_conv_desc *d, const void *x, const void *dy, float *workspace, int splits, void *stream);
 /* nn.Linear of the fusion block in the bf16 path ("mixed"): activations, gradients, biases and outputs stay
  * fp32 in memory, the operand loaders round to bf16 on the way into LDS and the product runs on the bf16
  * matrix cores against the bf16 weight copies (w_bf16 [fout][fin]; wt_bf16 [fin][fout] for backward-data).

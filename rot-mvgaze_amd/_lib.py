@@ -158,6 +158,7 @@ SIGNATURES = {
     "mvg_stem_wgrad_splits_bf16": (_I, [_D]),
     "mvg_stem_wgrad_bf16": (_I, [_D, _P, _P, _P, _P, _I, _I, _P]),
     "mvg_conv_wgrad_splits_bf16": (_I, [_D]),
+    "mvg_conv_wgrad_bf16_slabs": (_I, [_D, _P, _P, _P, _I, _P]),
     "mvg_linear_fprop_mixed": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "mvg_linear_dgrad_mixed": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "mvg_linear_wgrad_mixed": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _I, _I, _P]),

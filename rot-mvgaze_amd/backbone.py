@@ -565,7 +565,7 @@ class Backbone:
             else:
                 gv.copy_(dw4[..., :3])
         else:
-            ops.conv_wgrad(u.desc, u.x_in, dy, sink.view(wp), sink.accumulate(wp))
+            ops.conv_wgrad(u.desc, u.x_in, dy, sink.view(wp), sink.accumulate(wp), defer=self._wg_defer if self.bf16 else None)
 
     def _flush_wgrad_reduces(self, dev):
         """The slab sums of the weight gradients launched since the last flush, in one launch on the stream that wrote the slabs."""

@@ -1077,7 +1077,7 @@ int mvg_conv_wgrad_splits_bf16(const mvg_conv_desc *d) {
 }
 
 static int wgrad_bf16_impl(const mvg_conv_desc *d, const void *x, const void *dy, float *dw, float *db, float *workspace,
-                           int splits, int accumulate, void *stream, bool f32in, int stride_w = -1, int pad_w = -1) {
+                           int splits, int accumulate, void *stream, bool f32in, int stride_w = -1, int pad_w = -1, bool slabs_only = false) {
   if (stride_w < 0 && validate_bf16(d)) return 2;
   const long long EB = f32in ? 4 : 2;
   MVG_REQUIRE(!db || f32in, "wgrad_bf16: the bias gradient rides on the fp32-operand form only");
@@ -1142,7 +1142,7 @@ static int wgrad_bf16_impl(const mvg_conv_desc *d, const void *x, const void *dy
 #undef MVG_WGRAD_BF16
     if (check_launch("conv_wgrad_bf16")) return 1;
   }
-  if (splits > 1) {
+  if (splits > 1 && !slabs_only) {
     const long long n = (long long)d->cout * p.ncols;
     MVG_REQUIRE(n % 4 == 0, "wgrad_bf16: weight elements %% 4 != 0");
     ProfScope ps(MVG_K_WGRAD_REDUCE, st, 0.0, 4.0 * n * (splits + 1));
@@ -1165,6 +1165,11 @@ static int wgrad_bf16_impl(const mvg_conv_desc *d, const void *x, const void *dy
 int mvg_conv_wgrad_bf16(const mvg_conv_desc *d, const void *x, const void *dy, float *dw, float *workspace, int splits,
                         int accumulate, void *stream) {
   return wgrad_bf16_impl(d, x, dy, dw, nullptr, workspace, splits, accumulate, stream, false);
+}
+
+int mvg_conv_wgrad_bf16_slabs(const mvg_conv_desc *d, const void *x, const void *dy, float *workspace, int splits, void *stream) {
+  MVG_REQUIRE(splits > 1 && workspace, "wgrad_bf16_slabs: splits > 1 and a workspace (the slabs ARE the result)");
+  return wgrad_bf16_impl(d, x, dy, workspace, nullptr, workspace, splits, 0, stream, false, -1, -1, true);
 }
 
 int mvg_stem_wgrad_splits_bf16(const mvg_conv_desc *d) {

@@ -16,14 +16,18 @@ Tensor = torch.Tensor
 
 
 def _p(t: Optional[Tensor]):
+    """Device pointer of t for a `void *` argument (ctypes converts the int; None = NULL).  Kept minimal: a ResNet-50 step makes
+    ~6000 of these from the host."""
     if t is None:
         return None
-    assert t.is_cuda and t.dtype in (torch.float32, torch.int32, torch.uint8, torch.int16, torch.bfloat16, torch.float16), (t.device, t.dtype)
-    return C.c_void_p(t.data_ptr())
+    assert t.is_cuda and t.dtype in _PTR_DTYPES, (t.device, t.dtype)
+    return t.data_ptr()
 
 
+_PTR_DTYPES = frozenset((torch.float32, torch.int32, torch.uint8, torch.int16, torch.bfloat16, torch.float16))
 _workspaces = {}      # (device index, stream handle) -> the uint8 tensor registered with mvg_set_scratch (insertion = LRU order)
 _MAX_WORKSPACES = 8
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)      # the current stream's handle without building a Stream object
 
 
 def _s(scratch: bool = False):
@@ -33,9 +37,14 @@ def _s(scratch: bool = False):
     (mvg_set_scratch) - the library itself never allocates device memory ("caller owns every buffer
     incl. workspace").  At most _MAX_WORKSPACES stay registered; the least recently used one is dropped (uses are
     stream-ordered and the tensor was allocated on that stream, so queued kernels are safe)."""
-    st = torch.cuda.current_stream()
+    if _raw_stream is not None:
+        dev = torch.cuda.current_device()
+        handle = _raw_stream(dev)
+    else:
+        st = torch.cuda.current_stream()
+        dev, handle = st.device_index, st.cuda_stream
     if scratch:
-        key = (st.device_index, st.cuda_stream)
+        key = (dev, handle)
         ws = _workspaces.pop(key, None)
         if ws is None:
             while len(_workspaces) >= _MAX_WORKSPACES:
@@ -43,11 +52,11 @@ def _s(scratch: bool = False):
                 with torch.cuda.device(odev):
                     check(lib().mvg_set_scratch(None, 0, C.c_void_p(ohandle)), "set_scratch")
                 del _workspaces[(odev, ohandle)]
-            with torch.cuda.device(st.device_index):
-                ws = torch.empty(int(lib().mvg_scratch_bytes()), dtype=torch.uint8, device=torch.device("cuda", st.device_index))
-                check(lib().mvg_set_scratch(C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(st.cuda_stream)), "set_scratch")
+            with torch.cuda.device(dev):
+                ws = torch.empty(int(lib().mvg_scratch_bytes()), dtype=torch.uint8, device=torch.device("cuda", dev))
+                check(lib().mvg_set_scratch(C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(handle)), "set_scratch")
         _workspaces[key] = ws                      # (re)insert as most recently used
-    return C.c_void_p(st.cuda_stream)
+    return handle
 
 
 def release_workspaces():
@@ -101,13 +110,18 @@ def cast_weights_bf16(d: ConvDesc, w: Tensor, cin_src: int, need_transposed: boo
     return wk, wt
 
 
-def conv_wgrad(d: ConvDesc, x: Tensor, dy: Tensor, dw: Tensor, accumulate: bool = False):
+def conv_wgrad(d: ConvDesc, x: Tensor, dy: Tensor, dw: Tensor, accumulate: bool = False, defer: Optional[list] = None):
+    """defer (bf16 storage only): see conv_wgrad_split - slabs now, their sums in one wgrad_reduce_batch launch per residual block."""
     splits = _fn("mvg_conv_wgrad_splits", x)(C.byref(d))
     if splits < 1:
         check(1, "conv_wgrad_splits")
     ws = None
     if splits > 1:
         ws = torch.empty(splits * d.cout * d.r * d.s * d.cin, dtype=torch.float32, device=x.device)
+    if defer is not None and splits > 1 and x.dtype == torch.bfloat16 and dw.numel() == d.cout * d.r * d.s * d.cin and dw.numel() % 4 == 0:
+        check(lib().mvg_conv_wgrad_bf16_slabs(C.byref(d), _p(x), _p(dy), _p(ws), splits, _s()), "conv_wgrad_bf16_slabs")
+        defer.append((ws, dw, splits, bool(accumulate)))
+        return
     check(_fn("mvg_conv_wgrad", x)(C.byref(d), _p(x), _p(dy), _p(dw), _p(ws), splits, int(accumulate), _s()), "conv_wgrad")
 
 
