@@ -15,7 +15,7 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _setup(depth, V, B, hw, capturable=True):
+def _setup(depth, V, B, hw, capturable=True, bf16=False):
     from rot_mvgaze_amd.geometry import rotation_matrix_2d
     from rot_mvgaze_amd.losses import MultiViewIterationLoss
     from rot_mvgaze_amd.model import MultiViewGaze
@@ -23,6 +23,8 @@ def _setup(depth, V, B, hw, capturable=True):
     m = MultiViewGaze(depth, 3)
     m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in synth.make_state_dict(depth, 0, 3).items()}, strict=True)
     m.to(dev()).train()
+    if bf16:
+        m.compute_dtype = torch.bfloat16
     inp = synth.make_inputs(B, V, 77, hw)
     img = [torch.from_numpy(np.ascontiguousarray(inp["img"][:, v])).to(dev()) for v in range(V)]
     gt = torch.from_numpy(inp["gt_gaze"]).to(dev())
@@ -39,19 +41,20 @@ def _setup(depth, V, B, hw, capturable=True):
     return m, opt, step
 
 
-@pytest.mark.parametrize("depth,V,B,hw", [(18, 2, 4, 64), (50, 3, 2, 64)])
-def test_graphed_step_replays_the_eager_step_bit_for_bit(depth, V, B, hw):
+@pytest.mark.parametrize("depth,V,B,hw,bf16", [(18, 2, 4, 64, False), (50, 3, 2, 64, False), (50, 2, 2, 64, True)],
+                         ids=["r18_fp32", "r50_fp32", "r50_bf16_storage"])
+def test_graphed_step_replays_the_eager_step_bit_for_bit(depth, V, B, hw, bf16):
     from rot_mvgaze_amd.graph import GraphedStep
     warm, n = 2, 3
     lrs = [1e-3, 5e-4, 2e-3]
-    m1, o1, s1 = _setup(depth, V, B, hw)
+    m1, o1, s1 = _setup(depth, V, B, hw, bf16=bf16)
     eager_losses = []
     for _ in range(warm):
         s1()
     for k in range(n):
         o1.param_groups[0]["lr"] = lrs[k]            # a scheduler stepping between iterations
         eager_losses.append(float(s1().item()))
-    m2, o2, s2 = _setup(depth, V, B, hw)
+    m2, o2, s2 = _setup(depth, V, B, hw, bf16=bf16)
     gs = GraphedStep(m2, s2, o2, warmup=warm)
     graph_losses = []
     for k in range(n):
