@@ -251,3 +251,75 @@ def test_fusion_block_with_scaled_fuser_weights_against_the_fp64_oracle(depth, V
             continue
         got = m._grad_views[id(params[k])]
         assert rel_l2(got.cpu(), ref.grad) < 2e-5, k
+
+
+@pytest.mark.parametrize("kw,V,B", [({"ignore_rotmat": True}, 3, 176), ({"share_weights": True}, 8, 20), ({}, 2, 512),
+                                    ({"share_weights": True, "ignore_rotmat": True}, 5, 52)],
+                         ids=["ignore_rotmat_v3", "share_weights_v8", "default_v2_b512", "shared_unrotated_v5"])
+def test_split_fusion_path_covers_the_variants_and_view_counts(kw, V, B):
+    """The split path also serves ignore_rotmat (rot_mv.py:226-232: the partner feature is NOT rotated) and share_weights
+    (:148-156: one fuser / head for every iteration - their gradients accumulate over the iterations), at any V with
+    V (V - 1) B >= 1024 rows.  Same statement as above: fp64 oracle with the HIP forward's ReLU pattern, 2e-5."""
+    from oracle import restatement as R
+    from rot_mvgaze_amd import ops, synth
+    from rot_mvgaze_amd.arch import Variant
+    from rot_mvgaze_amd.geometry import rotation_matrix_2d
+    from rot_mvgaze_amd.model import MultiViewGaze
+    depth = 18
+    v = Variant(**kw)
+    torch.set_num_threads(min(16, __import__("os").cpu_count() or 1))
+    sd = {k: np.array(x) for k, x in synth.make_state_dict(depth, 0, 3, variant=v).items()}
+    m = MultiViewGaze(depth, 3, v)
+    m.load_state_dict({k: torch.from_numpy(x) for k, x in sd.items()}, strict=True)
+    m.to(dev()).train()
+    m.ensure_layout()
+    torch.manual_seed(6)
+    cf = m._fc_dim
+    img_feat = (torch.rand(V, B, cf, device=dev()) * 2.0).contiguous()
+    rot = rotation_matrix_2d(torch.rand(B * V, 2, device=dev()) - 0.5).reshape(B, V, 3, 3)
+    head = m._head
+    head.split, head.mixed = True, False
+    lifted, feats, preds, tape = head.forward(img_feat, rot, True, True)
+    assert tape["mode"] == "split" and V * (V - 1) * B >= 1024
+    gpred = torch.randn_like(preds)
+    m._sink.active = False
+    m._sink.begin()
+    dimg = head.backward(tape, None, None, gpred, m._sink, None)
+    m._sink.active = False
+    torch.cuda.synchronize()
+    sd64 = {k: torch.from_numpy(x).double() for k, x in sd.items() if x.dtype == np.float32 and not k.startswith("_feat_extractor")}
+    for t in sd64.values():
+        t.requires_grad_(True)
+    f64 = [img_feat[i].double().cpu().requires_grad_(True) for i in range(V)]
+    r64 = rot.double().cpu()
+    hl_mask = (tape["hl"][0] > 0).cpu().view(V, B, -1)
+    fuse_mask = [(ops.merge_sp(tape["saved"][it][1]) > 0).cpu().view(-1, B, tape["saved"][it][1].shape[-3] * 8) for it in range(3)]
+    head_mask = [(tape["saved"][it][3] > 0).cpu().view(-1, B, tape["saved"][it][3].shape[-1]) for it in range(3)]
+    lift64 = [R.lift(sd64, f64[i], hl_mask[i]) for i in range(V)]
+    total, p = 0.0, 0
+    for (i, j) in R.view_pairs(V):
+        masks = {}
+        for it in range(3):
+            masks[("fuse", it)] = [fuse_mask[it][2 * p], fuse_mask[it][2 * p + 1]]
+            masks[("head", it)] = [head_mask[it][2 * p], head_mask[it][2 * p + 1]]
+        o = R.fuse_pair(sd64, 3, f64[i], f64[j], lift64[i], lift64[j], r64[:, i], r64[:, j], masks, v)
+        for it in range(3):
+            for side in (0, 1):
+                d = 2 * p + side
+                assert rel_l2(feats[it, d].cpu().reshape(B, -1), o[f"iter_{it}"][f"feat_{side}"].detach().reshape(B, -1)) < 2e-5, (it, d)
+                assert rel_l2(preds[it, d].cpu(), o[f"iter_{it}"][f"pred_gaze_{side}"].detach()) < 2e-5, (it, d)
+                total = total + (o[f"iter_{it}"][f"pred_gaze_{side}"] * gpred[it, d].double().cpu()).sum()
+        p += 1
+    total.backward()
+    for i in range(V):
+        assert rel_l2(dimg[i].cpu(), f64[i].grad) < 2e-5, i
+    # share_weights: one device Parameter under several state_dict names - the oracle's gradient is the sum over the names
+    groups = {}
+    for k, prm in m.named_parameters(remove_duplicate=False):
+        if not k.startswith("_feat_extractor"):
+            groups.setdefault(id(prm), (prm, []))[1].append(k)
+    for prm, names in groups.values():
+        refs = [sd64[k].grad for k in names if sd64[k].grad is not None]
+        if not refs:
+            continue
+        assert rel_l2(m._grad_views[id(prm)].cpu(), sum(refs)) < 2e-5, names
