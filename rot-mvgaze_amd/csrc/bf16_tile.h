@@ -41,10 +41,12 @@ constexpr int bf16_epilogue_bytes() {
 // tensor scales by, and (ii) store an sp result times the power of two 2^k that a bound on the result allows -
 // |acc| <= ktotal * 2^30 in the operands' scaled units, so |result| <= ktotal * 2^30 * osc + max |bias| - with
 // *p.out_sinv = 2^-k for the consumers (IgemmParams::out_sinv / bias_absmax).
-template <int BM, int BN, int WGM, bool DGRAD, bool F32IO, int PASSES = 1, bool ACC16 = false, bool BNF = false, bool LIN = false, class AccT>
+// WGN: waves along the tile's columns (2; 1 for the 256 x 64 tile of the split kernels: four wave rows of 64 x 64).
+template <int BM, int BN, int WGM, bool DGRAD, bool F32IO, int PASSES = 1, bool ACC16 = false, bool BNF = false, bool LIN = false, int WGN = 2,
+          class AccT>
 __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmClass &c, AccT &acc,
                                               unsigned short *smem, int tid, int g, int mtile, int ntile) {
-  constexpr int WGN = 2, NT = WGM * WGN * 64;
+  constexpr int NT = WGM * WGN * 64;
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TS = ACC16 ? 16 : 32, NE = ACC16 ? 4 : 16;      // tile side, accumulator registers per tile
   constexpr int TM = WTM / TS, TN = WTN / TS;
@@ -95,9 +97,10 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
         }
       q += __shfl_xor(q, 32, 64);
       if (ACC16) q += __shfl_xor(q, 16, 64);
-      if (lh == 0 && col < p.ncols) {
-        long long P = p.stats_partials ? p.stats_partials : (long long)c.mtiles_per_group * WGM;
-        long long pi = (long long)mtile * WGM + wm;
+      long long P = p.stats_partials ? p.stats_partials : (long long)c.mtiles_per_group * WGM;
+      long long pi = (long long)mtile * WGM + wm;
+      // (a wave row entirely beyond the rows holds no partial: with 256-row tiles it may lie beyond the caller's P = 2 per 128 rows)
+      if (lh == 0 && col < p.ncols && (pi < P || p.stats_fold)) {
         int nc = p.ncols, ch = col;
         if (p.stats_fold) {                      // columns c and c + ncols/2 are the same channel (two output columns per row)
           nc = p.ncols >> 1;

@@ -327,9 +327,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int sp_row_swz(int R) { return ((R >> 1) & 1) | (((R >> 2) & 1) << 2); }
 
-template <int BN, bool DGRAD, bool LIN = false>
-__global__ __launch_bounds__(256, DGRAD ? 3 : 4) void igemm_split16_kernel(IgemmParams p) {
-  constexpr int BM = 128, WGM = 2, WGN = 2, NW = 4;
+// WGM = 4 (BN = 64 only): a 256 x 64 tile as four wave rows of 64 x 64 - the same accumulators and fragment reuse per wave as
+// the 128 x 128 tile - for the layers with 64 GEMM columns (64-channel 3x3 convs), where the 128 x 64 tile's 64 x 32 wave tiles
+// re-read every A fragment for half the products.
+template <int BN, bool DGRAD, bool LIN = false, int WGM = 2>
+__global__ __launch_bounds__(256, (DGRAD || WGM == 4) ? 3 : 4) void igemm_split16_kernel(IgemmParams p) {
+  constexpr int BM = 64 * WGM, WGN = 4 / WGM, NW = 4;
+  static_assert(WGM == 2 || (WGM == 4 && BN == 64), "tiles: 128 x BN (2 x 2 waves) or 256 x 64 (4 x 1)");
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 16, TN = WTN / 16;
   constexpr int SLOTS = 4 * SP_NP;                            // 16-byte slots per LDS row (8)
@@ -338,7 +342,7 @@ __global__ __launch_bounds__(256, DGRAD ? 3 : 4) void igemm_split16_kernel(Igemm
   constexpr int QA = BM * SLOTS / 64;                         // ... of which the first 16 fill the A rows
   constexpr int A_PER = QA / NW, B_PER = (NQ - QA) / NW;      // per wave: 4 and 4 / 2
   static_assert(QA % NW == 0 && (NQ - QA) % NW == 0, "whole instructions per wave");
-  constexpr int EPI_B = bf16_epilogue_bytes<BM, BN, 2, DGRAD>();
+  constexpr int EPI_B = bf16_epilogue_bytes<BM, BN, WGM, DGRAD>();          // one wave row (64 tile rows) per staging pass
   constexpr int INFO_OFF = STAGE_B > EPI_B ? STAGE_B : EPI_B;  // row table behind the stage / the epilogue tile
   constexpr int SMEM_B = INFO_OFF + BM * 8;
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_B];
@@ -473,7 +477,7 @@ __global__ __launch_bounds__(256, DGRAD ? 3 : 4) void igemm_split16_kernel(Igemm
     }
     __syncthreads();                                         // everyone is done reading before the next DMA lands
   }
-  bf16_epilogue<BM, BN, WGM, DGRAD, true, 2, true, DGRAD, LIN>(p, c, acc, reinterpret_cast<unsigned short *>(smem), tid, g, mtile, ntile);
+  bf16_epilogue<BM, BN, WGM, DGRAD, true, WGM, true, DGRAD, LIN, WGN>(p, c, acc, reinterpret_cast<unsigned short *>(smem), tid, g, mtile, ntile);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -800,12 +804,17 @@ static int validate_split(const mvg_conv_desc *d) {
   return 0;
 }
 
+// Row-tile height of a launch: 256 x 64 tiles when the GEMM has fewer than 128 columns, more than one tap (the 64-channel 3x3
+// convs: K = 576; the 1x1 layers with 64 columns are HBM-bound either way) and enough rows to fill the chip with the larger
+// tiles.  A function of the descriptor alone: mvg_conv_dgrad_bn_partials_split sizes the fused reduce's partials with it.
+static int split_tile_rows(int ncols, int taps, long long rows) { return (ncols < 128 && taps > 1 && rows >= 65536) ? 256 : SP_BM; }
+
 template <bool DGRAD>
-static int launch_igemm_split(IgemmParams &p, hipStream_t st, bool lin = false) {
+static int launch_igemm_split(IgemmParams &p, hipStream_t st, bool lin = false, int bm = SP_BM) {
   // (128 x 64 tiles for the short-K, write-heavy 1x1 layers - 64 -> 256 at 56 x 56 and the like - were measured in round 4:
   // within 2 % of 128 x 128 on every such shape, forward and backward-data)
   const int bn = p.ncols >= 128 ? 128 : 64;
-  const int bm = SP_BM;
+  MVG_REQUIRE(bm == SP_BM || (bm == 256 && bn == 64 && !lin), "split conv: 256-row tiles go with 64 columns");
   p.ntiles = ceil_div(p.ncols, bn);
   p.splits = 1;
   p.sk_tiles = 0;
@@ -830,7 +839,8 @@ static int launch_igemm_split(IgemmParams &p, hipStream_t st, bool lin = false) 
   if (lin) {                 // a Linear of the fusion block: the epilogue's scale / abs-max features compiled in
     if (bn == 128) hipLaunchKernelGGL((igemm_split16_kernel<128, DGRAD, true>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((igemm_split16_kernel<64, DGRAD, true>), grid, block, 0, st, p);
-  } else if (bn == 128) hipLaunchKernelGGL((igemm_split16_kernel<128, DGRAD>), grid, block, 0, st, p);
+  } else if (bm == 256) hipLaunchKernelGGL((igemm_split16_kernel<64, DGRAD, false, 4>), grid, block, 0, st, p);
+  else if (bn == 128) hipLaunchKernelGGL((igemm_split16_kernel<128, DGRAD>), grid, block, 0, st, p);
   else hipLaunchKernelGGL((igemm_split16_kernel<64, DGRAD>), grid, block, 0, st, p);
   return check_launch(DGRAD ? "conv_dgrad_split" : "conv_fprop_split");
 }
@@ -1025,7 +1035,8 @@ static int fprop_split_impl(const mvg_conv_desc *d, const void *x_sp, const floa
   p.stats_partials = ceil_div(p.rows_per_group, SP_BM) * 2;    // = mvg_conv_stats_partials_split
   p.ncls = 1;
   class_from_params(p.cls[0], p);
-  return launch_igemm_split<false>(p, (hipStream_t)stream, aff && aff->lin);
+  const bool lin_k = aff && aff->lin;
+  return launch_igemm_split<false>(p, (hipStream_t)stream, lin_k, lin_k ? SP_BM : split_tile_rows(d->cout, d->r * d->s, p.rows_per_group));
 }
 
 int mvg_conv_fprop_split(const mvg_conv_desc *d, const void *x_sp, const float *x_sinv, const void *w_sp, const float *w_sinv, float *y,
@@ -1166,7 +1177,8 @@ static int dgrad_split_impl(const mvg_conv_desc *d, const void *dy_sp, const flo
       cls_k[j - 1] = tk;
     }
   m.no_remap = m.ncls > 1;
-  return launch_igemm_split<true>(m, (hipStream_t)stream, lin_kernel);
+  return launch_igemm_split<true>(m, (hipStream_t)stream, lin_kernel,
+                                  lin_kernel ? SP_BM : split_tile_rows(d->cin, d->r * d->s, (long long)d->n * d->h * d->w));
 }
 
 int mvg_conv_dgrad_split(const mvg_conv_desc *d, const void *dy_sp, const float *dy_sinv, const void *w_crsk_sp, const float *w_sinv,
@@ -1177,7 +1189,7 @@ int mvg_conv_dgrad_split(const mvg_conv_desc *d, const void *dy_sp, const float 
 
 int mvg_conv_dgrad_bn_partials_split(const mvg_conv_desc *d) {
   if (validate_split(d)) return -1;
-  return dgrad_bn_partials(d, SP_BM);
+  return dgrad_bn_partials(d, split_tile_rows(d->cin, d->r * d->s, (long long)d->n * d->h * d->w));
 }
 
 int mvg_conv_dgrad_split_bnreduce(const mvg_conv_desc *d, const void *dy_sp, const float *dy_sinv, const void *w_crsk_sp,

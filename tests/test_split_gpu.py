@@ -88,6 +88,8 @@ CONV_CASES = [
     (4, 9, 15, 96, 160, 1, 1, 0),      # channel counts that are multiples of 32 but not powers of two (1x1 only)
     # few tiles, long K (less than one resident round of workgroups)
     (2, 16, 14, 256, 256, 3, 1, 1), (2, 16, 14, 1024, 256, 1, 1, 0), (2, 16, 28, 256, 256, 3, 2, 1), (3, 20, 7, 512, 64, 3, 1, 1),
+    # >= 65536 rows per group with 64 GEMM columns and several taps: the 256 x 64 tile (four wave rows); ragged last tile, stride 2
+    (2, 24, 56, 64, 64, 3, 1, 1), (1, 21, 57, 64, 64, 3, 1, 1), (1, 22, 112, 64, 64, 3, 2, 1),
 ]
 
 
@@ -223,7 +225,9 @@ def test_stem_tail_writing_sp_matches_the_fp32_kernel():
                                   # stride 2: four parity classes in one launch, each with its own partials; a 1x1 filter
                                   # leaves three of them without taps (epilogue-only tiles); odd maps: ragged classes
                                   (1, 5, 28, 128, 128, 3, 2, 1), (2, 3, 15, 64, 128, 3, 2, 1), (2, 3, 56, 256, 512, 1, 2, 0),
-                                  (1, 4, 9, 128, 256, 1, 2, 0)],
+                                  (1, 4, 9, 128, 256, 1, 2, 0),
+                                  # the 256 x 64 tile (>= 65536 rows, 64 columns, 3x3): one partial per 256-row tile; stride 2
+                                  (2, 24, 56, 64, 64, 3, 1, 1), (1, 21, 57, 64, 64, 3, 1, 1), (1, 22, 112, 64, 128, 3, 2, 1)],
                          ids=lambda c: "g%d_n%d_h%d_%dto%d_k%d_s%d" % c[:7])
 @pytest.mark.parametrize("mask", ["bits", "affine", "none"])
 def test_split_dgrad_fused_with_bn_backward_reduce(case, mask):
