@@ -492,13 +492,6 @@ int mvg_nchw_to_nhwc8_bf16(const float *src, uint16_t *dst, int n, int c, int h,
  * backbone but the 3-channel stem). */
 int mvg_split_f32(const float *x, void *out_sp, int64_t n, float scale, void *stream);        /* n % 8 == 0; out = sp(x * scale) */
 int mvg_merge_sp(const void *x_sp, float *out, int64_t n, float inv_scale, void *stream);     /* out = (h1 + h2) * inv_scale */
-/* A gradient of the fusion block on its way into the split kernels (a Linear = a 1x1 conv on a 1x1 map, blocks.py:41-47):
- * mvg_colsum_absmax: db[cols] (+)= column sums of g [rows][cols] (the bias gradient; db may be NULL), stat2 = {max |g| (bits),
- * -}; workspace: mvg_colsum_workspace_floats(rows, cols) floats; fixed summation order.  mvg_split_f32_dev: out = sp(g * 2^k),
- * k from stat2[0] (max |g| just below 2^15), stat2[1] = 2^-k (the dy_sinv of the consumers). */
-size_t mvg_colsum_workspace_floats(int rows, int cols);
-int mvg_colsum_absmax(const float *g, int rows, int cols, float *db, int accumulate, float *stat2, float *workspace, void *stream);
-int mvg_split_f32_dev(const float *x, void *out_sp, int64_t n, float *stat2, void *stream);
 /* fp32 KRSC weights -> sp KRSC (fprop) and, when w_crsk_sp != NULL, the sp transposed copy CRSK (dgrad), both scaled by the
  * 2^k that puts max |w| just below 2^15.  stat2: two device floats, receive {max |w| (bits), 2^-k}: pass stat2 + 1 as the
  * w_sinv of the consumers.  items_dev: 64 bytes of device memory (staging of the one-record table). */

@@ -77,9 +77,6 @@ SIGNATURES = {
     "mvg_conv_fprop_split": (_I, [_D, _P, _P, _P, _P, _P, _P, _P]),
     "mvg_conv_fprop_split_affine": (_I, [_D, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P]),
     "mvg_conv_dgrad_split": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "mvg_colsum_workspace_floats": (C.c_size_t, [_I, _I]),
-    "mvg_colsum_absmax": (_I, [_P, _I, _I, _P, _I, _P, _P, _P]),
-    "mvg_split_f32_dev": (_I, [_P, _P, _I64, _P, _P]),
     "mvg_bn_apply_split": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _I, _I64, _I, _P]),
     "mvg_bn_bwd_apply_split": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _P, _P, _P, _I, _P]),
     "mvg_bn_bwd_reduce_split": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),

@@ -63,53 +63,6 @@ __global__ __launch_bounds__(256) void merge_sp_kernel(const uint4 *__restrict__
   }
 }
 
-// fp32 [n8 * 8] -> sp with the scale taken from a device scalar: stat[0] = max |x| (float bits, e.g. from
-// colsum_absmax_kernel), stat[1] receives 2^-k.  (A gradient tensor of the fusion block on its way into the split kernels.)
-__global__ __launch_bounds__(256) void split_f32_dev_kernel(const float4 *__restrict__ x, uint4 *__restrict__ out, long long n8,
-                                                            float *__restrict__ stat) {
-  const float scale = sp_scale_for(__uint_as_float(*reinterpret_cast<const unsigned *>(stat)));
-  if (blockIdx.x == 0 && threadIdx.x == 0) stat[1] = 1.f / scale;
-  const long long stride = (long long)gridDim.x * 256;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += stride) {
-    const float4 lo = x[2 * i], hi = x[2 * i + 1];
-    const float v[8] = {lo.x * scale, lo.y * scale, lo.z * scale, lo.w * scale, hi.x * scale, hi.y * scale, hi.z * scale, hi.w * scale};
-    uint4 q1, q2;
-    split2_chunk(v, q1, q2);
-    out[2 * i] = q1;
-    out[2 * i + 1] = q2;
-  }
-}
-
-// Column sums (a Linear's bias gradient) and max |g| of g [rows][cols] in one pass: grid (cols / 256, chunks); a thread
-// owns one column of one row chunk (coalesced across the block), partial sums go to part [chunks][cols] and
-// colsum_finish_kernel adds them in chunk order (deterministic); the maximum is order-independent (atomicMax).
-__global__ __launch_bounds__(256) void colsum_absmax_kernel(const float *__restrict__ g, int rows, int cols, int rows_per_chunk,
-                                                            float *__restrict__ part, unsigned *__restrict__ absmax) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  const int r0 = blockIdx.y * rows_per_chunk;
-  int r1 = r0 + rows_per_chunk;
-  if (r1 > rows) r1 = rows;
-  float s = 0.f, m = 0.f;
-  if (c < cols)
-    for (int r = r0; r < r1; ++r) {
-      const float v = g[(long long)r * cols + c];
-      s += v;
-      m = fmaxf(m, fabsf(v));
-    }
-  if (c < cols) part[(long long)blockIdx.y * cols + c] = s;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(absmax, __float_as_uint(m));
-}
-__global__ __launch_bounds__(256) void colsum_finish_kernel(const float *__restrict__ part, int cols, int chunks, float *__restrict__ db,
-                                                            int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= cols) return;
-  float s = accumulate ? db[c] : 0.f;
-  for (int k = 0; k < chunks; ++k) s += part[(long long)k * cols + c];
-  db[c] = s;
-}
-
 // A gradient g [rows][cols] of the fusion block on its way into the split kernels, ONE launch: g -> sp times the 2^k that
 // max |g| allows (the maximum was left in *absmax - float bits - by g's producer: the LIN epilogue's atomicMax, or
 // fuse_unbuild / skinny_bwd_dx), *out_sinv = 2^-k, and db (+)= the column sums of g (the Linear's bias gradient).
@@ -900,40 +853,6 @@ int mvg_split_weights(const mvg_conv_desc *d, const float *w, void *w_krsc_sp, v
   const long long n8 = (long long)d->cout * it.rs * d->cin / 8;
   long long blocks = (n8 + 256 * 8 - 1) / (256 * 8);             // ~8 chunks per thread
   return mvg_weights_prep_batch(items_dev, 1, 1, (int)(blocks < 16 ? 16 : (blocks > 2048 ? 2048 : blocks)), stream);
-}
-
-int mvg_split_f32_dev(const float *x, void *out_sp, int64_t n, float *stat2, void *stream) {
-  MVG_REQUIRE(x && out_sp && stat2 && n >= 0 && n % 8 == 0, "split_f32_dev: null argument or n %% 8 != 0");
-  if (n == 0) return 0;
-  hipStream_t st = (hipStream_t)stream;
-  ProfScope ps(MVG_K_LAYOUT, st, 0.0, (4.0 + SP_BYTES) * (double)n);
-  long long blocks = (n / 8 + 255) / 256;
-  if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(split_f32_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float4 *)x, (uint4 *)out_sp, (long long)(n / 8),
-                     stat2);
-  return check_launch("split_f32_dev");
-}
-
-size_t mvg_colsum_workspace_floats(int rows, int cols) { return (size_t)ceil_div(rows, 32) * (size_t)cols; }
-
-int mvg_colsum_absmax(const float *g, int rows, int cols, float *db, int accumulate, float *stat2, float *workspace, void *stream) {
-  MVG_REQUIRE(g && stat2 && workspace && rows > 0 && cols > 0, "colsum_absmax: bad arguments");
-  hipStream_t st = (hipStream_t)stream;
-  ProfScope ps(MVG_K_LAYOUT, st, 0.0, 4.0 * (double)rows * cols);
-  if (hipMemsetAsync(stat2, 0, 2 * sizeof(float), st) != hipSuccess) {
-    (void)hipGetLastError();
-    set_error("colsum_absmax: clearing the statistics failed");
-    return 1;
-  }
-  const int rpc = 32, chunks = ceil_div(rows, rpc);
-  hipLaunchKernelGGL(colsum_absmax_kernel, dim3(ceil_div(cols, 256), chunks), dim3(256), 0, st, g, rows, cols, rpc, workspace,
-                     (unsigned *)stat2);
-  if (check_launch("colsum_absmax")) return 1;
-  if (db) {
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3(ceil_div(cols, 256)), dim3(256), 0, st, workspace, cols, chunks, db, accumulate);
-    return check_launch("colsum_finish");
-  }
-  return 0;
 }
 
 int mvg_weights_prep_batch(const void *items_dev, int n, int mode, int blocks_per_item, void *stream) {

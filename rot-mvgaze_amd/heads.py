@@ -106,12 +106,11 @@ class _Mlp:
         # forward() makes once per step (w [fout][fin] and its transpose for backward-data)
         self.mixed = False
         self._wbf: List[Optional[tuple]] = [None] * n_layers
-        # fp32 model, many rows (C3: 1536, C5's shapes: 3584): the Linears run on the split-operand kernels (conv_split.hip:
-        # a Linear is a 1x1 conv on a 1x1 map) - operands as two fp16 pieces, three fp16 MFMAs per product, fp32-accurate
-        # like the backbone's convs, 2-3x the fp32-MFMA kernels' rate.  forward() makes the sp weight copies once per step.
+        # fp32 model, many rows (C3: 1536, C5's shapes: 3584): the fuser / head Linears run on the split-operand kernels
+        # (FusionHead._forward_split / _backward_split drive them directly; this class's own forward / backward are the
+        # fp32-MFMA and bf16-mixed paths).  `split` only marks which layers FusionHead._prepare_split_weights copies to sp.
         self.split = False
         self._wsp: List[Optional[tuple]] = [None] * n_layers
-        self._ones: Dict[int, Tensor] = {}
 
     def _use_mixed(self, l: int) -> bool:
         return self.mixed and not self.padded[l] and not (l == self.n - 1 and self.fout[l] <= 4)
@@ -151,24 +150,6 @@ class _Mlp:
         for l in range(self.n):
             w, b = self._weights(l)
             last = l == self.n - 1
-            if self._use_split(l, rows):
-                assert gen is None
-                fin, fout = self.fin[l], self.fout[l]
-                d = ConvDesc.make(1, rows, 1, 1, fin, fout, 1, 1, 0)
-                assert self._wsp[l] is not None          # made by FusionHead._prepare_split_weights at the start of the step
-                x_sp = cur if ops.is_sp(cur) else ops.split_f32(cur)
-                # the hidden activation goes out in sp when the next layer reads it there (and the backward takes its ReLU
-                # mask and its wgrad operand from the same tensor); fp32 otherwise (the 512 -> 2 head layer)
-                to_sp = (not last) and self._use_split(l + 1, rows)
-                y = ops.sp_empty(rows, fout, device=dev) if to_sp else \
-                    (out if (last and out is not None) else torch.empty(rows, fout, dtype=torch.float32, device=dev))
-                if fout not in self._ones or self._ones[fout].device != dev:
-                    self._ones[fout] = torch.ones(fout, dtype=torch.float32, device=dev)
-                ops.conv_fprop_split_affine(d, x_sp, self._wsp[l][0], y, self._ones[fout], b, None, not last)
-                if not last:
-                    hs.append(y)
-                cur = y
-                continue
             y = out if (last and out is not None) else torch.empty(rows, self.fout_p[l], dtype=torch.float32, device=dev)
             if self._use_mixed(l):
                 assert gen is None
@@ -198,27 +179,6 @@ class _Mlp:
             w, _ = self._weights(l) if self.padded[l] else (self.w[l].detach(), None)
             last = l == self.n - 1
             fin, fout = self.fin_p[l], self.fout_p[l]
-            if self._use_split(l, rows):
-                assert gen is None
-                aw, ab = wr.acc(self.w[l]), wr.acc(self.b[l])
-                assert aw == ab
-                d = ConvDesc.make(1, rows, 1, 1, fin, fout, 1, 1, 0)
-                # one pass over g: its column sums (the bias gradient), its maximum -> the scale of its sp copy
-                g_sp = ops.split_grad(g, rows, fout, sink.view(self.b[l]), ab)
-                inp_sp = inp if ops.is_sp(inp) else ops.split_f32(inp)
-
-                def wgrad(inp_sp=inp_sp, g_sp=g_sp, d=d, l=l, aw=aw):
-                    ops.conv_wgrad_split(d, inp_sp, g_sp, sink.view(self.w[l]), aw)
-                wr.off_path(wgrad, inp_sp, g_sp, g_sp.sinv)
-                wt = self._wsp[l][1]
-                if l == 0:
-                    dx = dx_out if dx_out is not None else torch.empty(rows, fin, dtype=torch.float32, device=dev)
-                    ops.conv_dgrad_split(d, g_sp, wt, dx, dx_addend)
-                    return dx
-                dh = torch.empty(rows, fin, dtype=torch.float32, device=dev)
-                ops.conv_dgrad_split(d, g_sp, wt, dh, None, inp_sp)              # (g @ W) * (h > 0)
-                g = dh
-                continue
             # ---- weight / bias gradients
             if self.padded[l]:
                 accs = (wr.acc(self.w[l]), wr.acc(self.b[l]))
@@ -272,7 +232,6 @@ class _Mlp:
                     ops.linear_dgrad(g, w, None, dx_addend, dx, rows, fin, fout)
                 return dx
             dh = torch.empty(rows, fin, dtype=torch.float32, device=dev)
-            assert not ops.is_sp(hs[l - 1])
             if mixed:
                 ops.linear_dgrad_mixed(g, self._wbf[l][1], hs[l - 1], None, dh, rows, fin, fout)
             else:

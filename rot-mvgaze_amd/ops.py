@@ -246,19 +246,6 @@ def conv_dgrad_split(d: ConvDesc, dy_sp: Tensor, wt_sp: Tensor, dx: Tensor, adde
                                      _s()), "conv_dgrad_split")
 
 
-def split_grad(g: Tensor, rows: int, cols: int, db: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
-    """A gradient g [rows, cols] of the fusion block -> sp with its own power-of-two scale (from max |g|, found on the
-    device), and - in the same pass over g - db (+)= its column sums (the Linear's bias gradient)."""
-    assert g.dtype == torch.float32 and g.is_contiguous() and g.numel() == rows * cols and cols % 8 == 0
-    stat = torch.empty(2, dtype=torch.float32, device=g.device)
-    ws = torch.empty(lib().mvg_colsum_workspace_floats(rows, cols), dtype=torch.float32, device=g.device)
-    check(lib().mvg_colsum_absmax(_p(g), rows, cols, _p(db), int(accumulate), _p(stat), _p(ws), _s()), "colsum_absmax")
-    out = sp_empty(rows, cols, device=g.device)
-    check(lib().mvg_split_f32_dev(_p(g), _p(out), g.numel(), _p(stat), _s()), "split_f32_dev")
-    out.sinv = stat[1:2]
-    return out
-
-
 def stem_rowwindow_split(x_nhwc4: Tensor) -> Tensor:
     """[G, N, H, W, 4] fp32 image -> the stem's row-window operand [G, N, H, W/2, 32] in sp (mvg_stem_fprop_split)."""
     G, N, H, W, C = x_nhwc4.shape
