@@ -115,6 +115,12 @@ struct WPrepItem {
   float *stat;               // mode 1: [2] device floats {max |w| as uint bits (zero before the absmax launch), 2^-k}
 };
 
+// one record -> device memory, its stat pair cleared (mvg_split_weights: the single-conv form of the batched prep)
+__global__ void wprep_stage_item_kernel(WPrepItem it, WPrepItem *__restrict__ dst) {
+  if (threadIdx.x == 0) *dst = it;
+  if (threadIdx.x < 2) it.stat[threadIdx.x] = 0.f;
+}
+
 __global__ __launch_bounds__(256) void weights_absmax_kernel(const WPrepItem *__restrict__ items) {
   const WPrepItem it = items[blockIdx.y];
   const long long n4 = (long long)it.cout * it.rs * it.cin / 4;
@@ -283,10 +289,14 @@ __device__ __forceinline__ int sp_row_swz(int R) { return ((R >> 1) & 1) | (((R 
 // WGM = 4 (BN = 64 only): a 256 x 64 tile as four wave rows of 64 x 64 - the same accumulators and fragment reuse per wave as
 // the 128 x 128 tile - for the layers with 64 GEMM columns (64-channel 3x3 convs), where the 128 x 64 tile's 64 x 32 wave tiles
 // re-read every A fragment for half the products.
-template <int BN, bool DGRAD, bool LIN = false, int WGM = 2>
-__global__ __launch_bounds__(256, (DGRAD || WGM == 4) ? 3 : 4) void igemm_split16_kernel(IgemmParams p) {
+//
+// STAGES > 1 (the fusion block's Linears: 48 - 336 tiles of up to 112 K-steps on 256 CUs, i.e. ONE or two workgroups per CU and
+// nobody to cover a workgroup's waits): an explicit software pipeline, see the K loop.
+template <int BN, bool DGRAD, bool LIN = false, int WGM = 2, int STAGES = 1>
+__global__ __launch_bounds__(256, STAGES > 2 ? 1 : STAGES == 2 ? 2 : (DGRAD || WGM == 4) ? 3 : 4) void igemm_split16_kernel(IgemmParams p) {
   constexpr int BM = 64 * WGM, WGN = 4 / WGM, NW = 4;
   static_assert(WGM == 2 || (WGM == 4 && BN == 64), "tiles: 128 x BN (2 x 2 waves) or 256 x 64 (4 x 1)");
+  static_assert(STAGES >= 1 && STAGES <= 4, "1 - 4 LDS stages");
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 16, TN = WTN / 16;
   constexpr int SLOTS = 4 * SP_NP;                            // 16-byte slots per LDS row (8)
@@ -296,7 +306,7 @@ __global__ __launch_bounds__(256, (DGRAD || WGM == 4) ? 3 : 4) void igemm_split1
   constexpr int A_PER = QA / NW, B_PER = (NQ - QA) / NW;      // per wave: 4 and 4 / 2
   static_assert(QA % NW == 0 && (NQ - QA) % NW == 0, "whole instructions per wave");
   constexpr int EPI_B = bf16_epilogue_bytes<BM, BN, WGM, DGRAD>();          // one wave row (64 tile rows) per staging pass
-  constexpr int INFO_OFF = STAGE_B > EPI_B ? STAGE_B : EPI_B;  // row table behind the stage / the epilogue tile
+  constexpr int INFO_OFF = STAGES * STAGE_B > EPI_B ? STAGES * STAGE_B : EPI_B;  // row table behind the stages / the epilogue tile
   constexpr int SMEM_B = INFO_OFF + BM * 8;
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_B];
 
@@ -361,7 +371,7 @@ __global__ __launch_bounds__(256, (DGRAD || WGM == 4) ? 3 : 4) void igemm_split1
   const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(p.b, p.b_bytes);
   typedef __attribute__((address_space(3))) void *lds_vp;
 
-  auto issue = [&](int kt) {
+  auto issue = [&](int kt, int stage_off) {
     int kstart = kt * SP_BK;
     if (c.korder) {
       const int cblk = (int)fdiv((unsigned)kt, c.per_div), rem = kt - cblk * c.ntaps;
@@ -381,11 +391,11 @@ __global__ __launch_bounds__(256, (DGRAD || WGM == 4) ? 3 : 4) void igemm_split1
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
       const bool ok = ((a_vmask[i] >> tap_u) & 1u) != 0u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_vp)(smem + (wave + NW * i) * 1024), 16, (int)pred_off(a_base[i] + sdelta, ok), 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_vp)(smem + stage_off + (wave + NW * i) * 1024), 16, (int)pred_off(a_base[i] + sdelta, ok), 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < B_PER; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_vp)(smem + (wave + NW * (A_PER + i)) * 1024), 16, (int)(b_base[i] + kb), 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_vp)(smem + stage_off + (wave + NW * (A_PER + i)) * 1024), 16, (int)(b_base[i] + kb), 0, 0, 0);
   };
 
   f32x4 acc[TM][TN];
@@ -412,23 +422,63 @@ __global__ __launch_bounds__(256, (DGRAD || WGM == 4) ? 3 : 4) void igemm_split1
     for (int pc = 0; pc < SP_NP; ++pc) b_off[j][pc] = (BM + R) * ROWB + (((2 * cc_l + pc) ^ sp_row_swz(R)) << 4);
   }
 
-  for (int kt = 0; kt < KT; ++kt) {
-    issue(kt);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    {
-      f16x8 av[SP_NP][TM], bv[SP_NP][TN];
+  auto load_frags = [&](const unsigned char *stage, f16x8 (&av)[SP_NP][TM], f16x8 (&bv)[SP_NP][TN]) {
 #pragma unroll
-      for (int pc = 0; pc < SP_NP; ++pc) {
+    for (int pc = 0; pc < SP_NP; ++pc) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) av[pc][i] = *reinterpret_cast<const f16x8 *>(smem + a_off[i][pc]);
+      for (int i = 0; i < TM; ++i) av[pc][i] = *reinterpret_cast<const f16x8 *>(stage + a_off[i][pc]);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bv[pc][j] = *reinterpret_cast<const f16x8 *>(smem + b_off[j][pc]);
-      }
-      // smallest terms first: (a1 b2, a2 b1), a1 b1
-      SPLIT16_ONE(0, 1) SPLIT16_ONE(1, 0) SPLIT16_ONE(0, 0)
+      for (int j = 0; j < TN; ++j) bv[pc][j] = *reinterpret_cast<const f16x8 *>(stage + b_off[j][pc]);
     }
-    __syncthreads();                                         // everyone is done reading before the next DMA lands
+  };
+  // smallest terms first: (a1 b2, a2 b1), a1 b1
+  auto products = [&](const f16x8 (&av)[SP_NP][TM], const f16x8 (&bv)[SP_NP][TN]) { SPLIT16_ONE(0, 1) SPLIT16_ONE(1, 0) SPLIT16_ONE(0, 0) };
+  if constexpr (STAGES == 1) {
+    for (int kt = 0; kt < KT; ++kt) {
+      issue(kt, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      {
+        f16x8 av[SP_NP][TM], bv[SP_NP][TN];
+        load_frags(smem, av, bv);
+        products(av, bv);
+      }
+      __syncthreads();                                         // everyone is done reading before the next DMA lands
+    }
+  } else {
+    // Software pipeline, two levels: STAGES K-steps of DMA in LDS / in flight, and the fragments of K-step kt + 1 read into a
+    // second register set while K-step kt's MFMAs run (with one wave per SIMD nothing else overlaps the LDS reads with the
+    // matrix pipe).  At the top of K-step kt: wait until K-step kt + 1 has landed (vmcnt counts the newer groups in flight) and
+    // this wave's fragment reads of K-step kt are complete (lgkmcnt), barrier - now stage kt % STAGES is free for every wave:
+    // K-step kt + STAGES goes into it.  A bare s_barrier: __syncthreads() carries a fence that the compiler turns into
+    // s_waitcnt vmcnt(0), which would drain the K-steps in flight.
+    constexpr int G = A_PER + B_PER;                           // DMA instructions per wave and K-step
+    auto wait_barrier = [&](int newer) {
+      if (STAGES >= 4 && newer >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * G) : "memory");
+      else if (STAGES >= 3 && newer >= 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(G) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+#pragma unroll
+    for (int d = 0; d < STAGES; ++d)
+      if (d < KT) issue(d, d * STAGE_B);
+    f16x8 a0[SP_NP][TM], b0[SP_NP][TN], a1[SP_NP][TM], b1[SP_NP][TN];
+    wait_barrier((KT < STAGES ? KT : STAGES) - 1);
+    load_frags(smem, a0, b0);
+    int cur = 0;                                               // byte offset of K-step kt's stage
+    auto step = [&](int kt, const f16x8 (&ca)[SP_NP][TM], const f16x8 (&cb)[SP_NP][TN], f16x8 (&na)[SP_NP][TM], f16x8 (&nb)[SP_NP][TN]) {
+      if (kt + 1 < KT) {
+        wait_barrier(KT - 2 - kt);
+        if (kt + STAGES < KT) issue(kt + STAGES, cur);
+        cur = cur + STAGE_B == STAGES * STAGE_B ? 0 : cur + STAGE_B;
+        load_frags(smem + cur, na, nb);
+      }
+      products(ca, cb);
+    };
+    for (int kt = 0; kt < KT; kt += 2) {
+      step(kt, a0, b0, a1, b1);
+      if (kt + 1 < KT) step(kt + 1, a1, b1, a0, b0);
+    }
+    __syncthreads();                                           // the epilogue reuses the stages
   }
   bf16_epilogue<BM, BN, WGM, DGRAD, true, WGM, true, DGRAD, LIN, WGN>(p, c, acc, reinterpret_cast<unsigned short *>(smem), tid, g, mtile, ntile);
 }
@@ -790,7 +840,11 @@ static int launch_igemm_split(IgemmParams &p, hipStream_t st, bool lin = false, 
   if (tiles <= 0) return 0;
   dim3 grid((unsigned)tiles), block(256);
   if (lin) {                 // a Linear of the fusion block: the epilogue's scale / abs-max features compiled in
-    if (bn == 128) hipLaunchKernelGGL((igemm_split16_kernel<128, DGRAD, true>), grid, block, 0, st, p);
+    // <= four workgroups per CU: nobody covers a workgroup's waits - the two-stage software pipeline (measured per shape at
+    // C3's fusion rows, scripts/linear_split_bench.py: fprop 431 -> 320 us per iteration, dgrad 246 -> 210; three and four
+    // stages - one workgroup per CU - and an L2-blocked tile order changed nothing: a lone workgroup takes in ~41 GB/s)
+    if (bn == 128 && tiles <= 4LL * compute_cus()) hipLaunchKernelGGL((igemm_split16_kernel<128, DGRAD, true, 2, 2>), grid, block, 0, st, p);
+    else if (bn == 128) hipLaunchKernelGGL((igemm_split16_kernel<128, DGRAD, true>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((igemm_split16_kernel<64, DGRAD, true>), grid, block, 0, st, p);
   } else if (bm == 256) hipLaunchKernelGGL((igemm_split16_kernel<64, DGRAD, false, 4>), grid, block, 0, st, p);
   else if (bn == 128) hipLaunchKernelGGL((igemm_split16_kernel<128, DGRAD>), grid, block, 0, st, p);
@@ -845,11 +899,10 @@ int mvg_split_weights(const mvg_conv_desc *d, const float *w, void *w_krsc_sp, v
   it.cin_pad = d->cin;
   it.stat = stat2;
   static_assert(sizeof(WPrepItem) <= 64, "WPrepItem grew: update the callers' table record size");
-  if (hipMemsetAsync(stat2, 0, 2 * sizeof(float), st) != hipSuccess || hipMemcpyAsync(items_dev, &it, sizeof(it), hipMemcpyHostToDevice, st) != hipSuccess) {
-    (void)hipGetLastError();
-    set_error("split_weights: staging the table record failed");
-    return 1;
-  }
+  // the record travels as a kernel argument (captured at launch): an asynchronous copy from this stack frame could be read after
+  // the frame is gone when the stream is busy
+  hipLaunchKernelGGL(wprep_stage_item_kernel, dim3(1), dim3(64), 0, st, it, (WPrepItem *)items_dev);
+  if (check_launch("split_weights: staging the table record")) return 1;
   const long long n8 = (long long)d->cout * it.rs * d->cin / 8;
   long long blocks = (n8 + 256 * 8 - 1) / (256 * 8);             // ~8 chunks per thread
   return mvg_weights_prep_batch(items_dev, 1, 1, (int)(blocks < 16 ? 16 : (blocks > 2048 ? 2048 : blocks)), stream);

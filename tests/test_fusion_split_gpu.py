@@ -106,6 +106,34 @@ def test_split_linear_fprop_dgrad_wgrad_over_magnitudes(mag, rows, fin, fout):
     assert rel_l2(dw2, g2.double().t() @ ref.clamp_min(0)) < SPLIT_VS_F64
 
 
+@pytest.mark.parametrize("rows,fin,fout", [(6016, 256, 3584), (384, 32, 128), (384, 96, 256), (1536, 3584, 512), (200, 160, 1536)])
+def test_split_linear_k_loop_forms(rows, fin, fout):
+    """The Linears' two K-loop forms - the two-stage software pipeline (launches of <= four tiles per CU; one, two, three and
+    112 K-steps, i.e. odd and even counts and the prologue-only cases) and the single-stage loop (6016 x 3584 outputs: 1316
+    tiles) - forward, with ReLU into sp, and backward-data, against fp64."""
+    from rot_mvgaze_amd import ops
+    torch.manual_seed(11)
+    x = torch.randn(rows, fin, device=dev())
+    w = torch.randn(fout, fin, device=dev()) / fin ** 0.5
+    b = torch.randn(fout, device=dev())
+    g = torch.randn(rows, fout, device=dev())
+    st, s = _slots()
+    ops.absmax_multi([x, b, g], [s[0], s[1], s[2]])
+    x_sp, g_sp, h = _sp(rows, fin, s[3]), _sp(rows, fout, s[4]), _sp(rows, fout, s[5])
+    ops.split_colsum(x, rows, fin, s[0], x_sp)
+    ops.split_colsum(g, rows, fout, s[2], g_sp)
+    wk, wt = _weights_sp(w)
+    ref = x.double() @ w.double().t() + b.double()
+    y = torch.full((rows, fout), float("nan"), device=dev())
+    ops.linear_fprop_split(x_sp, wk, b, False, y, rows, fin, fout, out_absmax=s[6])
+    assert rel_l2(y, ref) < SPLIT_VS_F64 and float(s[6]) == float(y.abs().max())
+    ops.linear_fprop_split(x_sp, wk, b, True, h, rows, fin, fout, bias_absmax=s[1])
+    assert rel_l2(ops.merge_sp(h), ref.clamp_min(0)) < SPLIT_VS_F64
+    dx = torch.full((rows, fin), float("nan"), device=dev())
+    ops.linear_dgrad_split(g_sp, wt, dx, rows, fin, fout, out_absmax=s[7])
+    assert rel_l2(dx, g.double() @ w.double()) < SPLIT_VS_F64 and float(s[7]) == float(dx.abs().max())
+
+
 @pytest.mark.parametrize("mag", MAGS)
 def test_builders_write_scaled_sp_operands_and_their_backward(mag):
     """mvg_fuse_build_split / mvg_fuse_unbuild against their definition (rot_mv.py:44-50,234-239,249-254)."""
