@@ -839,14 +839,18 @@ static int launch_igemm_split(IgemmParams &p, hipStream_t st, bool lin = false, 
   MVG_REQUIRE(tiles < (1LL << 31), "split conv: grid too large");
   if (tiles <= 0) return 0;
   dim3 grid((unsigned)tiles), block(256);
+  // At most two workgroups per CU: nobody covers a workgroup's waits - the two-stage software pipeline.  Measured per shape
+  // (scripts/linear_split_bench.py, C3's fusion rows: fprop 431 -> 320 us per iteration, dgrad 246 -> 210;
+  // scripts/conv_bench.py 50 32 4, C4's per-GPU share: 15.2 -> 14.6 ms over the net, 512-channel 3x3 at 7x7 0.169 -> 0.127 ms;
+  // C3's conv launches all have >= 784 tiles).  Three and four stages - one workgroup per CU - and an L2-blocked tile order
+  // changed nothing: a lone workgroup takes in ~41 GB/s whatever it keeps in flight.
+  const bool pipelined = tiles <= 2LL * compute_cus();
   if (lin) {                 // a Linear of the fusion block: the epilogue's scale / abs-max features compiled in
-    // <= four workgroups per CU: nobody covers a workgroup's waits - the two-stage software pipeline (measured per shape at
-    // C3's fusion rows, scripts/linear_split_bench.py: fprop 431 -> 320 us per iteration, dgrad 246 -> 210; three and four
-    // stages - one workgroup per CU - and an L2-blocked tile order changed nothing: a lone workgroup takes in ~41 GB/s)
-    if (bn == 128 && tiles <= 4LL * compute_cus()) hipLaunchKernelGGL((igemm_split16_kernel<128, DGRAD, true, 2, 2>), grid, block, 0, st, p);
+    if (bn == 128 && pipelined) hipLaunchKernelGGL((igemm_split16_kernel<128, DGRAD, true, 2, 2>), grid, block, 0, st, p);
     else if (bn == 128) hipLaunchKernelGGL((igemm_split16_kernel<128, DGRAD, true>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((igemm_split16_kernel<64, DGRAD, true>), grid, block, 0, st, p);
   } else if (bm == 256) hipLaunchKernelGGL((igemm_split16_kernel<64, DGRAD, false, 4>), grid, block, 0, st, p);
+  else if (bn == 128 && pipelined) hipLaunchKernelGGL((igemm_split16_kernel<128, DGRAD, false, 2, 2>), grid, block, 0, st, p);
   else if (bn == 128) hipLaunchKernelGGL((igemm_split16_kernel<128, DGRAD>), grid, block, 0, st, p);
   else hipLaunchKernelGGL((igemm_split16_kernel<64, DGRAD>), grid, block, 0, st, p);
   return check_launch(DGRAD ? "conv_dgrad_split" : "conv_fprop_split");
