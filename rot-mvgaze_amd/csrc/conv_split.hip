@@ -816,7 +816,14 @@ template <bool DGRAD>
 static int launch_igemm_split(IgemmParams &p, hipStream_t st, bool lin = false, int bm = SP_BM) {
   // (128 x 64 tiles for the short-K, write-heavy 1x1 layers - 64 -> 256 at 56 x 56 and the like - were measured in round 4:
   // within 2 % of 128 x 128 on every such shape, forward and backward-data)
-  const int bn = p.ncols >= 128 ? 128 : 64;
+  int bn = p.ncols >= 128 ? 128 : 64;
+  if (lin && bn == 128 && p.ncls == 1) {
+    // a Linear whose 128 x 128 tiles would leave most CUs idle (C3's head layer: 48 tiles; C4's per-GPU share: 12 - 84):
+    // a lone workgroup takes in ~41 GB/s, so the launch is as fast as its busiest CU's operand bytes - 128 x 64 tiles
+    // (24 KB instead of 32 KB per K-step) on twice the CUs
+    const long long t128 = (long long)p.groups * ceil_div(p.cls[0].rows_per_group, bm) * ceil_div(p.ncols, 128);
+    if (2 * t128 <= compute_cus()) bn = 64;
+  }
   MVG_REQUIRE(bm == SP_BM || (bm == 256 && bn == 64 && !lin), "split conv: 256-row tiles go with 64 columns");
   p.ntiles = ceil_div(p.ncols, bn);
   p.splits = 1;
@@ -844,10 +851,16 @@ static int launch_igemm_split(IgemmParams &p, hipStream_t st, bool lin = false, 
   // scripts/conv_bench.py 50 32 4, C4's per-GPU share: 15.2 -> 14.6 ms over the net, 512-channel 3x3 at 7x7 0.169 -> 0.127 ms;
   // C3's conv launches all have >= 784 tiles).  Three and four stages - one workgroup per CU - and an L2-blocked tile order
   // changed nothing: a lone workgroup takes in ~41 GB/s whatever it keeps in flight.
-  const bool pipelined = tiles <= 2LL * compute_cus();
+  // Up to four per CU it still wins where the K loop is long (ResNet-50's 7x7 stage at C3, 784 tiles: 512-channel 3x3
+  // backward-data + reduce 0.399 -> 0.322 ms, 2048 <- 512 backward-data 0.218 -> 0.185); with every slot filled the
+  // single-stage loop at four workgroups per CU is faster (17.4 vs 19.5 ms over the forward net).
+  int kt_max = 0;
+  for (int i = 0; i < p.ncls; ++i) kt_max = p.cls[i].KT > kt_max ? p.cls[i].KT : kt_max;
+  const bool pipelined = tiles <= 2LL * compute_cus() || (tiles <= 4LL * compute_cus() && kt_max >= 48);
   if (lin) {                 // a Linear of the fusion block: the epilogue's scale / abs-max features compiled in
     if (bn == 128 && pipelined) hipLaunchKernelGGL((igemm_split16_kernel<128, DGRAD, true, 2, 2>), grid, block, 0, st, p);
     else if (bn == 128) hipLaunchKernelGGL((igemm_split16_kernel<128, DGRAD, true>), grid, block, 0, st, p);
+    else if (pipelined) hipLaunchKernelGGL((igemm_split16_kernel<64, DGRAD, true, 2, 2>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((igemm_split16_kernel<64, DGRAD, true>), grid, block, 0, st, p);
   } else if (bm == 256) hipLaunchKernelGGL((igemm_split16_kernel<64, DGRAD, false, 4>), grid, block, 0, st, p);
   else if (bn == 128 && pipelined) hipLaunchKernelGGL((igemm_split16_kernel<128, DGRAD, false, 2, 2>), grid, block, 0, st, p);
