@@ -286,8 +286,15 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
 #pragma unroll
         for (int k = 0; k < 8; ++k) lin_max = fmaxf(lin_max, fabsf(x[k]));
       }
-      *reinterpret_cast<float4 *>(out_f + off + col) = make_float4(x[0], x[1], x[2], x[3]);
-      *reinterpret_cast<float4 *>(out_f + off + col + 4) = make_float4(x[4], x[5], x[6], x[7]);
+      if (p.nt_out) {
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        f4v s0 = {x[0], x[1], x[2], x[3]}, s1 = {x[4], x[5], x[6], x[7]};
+        __builtin_nontemporal_store(s0, reinterpret_cast<f4v *>(out_f + off + col));
+        __builtin_nontemporal_store(s1, reinterpret_cast<f4v *>(out_f + off + col + 4));
+      } else {
+        *reinterpret_cast<float4 *>(out_f + off + col) = make_float4(x[0], x[1], x[2], x[3]);
+        *reinterpret_cast<float4 *>(out_f + off + col + 4) = make_float4(x[4], x[5], x[6], x[7]);
+      }
       return;
     }
     if (mask_g) {

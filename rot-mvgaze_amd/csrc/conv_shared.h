@@ -122,6 +122,7 @@ struct IgemmParams {
   // igemm_fixup_kernel sums the pieces in workgroup order and runs the epilogue.
   int sk_tiles;
   int no_remap;              // several classes, one tile per workgroup: keep the dispatch order (longest class first)
+  int nt_out;                // split kernels, fp32 result: non-temporal stores
   int ncls;
   IgemmClass cls[4];         // per-class view (one class unless this is a stride-2 dgrad)
   int b_row_len;             // bf16 kernels: elements per row of the (k-contiguous) weight operand

@@ -845,6 +845,12 @@ static int launch_igemm_split(IgemmParams &p, hipStream_t st, bool lin = false, 
   }
   MVG_REQUIRE(tiles < (1LL << 31), "split conv: grid too large");
   if (tiles <= 0) return 0;
+  // The backbone's fp32 results (y, dx: 0.2 - 1.7 GB per launch, next read by a BatchNorm pass that streams them once) leave
+  // with non-temporal stores: C3 81.4 -> 80.9 ms per step on one box (the passes that follow find more of their other
+  // operand in the Infinity Cache: bn_apply 8.8 -> 8.4 ms).  Not the stride-2 parity classes - they write every other pixel,
+  // which wants the cache to merge lines (0.96 -> 1.01 ms on 256 -> 512 at 56 x 56) - and not the fusion block's Linears,
+  // whose results are re-read at once.
+  p.nt_out = (!lin && !(DGRAD && p.cls_step == 2)) ? 1 : 0;
   dim3 grid((unsigned)tiles), block(256);
   // At most two workgroups per CU: nobody covers a workgroup's waits - the two-stage software pipeline.  Measured per shape
   // (scripts/linear_split_bench.py, C3's fusion rows: fprop 431 -> 320 us per iteration, dgrad 246 -> 210;

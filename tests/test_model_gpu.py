@@ -864,6 +864,50 @@ def test_benchmark_configuration_c3_full_size_against_oracle():
     assert int(m.state_dict()["_feat_extractor.0.bn1.num_batches_tracked"]) == V
 
 
+def test_benchmark_configuration_c3_full_size_backbone_gradients_on_both_kernel_families():
+    """C3 at FULL size, the part the oracle test above cannot afford (a 512-image CPU autograd graph): every BACKBONE
+    gradient of the split-operand step against the same step on the fp32-MFMA kernels (v_mfma_f32_32x32x2f32: exact fp32
+    products; that family is pinned to the oracle by the golden and strict tests at the sizes the CPU finishes).  Same
+    weights and inputs as bench.py.  Both runs choose their own ReLU patterns on bench.py's random-init weights (no
+    conditioning), so what is bounded is the flip noise of two fp32 implementations of a 50-layer ReLU network, not the
+    kernels' 2e-6 (same-pattern agreement: test_backward_strict_*): relative L2 per parameter tensor measured 2.2e-2 at the
+    median and 2.9e-2 at worst (layer2.0.bn1.bias) - the level test_against_reference_golden sees against the reference's
+    own fixtures (2.1e-2) and C4's share against the oracle (2.0e-2 on the stem) - asserted at 5e-2; loss to 1e-5."""
+    from rot_mvgaze_amd.geometry import rotation_matrix_2d
+    from rot_mvgaze_amd.losses import MultiViewIterationLoss
+    from rot_mvgaze_amd.model import MultiViewGaze
+    depth, V, B, hw = 50, 4, 128, 224
+    sdn = synth.make_state_dict(depth, 0, 3)
+    inp = synth.make_inputs(B, V, 1234, hw)
+    img, hp, gt = (torch.from_numpy(inp[k]) for k in ("img", "head_pose", "gt_gaze"))
+    rot_d = rotation_matrix_2d(hp.reshape(-1, 2).to(dev())).reshape(B, V, 3, 3)
+    views = [img[:, v].contiguous().to(dev()) for v in range(V)]
+    runs = []
+    for split in (True, False):
+        m = MultiViewGaze(depth, 3)
+        m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sdn.items()}, strict=True)
+        m.to(dev()).train()
+        m.ensure_layout()
+        m._backbone.split = split
+        out = m.forward_multiview(views, rot_d)
+        assert m._backbone._split_now is split
+        loss = MultiViewIterationLoss(rel_weight=0.01, reference_decay=1.0, iter_decay=0.5)(out, gt.to(dev()))
+        loss.backward()
+        runs.append((loss.item(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}))
+        del m, out, loss
+        torch.cuda.empty_cache()
+    rel_close(runs[0][0], runs[1][0], 1e-5, "C3 loss, split vs fp32-MFMA kernels")
+    errs = []
+    for k, g in runs[1][1].items():
+        if not k.startswith("_feat_extractor"):
+            continue
+        ref = g.double()
+        errs.append((((runs[0][1][k].double() - ref).norm() / ref.norm().clamp_min(1e-30)).item(), k))
+    errs.sort(reverse=True)
+    assert len(errs) == 159, len(errs)                      # 53 conv weights + 53 x (gamma, beta)
+    assert errs[0][0] < 5e-2, errs[:5]
+
+
 def test_fused_adam_matches_torch_adam():
     """mvg_adam_step over the arenas == torch.optim.Adam (trainer.py:54: lr, weight_decay 1e-6),
     three steps on the same gradients; CyclicLR drives it like the reference scheduler does."""
