@@ -355,7 +355,30 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
     }
     *reinterpret_cast<u32x4 *>(out_g + off + col) = o;
   };
-  if constexpr (BNF) {
+  // The plain fp32 result (a training forward's y; backward-data without mask / addend / fused reduce) has nothing per 8 channels
+  // to apply: a lane stores ONE 16-byte vector and 32 consecutive lanes cover a row's 512 bytes - whole 128-byte lines per store
+  // instruction, where the 8-channel form writes every line as two half-line stores of different instructions (C3: forward
+  // family 15.5 -> 14.9 ms, step 79.8 -> 79.1 ms on one box).  The same idea on the fused-reduce path - 4 channels per lane,
+  // whole-line y loads - LOST 0.9 ms (twice the iterations), and requesting iteration it + 1's y / bits / addend before iteration it
+  // is processed needs 26 spilled registers here and is worth 1.3 % where it fits (the two-workgroup pipelined form): that path
+  // is bound by the bytes of y, not by its load round trips.
+  bool plain4 = false;
+  if constexpr (F32IO && !LIN) plain4 = p.nt_out && !p.scale && !p.bias && !p.addend && !p.mask && !p.out_sp && !bnf && !p.relu;
+  if (plain4) {
+    constexpr int CV4 = BN / 4;
+#pragma unroll
+    for (int it = 0; it < PR * CV4 / NT; ++it) {
+      const int v = tid + it * NT;
+      const int rl = v / CV4, c4 = v - rl * CV4;
+      const int col = ntile * BN + c4 * 4;
+      const int off = rowoff[ph * PR + rl];
+      if (off < 0 || col >= p.ncols) continue;
+      const float4 q = *reinterpret_cast<const float4 *>(ot + rl * LDO + c4 * 4);
+      typedef float f4v __attribute__((ext_vector_type(4)));
+      const f4v sv = {q.x * osc, q.y * osc, q.z * osc, q.w * osc};
+      __builtin_nontemporal_store(sv, reinterpret_cast<f4v *>(out_f + off + col));
+    }
+  } else if constexpr (BNF) {
 #pragma unroll 1
     for (int it = 0; it < PR * CV / NT; ++it) store_rows(it);
   } else {
