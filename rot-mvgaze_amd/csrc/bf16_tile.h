@@ -153,6 +153,8 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
   // 32 values a thread would otherwise hold next to the accumulators and the 24 running sums - the kernels keep four
   // workgroups per CU (<= 128 VGPRs) with the reduce fused.
   const bool bnf = BNF && DGRAD && p.bn_part != nullptr;
+  bool quad = false;                             // fp32 backward-data: two whole-line quads per lane (below)
+  if constexpr (F32IO && DGRAD && !LIN) quad = !p.mask && (p.ncols % BN) == 0;
   float bn_s1[8], bn_s2[8], bn_mx[8];          // bn_mx: max |masked gradient| per channel
   const bool bn_aff = bnf && p.bn_rscale != nullptr;
   float *bnc = reinterpret_cast<float *>(smem) + (BM / PASSES) * LDO + BM;      // [4][BN]: mean, invstd, relu scale, relu shift
@@ -362,6 +364,71 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
   // whole-line y loads - LOST 0.9 ms (twice the iterations), and requesting iteration it + 1's y / bits / addend before iteration it
   // is processed needs 26 spilled registers here and is worth 1.3 % where it fits (the two-workgroup pipelined form): that path
   // is bound by the bytes of y, not by its load round trips.
+  if (quad) {
+    // fp32 backward-data (with or without the fused reduce): a lane's 8 channels are TWO quads half a tile apart - columns
+    // 4 cq .. 4 cq + 3 and BN/2 + 4 cq .. - so each of its two loads / stores per tensor is 16 bytes next to its neighbour
+    // lanes': whole 128-byte lines per instruction (y, the addend, dx), same registers and iteration count as 8 adjacent channels
+    // (C3: backward-data family 20.9 -> 20.2 ms, step 79.6 -> 79.3 ms on one box)
+    constexpr int HB = BN / 2;
+    const int cq = tid % CV;
+    const int cA = cq * 4, cB = HB + cq * 4;
+    const int colA = ntile * BN + cA, colB = ntile * BN + cB;
+#pragma unroll 1
+    for (int it = 0; it < PR * CV / NT; ++it) {
+      const int rl = (tid + it * NT) / CV;
+      const int off = rowoff[ph * PR + rl];
+      if (off < 0) continue;
+      const float4 qa = *reinterpret_cast<const float4 *>(ot + rl * LDO + cA);
+      const float4 qb = *reinterpret_cast<const float4 *>(ot + rl * LDO + cB);
+      float x[8] = {qa.x * osc, qa.y * osc, qa.z * osc, qa.w * osc, qb.x * osc, qb.y * osc, qb.z * osc, qb.w * osc};
+      if (add_f) {
+        const float4 a0 = *reinterpret_cast<const float4 *>(add_f + off + colA), a1 = *reinterpret_cast<const float4 *>(add_f + off + colB);
+        x[0] += a0.x; x[1] += a0.y; x[2] += a0.z; x[3] += a0.w; x[4] += a1.x; x[5] += a1.y; x[6] += a1.z; x[7] += a1.w;
+      }
+      if (bnf) {
+        const float *yg = p.bn_y + (long long)g * gelems + off;
+        const float4 y0 = *reinterpret_cast<const float4 *>(yg + colA), y1 = *reinterpret_cast<const float4 *>(yg + colB);
+        const float yy[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+        unsigned bits = 0xFFu;                      // no ReLU on that unit: every element passes
+        if (p.bn_bits) {
+          const uint8_t *bb = p.bn_bits + (((long long)g * gelems + off) >> 2);
+          bits = (bb[colA >> 2] & 0xFu) | ((bb[colB >> 2] & 0xFu) << 4);
+        }
+        asm volatile("" ::: "memory");              // re-read the constants here (not hoisted into 32 live registers)
+        auto ld44 = [&](const float *base, float (&v)[8]) {
+          const float4 u = *reinterpret_cast<const float4 *>(base + cA), w = *reinterpret_cast<const float4 *>(base + cB);
+          v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w; v[4] = w.x; v[5] = w.y; v[6] = w.z; v[7] = w.w;
+        };
+        if (bn_aff) {
+          float bn_ra[8], bn_rb[8];
+          ld44(bnc + 2 * BN, bn_ra);
+          ld44(bnc + 3 * BN, bn_rb);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) bits = (bits & ~(1u << k)) | ((__builtin_fmaf(yy[k], bn_ra[k], bn_rb[k]) > 0.f ? 1u : 0u) << k);
+        }
+        float bn_mu[8], bn_is[8];
+        ld44(bnc, bn_mu);
+        ld44(bnc + BN, bn_is);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          x[k] = ((bits >> k) & 1u) != 0u ? x[k] : 0.f;
+          bn_mx[k] = fmaxf(bn_mx[k], fabsf(x[k]));
+          bn_s1[k] += x[k];
+          bn_s2[k] += x[k] * ((yy[k] - bn_mu[k]) * bn_is[k]);
+        }
+      }
+      if (p.nt_out) {
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const f4v s0 = {x[0], x[1], x[2], x[3]}, s1 = {x[4], x[5], x[6], x[7]};
+        __builtin_nontemporal_store(s0, reinterpret_cast<f4v *>(out_f + off + colA));
+        __builtin_nontemporal_store(s1, reinterpret_cast<f4v *>(out_f + off + colB));
+      } else {
+        *reinterpret_cast<float4 *>(out_f + off + colA) = make_float4(x[0], x[1], x[2], x[3]);
+        *reinterpret_cast<float4 *>(out_f + off + colB) = make_float4(x[4], x[5], x[6], x[7]);
+      }
+    }
+    continue;
+  }
   bool plain4 = false;
   if constexpr (F32IO && !LIN) plain4 = p.nt_out && !p.scale && !p.bias && !p.addend && !p.mask && !p.out_sp && !bnf && !p.relu;
   if (plain4) {
@@ -410,9 +477,10 @@ __device__ __forceinline__ void bf16_epilogue(const IgemmParams &p, const IgemmC
     const int nred = p.bn_part_rows;                        // 2: (s1, s2); 3: (s1, s2, max |dz|)
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      red[(0 * RL + rlt) * BN + cvt * 8 + k] = bn_s1[k];
-      red[(1 * RL + rlt) * BN + cvt * 8 + k] = bn_s2[k];
-      if (F32IO) red[(2 * RL + rlt) * BN + cvt * 8 + k] = bn_mx[k];       // (bf16 storage: two rows, no maximum)
+      const int cc = quad ? (k < 4 ? cvt * 4 + k : BN / 2 + cvt * 4 + k - 4) : cvt * 8 + k;     // the thread's k-th channel
+      red[(0 * RL + rlt) * BN + cc] = bn_s1[k];
+      red[(1 * RL + rlt) * BN + cc] = bn_s2[k];
+      if (F32IO) red[(2 * RL + rlt) * BN + cc] = bn_mx[k];       // (bf16 storage: two rows, no maximum)
     }
     __syncthreads();
     for (int idx = tid; idx < nred * BN; idx += NT) {
