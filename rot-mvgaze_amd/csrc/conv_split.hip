@@ -290,13 +290,13 @@ __device__ __forceinline__ int sp_row_swz(int R) { return ((R >> 1) & 1) | (((R 
 // the 128 x 128 tile - for the layers with 64 GEMM columns (64-channel 3x3 convs), where the 128 x 64 tile's 64 x 32 wave tiles
 // re-read every A fragment for half the products.
 //
-// STAGES > 1 (the fusion block's Linears: 48 - 336 tiles of up to 112 K-steps on 256 CUs, i.e. ONE or two workgroups per CU and
-// nobody to cover a workgroup's waits): an explicit software pipeline, see the K loop.
+// STAGES = 2 (launches that leave a CU one or two workgroups - the fusion block's Linears, 48 - 336 tiles of up to 112 K-steps on
+// 256 CUs; every conv of a small batch - so that nobody covers a workgroup's waits): an explicit software pipeline, see the K loop.
 template <int BN, bool DGRAD, bool LIN = false, int WGM = 2, int STAGES = 1>
-__global__ __launch_bounds__(256, STAGES > 2 ? 1 : STAGES == 2 ? 2 : (DGRAD || WGM == 4) ? 3 : 4) void igemm_split16_kernel(IgemmParams p) {
+__global__ __launch_bounds__(256, STAGES == 2 ? 2 : (DGRAD || WGM == 4) ? 3 : 4) void igemm_split16_kernel(IgemmParams p) {
   constexpr int BM = 64 * WGM, WGN = 4 / WGM, NW = 4;
   static_assert(WGM == 2 || (WGM == 4 && BN == 64), "tiles: 128 x BN (2 x 2 waves) or 256 x 64 (4 x 1)");
-  static_assert(STAGES >= 1 && STAGES <= 4, "1 - 4 LDS stages");
+  static_assert(STAGES == 1 || STAGES == 2, "one LDS stage, or the two-stage pipeline");
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 16, TN = WTN / 16;
   constexpr int SLOTS = 4 * SP_NP;                            // 16-byte slots per LDS row (8)
@@ -446,30 +446,29 @@ __global__ __launch_bounds__(256, STAGES > 2 ? 1 : STAGES == 2 ? 2 : (DGRAD || W
       __syncthreads();                                         // everyone is done reading before the next DMA lands
     }
   } else {
-    // Software pipeline, two levels: STAGES K-steps of DMA in LDS / in flight, and the fragments of K-step kt + 1 read into a
-    // second register set while K-step kt's MFMAs run (with one wave per SIMD nothing else overlaps the LDS reads with the
-    // matrix pipe).  At the top of K-step kt: wait until K-step kt + 1 has landed (vmcnt counts the newer groups in flight) and
-    // this wave's fragment reads of K-step kt are complete (lgkmcnt), barrier - now stage kt % STAGES is free for every wave:
-    // K-step kt + STAGES goes into it.  A bare s_barrier: __syncthreads() carries a fence that the compiler turns into
-    // s_waitcnt vmcnt(0), which would drain the K-steps in flight.
+    // Software pipeline, two levels: two K-steps of DMA in LDS / in flight, and the fragments of K-step kt + 1 read into a second
+    // register set while K-step kt's MFMAs run (with one wave per SIMD nothing else overlaps the LDS reads with the matrix
+    // pipe).  At the top of K-step kt: wait until K-step kt + 1 has landed (the only group in flight: vmcnt(0)) and this wave's
+    // fragment reads of K-step kt are complete (lgkmcnt(0)), barrier - now K-step kt's stage is free for every wave and K-step
+    // kt + 2 goes into it.  A bare s_barrier: __syncthreads() carries a fence that the compiler turns into s_waitcnt vmcnt(0)
+    // wherever an LDS-DMA is pending, which in the prologue would wait for BOTH stages before the first multiply.  (Three and
+    // four stages with counted vmcnt waits - one workgroup per CU - measured the same as two: profiles/r04_lin_kloop_stages_ab.txt.)
     constexpr int G = A_PER + B_PER;                           // DMA instructions per wave and K-step
-    auto wait_barrier = [&](int newer) {
-      if (STAGES >= 4 && newer >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * G) : "memory");
-      else if (STAGES >= 3 && newer >= 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(G) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    };
-#pragma unroll
-    for (int d = 0; d < STAGES; ++d)
-      if (d < KT) issue(d, d * STAGE_B);
+    if (KT > 0) issue(0, 0);                                   // (KT = 0: a tap-less class of a fused-reduce launch, epilogue only)
+    if (KT > 1) {
+      issue(1, STAGE_B);
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(G) : "memory");     // K-step 0 has landed, K-step 1 is in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
     f16x8 a0[SP_NP][TM], b0[SP_NP][TN], a1[SP_NP][TM], b1[SP_NP][TN];
-    wait_barrier((KT < STAGES ? KT : STAGES) - 1);
     load_frags(smem, a0, b0);
     int cur = 0;                                               // byte offset of K-step kt's stage
     auto step = [&](int kt, const f16x8 (&ca)[SP_NP][TM], const f16x8 (&cb)[SP_NP][TN], f16x8 (&na)[SP_NP][TM], f16x8 (&nb)[SP_NP][TN]) {
       if (kt + 1 < KT) {
-        wait_barrier(KT - 2 - kt);
-        if (kt + STAGES < KT) issue(kt + STAGES, cur);
-        cur = cur + STAGE_B == STAGES * STAGE_B ? 0 : cur + STAGE_B;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kt + 2 < KT) issue(kt + 2, cur);
+        cur ^= STAGE_B;
         load_frags(smem + cur, na, nb);
       }
       products(ca, cb);
