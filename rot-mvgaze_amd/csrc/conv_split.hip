@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : (DGRAD || WGM == 4) ? 3 : 4)
 // with a 16-pixel step keeps more loads in flight per CU than a DMA stage that must drain before it is multiplied.
 // ------------------------------------------------------------------------------------------
 template <int BM, int BN, bool INCR>
-__global__ __launch_bounds__(256, 3) void wgrad_split_kernel(WgradParams p) {
+__global__ __launch_bounds__(256, BN >= 256 ? 2 : 3) void wgrad_split_kernel(WgradParams p) {
   constexpr int BK = 16, WGM = 2, WGN = 2;
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -1209,6 +1209,11 @@ static void wgrad_split_tile(const mvg_conv_desc *d, int &bm, int &bn) {
   const int ncols = d->r * d->s * d->cin;
   bm = d->cout >= 128 ? 128 : 64;
   bn = ncols >= 128 ? 128 : 64;
+  // 128 x 256 tiles (wave tile 64 x 128, two workgroups per CU) where the columns divide: 24 KB of operands per 16-pixel K-step for
+  // twice the products of the 128 x 128 tile's 16 KB - like every kernel of this family wgrad runs into the CU's operand intake,
+  // not the matrix pipe (scripts/conv_bench.py at C3: 5 - 14 % per layer, e.g. 512-channel 3x3 stride 2 0.377 -> 0.326 ms;
+  // inside the step the family 15.4 -> 14.7 ms, C3 79.2 -> 78.3 ms on one box)
+  if (bm == 128 && ncols >= 256 && ncols % 256 == 0) bn = 256;
 }
 
 int mvg_conv_wgrad_splits_split(const mvg_conv_desc *d) {
@@ -1219,7 +1224,7 @@ int mvg_conv_wgrad_splits_split(const mvg_conv_desc *d) {
   const long long tiles = (long long)ceil_div(d->cout, bm) * ceil_div(ncols, bn);
   const long long pixels = (long long)d->groups * d->n * d->ho * d->wo;
   const int cus = compute_cus();
-  long long want = (3LL * cus) / tiles;                    // one resident round at three workgroups per CU (measured at C3:
+  long long want = ((bn == 256 ? 2LL : 3LL) * cus) / tiles;                    // one resident round at three workgroups per CU (measured at C3:
                                                            // 2 / 3 / 4 / 6 per CU -> 17.8 / 16.8 / 16.7 / 17.7 ms of wgrad per step)
   long long maxs = pixels / 256;                           // at least 256 pixels (16 K-steps) per split
   if (maxs < 1) maxs = 1;
@@ -1285,7 +1290,8 @@ static int wgrad_split_impl(const mvg_conv_desc *d, const void *x_sp, const void
     if (incr) hipLaunchKernelGGL((wgrad_split_kernel<BM_, BN_, true>), grid, block, 0, st, p);     \
     else hipLaunchKernelGGL((wgrad_split_kernel<BM_, BN_, false>), grid, block, 0, st, p);         \
   } while (0)
-    if (bm == 128 && bn == 128) MVG_WGRAD_SPLIT(128, 128);
+    if (bm == 128 && bn == 256) MVG_WGRAD_SPLIT(128, 256);
+    else if (bm == 128 && bn == 128) MVG_WGRAD_SPLIT(128, 128);
     else if (bm == 64 && bn == 128) MVG_WGRAD_SPLIT(64, 128);
     else if (bm == 128 && bn == 64) MVG_WGRAD_SPLIT(128, 64);
     else MVG_WGRAD_SPLIT(64, 64);
