@@ -1224,8 +1224,9 @@ int mvg_conv_wgrad_splits_split(const mvg_conv_desc *d) {
   const long long tiles = (long long)ceil_div(d->cout, bm) * ceil_div(ncols, bn);
   const long long pixels = (long long)d->groups * d->n * d->ho * d->wo;
   const int cus = compute_cus();
-  long long want = ((bn == 256 ? 2LL : 3LL) * cus) / tiles;                    // one resident round at three workgroups per CU (measured at C3:
-                                                           // 2 / 3 / 4 / 6 per CU -> 17.8 / 16.8 / 16.7 / 17.7 ms of wgrad per step)
+  // one resident round: three workgroups per CU (128-column tiles; measured at C3: 2 / 3 / 4 / 6 per CU -> 17.8 / 16.8 / 16.7 /
+  // 17.7 ms of wgrad per step), two with the 256-column tiles (2 / 3 / 4 / 6 -> 15.6 / 16.8 / 16.4 / 17.3 ms)
+  long long want = ((bn == 256 ? 2LL : 3LL) * cus) / tiles;
   long long maxs = pixels / 256;                           // at least 256 pixels (16 K-steps) per split
   if (maxs < 1) maxs = 1;
   if (want > maxs) want = maxs;
